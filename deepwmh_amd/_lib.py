@@ -1,0 +1,76 @@
+"""ctypes binding of libdeepwmh_amd.so (include/deepwmh_amd.h).  There is NO fallback: if the HIP
+library is missing or a call fails, this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libdeepwmh_amd.so')
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); mirrors include/deepwmh_amd.h one to one
+SIGNATURES = {
+    'wmh_last_error': (C.c_char_p, []),
+    'wmh_abi_version': (_i, []),
+    'wmh_device_check': (_i, [_i]),
+    'wmh_conv3d_k3_config': (_i, [_i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_packed_floats': (_sz, [_i, _i, _i]),
+    'wmh_conv3d_k3_pack_weights': (_i, [_i, _vp, _i, _i, _vp]),
+    'wmh_conv3d_k3_num_partials': (_i, [_i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_fwd': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_instnorm_finalize': (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]),
+    'wmh_instnorm_stats': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _sz, _vp]),
+    'wmh_instnorm_lrelu_apply': (_i, [_vp, _vp, _vp, _i, _i, _sz, _f, _vp]),
+    'wmh_convtranspose3d_k2s2_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_extract_patches': (_i, [_vp, _vp, _i, _i, _i, _i, _ip, _i, _i, _i, _i, _ip, _ip, _vp]),
+    'wmh_seghead_softmax_accumulate': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ip, _i, _ip, _f, _vp]),
+    'wmh_seghead_logits': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _sz, _f, _vp]),
+    'wmh_accumulate_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _vp]),
+    'wmh_finalize_argmax': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _ip, _i, _i, _i, _vp]),
+    'wmh_selftest_mfma_32x32x2': (_i, [_vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class WMHError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "deepwmh_amd: %s not found. The HIP library is required (there is no CPU fallback); "
+            "build it with `python -c \"import __graft_entry__ as g; g.build()\"` or "
+            "`python deepwmh_amd/build.py`." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc < 0:
+        raise WMHError('%s failed (%d): %s' % (what, rc, load().wmh_last_error().decode()))
+    return rc
+
+
+def iarr(values):
+    values = [int(v) for v in values]
+    return (C.c_int * len(values))(*values)
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'tensor must be contiguous'
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,154 @@
+"""Generic_UNet forward on the HIP kernels (host orchestration; torch is the HBM allocator only).
+
+Mirrors nnU-Net `Generic_UNet.forward` [nnU-Net, not in tree; generic_UNet.py] layer for layer:
+encoder Conv-IN-LReLU x2 per stage (first conv of a stage strided), bottleneck, decoder
+ConvTranspose3d -> (concat-free) Conv-IN-LReLU x2, segmentation heads.  InstanceNorm+LeakyReLU of a
+layer is never materialised: the conv epilogue emits statistics, `wmh_instnorm_finalize` turns
+them into per-(n,c) {scale, shift}, and every consumer applies them while loading.
+Checkpoint keys are the `state_dict` keys of the reference's `model_best.model`
+(/root/reference/deepwmh/main/install_model.py:85-106 pins where that file lives).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .plan import UNetPlan
+
+LRELU_SLOPE = 1e-2
+IN_EPS = 1e-5
+
+
+def _np(v):
+    if isinstance(v, torch.Tensor):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(v, dtype=np.float32)
+
+
+class _ConvLayer:
+    """One Conv3d(3x3x3)+InstanceNorm layer: packed weights per kernel configuration."""
+
+    def __init__(self, lib, sd, prefix, cin, cout, stride, device):
+        self.lib, self.cin, self.cout, self.stride, self.device = lib, cin, cout, stride, device
+        self.w_host = _np(sd[prefix + '.conv.weight'])
+        assert self.w_host.shape == (cout, cin, 3, 3, 3), (prefix, self.w_host.shape)
+        self.bias = torch.from_numpy(_np(sd[prefix + '.conv.bias'])).to(device)
+        self.gamma = torch.from_numpy(_np(sd[prefix + '.instnorm.weight'])).to(device)
+        self.beta = torch.from_numpy(_np(sd[prefix + '.instnorm.bias'])).to(device)
+        self._packed = {}
+
+    def packed(self, cfg):
+        if cfg not in self._packed:
+            n = self.lib.wmh_conv3d_k3_packed_floats(cfg, self.cin, self.cout)
+            wf = np.empty(n, dtype=np.float32)
+            _lib.check(self.lib.wmh_conv3d_k3_pack_weights(
+                cfg, self.w_host.ctypes.data_as(C.c_void_p), self.cin, self.cout,
+                wf.ctypes.data_as(C.c_void_p)), 'wmh_conv3d_k3_pack_weights')
+            self._packed[cfg] = torch.from_numpy(wf).to(self.device)
+        return self._packed[cfg]
+
+
+class UNetEngine:
+    """Holds the weights in HBM and runs the forward graph on a HIP stream."""
+
+    def __init__(self, plan: UNetPlan, state_dict, device='cuda:0'):
+        plan.check_supported()
+        self.plan = plan
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('UNetEngine needs a HIP device (got %s); there is no CPU path' % device)
+        self.lib = _lib.load()
+        _lib.check(self.lib.wmh_device_check(self.device.index or 0), 'wmh_device_check')
+        sd = state_dict
+        dev = self.device
+        self.enc = [_ConvLayer(self.lib, sd, s.name, s.cin, s.cout, s.stride, dev) for s in plan.encoder_convs()]
+        self.dec = []
+        for st in plan.decoder_stages():
+            name, cdown, cskip = st['tu']
+            tu_w = torch.from_numpy(_np(sd[name + '.weight'])).to(dev)
+            assert tuple(tu_w.shape) == (cdown, cskip, 2, 2, 2)
+            convs = [_ConvLayer(self.lib, sd, c.name, c.cin, c.cout, 1, dev) for c in st['convs']]
+            seg_w = torch.from_numpy(_np(sd[st['seg'] + '.weight']).reshape(plan.num_classes, cskip)).contiguous().to(dev)
+            self.dec.append(dict(tu_w=tu_w, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
+        self._bufs = {}
+
+    # ---- buffers -------------------------------------------------------------------------------
+    def _buf(self, key, shape):
+        t = self._bufs.get(key)
+        n = int(np.prod(shape))
+        if t is None or t.numel() < n:
+            t = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._bufs[key] = t
+        return t[:n].view(*shape)
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---- layers --------------------------------------------------------------------------------
+    def _conv(self, key, layer, x0, ss0, x1=None, ss1=None):
+        N, C0, D, H, W = x0.shape
+        C1 = 0 if x1 is None else x1.shape[1]
+        assert C0 + C1 == layer.cin
+        s = layer.stride
+        Do, Ho, Wo = (D - 1) // s + 1, (H - 1) // s + 1, (W - 1) // s + 1
+        cfg = _lib.check(self.lib.wmh_conv3d_k3_config(layer.cin, layer.cout, D, H, W, s), 'wmh_conv3d_k3_config')
+        npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials')
+        y = self._buf(key + '.y', (N, layer.cout, Do, Ho, Wo))
+        part = self._buf(key + '.part', (N, layer.cout, npart, 4))
+        ss = self._buf(key + '.ss', (N, layer.cout, 2))
+        st = self._stream()
+        _lib.check(self.lib.wmh_conv3d_k3_fwd(
+            cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
+            _lib.ptr(layer.packed(cfg)), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part),
+            N, D, H, W, layer.cout, s, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd')
+        _lib.check(self.lib.wmh_instnorm_finalize(
+            _lib.ptr(part), npart, _lib.ptr(layer.gamma), _lib.ptr(layer.beta), IN_EPS, _lib.ptr(ss), None,
+            N, layer.cout, st), 'wmh_instnorm_finalize')
+        return y, ss
+
+    def _convT(self, key, w, x, ss, cout):
+        N, Cin, D, H, W = x.shape
+        y = self._buf(key + '.y', (N, cout, 2 * D, 2 * H, 2 * W))
+        _lib.check(self.lib.wmh_convtranspose3d_k2s2_fwd(
+            _lib.ptr(x), _lib.ptr(ss), _lib.ptr(w), _lib.ptr(y), N, Cin, cout, D, H, W, LRELU_SLOPE,
+            self._stream()), 'wmh_convtranspose3d_k2s2_fwd')
+        return y
+
+    # ---- graph ---------------------------------------------------------------------------------
+    def forward_features(self, x, deep_supervision=False):
+        """x: [N, Cin, P0, P1, P2] fp32 on the device.  Returns a list of (y, ss, seg_w) per decoder
+        stage output that was requested (last = full resolution): y is the raw conv output whose
+        InstanceNorm+LeakyReLU is still pending as ss."""
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.device == self.device
+        cur, cur_ss = x, None
+        skips = []
+        nenc = len(self.enc)
+        for i, layer in enumerate(self.enc):
+            cur, cur_ss = self._conv('enc%d' % i, layer, cur, cur_ss)
+            if i % 2 == 1 and i < nenc - 2:
+                skips.append((cur, cur_ss))
+        outs = []
+        for u, st in enumerate(self.dec):
+            up = self._convT('tu%d' % u, st['tu_w'], cur, cur_ss, st['cskip'])
+            skip, skip_ss = skips[-(u + 1)]
+            cur, cur_ss = self._conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss)
+            cur, cur_ss = self._conv('dec%d.1' % u, st['convs'][1], cur, cur_ss)
+            if deep_supervision or u == len(self.dec) - 1:
+                outs.append((cur, cur_ss, st['seg_w']))
+        return outs
+
+    def forward_logits(self, x, deep_supervision=False):
+        """Logits like Generic_UNet.forward: [N,K,...] (or the deep-supervision tuple, full res first)."""
+        outs = self.forward_features(x, deep_supervision)
+        K = self.plan.num_classes
+        res = []
+        for (y, ss, seg_w) in outs:
+            N, Cc = y.shape[:2]
+            sp = int(np.prod(y.shape[2:]))
+            lg = torch.empty((N, K) + tuple(y.shape[2:]), dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.wmh_seghead_logits(_lib.ptr(y), _lib.ptr(ss), _lib.ptr(seg_w), K, _lib.ptr(lg),
+                                                   N, Cc, sp, LRELU_SLOPE, self._stream()), 'wmh_seghead_logits')
+            res.append(lg)
+        return tuple(res[::-1]) if deep_supervision else res[-1]

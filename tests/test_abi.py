@@ -1,0 +1,82 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/deepwmh_amd.h declares,
+and its host-side entry points (configuration, weight packing, argument checks) behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from deepwmh_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_header_symbols_all_exported_and_bound(lib):
+    from deepwmh_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'deepwmh_amd.h')).read()
+    declared = set(re.findall(r'\b(wmh_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), 'library does not export %s' % name
+    assert declared == set(_lib.SIGNATURES), 'ctypes table and header disagree'
+    assert lib.wmh_abi_version() == 1
+
+
+def test_config_selection(lib):
+    assert lib.wmh_conv3d_k3_config(32, 32, 128, 128, 128, 1) == 0
+    assert lib.wmh_conv3d_k3_config(32, 64, 128, 128, 128, 2) == 1
+    assert lib.wmh_conv3d_k3_config(256, 256, 16, 16, 16, 1) == 2
+    assert lib.wmh_conv3d_k3_config(128, 256, 32, 32, 32, 2) == 3
+    assert lib.wmh_conv3d_k3_config(320, 320, 8, 8, 8, 1) == 4
+    assert lib.wmh_conv3d_k3_config(320, 320, 4, 4, 4, 1) == 6
+    assert lib.wmh_conv3d_k3_config(320, 320, 8, 8, 8, 2) == 7
+    assert lib.wmh_conv3d_k3_config(32, 32, 128, 128, 128, 3) < 0
+    assert b'bad shape' in lib.wmh_last_error()
+
+
+def test_pack_weights_layout(lib):
+    # fragment-major image: [G][chunk][tap][lane][CK/2], lane = (cin parity, cout row)
+    cin, cout, cfg = 6, 40, 0          # cfg 0: CK = 4 -> 2 chunks (2nd half-empty), G = 2 (2nd partial)
+    w = np.random.default_rng(0).standard_normal((cout, cin, 3, 3, 3)).astype(np.float32)
+    n = lib.wmh_conv3d_k3_packed_floats(cfg, cin, cout)
+    assert n == 2 * 2 * 27 * 64 * 2
+    wf = np.full(n, np.nan, np.float32)
+    rc = lib.wmh_conv3d_k3_pack_weights(cfg, w.ctypes.data_as(C.c_void_p), cin, cout, wf.ctypes.data_as(C.c_void_p))
+    assert rc == 0 and not np.isnan(wf).any()
+    wf = wf.reshape(2, 2, 27, 64, 2)
+    w27 = w.reshape(cout, cin, 27)
+    for g, ch, tap, lane, p in [(0, 0, 0, 0, 0), (0, 1, 13, 37, 0), (1, 0, 26, 7, 1), (1, 1, 5, 63, 1), (0, 1, 2, 33, 1)]:
+        co, ci = g * 32 + (lane & 31), ch * 4 + 2 * p + (lane >> 5)
+        exp = w27[co, ci, tap] if (co < cout and ci < cin) else 0.0
+        assert wf[g, ch, tap, lane, p] == exp
+    assert np.isclose(np.abs(wf).sum(), np.abs(w).sum(), rtol=1e-5)   # nothing lost, padding is zero
+
+
+def test_num_partials(lib):
+    # cfg 0 tiles 4x8x32 voxels, 4 waves per tile -> 128^3: 32*16*4 tiles * 4
+    assert lib.wmh_conv3d_k3_num_partials(0, 8, 128, 128, 128) == 32 * 16 * 4 * 4
+    assert lib.wmh_conv3d_k3_num_partials(6, 8, 4, 4, 4) == 1
+
+
+def test_argument_checks_fail_loudly(lib):
+    from deepwmh_amd import _lib
+    rc = lib.wmh_conv3d_k3_fwd(0, None, None, 1, None, None, 0, None, None, None, None, 1, 8, 8, 8, 8, 1, 0.01, None)
+    assert rc == -1
+    with pytest.raises(_lib.WMHError):
+        _lib.check(rc, 'wmh_conv3d_k3_fwd')
+    assert lib.wmh_seghead_softmax_accumulate(None, None, None, 2, None, None, 4, 8, 8, 8, 8, 8, 8, None, 1, None, 0.01, None) == -1
+
+
+def test_engine_refuses_cpu(tiny_net):
+    from deepwmh_amd.network import UNetEngine
+    plan, _, sd = tiny_net
+    with pytest.raises(RuntimeError):
+        UNetEngine(plan, sd, device='cpu')

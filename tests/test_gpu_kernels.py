@@ -1,0 +1,245 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (ctypes) against torch-CPU fp32 references
+of the same op (the arithmetic primitives nnU-Net itself is made of)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SLOPE = 0.01
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from deepwmh_amd import _lib
+    lib = _lib.load()
+    assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+    _lib.check(lib.wmh_device_check(0), 'wmh_device_check')
+    return lib
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def P(t):
+    from deepwmh_amd import _lib
+    return _lib.ptr(t)
+
+
+def iarr(v):
+    from deepwmh_amd import _lib
+    return _lib.iarr(v)
+
+
+def test_mfma_fragment_layout(lib):
+    # exact small integers, asymmetric B: a transposed or mis-mapped fragment cannot pass
+    rng = np.random.default_rng(0)
+    a = rng.integers(-8, 9, (32, 2)).astype(np.float32)
+    b = rng.integers(-8, 9, (2, 32)).astype(np.float32)
+    b[0, :] += np.arange(32, dtype=np.float32)
+    d = torch.full((32, 32), float('nan'), device='cuda')
+    assert lib.wmh_selftest_mfma_32x32x2(P(dev(a)), P(dev(b)), P(d), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), a @ b)
+
+
+def _lrelu_affine(x, ss):
+    if ss is None:
+        return x
+    y = x * ss[..., 0][:, :, None, None, None] + ss[..., 1][:, :, None, None, None]
+    return F.leaky_relu(y, SLOPE)
+
+
+CONV_CASES = [
+    # N, C0, C1, Cout, D, H, W, stride, ss0, ss1, expected cfg
+    (1, 1, 0, 8, 32, 32, 32, 1, False, False, 0),
+    (2, 8, 0, 8, 16, 24, 40, 1, True, False, 0),
+    (1, 32, 0, 32, 8, 16, 64, 1, True, False, 0),
+    (1, 6, 0, 40, 9, 17, 33, 1, False, False, 0),
+    (2, 8, 8, 8, 16, 16, 32, 1, False, True, 0),
+    (1, 4, 12, 16, 8, 8, 32, 1, True, True, 0),
+    (1, 8, 0, 16, 32, 32, 64, 2, True, False, 1),
+    (1, 5, 0, 8, 9, 11, 71, 2, False, False, 1),
+    (2, 16, 0, 16, 16, 16, 16, 1, True, False, 2),
+    (1, 8, 8, 24, 6, 20, 13, 1, False, True, 2),
+    (1, 16, 0, 32, 32, 32, 32, 2, True, False, 3),
+    (3, 32, 0, 32, 8, 8, 8, 1, True, False, 4),
+    (1, 16, 16, 40, 5, 9, 7, 1, True, True, 4),
+    (1, 16, 0, 32, 16, 16, 16, 2, True, False, 5),
+    (5, 32, 0, 32, 4, 4, 4, 1, True, False, 6),
+    (2, 16, 16, 8, 3, 4, 5, 1, False, True, 6),
+    (5, 16, 0, 32, 8, 8, 8, 2, True, False, 7),
+    (1, 64, 0, 64, 8, 8, 32, 1, True, False, 0),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv3d_k3_and_instnorm_partials(lib, case):
+    from deepwmh_amd import _lib
+    N, C0, C1, Cout, D, H, W, s, use_ss0, use_ss1, exp_cfg = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    Cin = C0 + C1
+    x0 = torch.randn(N, C0, D, H, W, generator=g) * 1.5 + 0.3
+    x1 = torch.randn(N, C1, D, H, W, generator=g) if C1 else None
+    ss0 = torch.stack([0.5 + torch.rand(N, C0, generator=g), 0.3 * torch.randn(N, C0, generator=g)], -1) if use_ss0 else None
+    ss1 = torch.stack([0.5 + torch.rand(N, C1, generator=g), 0.3 * torch.randn(N, C1, generator=g)], -1) if use_ss1 else None
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (27 * Cin)) ** 0.5
+    b = 0.1 * torch.randn(Cout, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+
+    xin = _lrelu_affine(x0, ss0)
+    if C1:
+        xin = torch.cat((xin, _lrelu_affine(x1, ss1)), 1)
+    ref = F.conv3d(xin, w, b, stride=s, padding=1)
+    Do, Ho, Wo = ref.shape[2:]
+
+    cfg = lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, s)
+    assert cfg == exp_cfg
+    nfl = lib.wmh_conv3d_k3_packed_floats(cfg, Cin, Cout)
+    wf = np.empty(nfl, np.float32)
+    wn = w.numpy()
+    assert lib.wmh_conv3d_k3_pack_weights(cfg, wn.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)) == 0
+    npart = lib.wmh_conv3d_k3_num_partials(cfg, N, Do, Ho, Wo)
+    y = torch.full((N, Cout, Do, Ho, Wo), float('nan'), device='cuda')
+    part = torch.full((N, Cout, npart, 4), float('nan'), device='cuda')
+    ss_out = torch.full((N, Cout, 2), float('nan'), device='cuda')
+    mr = torch.full((N, Cout, 2), float('nan'), device='cuda')
+    d = [t.cuda() if t is not None else None for t in (x0, ss0, x1, ss1)]
+    wfd, bd, gd, btd = dev(wf), b.cuda(), gamma.cuda(), beta.cuda()
+    _lib.check(lib.wmh_conv3d_k3_fwd(cfg, P(d[0]), P(d[1]), C0, P(d[2]), P(d[3]), C1, P(wfd), P(bd), P(y), P(part),
+                                     N, D, H, W, Cout, s, SLOPE, None), 'conv')
+    _lib.check(lib.wmh_instnorm_finalize(P(part), npart, P(gd), P(btd), 1e-5, P(ss_out), P(mr), N, Cout, None), 'fin')
+    torch.cuda.synchronize()
+    yh = y.cpu()
+    assert not torch.isnan(yh).any(), 'conv left output voxels unwritten'
+    scale = float(ref.abs().max())
+    err = float((yh - ref).abs().max())
+    assert err <= 1e-5 * scale + 1e-6, 'conv3d max err %.3g (scale %.3g)' % (err, scale)
+
+    # InstanceNorm3d statistics from the epilogue partials vs torch
+    mean = ref.mean((2, 3, 4), keepdim=False).double()
+    var = ref.double().var((2, 3, 4), unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    mrh = mr.cpu().double()
+    assert float((mrh[..., 0] - mean).abs().max()) <= 1e-5 * (1 + float(mean.abs().max()))
+    assert float(((mrh[..., 1] - rstd) / rstd).abs().max()) <= 1e-5
+    sc = gamma.double()[None] * rstd
+    sh = beta.double()[None] - mean * sc
+    ssh = ss_out.cpu().double()
+    assert float(((ssh[..., 0] - sc) / sc.abs().clamp_min(1e-3)).abs().max()) <= 1e-5
+    assert float((ssh[..., 1] - sh).abs().max()) <= 1e-5 * (1 + float(sh.abs().max()))
+    # and the normalised tensor a consumer would see equals torch's lrelu(instance_norm(conv))
+    full = F.leaky_relu(F.instance_norm(ref, weight=gamma, bias=beta, eps=1e-5), SLOPE)
+    mine = F.leaky_relu(yh * ss_out.cpu()[..., 0][:, :, None, None, None] + ss_out.cpu()[..., 1][:, :, None, None, None], SLOPE)
+    assert float((mine - full).abs().max()) <= 2e-5
+
+
+def test_instnorm_stats_and_apply(lib):
+    from deepwmh_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 7, 9, 10, 11, generator=g) * 3 + 20.0      # large mean: cancellation-prone
+    gamma, beta = 1 + 0.2 * torch.randn(7, generator=g), 0.1 * torch.randn(7, generator=g)
+    xd = x.cuda()
+    ss = torch.empty(3, 7, 2, device='cuda')
+    y = torch.empty_like(xd)
+    _lib.check(lib.wmh_instnorm_stats(P(xd), P(gamma.cuda()), P(beta.cuda()), 1e-5, P(ss), None, 3, 7, 990, None), 'stats')
+    _lib.check(lib.wmh_instnorm_lrelu_apply(P(xd), P(ss), P(y), 3, 7, 990, SLOPE, None), 'apply')
+    torch.cuda.synchronize()
+    ref = F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), SLOPE)
+    assert float((y.cpu() - ref).abs().max()) <= 3e-5
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 8, 4, 4, 4, True), (1, 8, 4, 5, 6, 7, False), (2, 12, 20, 3, 16, 33, True)])
+def test_convtranspose3d_k2s2(lib, shape):
+    from deepwmh_amd import _lib
+    N, Cin, Cout, D, H, W, use_ss = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 2, 2, 2, generator=g) * 0.2
+    ss = torch.stack([0.5 + torch.rand(N, Cin, generator=g), 0.3 * torch.randn(N, Cin, generator=g)], -1) if use_ss else None
+    ref = F.conv_transpose3d(_lrelu_affine(x, ss), w, None, stride=2)
+    y = torch.full((N, Cout, 2 * D, 2 * H, 2 * W), float('nan'), device='cuda')
+    _lib.check(lib.wmh_convtranspose3d_k2s2_fwd(P(x.cuda()), P(ss.cuda() if use_ss else None), P(w.cuda()), P(y),
+                                                N, Cin, Cout, D, H, W, SLOPE, None), 'convT')
+    torch.cuda.synchronize()
+    yh = y.cpu()
+    assert not torch.isnan(yh).any()
+    assert float((yh - ref).abs().max()) <= 1e-5 * (1 + float(ref.abs().max()))
+
+
+def test_extract_patches_flips_and_padding(lib):
+    from deepwmh_amd import _lib
+    rng = np.random.default_rng(2)
+    vol = rng.standard_normal((2, 10, 20, 13)).astype(np.float32)
+    Pz = (12, 8, 16)                         # first and last axes larger than the volume -> centred zero pad
+    A = (12, 20, 16)
+    pad_lo = [(A[i] - vol.shape[1 + i]) // 2 for i in range(3)]
+    padded = np.zeros((2,) + A, np.float32)
+    padded[:, pad_lo[0]:pad_lo[0] + 10, pad_lo[1]:pad_lo[1] + 20, pad_lo[2]:pad_lo[2] + 13] = vol
+    origins = [(0, 0, 0), (0, 12, 0), (0, 5, 0), (0, 5, 0)]
+    flips = [0, 0, 5, 7]
+    out = torch.full((4, 2) + Pz, float('nan'), device='cuda')
+    _lib.check(lib.wmh_extract_patches(P(dev(vol)), P(out), 2, 10, 20, 13, iarr(pad_lo), Pz[0], Pz[1], Pz[2], 4,
+                                       iarr([v for o in origins for v in o]), iarr(flips), None), 'extract')
+    torch.cuda.synchronize()
+    for b, (o, f) in enumerate(zip(origins, flips)):
+        ref = padded[:, o[0]:o[0] + Pz[0], o[1]:o[1] + Pz[1], o[2]:o[2] + Pz[2]]
+        axes = [ax for bit, ax in ((4, 1), (2, 2), (1, 3)) if f & bit]
+        if axes:
+            ref = np.flip(ref, axes)
+        assert np.array_equal(out[b].cpu().numpy(), ref), 'item %d' % b
+
+
+def test_seghead_softmax_mirror_accumulate_and_finalize(lib):
+    from deepwmh_amd import _lib
+    from deepwmh_amd.sliding_window import get_gaussian
+    g = torch.Generator().manual_seed(3)
+    n, Cc, K, Pz, A = 8, 6, 2, (8, 6, 10), (12, 6, 15)
+    x = torch.randn(n, Cc, *Pz, generator=g)
+    ss = torch.stack([0.5 + torch.rand(n, Cc, generator=g), 0.3 * torch.randn(n, Cc, generator=g)], -1)
+    wseg = torch.randn(K, Cc, generator=g)
+    gauss = torch.from_numpy(get_gaussian(Pz))
+    origin = (3, 0, 4)
+    agg0 = torch.rand(K, *A, generator=g)
+    agg = agg0.clone().cuda()
+    flips = list(range(8))
+    _lib.check(lib.wmh_seghead_softmax_accumulate(P(x.cuda()), P(ss.cuda()), P(wseg.cuda()), K, P(gauss.cuda()), P(agg), Cc,
+                                                  Pz[0], Pz[1], Pz[2], A[0], A[1], A[2], iarr(origin), n, iarr(flips),
+                                                  SLOPE, None), 'seghead')
+    lg = torch.empty(n, K, *Pz, device='cuda')
+    _lib.check(lib.wmh_seghead_logits(P(x.cuda()), P(ss.cuda()), P(wseg.cuda()), K, P(lg), n, Cc, int(np.prod(Pz)), SLOPE, None), 'logits')
+    torch.cuda.synchronize()
+    logits = torch.einsum('kc,ncxyz->nkxyz', wseg, _lrelu_affine(x, ss))
+    assert float((lg.cpu() - logits).abs().max()) <= 1e-5
+    res = torch.zeros(1, K, *Pz)
+    for m in range(8):
+        ax = tuple(a for bit, a in ((4, 2), (2, 3), (1, 4)) if m & bit)
+        pred = torch.softmax(logits[m:m + 1], 1)
+        res += 1 / 8 * (torch.flip(pred, ax) if ax else pred)
+    res[:, :] *= gauss
+    exp = agg0.clone()
+    exp[:, 3:11, 0:6, 4:14] += res[0]
+    assert float((agg.cpu() - exp).abs().max()) <= 2e-6
+
+    # count map + normalise + argmax with a crop window
+    cnt = torch.zeros(*A, device='cuda')
+    for o in [(0, 0, 0), (4, 0, 5), (2, 0, 3)]:
+        _lib.check(lib.wmh_accumulate_weight(P(gauss.cuda()), P(cnt), Pz[0], Pz[1], Pz[2], A[0], A[1], A[2], iarr(o), None), 'cnt')
+    cref = torch.zeros(*A)
+    for o in [(0, 0, 0), (4, 0, 5), (2, 0, 3)]:
+        cref[o[0]:o[0] + 8, o[1]:o[1] + 6, o[2]:o[2] + 10] += gauss
+    torch.cuda.synchronize()
+    assert torch.equal(cnt.cpu(), cref)
+    V, lo = (9, 6, 12), (1, 0, 2)
+    cnt2 = (cref + 0.5).cuda()
+    prob = torch.empty(K, *V, device='cuda')
+    seg = torch.empty(V, dtype=torch.uint8, device='cuda')
+    _lib.check(lib.wmh_finalize_argmax(P(agg), P(cnt2), P(prob), P(seg), K, A[0], A[1], A[2], iarr(lo), V[0], V[1], V[2], None), 'fin')
+    torch.cuda.synchronize()
+    pref = (agg.cpu() / (cref + 0.5))[:, 1:10, 0:6, 2:14]
+    assert torch.equal(prob.cpu(), pref)
+    assert torch.equal(seg.cpu(), pref.argmax(0).to(torch.uint8))

@@ -1,0 +1,137 @@
+"""GPU parity tests of the whole path (network forward, sliding-window predict) against the CPU
+oracle and the committed golden fixtures.  Tolerance (BASELINE.json north_star): max-abs 1e-4 on
+softmax outputs / logits, identical argmax mask (voxels whose oracle class margin is below the
+tolerance are excluded from the mask comparison and counted)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def tiny_engine(tiny_net):
+    from deepwmh_amd.network import UNetEngine
+    plan, net, sd = tiny_net
+    return UNetEngine(plan, sd, 'cuda:0')
+
+
+def _mask_check(seg, seg_ref, prob_ref, tol=2 * TOL):
+    sure = np.abs(prob_ref[1] - prob_ref[0]) > tol
+    mism = int((seg != seg_ref)[sure].sum())
+    return mism, int((~sure).sum())
+
+
+def test_tiny_net_logits_deep_supervision(tiny_engine, tiny_net, tiny_io):
+    plan, net, _ = tiny_net
+    x = torch.from_numpy(tiny_io['patch']).cuda()
+    ds = tiny_engine.forward_logits(x, deep_supervision=True)
+    torch.cuda.synchronize()
+    assert len(ds) == plan.num_pool
+    with torch.no_grad():
+        net.do_ds = True
+        ref = net(torch.from_numpy(tiny_io['patch']))
+        net.do_ds = False
+    for i, t in enumerate(ds):
+        got = t.cpu().numpy()
+        e_live = float(np.abs(got - ref[i].numpy()).max())
+        e_gold = float(np.abs(got - tiny_io['logits_ds%d' % i]).max())
+        print('ds%d: max|logit err| live %.3g golden %.3g (|logit| max %.3g)' % (i, e_live, e_gold, np.abs(got).max()))
+        assert e_live <= TOL and e_gold <= TOL
+    single = tiny_engine.forward_logits(x).cpu().numpy()
+    assert np.array_equal(single, ds[0].cpu().numpy())
+
+
+def test_batch_items_are_independent(tiny_engine, tiny_io):
+    # InstanceNorm is per sample: a batch of different patches must equal the per-patch results
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([tiny_io['patch'], rng.standard_normal((4, 1, 32, 32, 32)).astype(np.float32)], 0)
+    all5 = tiny_engine.forward_logits(torch.from_numpy(xs).cuda()).cpu().numpy()
+    for b in range(5):
+        one = tiny_engine.forward_logits(torch.from_numpy(xs[b:b + 1]).cuda()).cpu().numpy()
+        assert np.array_equal(one[0], all5[b]), 'batch item %d differs from its single-item run' % b
+
+
+@pytest.mark.parametrize('mirror,key', [(False, 'notta'), (True, 'tta')])
+def test_tiled_predict_matches_golden(tiny_engine, tiny_io, mirror, key):
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    from oracle.sliding_window import hard_dice_binary
+    pred = SlidingWindowPredictor(tiny_engine, do_mirroring=mirror, batch=8)
+    seg, prob = pred.predict(tiny_io['volume'])
+    err = float(np.abs(prob - tiny_io['prob_' + key]).max())
+    mism, unsure = _mask_check(seg, tiny_io['seg_' + key], tiny_io['prob_' + key])
+    dice = hard_dice_binary(tiny_io['seg_' + key], seg)
+    print('%s: max|softmax err| %.3g, argmax mismatches %d (+%d voxels inside the tolerance band), dice %.6f'
+          % (key, err, mism, unsure, dice))
+    assert err <= TOL and mism == 0 and dice > 0.9999
+    np.testing.assert_allclose(prob.sum(0), 1.0, atol=1e-5)
+    # batch size must not change results (patches are accumulated in a fixed order)
+    if not mirror:
+        seg3, prob3 = SlidingWindowPredictor(tiny_engine, do_mirroring=False, batch=3).predict(tiny_io['volume'])
+        assert np.array_equal(prob3, prob) and np.array_equal(seg3, seg)
+
+
+def test_predict_volume_smaller_than_patch(tiny_engine, tiny_io):
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    seg, prob = SlidingWindowPredictor(tiny_engine, do_mirroring=False).predict(tiny_io['small_volume'])
+    assert seg.shape == tiny_io['small_volume'].shape[1:]
+    assert float(np.abs(prob - tiny_io['prob_small']).max()) <= TOL
+    assert _mask_check(seg, tiny_io['seg_small'], tiny_io['prob_small'])[0] == 0
+
+
+def test_single_tile_volume_uses_unit_weights(tiny_engine, tiny_net, tiny_io):
+    # one tile -> nnU-Net skips the Gaussian (weights 1); volume == patch
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    from oracle import sliding_window as osw
+    plan, net, _ = tiny_net
+    vol = tiny_io['patch'][0]
+    seg, prob = SlidingWindowPredictor(tiny_engine, do_mirroring=False).predict(vol)
+    seg_o, prob_o = osw.predict_3d_tiled(net, vol, plan.patch_size, 0.5, False, True)
+    assert float(np.abs(prob - prob_o).max()) <= TOL
+
+
+def test_mirroring_flip_equivariance(tiny_engine, tiny_io):
+    # size-independent property: with all 8 mirrors averaged, predicting a flipped patch-sized volume
+    # gives the flipped prediction (single tile, so no Gaussian asymmetry enters)
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    pred = SlidingWindowPredictor(tiny_engine, do_mirroring=True)
+    vol = tiny_io['patch'][0]
+    _, p = pred.predict(vol)
+    _, pf = pred.predict(np.ascontiguousarray(vol[:, ::-1, :, ::-1]))
+    assert float(np.abs(pf[:, ::-1, :, ::-1] - p).max()) <= 2e-5
+
+
+def test_full_size_patch_forward_vs_oracle():
+    """BASELINE.json architecture (31.2 M parameters) on one 128^3 patch against the CPU oracle."""
+    import time
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.plan import baseline_plan
+    from oracle.generic_unet import unet_from_plan, perturb_like_trained, state_dict_numpy
+    from oracle.sliding_window import synthetic_flair
+    torch.manual_seed(0)
+    plan = baseline_plan()
+    net = perturb_like_trained(unet_from_plan(plan), seed=2).eval()
+    net.do_ds = False
+    vol = synthetic_flair((128, 128, 128), seed=1)
+    eng = UNetEngine(plan, state_dict_numpy(net), 'cuda:0')
+    x = torch.from_numpy(vol[None]).cuda()
+    got = eng.forward_logits(x)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    got = eng.forward_logits(x).cpu().numpy()
+    t_gpu = time.time() - t0
+    t0 = time.time()
+    with torch.no_grad():
+        ref = net(torch.from_numpy(vol[None])).numpy()
+    t_cpu = time.time() - t0
+    err = float(np.abs(got - ref).max())
+    sm = lambda a: np.exp(a - a.max(1, keepdims=True)) / np.exp(a - a.max(1, keepdims=True)).sum(1, keepdims=True)
+    perr = float(np.abs(sm(got) - sm(ref)).max())
+    margin = np.abs(ref[:, 1] - ref[:, 0])
+    mism = int(((got.argmax(1) != ref.argmax(1)) & (margin > 4 * TOL)).sum())
+    print('full-size patch: max|logit err| %.3g, max|softmax err| %.3g, |logit| max %.3g, argmax mismatches %d; '
+          'GPU %.3f s (incl. D2H), CPU oracle %.1f s on %d threads'
+          % (err, perr, np.abs(ref).max(), mism, t_gpu, t_cpu, torch.get_num_threads()))
+    assert perr <= TOL and mism == 0
