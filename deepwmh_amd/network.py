@@ -72,6 +72,9 @@ class UNetEngine:
             seg_w = torch.from_numpy(_np(sd[st['seg'] + '.weight']).reshape(plan.num_classes, cskip)).contiguous().to(dev)
             self.dec.append(dict(tu_w=tu_w, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
         self._bufs = {}
+        # optional live kernel timing (bench.py): conv configs to bracket with HIP events on the launch stream
+        self.timed_cfgs = set()
+        self.timings = []          # (cfg, start_event, end_event, algorithmic_flop, algorithmic_bytes)
 
     # ---- buffers -------------------------------------------------------------------------------
     def _buf(self, key, shape):
@@ -99,10 +102,21 @@ class UNetEngine:
         part = self._buf(key + '.part', (N, layer.cout, npart, 4))
         ss = self._buf(key + '.ss', (N, layer.cout, 2))
         st = self._stream()
+        wf = layer.packed(cfg)
+        timed = cfg in self.timed_cfgs
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(self.lib.wmh_conv3d_k3_fwd(
             cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
-            _lib.ptr(layer.packed(cfg)), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part),
+            _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part),
             N, D, H, W, layer.cout, s, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd')
+        if timed:
+            e1.record()
+            vox = N * Do * Ho * Wo
+            flop = 2.0 * layer.cin * layer.cout * 27 * vox
+            nbytes = 4.0 * (N * layer.cin * D * H * W + layer.cout * vox + layer.cout * layer.cin * 27)
+            self.timings.append((cfg, e0, e1, flop, nbytes))
         _lib.check(self.lib.wmh_instnorm_finalize(
             _lib.ptr(part), npart, _lib.ptr(layer.gamma), _lib.ptr(layer.beta), IN_EPS, _lib.ptr(ss), None,
             N, layer.cout, st), 'wmh_instnorm_finalize')

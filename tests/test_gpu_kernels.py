@@ -42,7 +42,8 @@ def test_mfma_fragment_layout(lib):
     b = rng.integers(-8, 9, (2, 32)).astype(np.float32)
     b[0, :] += np.arange(32, dtype=np.float32)
     d = torch.full((32, 32), float('nan'), device='cuda')
-    assert lib.wmh_selftest_mfma_32x32x2(P(dev(a)), P(dev(b)), P(d), None) == 0
+    ad, bd = dev(a), dev(b)
+    assert lib.wmh_selftest_mfma_32x32x2(P(ad), P(bd), P(d), None) == 0
     torch.cuda.synchronize()
     assert np.array_equal(d.cpu().numpy(), a @ b)
 
@@ -146,7 +147,8 @@ def test_instnorm_stats_and_apply(lib):
     xd = x.cuda()
     ss = torch.empty(3, 7, 2, device='cuda')
     y = torch.empty_like(xd)
-    _lib.check(lib.wmh_instnorm_stats(P(xd), P(gamma.cuda()), P(beta.cuda()), 1e-5, P(ss), None, 3, 7, 990, None), 'stats')
+    gd, bd = gamma.cuda(), beta.cuda()      # keep device copies alive: a freed temporary's block is reused at once
+    _lib.check(lib.wmh_instnorm_stats(P(xd), P(gd), P(bd), 1e-5, P(ss), None, 3, 7, 990, None), 'stats')
     _lib.check(lib.wmh_instnorm_lrelu_apply(P(xd), P(ss), P(y), 3, 7, 990, SLOPE, None), 'apply')
     torch.cuda.synchronize()
     ref = F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), SLOPE)
@@ -163,7 +165,8 @@ def test_convtranspose3d_k2s2(lib, shape):
     ss = torch.stack([0.5 + torch.rand(N, Cin, generator=g), 0.3 * torch.randn(N, Cin, generator=g)], -1) if use_ss else None
     ref = F.conv_transpose3d(_lrelu_affine(x, ss), w, None, stride=2)
     y = torch.full((N, Cout, 2 * D, 2 * H, 2 * W), float('nan'), device='cuda')
-    _lib.check(lib.wmh_convtranspose3d_k2s2_fwd(P(x.cuda()), P(ss.cuda() if use_ss else None), P(w.cuda()), P(y),
+    xd, ssd, wd = x.cuda(), (ss.cuda() if use_ss else None), w.cuda()
+    _lib.check(lib.wmh_convtranspose3d_k2s2_fwd(P(xd), P(ssd), P(wd), P(y),
                                                 N, Cin, Cout, D, H, W, SLOPE, None), 'convT')
     torch.cuda.synchronize()
     yh = y.cpu()
@@ -183,7 +186,8 @@ def test_extract_patches_flips_and_padding(lib):
     origins = [(0, 0, 0), (0, 12, 0), (0, 5, 0), (0, 5, 0)]
     flips = [0, 0, 5, 7]
     out = torch.full((4, 2) + Pz, float('nan'), device='cuda')
-    _lib.check(lib.wmh_extract_patches(P(dev(vol)), P(out), 2, 10, 20, 13, iarr(pad_lo), Pz[0], Pz[1], Pz[2], 4,
+    vd = dev(vol)
+    _lib.check(lib.wmh_extract_patches(P(vd), P(out), 2, 10, 20, 13, iarr(pad_lo), Pz[0], Pz[1], Pz[2], 4,
                                        iarr([v for o in origins for v in o]), iarr(flips), None), 'extract')
     torch.cuda.synchronize()
     for b, (o, f) in enumerate(zip(origins, flips)):
@@ -207,11 +211,12 @@ def test_seghead_softmax_mirror_accumulate_and_finalize(lib):
     agg0 = torch.rand(K, *A, generator=g)
     agg = agg0.clone().cuda()
     flips = list(range(8))
-    _lib.check(lib.wmh_seghead_softmax_accumulate(P(x.cuda()), P(ss.cuda()), P(wseg.cuda()), K, P(gauss.cuda()), P(agg), Cc,
+    xd, ssd, wd, gd = x.cuda(), ss.cuda(), wseg.cuda(), gauss.cuda()
+    _lib.check(lib.wmh_seghead_softmax_accumulate(P(xd), P(ssd), P(wd), K, P(gd), P(agg), Cc,
                                                   Pz[0], Pz[1], Pz[2], A[0], A[1], A[2], iarr(origin), n, iarr(flips),
                                                   SLOPE, None), 'seghead')
     lg = torch.empty(n, K, *Pz, device='cuda')
-    _lib.check(lib.wmh_seghead_logits(P(x.cuda()), P(ss.cuda()), P(wseg.cuda()), K, P(lg), n, Cc, int(np.prod(Pz)), SLOPE, None), 'logits')
+    _lib.check(lib.wmh_seghead_logits(P(xd), P(ssd), P(wd), K, P(lg), n, Cc, int(np.prod(Pz)), SLOPE, None), 'logits')
     torch.cuda.synchronize()
     logits = torch.einsum('kc,ncxyz->nkxyz', wseg, _lrelu_affine(x, ss))
     assert float((lg.cpu() - logits).abs().max()) <= 1e-5
@@ -228,7 +233,7 @@ def test_seghead_softmax_mirror_accumulate_and_finalize(lib):
     # count map + normalise + argmax with a crop window
     cnt = torch.zeros(*A, device='cuda')
     for o in [(0, 0, 0), (4, 0, 5), (2, 0, 3)]:
-        _lib.check(lib.wmh_accumulate_weight(P(gauss.cuda()), P(cnt), Pz[0], Pz[1], Pz[2], A[0], A[1], A[2], iarr(o), None), 'cnt')
+        _lib.check(lib.wmh_accumulate_weight(P(gd), P(cnt), Pz[0], Pz[1], Pz[2], A[0], A[1], A[2], iarr(o), None), 'cnt')
     cref = torch.zeros(*A)
     for o in [(0, 0, 0), (4, 0, 5), (2, 0, 3)]:
         cref[o[0]:o[0] + 8, o[1]:o[1] + 6, o[2]:o[2] + 10] += gauss
