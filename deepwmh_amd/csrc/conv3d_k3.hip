@@ -3,21 +3,30 @@
 //
 //   D[cout 32][voxel 32] += A[cout 32][k 2] * B[k 2][voxel 32],   k = (tap, cin) pairs
 //
-// * B (activations) comes from an LDS halo tile [CK cin][TN][IZ][IY][IX] staged once per cin
-//   chunk with coalesced NCDHW row reads; a lane's 27 taps are immediate offsets from one LDS
-//   address, so the inner loop carries no address arithmetic.  The producer layer's
-//   InstanceNorm+LeakyReLU is applied while staging (x' = lrelu(x*scale+shift)); halo voxels
-//   outside the tensor are written as 0 AFTER that transform (torch pads the normalised tensor).
-// * A (weights) is read straight from a fragment-major image in HBM/L2 ([G][chunk][tap][lane][CK/2]),
-//   one vector load per tap per lane, shared by all MT voxel tiles of the wave.
+// * B (activations) comes from an LDS halo tile [CK cin][TN][IZ][IY][IX], double buffered and staged
+//   once per cin chunk with coalesced NCDHW row reads; a lane's 27 taps are immediate offsets from one
+//   LDS address, so the inner loop carries no address arithmetic.  The producer layer's
+//   InstanceNorm+LeakyReLU is applied while staging (x' = lrelu(x*scale+shift)); halo voxels outside
+//   the tensor are written as 0 AFTER that transform (torch pads the normalised tensor).
+//   The next chunk's global loads are issued at the top of a chunk and its LDS writes are spread over
+//   the chunk's last taps, between MFMAs: one barrier per chunk, no exposed load latency.
+// * A (weights) is read straight from a fragment-major image in HBM/L2 ([G][chunk][tap][NT][lane][CK/2]),
+//   one vector load per tap per lane through a prefetch ring that runs APF taps ahead ACROSS chunk
+//   boundaries: vmcnt retires in order, so a weight load issued behind the staging loads would make
+//   every chunk's first MFMA wait a full HBM latency.
+// * Each wave owns MT voxel tiles x NT cout tiles (MT*NT accumulators of 16 registers).
 // * Two input tensors may be given (concat-free torch.cat((up, skip), 1)).
-// * Epilogue: + bias, coalesced 128-B row-segment stores, and per-wave InstanceNorm partials
+// * Split-K over cin chunks (KS > 1) writes raw partial sums to a slab per split; a reduce kernel adds
+//   them in fixed order together with the bias and produces the InstanceNorm statistics.
+// * Epilogue (KS == 1): + bias, coalesced 128-B row-segment stores, per-wave InstanceNorm partials
 //   (count, sum, M2 about the wave's own mean) for every output channel.
 //
 // Stands in for torch.nn.Conv3d inside nnU-Net's ConvDropoutNormNonlin [nnU-Net, not in tree];
 // call sites in the reference: deepwmh/main/predict.py:153-156 (nnUNet_predict).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "wmh_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -28,13 +37,14 @@ struct ConvArgs {
     const float* wf; const float* bias; float* y; float* part;
     int N, D, H, W, Do, Ho, Wo, Cout;
     int nchunks, ntx, nty, ntz, npart;
+    int G, KS, xcd_swizzle;
     float slope;
 };
 
-template <int S_, int LX_, int LY_, int TZ_, int TY_, int TN_, int MT_, int CK_>
+template <int S_, int LX_, int LY_, int TZ_, int TY_, int TN_, int MT_, int NT_, int CK_, int APF_>
 struct ConvCfg {
     static constexpr int S = S_, LX = LX_, LY = LY_, LZ = 32 / (LX_ * LY_);
-    static constexpr int TX = LX_, TY = TY_, TZ = TZ_, TN = TN_, MT = MT_, CK = CK_;
+    static constexpr int TX = LX_, TY = TY_, TZ = TZ_, TN = TN_, MT = MT_, NT = NT_, CK = CK_, APF = APF_;
     static constexpr int MY = TY / LY, MZ = TZ / LZ, MPS = MY * MZ;  // M-tiles per sample
     static constexpr int NMT = TN * MPS;                             // M-tiles per workgroup
     static constexpr int WM = NMT / MT;                              // waves per workgroup
@@ -44,14 +54,18 @@ struct ConvCfg {
     static constexpr int YS = IX, ZS = IY * YS, NS = IZ * ZS, CS = TN * NS;
     static constexpr int SP = CS;                                    // staged elements per channel
     static constexpr int NIT = (SP + THREADS - 1) / THREADS;
-    static constexpr int LDS_FLOATS = CK * CS;
+    static constexpr int TILE = CK * CS;                             // floats per LDS buffer
+    static constexpr int LDS_FLOATS = 2 * TILE;
+    static constexpr int WT0 = (NIT >= 27) ? 0 : 27 - NIT;           // tap at which the staged writes start
+    static constexpr int WPT = (NIT + 26) / 27;                      // write slices per tap
     static_assert(LX * LY * LZ == 32, "lane map must cover 32 voxels");
     static_assert(TY % LY == 0 && TZ % LZ == 0, "tile must be whole M-tiles");
     static_assert(MPS % MT == 0, "a wave's M-tiles must belong to one sample");
     static_assert(NMT % MT == 0 && WM >= 1 && WM <= 4, "1..4 waves");
     static_assert(NIT <= 32, "validity mask is 32 bits");
     static_assert(CK % 2 == 0, "k step is a cin pair");
-    static_assert(((2 * ZS + 2 * YS + 2) + (CK - 2) * CS) * 4 < 65536, "ds_read immediate range");
+    static_assert(((2 * ZS + 2 * YS + 2) + (CK - 2) * CS + TILE) * 4 < 65536, "ds_read immediate range");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 };
 
 template <int V> struct AVec;
@@ -70,7 +84,7 @@ __device__ __forceinline__ float sum32(float v) {   // sum over the 32 lanes of 
 
 template <class C>
 __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs a) {
-    constexpr int S = C::S, MT = C::MT, CK = C::CK, NIT = C::NIT, THREADS = C::THREADS;
+    constexpr int S = C::S, MT = C::MT, NT = C::NT, CK = C::CK, NIT = C::NIT, THREADS = C::THREADS, APF = C::APF;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
@@ -79,16 +93,28 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
     const int j = lane & 31, kh = lane >> 5;
     const int dx = j % C::LX, dy = (j / C::LX) % C::LY, dz = j / (C::LX * C::LY);
 
-    int b = blockIdx.x;
+    // 1-D grid over (tile, cout group, k split).  XCD-aware order: blocks are dealt round-robin to the 8
+    // XCDs (bid % 8), so give each XCD one contiguous run of the sequence: halo neighbours and the cout
+    // groups of one tile then share that XCD's L2.  Placement only affects speed, never results.
+    int bid = blockIdx.x;
+    if (a.xcd_swizzle) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int ks = bid % a.KS; bid /= a.KS;
+    const int g = bid % a.G;
+    int b = bid / a.G;
     const int tx = b % a.ntx; b /= a.ntx;
     const int ty = b % a.nty; b /= a.nty;
     const int tz = b % a.ntz; b /= a.ntz;
     const int n0 = b * C::TN;
-    const int g = blockIdx.y;
     const int ox0 = tx * C::TX, oy0 = ty * C::TY, oz0 = tz * C::TZ;
     const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
     const int HW = a.H * a.W;
     const size_t DHW = (size_t)a.D * HW;
+    // this block's range of cin chunks (split-K)
+    const int ch_lo = (int)(((long long)a.nchunks * ks) / a.KS);
+    const int ch_hi = (int)(((long long)a.nchunks * (ks + 1)) / a.KS);
 
     // ---- per-thread staging map: element e of the [TN][IZ][IY][IX] tile <-> global voxel ------
     int sp_off[NIT];          // offset inside one (n,c) plane volume, valid when bit set in okmask
@@ -116,16 +142,29 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
         baddr[m] = kh * C::CS + tn_w * C::NS + S * ((tzi * C::LZ + dz) * C::ZS + (tyi * C::LY + dy) * C::YS + dx);
     }
 
-    f32x16 acc[MT];
+    f32x16 acc[NT][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][m][r] = 0.f;
 
+    // ---- weights: prefetch ring over the linear (chunk, tap) sequence ---------------------------
     typedef typename AVec<CK / 2>::T AV;
-    const AV* wbase = reinterpret_cast<const AV*>(a.wf) + (size_t)g * a.nchunks * 27 * 64 + lane;
+    const AV* wl = reinterpret_cast<const AV*>(a.wf) + (size_t)g * a.nchunks * 27 * NT * 64 + lane;
+    const int Tlast = ch_hi * 27 - 1;
+    AV aring[APF][NT];
+    auto loadA = [&](int T, AV (&dst)[NT]) {
+        T = min(T, Tlast);                           // past the end: harmless re-read of the last tap
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dst[nt] = wl[((size_t)T * NT + nt) * 64];
+    };
 
+    // ---- activations: staging registers, per-chunk scale/shift ----------------------------------
     float stg[CK][NIT];
+    float sc[CK], sh[CK];      // used when TN == 1 (one sample per workgroup: wave-uniform)
+    bool has_ss = false;
 
     auto src_of = [&](int ch, const float*& xs, const float*& ss, int& Cs, int& c0) {
         const int cb = ch * CK;
@@ -144,79 +183,103 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
                 stg[cc][it] = xs[((size_t)(n0 + ni) * Cs + c) * DHW + sp_off[it]];
             }
         }
-    };
-    auto write_chunk = [&](int ch) {
-        const float* xs; const float* ss; int Cs, c0;
-        src_of(ch, xs, ss, Cs, c0);
+        if (C::TN == 1) {
+            has_ss = (ss != nullptr);
 #pragma unroll
-        for (int cc = 0; cc < CK; ++cc) {
-            const bool cok = (c0 + cc) < Cs;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int e = tid + it * THREADS;
-                const int ni = (C::TN == 1) ? 0 : min(e / C::NS, a.N - 1 - n0);
-                const bool ok = cok && ((okmask >> it) & 1u);
-                float v = stg[cc][it];
-                if (ss != nullptr) {
-                    const float* q = ss + ((size_t)(n0 + ni) * Cs + min(c0 + cc, Cs - 1)) * 2;
-                    v = fmaf(v, q[0], q[1]);
-                    v = v > 0.f ? v : v * a.slope;
-                }
-                v = ok ? v : 0.f;
-                if (NIT * THREADS == C::SP || e < C::SP) lds[cc * C::CS + e] = v;
+            for (int cc = 0; cc < CK; ++cc) {
+                const int c = min(c0 + cc, Cs - 1);
+                sc[cc] = has_ss ? ss[((size_t)n0 * Cs + c) * 2] : 1.f;
+                sh[cc] = has_ss ? ss[((size_t)n0 * Cs + c) * 2 + 1] : 0.f;
             }
         }
     };
+    // write slice `it` (all CK channels) of chunk `ch` into LDS buffer `buf`
+    auto write_slice = [&](int ch, int it, float* dstbuf) {
+        const float* xs; const float* ss; int Cs, c0;
+        src_of(ch, xs, ss, Cs, c0);
+        const int e = tid + it * THREADS;
+#pragma unroll
+        for (int cc = 0; cc < CK; ++cc) {
+            const bool ok = ((c0 + cc) < Cs) && ((okmask >> it) & 1u);
+            float v = stg[cc][it];
+            if (C::TN == 1) {
+                if (has_ss) { v = fmaf(v, sc[cc], sh[cc]); v = v > 0.f ? v : v * a.slope; }
+            } else if (ss != nullptr) {
+                const int ni = min(e / C::NS, a.N - 1 - n0);
+                const float* q = ss + ((size_t)(n0 + ni) * Cs + min(c0 + cc, Cs - 1)) * 2;
+                v = fmaf(v, q[0], q[1]);
+                v = v > 0.f ? v : v * a.slope;
+            }
+            v = ok ? v : 0.f;
+            if (NIT * THREADS == C::SP || e < C::SP) dstbuf[cc * C::CS + e] = v;
+        }
+    };
 
-    // ---- main loop over cin chunks -------------------------------------------------------------
-    load_chunk(0);
-    write_chunk(0);
+    // ---- prologue ---------------------------------------------------------------------------------
+    load_chunk(ch_lo);
+#pragma unroll
+    for (int d = 0; d < APF; ++d) loadA(ch_lo * 27 + d, aring[d]);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) write_slice(ch_lo, it, lds);
     __syncthreads();
-    for (int ch = 0; ch < a.nchunks; ++ch) {
-        const bool more = (ch + 1) < a.nchunks;
-        if (more) load_chunk(ch + 1);           // global loads in flight under the MFMAs below
 
-        const AV* wp = wbase + (size_t)ch * 27 * 64;
-        AV a_cur = wp[0];
+    // ---- one cin chunk: 27 taps x CK/2 cin pairs x NT x MT MFMAs out of LDS buffer BUF -------------
+    auto chunk = [&](auto bufc, int ch) {
+        constexpr int BUF = decltype(bufc)::value;
+        const float* cur = lds + BUF * C::TILE;
+        float* nxt = lds + (BUF ^ 1) * C::TILE;
+        const bool more = (ch + 1) < ch_hi;
+        if (more) load_chunk(ch + 1);               // global loads stay in flight under the MFMAs below
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int toff = (tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS + (tap % 3);
-            AV a_nxt = a_cur;
-            if (tap + 1 < 27) a_nxt = wp[(tap + 1) * 64];
+            AV anew[NT];
+            loadA(ch * 27 + tap + APF, anew);
+            if (more) {
 #pragma unroll
-            for (int p = 0; p < CK / 2; ++p) {
-                const float av = avec_get(a_cur, p);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float bv = lds[baddr[m] + toff + 2 * p * C::CS];
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+                for (int k = 0; k < C::WPT; ++k) {
+                    const int it = (tap - C::WT0) * C::WPT + k;
+                    if (tap >= C::WT0 && it < NIT) write_slice(ch + 1, it, nxt);
                 }
             }
-            a_cur = a_nxt;
+#pragma unroll
+            for (int p = 0; p < CK / 2; ++p) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float bv = cur[baddr[m] + toff + 2 * p * C::CS];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(avec_get(aring[0][nt], p), bv, acc[nt][m], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d + 1 < APF; ++d)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) aring[d][nt] = aring[d + 1][nt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) aring[APF - 1][nt] = anew[nt];
         }
-        __syncthreads();                        // every wave is done reading this chunk's tile
-        if (more) {
-            write_chunk(ch + 1);
-            __syncthreads();
+        __syncthreads();     // next buffer fully written, this one fully read
+    };
+    {
+        int ch = ch_lo;
+        for (; ch + 1 < ch_hi; ch += 2) {
+            chunk(std::integral_constant<int, 0>{}, ch);
+            chunk(std::integral_constant<int, 1>{}, ch + 1);
         }
+        if (ch < ch_hi) chunk(std::integral_constant<int, 0>{}, ch);
     }
 
-    // ---- epilogue: bias, store, InstanceNorm partials -------------------------------------------
+    // ---- epilogue ---------------------------------------------------------------------------------
     const int HoWo = a.Ho * a.Wo;
     const size_t DoHoWo = (size_t)a.Do * HoWo;
     const int n = n0 + tn_w;
-    float bias_r[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        bias_r[r] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
-    }
-    float s[16], q[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; q[r] = 0.f; }
-    int cnt = 0;
+    const bool split = a.KS > 1;
+    // split-K: raw partial sums into slab ks of y ([KS][N][Cout][Do][Ho][Wo]); bias/statistics come later
+    float* ybase = a.y + (split ? (size_t)ks * a.N * a.Cout * DoHoWo : 0);
     unsigned vmask = 0;
-    const bool full_rows = (g * 32 + 32) <= a.Cout;
+    int cnt = 0;
+    size_t voff[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int ts = ts0 + m;
@@ -224,92 +287,154 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
         const bool valid = (n < a.N) && oz < a.Do && oy < a.Ho && ox < a.Wo;
         vmask |= valid ? (1u << m) : 0u;
         cnt += __popcll(__ballot(valid) & 0xffffffffull);
-        float* yp = a.y + ((size_t)n * a.Cout + g * 32 + 4 * kh) * DoHoWo + (size_t)oz * HoWo + oy * a.Wo + ox;
+        voff[m] = (size_t)oz * HoWo + oy * a.Wo + ox;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cob = (g * NT + nt) * 32;           // first output channel of this 32-row tile
+        if (cob >= a.Cout) continue;                  // wave-uniform
+        const bool full_rows = (cob + 32) <= a.Cout;
+        float bias_r[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float v = acc[m][r] + bias_r[r];
-            acc[m][r] = v;
-            s[r] += valid ? v : 0.f;
+            const int co = cob + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            bias_r[r] = (!split && a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
         }
-        if (valid) {
-            if (full_rows) {                    // wave-uniform: all 32 output channels of this group exist
+        float s[16], q[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * DoHoWo] = acc[m][r];
-            } else {
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; q[r] = 0.f; }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bool valid = (vmask >> m) & 1u;
+            float* yp = ybase + ((size_t)n * a.Cout + cob + 4 * kh) * DoHoWo + voff[m];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[nt][m][r] + bias_r[r];
+                acc[nt][m][r] = v;
+                s[r] += valid ? v : 0.f;
+            }
+            if (valid) {
+                if (full_rows) {                    // wave-uniform: all 32 output channels of this tile exist
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * DoHoWo] = acc[nt][m][r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2);
+                        if ((cob + 4 * kh + row) < a.Cout) yp[(size_t)row * DoHoWo] = acc[nt][m][r];
+                    }
+                }
+            }
+        }
+        if (a.part != nullptr && !split) {
+            const float fc = (float)cnt;
+            const float inv = cnt > 0 ? 1.f / fc : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = sum32(s[r]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bool valid = (vmask >> m) & 1u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2);
-                    if ((g * 32 + 4 * kh + row) < a.Cout) yp[(size_t)row * DoHoWo] = acc[m][r];
+                    const float d = acc[nt][m][r] - s[r] * inv;
+                    q[r] += valid ? d * d : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[r] = sum32(q[r]);
+            if (j == 0 && n < a.N) {
+                const int tile_sp = (tz * a.nty + ty) * a.ntx + tx;
+                const int pidx = tile_sp * C::WPS + (wave % C::WPS);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cob + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (co < a.Cout) {
+                        float4* pp = reinterpret_cast<float4*>(a.part) + ((size_t)n * a.Cout + co) * a.npart + pidx;
+                        *pp = make_float4(fc, s[r], q[r], 0.f);
+                    }
                 }
             }
         }
     }
-    if (a.part != nullptr) {
-        const float fc = (float)cnt;
-        const float inv = cnt > 0 ? 1.f / fc : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = sum32(s[r]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const bool valid = (vmask >> m) & 1u;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float d = acc[m][r] - s[r] * inv;
-                q[r] += valid ? d * d : 0.f;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) q[r] = sum32(q[r]);
-        if (j == 0 && n < a.N) {
-            const int tile_sp = (tz * a.nty + ty) * a.ntx + tx;
-            const int pidx = tile_sp * C::WPS + (wave % C::WPS);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (co < a.Cout) {
-                    float4* pp = reinterpret_cast<float4*>(a.part) + ((size_t)n * a.Cout + co) * a.npart + pidx;
-                    *pp = make_float4(fc, s[r], q[r], 0.f);
-                }
-            }
-        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-K reduce: y[n,c,:] = bias[c] + sum_ks slab[ks][n,c,:] (fixed order), and InstanceNorm moments.
+// One workgroup per (n,c); the layers that use split-K are the low-resolution ones (<= 16^3 voxels).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, const float* bias, float* y, float* part,
+                                                            int npart, int KS, int C, size_t NC, size_t spatial) {
+    __shared__ float sh_s[4], sh_q[4];
+    const size_t nc = blockIdx.x;
+    const int c = (int)(nc % C);
+    const float bv = bias ? bias[c] : 0.f;
+    const size_t slab = NC * spatial;
+    const float* p = slabs + nc * spatial;
+    float* o = y + nc * spatial;
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < spatial; i += 256) {
+        float v = p[i];
+        for (int k = 1; k < KS; ++k) v += p[(size_t)k * slab + i];
+        v += bv;
+        o[i] = v;
+        s += v;
+    }
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if ((threadIdx.x & 63) == 0) sh_s[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float tot = (sh_s[0] + sh_s[1]) + (sh_s[2] + sh_s[3]);
+    const float mean = tot / (float)spatial;
+    __syncthreads();
+    float q = 0.f;
+    for (size_t i = threadIdx.x; i < spatial; i += 256) { const float d = o[i] - mean; q += d * d; }   // own writes: visible
+    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m);
+    if ((threadIdx.x & 63) == 0) sh_q[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (part) {   // record 0 carries the moments, the remaining records of this (n,c) row are empty (count 0)
+        float4* row = reinterpret_cast<float4*>(part) + nc * npart;
+        for (int i = threadIdx.x; i < npart; i += 256)
+            row[i] = (i == 0) ? make_float4((float)spatial, tot, (sh_q[0] + sh_q[1]) + (sh_q[2] + sh_q[3]), 0.f)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // configuration table
 // ------------------------------------------------------------------------------------------------
-//                      S  LX LY TZ TY TN MT CK
-typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 4> Cfg0;   // stride 1, rows of >=32 voxels (128^3, 64^3, 32^3)
-typedef ConvCfg<2, 32, 1, 2, 8, 1, 4, 2> Cfg1;   // stride 2, output rows of >=32
-typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 4> Cfg2;  // stride 1, 16-wide
-typedef ConvCfg<2, 16, 2, 2, 16, 1, 4, 2> Cfg3;  // stride 2, 16-wide output
-typedef ConvCfg<1, 8, 4, 4, 8, 1, 2, 8> Cfg4;    // stride 1, 8-wide
-typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 4> Cfg5;    // stride 2, 8-wide output
-typedef ConvCfg<1, 4, 4, 4, 4, 4, 2, 8> Cfg6;    // stride 1, 4-wide, 4 samples per workgroup
-typedef ConvCfg<2, 4, 4, 4, 4, 4, 2, 4> Cfg7;    // stride 2, 4-wide output
+//                      S  LX LY TZ TY TN MT NT CK APF
+typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> Cfg0;    // stride 1, rows of >=32 voxels (128^3, 64^3, 32^3)
+typedef ConvCfg<2, 32, 1, 2, 8, 1, 4, 2, 2, 6> Cfg1;    // stride 2, output rows of >=32
+typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> Cfg2;   // stride 1, 16-wide
+typedef ConvCfg<2, 16, 2, 2, 16, 1, 4, 2, 2, 6> Cfg3;   // stride 2, 16-wide output
+typedef ConvCfg<1, 8, 4, 4, 8, 1, 2, 1, 8, 6> Cfg4;     // stride 1, 8-wide
+typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 1, 4, 6> Cfg5;     // stride 2, 8-wide output
+typedef ConvCfg<1, 4, 4, 4, 4, 4, 2, 1, 8, 6> Cfg6;     // stride 1, 4-wide, 4 samples per workgroup
+typedef ConvCfg<2, 4, 4, 4, 4, 4, 2, 1, 2, 6> Cfg7;     // stride 2, 4-wide output
 #define WMH_NUM_CONV_CFG 8
 
-struct CfgInfo { int S, TX, TY, TZ, TN, CK, WPS, threads, lds_bytes; };
+struct CfgInfo { int S, TX, TY, TZ, TN, NT, CK, WPS, threads, lds_bytes; };
 template <class C> static CfgInfo info_of() {
-    return CfgInfo{C::S, C::TX, C::TY, C::TZ, C::TN, C::CK, C::WPS, C::THREADS, C::LDS_FLOATS * 4};
+    return CfgInfo{C::S, C::TX, C::TY, C::TZ, C::TN, C::NT, C::CK, C::WPS, C::THREADS, C::LDS_FLOATS * 4};
 }
 static const CfgInfo& cfg_info(int cfg) {
     static const CfgInfo t[WMH_NUM_CONV_CFG] = {info_of<Cfg0>(), info_of<Cfg1>(), info_of<Cfg2>(), info_of<Cfg3>(),
                                                 info_of<Cfg4>(), info_of<Cfg5>(), info_of<Cfg6>(), info_of<Cfg7>()};
     return t[cfg];
 }
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 template <class C>
-static int launch_conv(const ConvArgs& a, dim3 grid, hipStream_t st) {
+static int launch_conv(const ConvArgs& a, unsigned nblk, hipStream_t st) {
     static bool attr_set = false;
-    const int lds = C::LDS_FLOATS * 4;
+    static const int lds_extra = env_int("WMH_LDS_EXTRA", 0);   // experiments: limit residency
+    const int lds = C::LDS_FLOATS * 4 + lds_extra;
     if (!attr_set) {
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_kernel<C>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3d_k3_kernel<C>), grid, dim3(C::THREADS), lds, st, a);
+    hipLaunchKernelGGL((conv3d_k3_kernel<C>), dim3(nblk), dim3(C::THREADS), lds, st, a);
     return wmh_check_launch("conv3d_k3_kernel");
 }
 
@@ -325,24 +450,37 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 extern "C" size_t wmh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg < 0 || cfg >= WMH_NUM_CONV_CFG) return 0;
-    const int CK = cfg_info(cfg).CK;
-    return (size_t)cdiv(Cout, 32) * cdiv(Cin, CK) * 27 * 64 * (CK / 2);
+    const CfgInfo& c = cfg_info(cfg);
+    return (size_t)cdiv(Cout, 32 * c.NT) * cdiv(Cin, c.CK) * 27 * c.NT * 64 * (c.CK / 2);
 }
 
 extern "C" int wmh_conv3d_k3_pack_weights(int cfg, const float* w, int Cin, int Cout, float* wf) {
     if (cfg < 0 || cfg >= WMH_NUM_CONV_CFG || !w || !wf) return wmh_fail(WMH_EINVAL, "pack_weights: bad args");
-    const int CK = cfg_info(cfg).CK, G = cdiv(Cout, 32), NCH = cdiv(Cin, CK), V = CK / 2;
+    const CfgInfo& c = cfg_info(cfg);
+    const int CK = c.CK, NT = c.NT, G = cdiv(Cout, 32 * NT), NCH = cdiv(Cin, CK), V = CK / 2;
     for (int g = 0; g < G; ++g)
         for (int ch = 0; ch < NCH; ++ch)
             for (int tap = 0; tap < 27; ++tap)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int p = 0; p < V; ++p) {
-                        const int co = g * 32 + (lane & 31), ci = ch * CK + 2 * p + (lane >> 5);
-                        float v = 0.f;
-                        if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 27 + tap];
-                        wf[((((size_t)g * NCH + ch) * 27 + tap) * 64 + lane) * V + p] = v;
-                    }
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int p = 0; p < V; ++p) {
+                            const int co = (g * NT + nt) * 32 + (lane & 31), ci = ch * CK + 2 * p + (lane >> 5);
+                            float v = 0.f;
+                            if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 27 + tap];
+                            wf[(((((size_t)g * NCH + ch) * 27 + tap) * NT + nt) * 64 + lane) * V + p] = v;
+                        }
     return WMH_OK;
+}
+
+// split-K factor for a launch: only the small, under-filled layers split
+static int pick_ksplit(const CfgInfo& c, long long nblk, int nchunks) {
+    static const int force = env_int("WMH_KSPLIT", 0);
+    if (force > 0) return force < nchunks ? force : nchunks;
+    if (nblk >= 512) return 1;
+    int ks = (int)((1024 + nblk - 1) / nblk);
+    if (ks > 16) ks = 16;
+    if (ks > nchunks / 2) ks = nchunks / 2;
+    return ks < 1 ? 1 : ks;
 }
 
 extern "C" int wmh_conv3d_k3_num_partials(int cfg, int N, int Do, int Ho, int Wo) {
@@ -352,9 +490,18 @@ extern "C" int wmh_conv3d_k3_num_partials(int cfg, int N, int Do, int Ho, int Wo
     return cdiv(Wo, c.TX) * cdiv(Ho, c.TY) * cdiv(Do, c.TZ) * c.WPS;
 }
 
+extern "C" size_t wmh_conv3d_k3_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout, int stride) {
+    if (cfg < 0 || cfg >= WMH_NUM_CONV_CFG) return 0;
+    const CfgInfo& c = cfg_info(cfg);
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long long nblk = (long long)cdiv(Wo, c.TX) * cdiv(Ho, c.TY) * cdiv(Do, c.TZ) * cdiv(N, c.TN) * cdiv(Cout, 32 * c.NT);
+    const int ks = pick_ksplit(c, nblk, cdiv(Cin, c.CK));
+    return ks > 1 ? (size_t)ks * N * Cout * Do * Ho * Wo : 0;
+}
+
 extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int C0, const float* x1,
                                  const float* ss1, int C1, const float* wf, const float* bias, float* y,
-                                 float* partials, int N, int D, int H, int W, int Cout, int stride,
+                                 float* partials, float* workspace, int N, int D, int H, int W, int Cout, int stride,
                                  float lrelu_slope, void* stream) {
     if (cfg < 0 || cfg >= WMH_NUM_CONV_CFG) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd: bad cfg");
     const CfgInfo& c = cfg_info(cfg);
@@ -372,21 +519,35 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
     a.ntx = cdiv(a.Wo, c.TX); a.nty = cdiv(a.Ho, c.TY); a.ntz = cdiv(a.Do, c.TZ);
     a.npart = a.ntx * a.nty * a.ntz * c.WPS;
     a.slope = lrelu_slope;
-    const long long nblk = (long long)a.ntx * a.nty * a.ntz * cdiv(N, c.TN);
+    a.G = cdiv(Cout, 32 * c.NT);
+    static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
+    a.xcd_swizzle = swz_env;
+    long long nblk = (long long)a.ntx * a.nty * a.ntz * cdiv(N, c.TN) * a.G;
+    a.KS = pick_ksplit(c, nblk, a.nchunks);
+    if (a.KS > 1 && workspace == nullptr) a.KS = 1;          // no slab memory given: run unsplit
+    nblk *= a.KS;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd: grid too large");
-    dim3 grid((unsigned)nblk, (unsigned)cdiv(Cout, 32));
     hipStream_t st = (hipStream_t)stream;
+    if (a.KS > 1) a.y = workspace;
+    int rc;
     switch (cfg) {
-        case 0: return launch_conv<Cfg0>(a, grid, st);
-        case 1: return launch_conv<Cfg1>(a, grid, st);
-        case 2: return launch_conv<Cfg2>(a, grid, st);
-        case 3: return launch_conv<Cfg3>(a, grid, st);
-        case 4: return launch_conv<Cfg4>(a, grid, st);
-        case 5: return launch_conv<Cfg5>(a, grid, st);
-        case 6: return launch_conv<Cfg6>(a, grid, st);
-        case 7: return launch_conv<Cfg7>(a, grid, st);
+        case 0: rc = launch_conv<Cfg0>(a, (unsigned)nblk, st); break;
+        case 1: rc = launch_conv<Cfg1>(a, (unsigned)nblk, st); break;
+        case 2: rc = launch_conv<Cfg2>(a, (unsigned)nblk, st); break;
+        case 3: rc = launch_conv<Cfg3>(a, (unsigned)nblk, st); break;
+        case 4: rc = launch_conv<Cfg4>(a, (unsigned)nblk, st); break;
+        case 5: rc = launch_conv<Cfg5>(a, (unsigned)nblk, st); break;
+        case 6: rc = launch_conv<Cfg6>(a, (unsigned)nblk, st); break;
+        case 7: rc = launch_conv<Cfg7>(a, (unsigned)nblk, st); break;
+        default: return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd: bad cfg");
     }
-    return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd: bad cfg");
+    if (rc != WMH_OK || a.KS == 1) return rc;
+    // split-K: fixed-order slab sum + bias + statistics.  The reduce writes ONE moments record per (n,c);
+    // fill the rest of the caller's [npart] records with zeros so wmh_instnorm_finalize can be used unchanged.
+    const size_t NC = (size_t)N * Cout, spatial = (size_t)a.Do * a.Ho * a.Wo;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)NC), dim3(256), 0, st, workspace, bias, y, partials, a.npart,
+                       a.KS, Cout, NC, spatial);
+    return wmh_check_launch("splitk_reduce_kernel");
 }
 
 // ---- MFMA layout self-test -----------------------------------------------------------------------

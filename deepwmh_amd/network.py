@@ -101,6 +101,8 @@ class UNetEngine:
         y = self._buf(key + '.y', (N, layer.cout, Do, Ho, Wo))
         part = self._buf(key + '.part', (N, layer.cout, npart, 4))
         ss = self._buf(key + '.ss', (N, layer.cout, 2))
+        nws = self.lib.wmh_conv3d_k3_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout, s)
+        ws = self._buf('splitk.ws', (nws,)) if nws else None      # shared: layers run one after another
         st = self._stream()
         wf = layer.packed(cfg)
         timed = cfg in self.timed_cfgs
@@ -109,7 +111,7 @@ class UNetEngine:
             e0.record()
         _lib.check(self.lib.wmh_conv3d_k3_fwd(
             cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
-            _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part),
+            _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws),
             N, D, H, W, layer.cout, s, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd')
         if timed:
             e1.record()

@@ -61,6 +61,9 @@ size_t wmh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout);
 int wmh_conv3d_k3_pack_weights(int cfg, const float* w, int Cin, int Cout, float* wf);
 /* Partial-statistics records per (n, cout) for an output of Do x Ho x Wo (each record = 4 floats). */
 int wmh_conv3d_k3_num_partials(int cfg, int N, int Do, int Ho, int Wo);
+/* Floats of scratch the layer needs (0 for most): small, under-filled layers split the cin reduction
+ * over workgroups (split-K) and sum the partial outputs in a fixed order afterwards. */
+size_t wmh_conv3d_k3_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout, int stride);
 
 int wmh_conv3d_k3_fwd(int cfg,
                       const float* x0, const float* ss0, int C0, /* [N,C0,D,H,W]; ss0 [N,C0,2] or NULL */
@@ -68,6 +71,7 @@ int wmh_conv3d_k3_fwd(int cfg,
                       const float* wf, const float* bias,        /* packed weights (device), bias [Cout] or NULL */
                       float* y,                                  /* [N,Cout,Do,Ho,Wo], Do = (D-1)/stride+1 */
                       float* partials,                           /* [N,Cout,num_partials,4] or NULL */
+                      float* workspace,                          /* wmh_conv3d_k3_workspace_floats() floats, or NULL */
                       int N, int D, int H, int W, int Cout, int stride,
                       float lrelu_slope, void* stream);
 

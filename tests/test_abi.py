@@ -51,12 +51,22 @@ def test_pack_weights_layout(lib):
     wf = np.full(n, np.nan, np.float32)
     rc = lib.wmh_conv3d_k3_pack_weights(cfg, w.ctypes.data_as(C.c_void_p), cin, cout, wf.ctypes.data_as(C.c_void_p))
     assert rc == 0 and not np.isnan(wf).any()
-    wf = wf.reshape(2, 2, 27, 64, 2)
+    wf = wf.reshape(2, 2, 27, 1, 64, 2)     # [G][chunk][tap][NT][lane][CK/2], NT = 1 for cfg 0
     w27 = w.reshape(cout, cin, 27)
     for g, ch, tap, lane, p in [(0, 0, 0, 0, 0), (0, 1, 13, 37, 0), (1, 0, 26, 7, 1), (1, 1, 5, 63, 1), (0, 1, 2, 33, 1)]:
         co, ci = g * 32 + (lane & 31), ch * 4 + 2 * p + (lane >> 5)
         exp = w27[co, ci, tap] if (co < cout and ci < cin) else 0.0
-        assert wf[g, ch, tap, lane, p] == exp
+        assert wf[g, ch, tap, 0, lane, p] == exp
+    # cfg 2 has NT = 2: 64 output channels per group, [G=1][chunk][tap][2][64][2]
+    n2 = lib.wmh_conv3d_k3_packed_floats(2, cin, cout)
+    assert n2 == 1 * 2 * 27 * 2 * 64 * 2
+    wf2 = np.empty(n2, np.float32)
+    assert lib.wmh_conv3d_k3_pack_weights(2, w.ctypes.data_as(C.c_void_p), cin, cout, wf2.ctypes.data_as(C.c_void_p)) == 0
+    wf2 = wf2.reshape(1, 2, 27, 2, 64, 2)
+    for ch, tap, nt, lane, p in [(0, 3, 1, 5, 0), (1, 20, 0, 40, 0), (0, 26, 1, 20, 1)]:
+        co, ci = nt * 32 + (lane & 31), ch * 4 + 2 * p + (lane >> 5)
+        exp = w27[co, ci, tap] if (co < cout and ci < cin) else 0.0
+        assert wf2[0, ch, tap, nt, lane, p] == exp
     assert np.isclose(np.abs(wf).sum(), np.abs(w).sum(), rtol=1e-5)   # nothing lost, padding is zero
 
 
@@ -68,7 +78,7 @@ def test_num_partials(lib):
 
 def test_argument_checks_fail_loudly(lib):
     from deepwmh_amd import _lib
-    rc = lib.wmh_conv3d_k3_fwd(0, None, None, 1, None, None, 0, None, None, None, None, 1, 8, 8, 8, 8, 1, 0.01, None)
+    rc = lib.wmh_conv3d_k3_fwd(0, None, None, 1, None, None, 0, None, None, None, None, None, 1, 8, 8, 8, 8, 1, 0.01, None)
     assert rc == -1
     with pytest.raises(_lib.WMHError):
         _lib.check(rc, 'wmh_conv3d_k3_fwd')

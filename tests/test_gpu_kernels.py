@@ -111,7 +111,9 @@ def test_conv3d_k3_and_instnorm_partials(lib, case):
     mr = torch.full((N, Cout, 2), float('nan'), device='cuda')
     d = [t.cuda() if t is not None else None for t in (x0, ss0, x1, ss1)]
     wfd, bd, gd, btd = dev(wf), b.cuda(), gamma.cuda(), beta.cuda()
-    _lib.check(lib.wmh_conv3d_k3_fwd(cfg, P(d[0]), P(d[1]), C0, P(d[2]), P(d[3]), C1, P(wfd), P(bd), P(y), P(part),
+    nws = lib.wmh_conv3d_k3_workspace_floats(cfg, Cin, N, D, H, W, Cout, s)
+    ws = torch.full((nws,), float('nan'), device='cuda') if nws else None
+    _lib.check(lib.wmh_conv3d_k3_fwd(cfg, P(d[0]), P(d[1]), C0, P(d[2]), P(d[3]), C1, P(wfd), P(bd), P(y), P(part), P(ws),
                                      N, D, H, W, Cout, s, SLOPE, None), 'conv')
     _lib.check(lib.wmh_instnorm_finalize(P(part), npart, P(gd), P(btd), 1e-5, P(ss_out), P(mr), N, Cout, None), 'fin')
     torch.cuda.synchronize()
