@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libdeepwmh_amd.so')
+LIB_PATH = os.environ.get('WMH_LIB_PATH', os.path.join(_HERE, 'lib', 'libdeepwmh_amd.so'))   # override: diagnostic builds
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _ip = C.POINTER(C.c_int)

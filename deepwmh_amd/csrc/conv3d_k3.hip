@@ -39,6 +39,7 @@ struct ConvArgs {
     int nchunks, ntx, nty, ntz, npart;
     int G, KS, xcd_swizzle;
     float slope;
+    unsigned long long* stamps;     // diagnostics only (NULL in production): per-workgroup cycle counts
 };
 
 template <int S_, int LX_, int LY_, int TZ_, int TY_, int TN_, int MT_, int NT_, int CK_, int APF_>
@@ -51,9 +52,11 @@ struct ConvCfg {
     static constexpr int THREADS = WM * 64;
     static constexpr int WPS = MPS / MT;                             // waves per sample
     static constexpr int IX = S * (TX - 1) + 3, IY = S * (TY - 1) + 3, IZ = S * (TZ - 1) + 3;
-    static constexpr int YS = IX, ZS = IY * YS, NS = IZ * ZS, CS = TN * NS;
-    static constexpr int SP = CS;                                    // staged elements per channel
+    static constexpr int YS = IX, ZS = IY * YS, NS = IZ * ZS;
+    static constexpr int SP = TN * NS;                               // staged elements per channel
     static constexpr int NIT = (SP + THREADS - 1) / THREADS;
+    static constexpr int CS = NIT * THREADS;                         // channel stride in LDS: padded so that every
+                                                                     // thread's every store is in range (no branches)
     static constexpr int TILE = CK * CS;                             // floats per LDS buffer
     static constexpr int LDS_FLOATS = 2 * TILE;
     static constexpr int WT0 = (NIT >= 27) ? 0 : 27 - NIT;           // tap at which the staged writes start
@@ -82,7 +85,9 @@ __device__ __forceinline__ float sum32(float v) {   // sum over the 32 lanes of 
     return v;
 }
 
-template <class C>
+// ABL: timing-only ablations (diagnostics; results are wrong when != 0): 1 no LDS writes of the next chunk,
+// 2 no staging loads, 4 no weight loads, 8 B operand not read from LDS, 16 no per-chunk barrier
+template <class C, int ABL = 0>
 __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs a) {
     constexpr int S = C::S, MT = C::MT, NT = C::NT, CK = C::CK, NIT = C::NIT, THREADS = C::THREADS, APF = C::APF;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -142,13 +147,17 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
         baddr[m] = kh * C::CS + tn_w * C::NS + S * ((tzi * C::LZ + dz) * C::ZS + (tyi * C::LY + dy) * C::YS + dx);
     }
 
+    // accumulators start at the bias (split-K slabs start at 0: the reduce kernel adds the bias once)
     f32x16 acc[NT][MT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int r = 0; r < 16; ++r) {
+            const int co = (g * NT + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const float bv = (a.KS == 1 && a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][m][r] = 0.f;
+            for (int m = 0; m < MT; ++m) acc[nt][m][r] = bv;
+        }
 
     // ---- weights: prefetch ring over the linear (chunk, tap) sequence ---------------------------
     typedef typename AVec<CK / 2>::T AV;
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
     // ---- activations: staging registers, per-chunk scale/shift ----------------------------------
     float stg[CK][NIT];
     float sc[CK], sh[CK];      // used when TN == 1 (one sample per workgroup: wave-uniform)
-    bool has_ss = false;
+    float slope_eff = 1.f;     // 1 = identity when the source carries no pending InstanceNorm+LeakyReLU
 
     auto src_of = [&](int ch, const float*& xs, const float*& ss, int& Cs, int& c0) {
         const int cb = ch * CK;
@@ -184,7 +193,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
             }
         }
         if (C::TN == 1) {
-            has_ss = (ss != nullptr);
+            const bool has_ss = (ss != nullptr);
+            slope_eff = has_ss ? a.slope : 1.f;
 #pragma unroll
             for (int cc = 0; cc < CK; ++cc) {
                 const int c = min(c0 + cc, Cs - 1);
@@ -202,8 +212,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
         for (int cc = 0; cc < CK; ++cc) {
             const bool ok = ((c0 + cc) < Cs) && ((okmask >> it) & 1u);
             float v = stg[cc][it];
-            if (C::TN == 1) {
-                if (has_ss) { v = fmaf(v, sc[cc], sh[cc]); v = v > 0.f ? v : v * a.slope; }
+            if (C::TN == 1) {          // fmaf(v,1,0) and v*1 are exact: no branch for the "no transform" case
+                v = fmaf(v, sc[cc], sh[cc]);
+                v = v > 0.f ? v : v * slope_eff;
             } else if (ss != nullptr) {
                 const int ni = min(e / C::NS, a.N - 1 - n0);
                 const float* q = ss + ((size_t)(n0 + ni) * Cs + min(c0 + cc, Cs - 1)) * 2;
@@ -211,11 +222,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
                 v = v > 0.f ? v : v * a.slope;
             }
             v = ok ? v : 0.f;
-            if (NIT * THREADS == C::SP || e < C::SP) dstbuf[cc * C::CS + e] = v;
+            dstbuf[cc * C::CS + e] = v;
         }
     };
 
     // ---- prologue ---------------------------------------------------------------------------------
+    unsigned long long t_begin = 0, t_loop = 0, t_epi = 0;
+    if (a.stamps) t_begin = __builtin_amdgcn_s_memtime();
     load_chunk(ch_lo);
 #pragma unroll
     for (int d = 0; d < APF; ++d) loadA(ch_lo * 27 + d, aring[d]);
@@ -228,25 +241,35 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
         constexpr int BUF = decltype(bufc)::value;
         const float* cur = lds + BUF * C::TILE;
         float* nxt = lds + (BUF ^ 1) * C::TILE;
-        const bool more = (ch + 1) < ch_hi;
-        if (more) load_chunk(ch + 1);               // global loads stay in flight under the MFMAs below
+        // The next chunk is staged unconditionally (the last chunk re-stages itself into the idle buffer):
+        // the body below is one branch-free basic block.
+        const int chn = min(ch + 1, ch_hi - 1);
+        if (!(ABL & 2)) load_chunk(chn);            // global loads stay in flight under the MFMAs below
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int toff = (tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS + (tap % 3);
             AV anew[NT];
-            loadA(ch * 27 + tap + APF, anew);
-            if (more) {
+            if (!(ABL & 4)) loadA(ch * 27 + tap + APF, anew);
+            else {
 #pragma unroll
-                for (int k = 0; k < C::WPT; ++k) {
-                    const int it = (tap - C::WT0) * C::WPT + k;
-                    if (tap >= C::WT0 && it < NIT) write_slice(ch + 1, it, nxt);
-                }
+                for (int nt = 0; nt < NT; ++nt) anew[nt] = aring[0][nt];
+            }
+            // pin the prefetch here: left alone, the scheduler sinks the load to its use APF taps later
+            // and the in-order vmcnt wait for it then drains the staging loads too
+            // (mask 0x38F: ALU, VALU, SALU, MFMA and DS instructions may still cross; only VMEM is pinned)
+            __builtin_amdgcn_sched_barrier(0x38F);
+#pragma unroll
+            for (int k = 0; k < C::WPT; ++k) {
+                const int it = (tap - C::WT0) * C::WPT + k;
+                if (!(ABL & 1) && tap >= C::WT0 && it < NIT) write_slice(chn, it, nxt);
             }
 #pragma unroll
             for (int p = 0; p < CK / 2; ++p) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const float bv = cur[baddr[m] + toff + 2 * p * C::CS];
+                    float bv;
+                    if (!(ABL & 8)) bv = cur[baddr[m] + toff + 2 * p * C::CS];
+                    else { bv = __int_as_float(baddr[m] + toff); asm volatile("" : "+v"(bv)); }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(avec_get(aring[0][nt], p), bv, acc[nt][m], 0, 0, 0);
@@ -259,8 +282,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) aring[APF - 1][nt] = anew[nt];
         }
-        __syncthreads();     // next buffer fully written, this one fully read
+        if (!(ABL & 16)) __syncthreads();     // next buffer fully written, this one fully read
     };
+    if (a.stamps) t_loop = __builtin_amdgcn_s_memtime();
     {
         int ch = ch_lo;
         for (; ch + 1 < ch_hi; ch += 2) {
@@ -271,15 +295,16 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
+    if (a.stamps) t_epi = __builtin_amdgcn_s_memtime();
     const int HoWo = a.Ho * a.Wo;
     const size_t DoHoWo = (size_t)a.Do * HoWo;
     const int n = n0 + tn_w;
     const bool split = a.KS > 1;
     // split-K: raw partial sums into slab ks of y ([KS][N][Cout][Do][Ho][Wo]); bias/statistics come later
     float* ybase = a.y + (split ? (size_t)ks * a.N * a.Cout * DoHoWo : 0);
+
     unsigned vmask = 0;
     int cnt = 0;
-    size_t voff[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int ts = ts0 + m;
@@ -287,74 +312,89 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
         const bool valid = (n < a.N) && oz < a.Do && oy < a.Ho && ox < a.Wo;
         vmask |= valid ? (1u << m) : 0u;
         cnt += __popcll(__ballot(valid) & 0xffffffffull);
-        voff[m] = (size_t)oz * HoWo + oy * a.Wo + ox;
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int cob = (g * NT + nt) * 32;           // first output channel of this 32-row tile
-        if (cob >= a.Cout) continue;                  // wave-uniform
-        const bool full_rows = (cob + 32) <= a.Cout;
-        float bias_r[16];
+        if (cob >= a.Cout) continue;                  // uniform over the workgroup
+        const int nrows = min(32, a.Cout - cob);
+        // ---- bias; InstanceNorm moments in ONE pass about a per-row shift K (one sample of the row) ----
+        float vals[32];                               // [2r] = sum(v-K), [2r+1] = sum((v-K)^2) over this lane's voxels
+        float kshift[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = cob + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            bias_r[r] = (!split && a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
-        }
-        float s[16], q[16];
+            const float v0 = acc[nt][0][r];
+            const float k0 = __builtin_amdgcn_readlane(v0, 0), k1 = __builtin_amdgcn_readlane(v0, 32);
+            const float K = kh ? k1 : k0;
+            kshift[r] = K;
+            float sd = 0.f, sq = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; q[r] = 0.f; }
+            for (int m = 0; m < MT; ++m) {
+                const float v = acc[nt][m][r];
+                const float d = ((vmask >> m) & 1u) ? v - K : 0.f;
+                sd += d;
+                sq = fmaf(d, d, sq);
+            }
+            vals[2 * r] = sd; vals[2 * r + 1] = sq;
+        }
+        if (a.part != nullptr && !split) {
+            // recursive halving over the 32 lanes of each half-wave: 16+8+4+2+1 shuffles; lane j ends with vals[j]
+#pragma unroll
+            for (int M = 16, K2 = 16; M >= 1; M >>= 1, K2 >>= 1) {
+                const bool up = (j & M) != 0;
+#pragma unroll
+                for (int i = 0; i < K2; ++i) {
+                    const float keep = up ? vals[i + K2] : vals[i];
+                    const float send = up ? vals[i] : vals[i + K2];
+                    vals[i] = keep + __shfl_xor(send, M);
+                }
+            }
+            const float mine = vals[0];                       // lane j: (j&1) ? sum d^2 : sum d, of row j>>1
+            const float other = __shfl_xor(mine, 1);
+            float Kr = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Kr = ((j >> 1) == r) ? kshift[r] : Kr;
+            if ((j & 1) == 0 && n < a.N) {
+                const int r = j >> 1;
+                const int co = cob + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (co < a.Cout) {
+                    const float fc = (float)cnt;
+                    const float sd = mine, sq = other;
+                    const float m2 = cnt > 0 ? fmaxf(sq - sd * sd / fc, 0.f) : 0.f;
+                    const int tile_sp = (tz * a.nty + ty) * a.ntx + tx;
+                    const int pidx = tile_sp * C::WPS + (wave % C::WPS);
+                    float4* pp = reinterpret_cast<float4*>(a.part) + ((size_t)n * a.Cout + co) * a.npart + pidx;
+                    *pp = make_float4(fc, fmaf(fc, Kr, sd), m2, 0.f);
+                }
+            }
+        }
+        // ---- stores: one acc register = two 128-B row segments (two output channels) per wave-instruction.
+        // (An LDS-transposed 16-byte-store variant measured slower: the epilogue is bound by the store path,
+        // ~16 B/clk/CU, not by instruction count.)
+        float* ych = ybase + ((size_t)n * a.Cout + cob) * DoHoWo;          // channel cob of sample n
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const bool valid = (vmask >> m) & 1u;
-            float* yp = ybase + ((size_t)n * a.Cout + cob + 4 * kh) * DoHoWo + voff[m];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[nt][m][r] + bias_r[r];
-                acc[nt][m][r] = v;
-                s[r] += valid ? v : 0.f;
-            }
-            if (valid) {
-                if (full_rows) {                    // wave-uniform: all 32 output channels of this tile exist
+            const int ts = ts0 + m;
+            const int oz = oz0 + (ts / C::MY) * C::LZ + dz, oy = oy0 + (ts % C::MY) * C::LY + dy, ox = ox0 + dx;
+            if ((vmask >> m) & 1u) {
+                float* yp = ych + (size_t)(4 * kh) * DoHoWo + (size_t)oz * HoWo + oy * a.Wo + ox;
+                if (nrows == 32) {                  // uniform: all 32 output channels of this tile exist
 #pragma unroll
                     for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * DoHoWo] = acc[nt][m][r];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2);
-                        if ((cob + 4 * kh + row) < a.Cout) yp[(size_t)row * DoHoWo] = acc[nt][m][r];
+                        if (4 * kh + row < nrows) yp[(size_t)row * DoHoWo] = acc[nt][m][r];
                     }
                 }
             }
         }
-        if (a.part != nullptr && !split) {
-            const float fc = (float)cnt;
-            const float inv = cnt > 0 ? 1.f / fc : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = sum32(s[r]);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const bool valid = (vmask >> m) & 1u;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = acc[nt][m][r] - s[r] * inv;
-                    q[r] += valid ? d * d : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) q[r] = sum32(q[r]);
-            if (j == 0 && n < a.N) {
-                const int tile_sp = (tz * a.nty + ty) * a.ntx + tx;
-                const int pidx = tile_sp * C::WPS + (wave % C::WPS);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = cob + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (co < a.Cout) {
-                        float4* pp = reinterpret_cast<float4*>(a.part) + ((size_t)n * a.Cout + co) * a.npart + pidx;
-                        *pp = make_float4(fc, s[r], q[r], 0.f);
-                    }
-                }
-            }
-        }
+    }
+    if (a.stamps && tid == 0) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = a.stamps + (size_t)blockIdx.x * 4;
+        o[0] = t_loop - t_begin; o[1] = t_epi - t_loop; o[2] = t_end - t_epi; o[3] = (unsigned long long)(ch_hi - ch_lo);
     }
 }
 
@@ -407,7 +447,7 @@ typedef ConvCfg<2, 32, 1, 2, 8, 1, 4, 2, 2, 6> Cfg1;    // stride 2, output rows
 typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> Cfg2;   // stride 1, 16-wide
 typedef ConvCfg<2, 16, 2, 2, 16, 1, 4, 2, 2, 6> Cfg3;   // stride 2, 16-wide output
 typedef ConvCfg<1, 8, 4, 4, 8, 1, 2, 1, 8, 6> Cfg4;     // stride 1, 8-wide
-typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 1, 4, 6> Cfg5;     // stride 2, 8-wide output
+typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 1, 2, 6> Cfg5;     // stride 2, 8-wide output
 typedef ConvCfg<1, 4, 4, 4, 4, 4, 2, 1, 8, 6> Cfg6;     // stride 1, 4-wide, 4 samples per workgroup
 typedef ConvCfg<2, 4, 4, 4, 4, 4, 2, 1, 2, 6> Cfg7;     // stride 2, 4-wide output
 #define WMH_NUM_CONV_CFG 8
@@ -421,6 +461,9 @@ static const CfgInfo& cfg_info(int cfg) {
                                                 info_of<Cfg4>(), info_of<Cfg5>(), info_of<Cfg6>(), info_of<Cfg7>()};
     return t[cfg];
 }
+static unsigned long long* g_conv_stamps = nullptr;
+// diagnostics: device buffer of 4 x uint64 per workgroup that the next conv launches fill (NULL = off)
+extern "C" void wmh_debug_set_conv_stamps(void* p) { g_conv_stamps = (unsigned long long*)p; }
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 template <class C>
@@ -437,6 +480,31 @@ static int launch_conv(const ConvArgs& a, unsigned nblk, hipStream_t st) {
     hipLaunchKernelGGL((conv3d_k3_kernel<C>), dim3(nblk), dim3(C::THREADS), lds, st, a);
     return wmh_check_launch("conv3d_k3_kernel");
 }
+
+#ifdef WMH_DIAG_ABLATIONS
+template <int ABL>
+static int launch_abl(const ConvArgs& a, unsigned nblk, hipStream_t st) {
+    const int lds = Cfg0::LDS_FLOATS * 4 + env_int("WMH_LDS_EXTRA", 0);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_kernel<Cfg0, ABL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((conv3d_k3_kernel<Cfg0, ABL>), dim3(nblk), dim3(Cfg0::THREADS), lds, st, a);
+    return wmh_check_launch("conv3d_k3_kernel<abl>");
+}
+static int launch_cfg0_ablation(int abl, const ConvArgs& a, unsigned nblk, hipStream_t st) {
+    switch (abl) {
+        case 1: return launch_abl<1>(a, nblk, st);
+        case 2: return launch_abl<2>(a, nblk, st);
+        case 3: return launch_abl<3>(a, nblk, st);
+        case 4: return launch_abl<4>(a, nblk, st);
+        case 7: return launch_abl<7>(a, nblk, st);
+        case 8: return launch_abl<8>(a, nblk, st);
+        case 15: return launch_abl<15>(a, nblk, st);
+        case 16: return launch_abl<16>(a, nblk, st);
+        case 31: return launch_abl<31>(a, nblk, st);
+    }
+    return -1;
+}
+#endif
 
 extern "C" int wmh_conv3d_k3_config(int Cin, int Cout, int D, int H, int W, int stride) {
     if (Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2))
@@ -522,6 +590,7 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
     a.G = cdiv(Cout, 32 * c.NT);
     static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
     a.xcd_swizzle = swz_env;
+    a.stamps = g_conv_stamps;
     long long nblk = (long long)a.ntx * a.nty * a.ntz * cdiv(N, c.TN) * a.G;
     a.KS = pick_ksplit(c, nblk, a.nchunks);
     if (a.KS > 1 && workspace == nullptr) a.KS = 1;          // no slab memory given: run unsplit
@@ -530,6 +599,10 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
     hipStream_t st = (hipStream_t)stream;
     if (a.KS > 1) a.y = workspace;
     int rc;
+#ifdef WMH_DIAG_ABLATIONS
+    static const int abl = env_int("WMH_ABL", 0);
+    if (cfg == 0 && abl) return launch_cfg0_ablation(abl, a, (unsigned)nblk, st);
+#endif
     switch (cfg) {
         case 0: rc = launch_conv<Cfg0>(a, (unsigned)nblk, st); break;
         case 1: rc = launch_conv<Cfg1>(a, (unsigned)nblk, st); break;

@@ -40,7 +40,7 @@ for name, C0, C1, Cout, D, s in LAYERS:
     bias = torch.zeros(Cout, device='cuda')
     y = torch.empty(B, Cout, Do, Do, Do, device='cuda')
     npart = lib.wmh_conv3d_k3_num_partials(cfg, B, Do, Do, Do)
-    part = torch.empty(B, Cout, npart, 4, device='cuda')
+    part = torch.empty(B, Cout, npart, 4, device='cuda') if not os.environ.get('WMH_NOPART') else None
     nws = lib.wmh_conv3d_k3_workspace_floats(cfg, Cin, B, D, D, D, Cout, s)
     ws = torch.empty(nws, device='cuda') if nws else None
 
@@ -53,6 +53,17 @@ for name, C0, C1, Cout, D, s in LAYERS:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); run(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
+    if os.environ.get('WMH_STAMPS'):
+        import ctypes
+        nblk = 1 << 22
+        stamps = torch.zeros(nblk * 4, dtype=torch.int64, device='cuda')
+        lib.wmh_debug_set_conv_stamps(ctypes.c_void_p(stamps.data_ptr()))
+        run(); torch.cuda.synchronize()
+        lib.wmh_debug_set_conv_stamps(None)
+        st = stamps.view(-1, 4).cpu().numpy()
+        st = st[st[:, 3] > 0]
+        print('   stamps over %d workgroups: prologue %.0f, loop %.0f (%.0f per chunk, %d chunks), epilogue %.0f cycles (100 MHz? see s_memtime)'
+              % (len(st), st[:, 0].mean(), st[:, 1].mean(), (st[:, 1] / st[:, 3]).mean(), st[0, 3], st[:, 2].mean()))
     fl = 2.0 * Cin * Cout * 27 * B * Do ** 3
     ms = float(np.median(ts))
     tot_ms += ms; tot_fl += fl
