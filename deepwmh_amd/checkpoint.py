@@ -1,0 +1,114 @@
+"""nnU-Net checkpoint / plans files in the directory layout DeepWMH installs and reads.
+
+Layout (reference: /root/reference/deepwmh/pipeline/DCNN_multistage.py:608-631,
+/root/reference/deepwmh/main/install_model.py:18-43,85-106, /root/reference/deepwmh/main/predict.py:104,139):
+
+  <RESULTS_FOLDER>/nnUNet/3d_fullres/<Task>/nnUNetTrainerV2__nnUNetPlansv2.1/plans.pkl
+  <RESULTS_FOLDER>/nnUNet/3d_fullres/<Task>/nnUNetTrainerV2__nnUNetPlansv2.1/all/model_best.model      (torch.save dict)
+  <RESULTS_FOLDER>/nnUNet/3d_fullres/<Task>/nnUNetTrainerV2__nnUNetPlansv2.1/all/model_best.model.pkl  (pickle)
+
+[nnU-Net, not in tree] `.model` = {'epoch','state_dict','optimizer_state_dict','lr_scheduler_state_dict',
+'plot_stuff','best_stuff','amp_grad_scaler'}; `.model.pkl` = {'init','name','class','plans'} where `init` is
+the positional argument tuple of nnUNetTrainer.__init__ (install_model.py:93-103 rewrites init[0], [2], [3]).
+"""
+import os
+import pickle
+from collections import OrderedDict
+
+import numpy as np
+
+from .plan import UNetPlan
+
+TRAINER = 'nnUNetTrainerV2'
+PLANS_ID = 'nnUNetPlansv2.1'
+NETWORK = '3d_fullres'
+
+
+def trainer_folder(results_folder, task, network=NETWORK, trainer=TRAINER, plans_id=PLANS_ID):
+    return os.path.join(results_folder, 'nnUNet', network, task, '%s__%s' % (trainer, plans_id))
+
+
+def resolve_task(results_folder, task, network=NETWORK):
+    """`-t` may be a full name (TaskNNN_Name) or an integer id."""
+    base = os.path.join(results_folder, 'nnUNet', network)
+    if os.path.isdir(os.path.join(base, str(task))):
+        return str(task)
+    try:
+        tid = int(task)
+    except ValueError:
+        raise FileNotFoundError('task "%s" not found under %s' % (task, base))
+    hits = [d for d in sorted(os.listdir(base)) if d.startswith('Task%03d_' % tid)] if os.path.isdir(base) else []
+    if len(hits) != 1:
+        raise FileNotFoundError('task id %d: %d matching folders under %s' % (tid, len(hits), base))
+    return hits[0]
+
+
+def fold_folder(fold):
+    return 'all' if str(fold) == 'all' else 'fold_%d' % int(fold)
+
+
+def load_checkpoint(folder, fold='all', checkpoint_name='model_best'):
+    """Returns (UNetPlan, plans dict, state_dict of numpy arrays, info dict)."""
+    import torch
+    fdir = os.path.join(folder, fold_folder(fold))
+    model = os.path.join(fdir, checkpoint_name + '.model')
+    pkl = model + '.pkl'
+    for p in (model, pkl):
+        if not os.path.isfile(p):
+            raise FileNotFoundError('missing checkpoint file %s' % p)
+    with open(pkl, 'rb') as f:
+        info = pickle.load(f)
+    plans = info['plans']
+    stage = None
+    init = info.get('init')
+    if init is not None and len(init) > 5 and init[5] is not None:
+        stage = init[5]
+    plan = UNetPlan.from_nnunet_plans(plans, stage)
+    ck = torch.load(model, map_location='cpu', weights_only=False)
+    sd = OrderedDict()
+    for k, v in ck['state_dict'].items():
+        k = k[7:] if k.startswith('module.') else k
+        sd[k] = v.detach().cpu().float().numpy()
+    return plan, plans, sd, dict(epoch=ck.get('epoch'), init=init, name=info.get('name'), checkpoint=ck)
+
+
+def make_plans(plan: UNetPlan, spacing=(1.0, 1.0, 1.0), use_mask_for_norm=True, batch_size=2):
+    """An nnU-Net-shaped plans dict for `plan` (what nnUNet_plan_and_preprocess would have pickled)."""
+    st = OrderedDict(batch_size=batch_size, num_pool_per_axis=[plan.num_pool] * 3,
+                     patch_size=np.array(plan.patch_size), median_patient_size_in_voxels=np.array(plan.patch_size),
+                     current_spacing=np.array(spacing, dtype=np.float64), original_spacing=np.array(spacing, dtype=np.float64),
+                     do_dummy_2D_data_aug=False, pool_op_kernel_sizes=[list(p) for p in plan.pool_op_kernel_sizes],
+                     conv_kernel_sizes=[list(k) for k in plan.conv_kernel_sizes])
+    nmod = plan.num_input_channels
+    return OrderedDict(
+        num_stages=1, num_modalities=nmod, modalities={i: 'FLAIR' for i in range(nmod)},
+        normalization_schemes=OrderedDict((i, 'nonCT') for i in range(nmod)), dataset_properties={},
+        list_of_npz_files=[], original_spacings=[], original_sizes=[], preprocessed_data_folder='',
+        num_classes=plan.num_classes - 1, all_classes=list(range(1, plan.num_classes)),
+        base_num_features=plan.base_num_features, use_mask_for_norm=OrderedDict((i, use_mask_for_norm) for i in range(nmod)),
+        keep_only_largest_region=None, min_region_size_per_class=None, min_size_per_class=None,
+        transpose_forward=[0, 1, 2], transpose_backward=[0, 1, 2], data_identifier='nnUNetData_plans_v2.1',
+        plans_per_stage={0: st}, preprocessor_name='GenericPreprocessor', conv_per_stage=plan.conv_per_stage)
+
+
+def save_checkpoint(folder, state_dict, plans, fold='all', checkpoint_name='model_best', epoch=0, extra=None):
+    """Writes `<name>.model` + `<name>.model.pkl` (+ plans.pkl beside the fold folder) in nnU-Net's format."""
+    import torch
+    fdir = os.path.join(folder, fold_folder(fold))
+    os.makedirs(fdir, exist_ok=True)
+    sd = OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)
+                     for k, v in state_dict.items())
+    ck = dict(epoch=epoch, state_dict=sd, optimizer_state_dict=None, lr_scheduler_state_dict=None,
+              plot_stuff=([], [], [], []), best_stuff=(None, None, None), amp_grad_scaler=None)
+    if extra:
+        ck.update(extra)
+    model = os.path.join(fdir, checkpoint_name + '.model')
+    torch.save(ck, model)
+    plans_file = os.path.join(folder, 'plans.pkl')
+    init = (plans_file, fold, folder, '', True, 0, True, False, True)
+    with open(model + '.pkl', 'wb') as f:
+        pickle.dump(OrderedDict(init=init, name=TRAINER, **{'class': "<class 'nnunet.training.network_training.nnUNetTrainerV2.nnUNetTrainerV2'>"},
+                                plans=plans), f)
+    with open(plans_file, 'wb') as f:
+        pickle.dump(plans, f)
+    return model

@@ -1,0 +1,112 @@
+"""`nnUNet_predict` drop-in: the command DeepWMH shells out to for every prediction.
+
+Accepts exactly the flag set the reference emits
+(/root/reference/deepwmh/main/predict.py:153-155;
+ /root/reference/deepwmh/pipeline/DCNN_multistage.py:331-336,531-533):
+  -i IN -o OUT -tr nnUNetTrainerV2 -m 3d_fullres -p nnUNetPlansv2.1 -t TASK -f all -chk NAME
+  --disable_post_processing [--disable_tta] [--save_softmax] --selected_cases c1 c2 ...
+and the environment contract RESULTS_FOLDER / CUDA_VISIBLE_DEVICES (predict.py:101,150-152).
+`--selected_cases` and `--save_softmax` follow the fork's semantics: only the listed cases are predicted;
+`--save_softmax` additionally writes channel 0 (background probability) as <case>_0.nii.gz
+(DCNN_multistage.py:340-344,359).  Errors exit non-zero (external_call.py:64-72 aborts the pipeline).
+"""
+import argparse
+import os
+import sys
+import time
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(prog='nnUNet_predict', description='MI355X-native nnU-Net 3d_fullres prediction for DeepWMH')
+    ap.add_argument('-i', '--input_folder', required=True)
+    ap.add_argument('-o', '--output_folder', required=True)
+    ap.add_argument('-t', '--task_name', required=True)
+    ap.add_argument('-tr', '--trainer_class_name', default='nnUNetTrainerV2')
+    ap.add_argument('-ctr', '--cascade_trainer_class_name', default=None)
+    ap.add_argument('-m', '--model', default='3d_fullres')
+    ap.add_argument('-p', '--plans_identifier', default='nnUNetPlansv2.1')
+    ap.add_argument('-f', '--folds', nargs='+', default=['all'])
+    ap.add_argument('-z', '--save_npz', action='store_true')
+    ap.add_argument('-l', '--lowres_segmentations', default='None')
+    ap.add_argument('--part_id', type=int, default=0)
+    ap.add_argument('--num_parts', type=int, default=1)
+    ap.add_argument('--num_threads_preprocessing', type=int, default=6)
+    ap.add_argument('--num_threads_nifti_save', type=int, default=2)
+    ap.add_argument('--disable_tta', action='store_true')
+    ap.add_argument('--overwrite_existing', action='store_true')
+    ap.add_argument('--mode', default='normal')
+    ap.add_argument('--all_in_gpu', default='None')
+    ap.add_argument('--step_size', type=float, default=0.5)
+    ap.add_argument('-chk', default='model_final_checkpoint')
+    ap.add_argument('--disable_mixed_precision', action='store_true')
+    ap.add_argument('--disable_post_processing', action='store_true')
+    ap.add_argument('--selected_cases', nargs='*', default=None)      # fork-only
+    ap.add_argument('--save_softmax', action='store_true')            # fork-only
+    return ap
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.model != '3d_fullres':
+        sys.exit('nnUNet_predict (deepwmh_amd): only -m 3d_fullres is implemented (DeepWMH uses nothing else)')
+    if len(args.folds) != 1:
+        sys.exit('nnUNet_predict (deepwmh_amd): exactly one fold (-f all) is supported')
+    results = os.environ.get('RESULTS_FOLDER')
+    if not results:
+        sys.exit('RESULTS_FOLDER is not set')
+
+    import numpy as np
+    import torch
+    from .. import nifti
+    from ..checkpoint import load_checkpoint, resolve_task, trainer_folder
+    from ..network import UNetEngine
+    from ..preprocess import export_prediction, preprocess_case
+    from ..sliding_window import SlidingWindowPredictor
+
+    task = resolve_task(results, args.task_name, args.model)
+    folder = trainer_folder(results, task, args.model, args.trainer_class_name, args.plans_identifier)
+    plan, plans, sd, info = load_checkpoint(folder, args.folds[0], args.chk)
+    if not torch.cuda.is_available():
+        sys.exit('nnUNet_predict (deepwmh_amd): no HIP device visible (CUDA_VISIBLE_DEVICES=%s)'
+                 % os.environ.get('CUDA_VISIBLE_DEVICES'))
+    eng = UNetEngine(plan, sd, 'cuda:0')           # CUDA_VISIBLE_DEVICES already selected the GPU (predict.py:150)
+    pred = SlidingWindowPredictor(eng, plan.patch_size, args.step_size, True, not args.disable_tta, batch=8)
+
+    files = sorted(f for f in os.listdir(args.input_folder) if f.endswith('_0000.nii.gz'))
+    cases = [f[:-len('_0000.nii.gz')] for f in files]
+    if args.selected_cases:
+        wanted = [c for c in args.selected_cases if c]
+        missing = [c for c in wanted if c not in cases]
+        if missing:
+            sys.exit('selected cases not found in %s: %s' % (args.input_folder, ' '.join(missing)))
+        cases = [c for c in cases if c in wanted]
+    cases = cases[args.part_id::args.num_parts]
+    os.makedirs(args.output_folder, exist_ok=True)
+    nmod = plan.num_input_channels
+    print('deepwmh_amd nnUNet_predict: task %s, checkpoint %s (epoch %s), %d case(s), mirroring %s'
+          % (task, args.chk, info.get('epoch'), len(cases), 'off' if args.disable_tta else 'on'), flush=True)
+    for case in cases:
+        out = os.path.join(args.output_folder, case + '.nii.gz')
+        if os.path.isfile(out) and not args.overwrite_existing and not args.save_softmax:
+            continue
+        t0 = time.time()
+        vols, meta = [], None
+        for m in range(nmod):
+            arr, mt = nifti.read(os.path.join(args.input_folder, '%s_%04d.nii.gz' % (case, m)))
+            vols.append(arr)
+            meta = meta or mt
+        data, props = preprocess_case(np.stack(vols), meta['spacing'], plans, info['init'][5] if info.get('init') else None)
+        t1 = time.time()
+        seg, prob = pred.predict(data, return_prob=True)
+        t2 = time.time()
+        seg_full, prob_full = export_prediction(prob, props)
+        nifti.write(out, seg_full, like=meta, dtype=np.uint8)
+        if args.save_softmax:
+            nifti.write(os.path.join(args.output_folder, case + '_0.nii.gz'), prob_full[0], like=meta, dtype=np.float32)
+        print('  %s: shape %s, load+preprocess %.2f s, predict %.2f s, export %.2f s'
+              % (case, tuple(data.shape[1:]), t1 - t0, t2 - t1, time.time() - t2), flush=True)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

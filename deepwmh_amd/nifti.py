@@ -1,0 +1,115 @@
+"""Minimal NIfTI-1 (.nii / .nii.gz) reader and writer: no nibabel / SimpleITK on either box.
+
+The reference reads volumes with nibabel (`load_nifti` -> float32,
+/root/reference/deepwmh/utilities/data_io.py:223-263) and always writes float32
+(`save_nifti`, data_io.py:285-286); nnU-Net reads/writes with SimpleITK, whose arrays are (z, y, x),
+i.e. the file's data block read in C order.  `read()` returns that (z, y, x) array, so volumes enter
+the network in the orientation nnU-Net trained on; `spacing` is (dz, dy, dx) likewise.
+"""
+import gzip
+import os
+
+import numpy as np
+
+HDR = np.dtype([
+    ('sizeof_hdr', '<i4'), ('data_type', 'S10'), ('db_name', 'S18'), ('extents', '<i4'), ('session_error', '<i2'),
+    ('regular', 'S1'), ('dim_info', 'u1'), ('dim', '<i2', 8), ('intent_p1', '<f4'), ('intent_p2', '<f4'),
+    ('intent_p3', '<f4'), ('intent_code', '<i2'), ('datatype', '<i2'), ('bitpix', '<i2'), ('slice_start', '<i2'),
+    ('pixdim', '<f4', 8), ('vox_offset', '<f4'), ('scl_slope', '<f4'), ('scl_inter', '<f4'), ('slice_end', '<i2'),
+    ('slice_code', 'u1'), ('xyzt_units', 'u1'), ('cal_max', '<f4'), ('cal_min', '<f4'), ('slice_duration', '<f4'),
+    ('toffset', '<f4'), ('glmax', '<i4'), ('glmin', '<i4'), ('descrip', 'S80'), ('aux_file', 'S24'),
+    ('qform_code', '<i2'), ('sform_code', '<i2'), ('quatern_b', '<f4'), ('quatern_c', '<f4'), ('quatern_d', '<f4'),
+    ('qoffset_x', '<f4'), ('qoffset_y', '<f4'), ('qoffset_z', '<f4'), ('srow_x', '<f4', 4), ('srow_y', '<f4', 4),
+    ('srow_z', '<f4', 4), ('intent_name', 'S16'), ('magic', 'S4')])
+assert HDR.itemsize == 348
+
+DTYPES = {2: np.uint8, 4: np.int16, 8: np.int32, 16: np.float32, 64: np.float64, 256: np.int8, 512: np.uint16,
+          768: np.uint32, 1024: np.int64, 1280: np.uint64}
+CODES = {np.dtype(v).name: k for k, v in DTYPES.items()}
+
+
+class NiftiError(ValueError):
+    pass
+
+
+def _open(path, mode):
+    return gzip.open(path, mode) if str(path).endswith('.gz') else open(path, mode)
+
+
+def read_header(raw):
+    if len(raw) < 348:
+        raise NiftiError('file too short for a NIfTI-1 header')
+    hdr = np.frombuffer(raw[:348], dtype=HDR)[0]
+    swapped = False
+    if hdr['sizeof_hdr'] != 348:
+        hdr = np.frombuffer(raw[:348], dtype=HDR.newbyteorder('>'))[0]
+        swapped = True
+        if hdr['sizeof_hdr'] != 348:
+            raise NiftiError('not a NIfTI-1 file (sizeof_hdr != 348)')
+    if bytes(hdr['magic'])[:3] not in (b'n+1', b'ni1'):
+        raise NiftiError('bad NIfTI magic %r' % bytes(hdr['magic']))
+    return hdr, swapped
+
+
+def read(path):
+    """Returns (array float32 (z, y, x) [or (t, z, y, x)], meta).  meta['spacing'] = (dz, dy, dx)."""
+    with _open(path, 'rb') as f:
+        raw = f.read()
+    hdr, swapped = read_header(raw)
+    ndim = int(hdr['dim'][0])
+    if not 1 <= ndim <= 7:
+        raise NiftiError('bad dim[0] = %d' % ndim)
+    shape = [int(v) for v in hdr['dim'][1:1 + ndim]]
+    while len(shape) > 3 and shape[-1] == 1:
+        shape.pop()
+    code = int(hdr['datatype'])
+    if code not in DTYPES:
+        raise NiftiError('unsupported NIfTI datatype %d' % code)
+    dt = np.dtype(DTYPES[code]).newbyteorder('>' if swapped else '<')
+    off = int(hdr['vox_offset']) if bytes(hdr['magic'])[:3] == b'n+1' else 0
+    off = max(off, 352) if bytes(hdr['magic'])[:3] == b'n+1' else off
+    n = int(np.prod(shape))
+    if len(raw) < off + n * dt.itemsize:
+        raise NiftiError('data block shorter than the header says')
+    data = np.frombuffer(raw, dtype=dt, count=n, offset=off).reshape(shape[::-1])   # x fastest -> (.., z, y, x)
+    slope, inter = float(hdr['scl_slope']), float(hdr['scl_inter'])
+    arr = data.astype(np.float32)
+    if slope not in (0.0, 1.0) or inter != 0.0:
+        if slope != 0.0 and np.isfinite(slope):
+            arr = arr * np.float32(slope) + np.float32(inter)
+    pix = [float(v) for v in hdr['pixdim'][1:4]]
+    meta = dict(header=hdr.copy(), spacing=tuple(pix[::-1]), shape_xyz=tuple(shape[:3]), swapped=swapped)
+    return np.ascontiguousarray(arr), meta
+
+
+def write(path, array_zyx, like=None, spacing=None, dtype=np.float32):
+    """Writes a (z, y, x) array.  `like` = meta of a volume whose geometry to copy (header passthrough,
+    as the reference does: data_io.py:285-309); `spacing` = (dz, dy, dx) when there is no `like`."""
+    arr = np.ascontiguousarray(array_zyx, dtype=dtype)
+    if arr.ndim != 3:
+        raise NiftiError('write() takes a 3-D array')
+    if like is not None:
+        hdr = like['header'].copy()
+        if hdr.dtype.byteorder == '>' or like.get('swapped'):
+            hdr = hdr.astype(HDR)
+    else:
+        hdr = np.zeros((), dtype=HDR)
+        sp = spacing or (1.0, 1.0, 1.0)
+        hdr['pixdim'] = [1.0, sp[2], sp[1], sp[0], 1.0, 1.0, 1.0, 1.0]
+        hdr['srow_x'] = [sp[2], 0, 0, 0]; hdr['srow_y'] = [0, sp[1], 0, 0]; hdr['srow_z'] = [0, 0, sp[0], 0]
+        hdr['sform_code'] = 2
+        hdr['xyzt_units'] = 2
+    hdr['sizeof_hdr'] = 348
+    hdr['dim'] = [3, arr.shape[2], arr.shape[1], arr.shape[0], 1, 1, 1, 1]
+    hdr['datatype'] = CODES[np.dtype(dtype).name]
+    hdr['bitpix'] = np.dtype(dtype).itemsize * 8
+    hdr['vox_offset'] = 352
+    hdr['scl_slope'] = 1.0
+    hdr['scl_inter'] = 0.0
+    hdr['magic'] = b'n+1\x00'
+    hdr['regular'] = b'r'
+    payload = hdr.tobytes() + b'\x00\x00\x00\x00' + arr.tobytes()
+    tmp = str(path) + '.tmp%d' % os.getpid()
+    with (gzip.open(tmp, 'wb', compresslevel=1) if str(path).endswith('.gz') else open(tmp, 'wb')) as f:
+        f.write(payload)
+    os.replace(tmp, path)

@@ -1,0 +1,100 @@
+"""Host-side pre/post steps either side of the network inside `nnUNet_predict`
+[nnU-Net, not in tree: preprocessing.GenericPreprocessor.preprocess_test_case, cropping.crop_to_nonzero,
+inference.segmentation_export.save_segmentation_nifti_from_softmax].  CPU numpy/scipy (SURVEY.md 8f row 1:
+"next" after the network path); with volumes already at the plan's spacing (the synthetic benchmark and
+1 mm FLAIR) crop / z-score / uncrop are all that run.  Parity unpinned: restated from upstream nnU-Net v1."""
+import numpy as np
+from scipy.ndimage import binary_fill_holes, zoom
+
+
+def create_nonzero_mask(data):
+    mask = np.zeros(data.shape[1:], dtype=bool)
+    for c in range(data.shape[0]):
+        mask |= data[c] != 0
+    return binary_fill_holes(mask)
+
+
+def crop_to_nonzero(data):
+    """data [C,z,y,x] -> (cropped data, nonzero mask cropped (bool), bbox [[z0,z1],[y0,y1],[x0,x1]])."""
+    mask = create_nonzero_mask(data)
+    idx = np.where(mask)
+    if len(idx[0]) == 0:
+        bbox = [[0, s] for s in data.shape[1:]]
+    else:
+        bbox = [[int(i.min()), int(i.max()) + 1] for i in idx]
+    sl = tuple(slice(a, b) for a, b in bbox)
+    return data[(slice(None),) + sl], mask[sl], bbox
+
+
+def normalize_noncT(data, nonzero_mask, use_mask_for_norm):
+    """nnU-Net non-CT scheme: per-channel z-score (inside the non-zero mask when use_mask_for_norm)."""
+    out = data.astype(np.float32, copy=True)
+    for c in range(out.shape[0]):
+        if use_mask_for_norm:
+            v = out[c][nonzero_mask]
+            out[c][nonzero_mask] = (v - v.mean()) / (v.std() + 1e-8)
+            out[c][~nonzero_mask] = 0
+        else:
+            out[c] = (out[c] - out[c].mean()) / (out[c].std() + 1e-8)
+    return out
+
+
+def _resize(vol, new_shape, order):
+    """skimage.transform.resize(order, mode='edge', anti_aliasing=False) == pixel-area-aligned spline zoom."""
+    if tuple(vol.shape) == tuple(new_shape):
+        return vol
+    factors = [n / o for n, o in zip(new_shape, vol.shape)]
+    return zoom(vol, factors, order=order, mode='nearest', grid_mode=True, prefilter=order > 1)
+
+
+def resample_to_spacing(data, spacing, target_spacing, order=3):
+    spacing, target_spacing = np.asarray(spacing, float), np.asarray(target_spacing, float)
+    new_shape = np.round(spacing / target_spacing * np.array(data.shape[1:])).astype(int)
+    if np.all(new_shape == np.array(data.shape[1:])):
+        return data
+    return np.stack([_resize(data[c].astype(np.float64), new_shape, order).astype(np.float32) for c in range(data.shape[0])])
+
+
+def preprocess_case(volume_zyx, spacing, plans, stage=None):
+    """volume_zyx: float32 [z,y,x] (one modality) or [C,z,y,x].  Returns (data [C,...] for the network, props)."""
+    data = volume_zyx[None] if volume_zyx.ndim == 3 else volume_zyx
+    data = data.astype(np.float32)
+    orig_shape = data.shape[1:]
+    cropped, nzmask, bbox = crop_to_nonzero(data)
+    stages = plans['plans_per_stage']
+    st = stages[stage if stage is not None else (max(stages.keys()) if isinstance(stages, dict) else len(stages) - 1)]
+    tf = list(plans.get('transpose_forward', [0, 1, 2]))
+    target = np.asarray(st['current_spacing'], float)
+    cropped = cropped.transpose([0] + [i + 1 for i in tf])
+    nzmask = nzmask.transpose(tf)
+    sp = np.asarray(spacing, float)[tf]
+    shape_after_crop = cropped.shape[1:]
+    res = resample_to_spacing(cropped, sp, target, order=3)
+    if res.shape[1:] != nzmask.shape:
+        nzmask = _resize(nzmask.astype(np.float64), res.shape[1:], 0) > 0.5
+    umn = plans.get('use_mask_for_norm', {0: False})
+    use_mask = bool(umn[0] if isinstance(umn, dict) else umn)
+    out = normalize_noncT(res, nzmask, use_mask)
+    props = dict(original_shape=orig_shape, bbox=bbox, shape_after_crop=tuple(shape_after_crop), transpose_forward=tf,
+                 transpose_backward=list(plans.get('transpose_backward', [0, 1, 2])))
+    return np.ascontiguousarray(out), props
+
+
+def export_prediction(prob, props):
+    """prob [K, ...] in network geometry -> (segmentation uint8, probabilities [K]) in the input's geometry:
+    transpose back, resample to the cropped shape (order 1), argmax, un-crop into zeros."""
+    tb = props['transpose_backward']
+    prob = prob.transpose([0] + [i + 1 for i in tb])
+    tgt = props['shape_after_crop']
+    tgt = tuple(np.array(tgt)[[props['transpose_forward'].index(i) for i in range(3)]]) if tb != [0, 1, 2] else tuple(tgt)
+    if prob.shape[1:] != tgt:
+        prob = np.stack([_resize(prob[k].astype(np.float64), tgt, 1).astype(np.float32) for k in range(prob.shape[0])])
+    seg_c = prob.argmax(0).astype(np.uint8)
+    full = np.zeros(props['original_shape'], dtype=np.uint8)
+    bb = props['bbox']
+    sl = tuple(slice(a, b) for a, b in bb)
+    full[sl] = seg_c
+    pfull = np.zeros((prob.shape[0],) + tuple(props['original_shape']), dtype=np.float32)
+    pfull[0] = 1.0                                  # outside the crop everything is background
+    pfull[(slice(None),) + sl] = prob
+    return full, pfull

@@ -1,0 +1,56 @@
+"""GPU end-to-end test of the process-level drop-in: the command line DeepWMH formats
+(reference deepwmh/main/predict.py:153-156), launched the way its run_shell does
+(Popen(shlex.split(cmd), shell=False), deepwmh/utilities/external_call.py:50-52), against the oracle."""
+import os
+import shlex
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_nnunet_predict_cli_end_to_end(tmp_path, tiny_net, tiny_io):
+    from deepwmh_amd import checkpoint as ck
+    from deepwmh_amd import nifti, preprocess
+    from oracle import sliding_window as osw
+    plan, net, sd = tiny_net
+    model_dir = str(tmp_path / 'model')
+    plans = ck.make_plans(plan, spacing=(1.0, 1.0, 1.0), use_mask_for_norm=True)
+    folder = ck.trainer_folder(model_dir, 'Task002_FinalModel')
+    ck.save_checkpoint(folder, sd, plans, 'all', 'model_best', epoch=100)
+    img_dir, out_dir = str(tmp_path / '001_Preprocessed_Images'), str(tmp_path / '002_Segmentations' / '001_raw')
+    os.makedirs(img_dir)
+    rng = np.random.default_rng(7)
+    cases = {}
+    for name in ('caseA', 'case_B.1', 'unselected'):
+        vol = np.zeros((46, 52, 44), np.float32)
+        vol[3:43, 2:50, 2:42] = tiny_io['volume'][0] * 40 + 200 + rng.standard_normal((40, 48, 40)).astype(np.float32)
+        nifti.write(os.path.join(img_dir, name + '_0000.nii.gz'), vol, spacing=(1.0, 1.0, 1.0))
+        cases[name] = vol
+    cmd = 'nnUNet_predict -i %s -o %s -tr %s -m %s -p %s -t %s -f %s -chk %s --disable_post_processing --selected_cases %s ' % \
+        (img_dir, out_dir, 'nnUNetTrainerV2', '3d_fullres', 'nnUNetPlansv2.1', 'Task002_FinalModel', 'all', 'model_best',
+         ' '.join(['caseA', 'case_B.1'])) + '--save_softmax --disable_tta'
+    env = dict(os.environ, RESULTS_FOLDER=model_dir, PATH=os.path.join(ROOT, 'bin') + os.pathsep + os.environ['PATH'],
+               CUDA_VISIBLE_DEVICES='0')
+    p = subprocess.run(shlex.split(cmd), env=env, capture_output=True, text=True)
+    print(p.stdout[-2000:], p.stderr[-2000:])
+    assert p.returncode == 0
+    assert sorted(os.listdir(out_dir)) == ['caseA.nii.gz', 'caseA_0.nii.gz', 'case_B.1.nii.gz', 'case_B.1_0.nii.gz']
+    for name in ('caseA', 'case_B.1'):
+        seg, meta = nifti.read(os.path.join(out_dir, name + '.nii.gz'))
+        p0, _ = nifti.read(os.path.join(out_dir, name + '_0.nii.gz'))
+        assert seg.shape == cases[name].shape and int(meta['header']['datatype']) == 2
+        data, props = preprocess.preprocess_case(cases[name], (1.0, 1.0, 1.0), plans)
+        seg_o, prob_o = osw.predict_3d_tiled(net, data, plan.patch_size, 0.5, False, True)
+        seg_ref, prob_ref = preprocess.export_prediction(prob_o, props)
+        assert float(np.abs(p0 - prob_ref[0]).max()) <= 1e-4
+        sure = np.abs(prob_ref[1] - prob_ref[0]) > 2e-4
+        assert int((seg != seg_ref)[sure].sum()) == 0
+        assert osw.hard_dice_binary(seg_ref, seg) > 0.9999
+    # a missing checkpoint must fail loudly (non-zero exit aborts the reference pipeline)
+    bad = subprocess.run(shlex.split(cmd.replace('model_best', 'model_ep_0046')), env=env, capture_output=True, text=True)
+    assert bad.returncode != 0
