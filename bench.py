@@ -75,6 +75,9 @@ def main():
     ap.add_argument('--tta', type=int, default=1, help='1: 8-fold mirroring as DeepWMH_predict; 0: --disable_tta')
     ap.add_argument('--shape', type=int, nargs=3, default=[160, 192, 160])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shard', choices=['volumes', 'patches'], default='volumes',
+                    help='volumes: one volume per rank per step (weak scaling, no collective); patches: ONE volume per '
+                         'step, its patches split over the ranks with an RCCL all-gather of the weighted tiles (strong)')
     args = ap.parse_args()
 
     import torch
@@ -99,8 +102,15 @@ def main():
     eng = UNetEngine(plan, sd, device)
     tta = bool(args.tta)
     pred = SlidingWindowPredictor(eng, do_mirroring=tta, batch=8)
-    vol_h = synthetic_flair(tuple(args.shape), seed=rank)
+    by_patch = args.shard == 'patches'
+    vol_h = synthetic_flair(tuple(args.shape), seed=0 if by_patch else rank)
     vol = torch.from_numpy(vol_h).to(device)          # resident in HBM before the timed region
+    if by_patch:
+        from deepwmh_amd.distributed import HipTileBackend, PatchShardedPredictor
+        sharded = PatchShardedPredictor(HipTileBackend(pred))
+        run_step = lambda: sharded.predict(vol)
+    else:
+        run_step = lambda: pred.predict_device(vol, return_prob=True)
 
     def barrier():
         if world > 1:
@@ -108,13 +118,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        pred.predict_device(vol, return_prob=True)
+        run_step()
     eng.timed_cfgs = {0}                               # dominant kernel: conv3d_k3 config 0
     eng.timings = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        seg, prob = pred.predict_device(vol, return_prob=True)
+        seg, prob = run_step()
     barrier()
     dt = time.perf_counter() - t0
     eng.timed_cfgs = set()
@@ -139,16 +149,18 @@ def main():
 
     if rank == 0:
         forwards = 8 * (8 if tta else 1)
-        res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=args.gpus * args.steps / dt,
+        nvol = args.steps if by_patch else args.gpus * args.steps
+        res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=nvol / dt,
                    unit='volumes/s', n_gpus=args.gpus, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
+                   ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='strong' if by_patch else 'weak', vs_baseline=None,
                    dtype='f32', data='synthetic',
                    config=dict(workload='configs[1]: one %dx%dx%d FLAIR volume per GPU, 128^3 patches, step 0.5, fp32, '
                                         'Gaussian aggregation, mirroring (TTA x8) %s; %d patch forwards per volume'
                                         % (args.shape[0], args.shape[1], args.shape[2], 'on' if tta else 'off', forwards),
                                tta=tta, patch=[128, 128, 128], step=0.5, batch=8, weights='random He-init (seed 0)',
-                               parallelism='volumes sharded over ranks, no collective'),
-                   end_to_end_tflops=round(forwards * FWD_GFLOP_PER_PATCH / 1e3 * args.steps * args.gpus / dt, 2),
+                               parallelism='patches of one volume sharded over ranks, RCCL all-gather of weighted tiles' if by_patch
+                               else 'volumes sharded over ranks, no collective'),
+                   end_to_end_tflops=round(forwards * FWD_GFLOP_PER_PATCH / 1e3 * nvol / dt, 2),
                    roofline=roofline)
         if args.gpus == 1 and not args.no_cpu_baseline:
             # first patch, no mirroring, for the parity figure reported next to the baseline

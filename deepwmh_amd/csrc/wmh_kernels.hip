@@ -290,8 +290,16 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum_kernel(const float*
         }
         const float gw = gauss ? gauss[p] : 1.f;
         const size_t dst = ((size_t)(g0 + p0) * A1 + (g1 + p1)) * A2 + (g2 + p2);
+        // product and sum rounded separately (no fma contraction), as numpy's `patch *= gaussian; agg += patch`
+        // does; it also makes "accumulate a tile computed elsewhere" (patch-sharded multi-GPU) bit-identical
+        {
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int k = 0; k < K; ++k) agg[(size_t)k * A + dst] += res[k] * gw;
+            for (int k = 0; k < K; ++k) {
+                const float t = res[k] * gw;
+                agg[(size_t)k * A + dst] = agg[(size_t)k * A + dst] + t;
+            }
+        }
     }
 }
 

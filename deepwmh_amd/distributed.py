@@ -1,0 +1,114 @@
+"""Multi-GPU modes of the sliding-window path (one process per GPU, torch.distributed; backend "nccl" = RCCL).
+
+The reference is single-GPU (`CUDA_VISIBLE_DEVICES=<one id>`, /root/reference/deepwmh/main/predict.py:150), so both
+modes are new design:
+
+* volume sharding  -- cases are independent: rank r takes cases r, r+W, ...  No data-path collective.
+* patch sharding   -- one volume, rank r computes patches r, r+W, ... (all 8 mirrored forwards of a patch stay on
+  its rank), producing Gaussian-weighted softmax tiles; ONE exchange step (all-gather of the tiles over xGMI); every
+  rank then accumulates all tiles in nnU-Net's x->y->z patch order, so the result is bit-identical to the
+  single-GPU path (the accumulation adds rounded products, never fused: see seghead_softmax_accum_kernel).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_cases(cases, rank, world):
+    """Round-robin assignment of independent cases to ranks."""
+    return list(cases)[rank::world]
+
+
+class PatchShardedPredictor:
+    """Host logic of the patch-sharded mode, independent of where the arithmetic runs.
+
+    backend object (GPU: `HipTileBackend`; CPU tests: an oracle-backed stand-in) provides
+      geometry(vshape) -> (A, pad_lo, origins, gauss_or_None)
+      tile(vol, origin) -> tensor [K, P0, P1, P2]  (mirror-averaged softmax x Gaussian for that patch)
+      zeros(shape) / accumulate(agg, tile, origin) / count_map(A, origins) / finalize(agg, cnt, pad_lo, V)
+    """
+
+    def __init__(self, backend, group=None):
+        self.b = backend
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def predict(self, vol):
+        V = tuple(int(v) for v in vol.shape[1:])
+        A, pad_lo, origins, K, P = self.b.geometry(V)
+        W, r = self.world, self.rank
+        rounds = (len(origins) + W - 1) // W
+        agg = self.b.zeros((K,) + A)
+        for rd in range(rounds):
+            idx = rd * W + r
+            # ranks without a patch in the last round contribute a zero tile that nobody accumulates
+            mine = self.b.tile(vol, origins[idx]) if idx < len(origins) else self.b.zeros((K,) + P)
+            if W > 1:
+                gathered = self.b.zeros((W, K) + P)
+                # the one exchange step (output viewed as the concatenation along dim 0: accepted by RCCL and gloo)
+                dist.all_gather_into_tensor(gathered.view((W * K,) + tuple(P)), mine.contiguous(), group=self.group)
+            else:
+                gathered = mine[None]
+            for w in range(W):                               # fixed global patch order
+                j = rd * W + w
+                if j < len(origins):
+                    self.b.accumulate(agg, gathered[w], origins[j])
+        cnt = self.b.count_map(A, origins)
+        return self.b.finalize(agg, cnt, pad_lo, V)
+
+
+class HipTileBackend:
+    """The arithmetic of PatchShardedPredictor on the HIP kernels."""
+
+    def __init__(self, predictor):
+        from . import _lib
+        self.p = predictor                 # deepwmh_amd.sliding_window.SlidingWindowPredictor
+        self._lib = _lib
+        self.lib = predictor.lib
+        self.dev = predictor.device
+
+    def geometry(self, V):
+        A, pad_lo, origins = self.p._geometry(V)
+        self._V, self._pad_lo = V, pad_lo
+        self._gauss = self.p.gaussian() if (self.p.use_gaussian and len(origins) > 1) else None
+        return A, pad_lo, origins, self.p.engine.plan.num_classes, self.p.patch
+
+    def zeros(self, shape):
+        return torch.zeros(shape, dtype=torch.float32, device=self.dev)
+
+    def tile(self, vol, origin):
+        L, lib, p = self._lib, self.lib, self.p
+        P, V, K = p.patch, self._V, p.engine.plan.num_classes
+        n = 8 if p.do_mirroring else 1
+        flips = list(range(8)) if p.do_mirroring else [0]
+        patches = p._scratch('patches', (n, vol.shape[0]) + P)
+        L.check(lib.wmh_extract_patches(L.ptr(vol), L.ptr(patches), vol.shape[0], V[0], V[1], V[2], L.iarr(self._pad_lo),
+                                        P[0], P[1], P[2], n, L.iarr(list(origin) * n), L.iarr(flips), p._stream()), 'extract')
+        y, ss, seg_w = p.engine.forward_features(patches)[-1]
+        tile = self.zeros((K,) + P)        # 0 + x == x exactly: the tile is the weighted softmax itself
+        from .network import LRELU_SLOPE
+        L.check(lib.wmh_seghead_softmax_accumulate(L.ptr(y), L.ptr(ss), L.ptr(seg_w), K, L.ptr(self._gauss), L.ptr(tile),
+                                                   y.shape[1], P[0], P[1], P[2], P[0], P[1], P[2], L.iarr((0, 0, 0)), n,
+                                                   L.iarr(flips), LRELU_SLOPE, p._stream()), 'seghead')
+        return tile
+
+    def accumulate(self, agg, tile, origin):
+        L, P = self._lib, self.p.patch
+        A = tuple(agg.shape[1:])
+        for k in range(agg.shape[0]):      # agg[k, window] += tile[k]
+            L.check(self.lib.wmh_accumulate_weight(L.ptr(tile[k]), L.ptr(agg[k]), P[0], P[1], P[2], A[0], A[1], A[2],
+                                                   L.iarr(origin), self.p._stream()), 'accumulate')
+
+    def count_map(self, A, origins):
+        return self.p._count_map(A, origins, self._gauss)
+
+    def finalize(self, agg, cnt, pad_lo, V):
+        L = self._lib
+        K = agg.shape[0]
+        A = tuple(agg.shape[1:])
+        seg = torch.empty(V, dtype=torch.uint8, device=self.dev)
+        prob = torch.empty((K,) + V, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.wmh_finalize_argmax(L.ptr(agg), L.ptr(cnt), L.ptr(prob), L.ptr(seg), K, A[0], A[1], A[2],
+                                             L.iarr(pad_lo), V[0], V[1], V[2], self.p._stream()), 'finalize')
+        return seg, prob

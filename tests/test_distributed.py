@@ -1,0 +1,95 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU host logic: case sharding and the patch-sharded
+all-gather mode, with the oracle standing in for the HIP arithmetic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from deepwmh_amd.distributed import PatchShardedPredictor, shard_cases
+
+
+def test_shard_cases_partition():
+    cases = ['c%d' % i for i in range(7)]
+    parts = [shard_cases(cases, r, 3) for r in range(3)]
+    assert sorted(sum(parts, [])) == sorted(cases) and parts[0] == ['c0', 'c3', 'c6']
+    assert shard_cases([], 0, 2) == []
+
+
+class OracleTileBackend:
+    """CPU stand-in: same interface as HipTileBackend, arithmetic by the oracle."""
+
+    def __init__(self, net, patch, mirror):
+        self.net, self.patch, self.mirror = net, tuple(patch), mirror
+
+    def geometry(self, V):
+        from deepwmh_amd.sliding_window import compute_steps_for_sliding_window, get_gaussian
+        A = tuple(max(v, p) for v, p in zip(V, self.patch))
+        self.pad_lo = tuple((a - v) // 2 for a, v in zip(A, V))
+        st = compute_steps_for_sliding_window(self.patch, A, 0.5)
+        origins = [(x, y, z) for x in st[0] for y in st[1] for z in st[2]]
+        self.gauss = torch.from_numpy(get_gaussian(self.patch)) if len(origins) > 1 else None
+        return A, self.pad_lo, origins, self.net.num_classes, self.patch
+
+    def zeros(self, shape):
+        return torch.zeros(shape, dtype=torch.float32)
+
+    def tile(self, vol, origin):
+        from oracle.sliding_window import mirror_and_predict, pad_nd_image
+        data, _ = pad_nd_image(vol.numpy(), self.patch)
+        x, y, z = origin
+        P = self.patch
+        patch = torch.from_numpy(np.ascontiguousarray(data[None, :, x:x + P[0], y:y + P[1], z:z + P[2]]))
+        return mirror_and_predict(self.net, patch, self.mirror, self.gauss)[0]
+
+    def accumulate(self, agg, tile, origin):
+        x, y, z = origin
+        P = self.patch
+        agg[:, x:x + P[0], y:y + P[1], z:z + P[2]] += tile
+
+    def count_map(self, A, origins):
+        cnt = torch.zeros(A)
+        P = self.patch
+        for (x, y, z) in origins:
+            cnt[x:x + P[0], y:y + P[1], z:z + P[2]] += self.gauss if self.gauss is not None else 1.0
+        return cnt
+
+    def finalize(self, agg, cnt, pad_lo, V):
+        sl = tuple(slice(l, l + v) for l, v in zip(pad_lo, V))
+        prob = (agg / cnt)[(slice(None),) + sl]
+        return prob.argmax(0).to(torch.uint8), prob
+
+
+def _worker(rank, world, port, golden, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from deepwmh_amd.plan import tiny_plan
+    from oracle.generic_unet import unet_from_plan
+    plan = tiny_plan(patch=32, base=4, num_pool=3, max_feat=32)
+    sd = dict(np.load(os.path.join(golden, 'tiny_net_weights.npz')))
+    net = unet_from_plan(plan).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    io = np.load(os.path.join(golden, 'tiny_net_io.npz'))
+    pred = PatchShardedPredictor(OracleTileBackend(net, plan.patch_size, False))
+    seg, prob = pred.predict(torch.from_numpy(io['volume']))
+    # every rank holds the full result; they must agree bit for bit
+    ref = prob.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(ref, prob)
+    if rank == 0:
+        np.save(out, prob.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_patch_sharded_predict_gloo(world, golden_dir, tmp_path, tiny_io):
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'prob.npy')
+    mp.spawn(_worker, args=(world, port, golden_dir, out), nprocs=world, join=True)
+    prob = np.load(out)
+    # 8 patches over 2 (even) or 3 (ragged last round) ranks == the serial oracle, bit for bit
+    assert np.array_equal(prob, tiny_io['prob_notta']) or float(np.abs(prob - tiny_io['prob_notta']).max()) <= 2e-6

@@ -73,6 +73,19 @@ def test_tiled_predict_matches_golden(tiny_engine, tiny_io, mirror, key):
         assert np.array_equal(prob3, prob) and np.array_equal(seg3, seg)
 
 
+@pytest.mark.parametrize('mirror', [False, True])
+def test_patch_sharded_backend_is_bit_identical_to_serial(tiny_engine, tiny_io, mirror):
+    # the multi-GPU tile/gather/accumulate path (world size 1 here; W > 1 is covered by the gloo CPU tests)
+    from deepwmh_amd.distributed import HipTileBackend, PatchShardedPredictor
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    serial = SlidingWindowPredictor(tiny_engine, do_mirroring=mirror)
+    seg, prob = serial.predict(tiny_io['volume'])
+    sharded = PatchShardedPredictor(HipTileBackend(SlidingWindowPredictor(tiny_engine, do_mirroring=mirror)))
+    seg2, prob2 = sharded.predict(torch.from_numpy(tiny_io['volume']).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(prob2.cpu().numpy(), prob) and np.array_equal(seg2.cpu().numpy(), seg)
+
+
 def test_predict_volume_smaller_than_patch(tiny_engine, tiny_io):
     from deepwmh_amd.sliding_window import SlidingWindowPredictor
     seg, prob = SlidingWindowPredictor(tiny_engine, do_mirroring=False).predict(tiny_io['small_volume'])
