@@ -24,6 +24,9 @@ SIGNATURES = {
     'wmh_instnorm_stats': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _sz, _vp]),
     'wmh_instnorm_lrelu_apply': (_i, [_vp, _vp, _vp, _i, _i, _sz, _f, _vp]),
     'wmh_convtranspose3d_k2s2_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_convtranspose3d_k2s2_packed_floats': (_sz, [_i, _i]),
+    'wmh_convtranspose3d_k2s2_pack_weights': (_i, [_vp, _i, _i, _vp]),
+    'wmh_convtranspose3d_k2s2_mfma_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_extract_patches': (_i, [_vp, _vp, _i, _i, _i, _i, _ip, _i, _i, _i, _i, _ip, _ip, _vp]),
     'wmh_seghead_softmax_accumulate': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ip, _i, _ip, _f, _vp]),
     'wmh_seghead_logits': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _sz, _f, _vp]),

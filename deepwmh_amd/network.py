@@ -66,11 +66,16 @@ class UNetEngine:
         self.dec = []
         for st in plan.decoder_stages():
             name, cdown, cskip = st['tu']
-            tu_w = torch.from_numpy(_np(sd[name + '.weight'])).to(dev)
-            assert tuple(tu_w.shape) == (cdown, cskip, 2, 2, 2)
+            tu_host = _np(sd[name + '.weight'])
+            assert tuple(tu_host.shape) == (cdown, cskip, 2, 2, 2)
+            tu_w = torch.from_numpy(tu_host).to(dev)
+            wf = np.empty(self.lib.wmh_convtranspose3d_k2s2_packed_floats(cdown, cskip), dtype=np.float32)
+            _lib.check(self.lib.wmh_convtranspose3d_k2s2_pack_weights(tu_host.ctypes.data_as(C.c_void_p), cdown, cskip,
+                                                                      wf.ctypes.data_as(C.c_void_p)), 'convT pack')
+            tu_wf = torch.from_numpy(wf).to(dev)
             convs = [_ConvLayer(self.lib, sd, c.name, c.cin, c.cout, 1, dev) for c in st['convs']]
             seg_w = torch.from_numpy(_np(sd[st['seg'] + '.weight']).reshape(plan.num_classes, cskip)).contiguous().to(dev)
-            self.dec.append(dict(tu_w=tu_w, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
+            self.dec.append(dict(tu_w=tu_w, tu_wf=tu_wf, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
         self._bufs = {}
         # optional live kernel timing (bench.py): conv configs to bracket with HIP events on the launch stream
         self.timed_cfgs = set()
@@ -124,12 +129,17 @@ class UNetEngine:
             N, layer.cout, st), 'wmh_instnorm_finalize')
         return y, ss
 
-    def _convT(self, key, w, x, ss, cout):
+    def _convT(self, key, w, wf, x, ss, cout):
         N, Cin, D, H, W = x.shape
         y = self._buf(key + '.y', (N, cout, 2 * D, 2 * H, 2 * W))
-        _lib.check(self.lib.wmh_convtranspose3d_k2s2_fwd(
-            _lib.ptr(x), _lib.ptr(ss), _lib.ptr(w), _lib.ptr(y), N, Cin, cout, D, H, W, LRELU_SLOPE,
-            self._stream()), 'wmh_convtranspose3d_k2s2_fwd')
+        if (D * H * W) % 4 == 0:           # matrix-core kernel (16-byte staging loads)
+            _lib.check(self.lib.wmh_convtranspose3d_k2s2_mfma_fwd(
+                _lib.ptr(x), _lib.ptr(ss), _lib.ptr(wf), _lib.ptr(y), N, Cin, cout, D, H, W, LRELU_SLOPE,
+                self._stream()), 'wmh_convtranspose3d_k2s2_mfma_fwd')
+        else:                              # odd-sized tensors: vector-ALU kernel
+            _lib.check(self.lib.wmh_convtranspose3d_k2s2_fwd(
+                _lib.ptr(x), _lib.ptr(ss), _lib.ptr(w), _lib.ptr(y), N, Cin, cout, D, H, W, LRELU_SLOPE,
+                self._stream()), 'wmh_convtranspose3d_k2s2_fwd')
         return y
 
     # ---- graph ---------------------------------------------------------------------------------
@@ -147,7 +157,7 @@ class UNetEngine:
                 skips.append((cur, cur_ss))
         outs = []
         for u, st in enumerate(self.dec):
-            up = self._convT('tu%d' % u, st['tu_w'], cur, cur_ss, st['cskip'])
+            up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'])
             skip, skip_ss = skips[-(u + 1)]
             cur, cur_ss = self._conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss)
             cur, cur_ss = self._conv('dec%d.1' % u, st['convs'][1], cur, cur_ss)

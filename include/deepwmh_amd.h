@@ -100,6 +100,13 @@ int wmh_instnorm_lrelu_apply(const float* x, const float* ss, float* y, int N, i
 int wmh_convtranspose3d_k2s2_fwd(const float* x, const float* ss, const float* w, float* y,
                                  int N, int Cin, int Cout, int D, int H, int W,
                                  float lrelu_slope, void* stream);
+/* The same operation on the fp32 matrix cores (the path the network uses): weights repacked once into a
+ * fragment-major image (host: w torch layout -> wf, packed_floats() floats); x 16-byte aligned, D*H*W % 4 == 0. */
+size_t wmh_convtranspose3d_k2s2_packed_floats(int Cin, int Cout);
+int wmh_convtranspose3d_k2s2_pack_weights(const float* w, int Cin, int Cout, float* wf);
+int wmh_convtranspose3d_k2s2_mfma_fwd(const float* x, const float* ss, const float* wf, float* y,
+                                      int N, int Cin, int Cout, int D, int H, int W,
+                                      float lrelu_slope, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sliding-window glue [nnU-Net neural_network.py::_internal_predict_3D_3Dconv_tiled and

@@ -176,6 +176,28 @@ def test_convtranspose3d_k2s2(lib, shape):
     assert float((yh - ref).abs().max()) <= 1e-5 * (1 + float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 8, 4, 4, 4, True), (1, 8, 4, 2, 6, 8, False), (2, 24, 20, 3, 16, 32, True),
+                                   (3, 64, 32, 8, 8, 8, True), (1, 40, 72, 4, 4, 5, True)])
+def test_convtranspose3d_k2s2_mfma(lib, shape):
+    from deepwmh_amd import _lib
+    N, Cin, Cout, D, H, W, use_ss = shape
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 2, 2, 2, generator=g) * 0.2
+    ss = torch.stack([0.5 + torch.rand(N, Cin, generator=g), 0.3 * torch.randn(N, Cin, generator=g)], -1) if use_ss else None
+    ref = F.conv_transpose3d(_lrelu_affine(x, ss), w, None, stride=2)
+    wf = np.empty(lib.wmh_convtranspose3d_k2s2_packed_floats(Cin, Cout), np.float32)
+    wn = w.numpy()
+    assert lib.wmh_convtranspose3d_k2s2_pack_weights(wn.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)) == 0
+    y = torch.full((N, Cout, 2 * D, 2 * H, 2 * W), float('nan'), device='cuda')
+    xd, ssd, wd = x.cuda(), (ss.cuda() if use_ss else None), dev(wf)
+    _lib.check(lib.wmh_convtranspose3d_k2s2_mfma_fwd(P(xd), P(ssd), P(wd), P(y), N, Cin, Cout, D, H, W, SLOPE, None), 'convT mfma')
+    torch.cuda.synchronize()
+    yh = y.cpu()
+    assert not torch.isnan(yh).any()
+    assert float((yh - ref).abs().max()) <= 1e-5 * (1 + float(ref.abs().max()))
+
+
 def test_extract_patches_flips_and_padding(lib):
     from deepwmh_amd import _lib
     rng = np.random.default_rng(2)

@@ -70,4 +70,28 @@ for name, C0, C1, Cout, D, s in LAYERS:
     print('%-7s ws %5.1f MB cfg%d Cin %3d Cout %3d out %3d^3 s%d: %8.3f ms (min %8.3f)  %7.1f GFLOP  %6.1f TFLOP/s'
           % (name, nws * 4 / 1e6, cfg, Cin, Cout, Do, s, ms, min(ts), fl / 1e9, fl / ms / 1e9), flush=True)
     del x0, x1, y, part
-print('TOTAL %.3f ms  %.1f GFLOP  %.1f TFLOP/s' % (tot_ms, tot_fl / 1e9, tot_fl / tot_ms / 1e9))
+if tot_ms > 0:
+    print('TOTAL %.3f ms  %.1f GFLOP  %.1f TFLOP/s' % (tot_ms, tot_fl / 1e9, tot_fl / tot_ms / 1e9))
+
+# transposed convolutions of the BASELINE decoder
+if not sel or any('tu' in k for k in sel):
+    import ctypes as C2
+    for name, Cin, Cout, D in [('tu0', 320, 320, 4), ('tu1', 320, 256, 8), ('tu2', 256, 128, 16), ('tu3', 128, 64, 32), ('tu4', 64, 32, 64)]:
+        x = torch.randn(B, Cin, D, D, D, device='cuda')
+        ss = torch.rand(B, Cin, 2, device='cuda') + 0.5
+        w = (np.random.default_rng(1).standard_normal((Cin, Cout, 2, 2, 2)) * 0.1).astype(np.float32)
+        wf = np.empty(lib.wmh_convtranspose3d_k2s2_packed_floats(Cin, Cout), np.float32)
+        lib.wmh_convtranspose3d_k2s2_pack_weights(w.ctypes.data_as(C2.c_void_p), Cin, Cout, wf.ctypes.data_as(C2.c_void_p))
+        wd, wfd = torch.from_numpy(w).cuda(), torch.from_numpy(wf).cuda()
+        y = torch.empty(B, Cout, 2 * D, 2 * D, 2 * D, device='cuda')
+        for label, fn in (('valu', lambda: lib.wmh_convtranspose3d_k2s2_fwd(_lib.ptr(x), _lib.ptr(ss), _lib.ptr(wd), _lib.ptr(y), B, Cin, Cout, D, D, D, 0.01, None)),
+                          ('mfma', lambda: lib.wmh_convtranspose3d_k2s2_mfma_fwd(_lib.ptr(x), _lib.ptr(ss), _lib.ptr(wfd), _lib.ptr(y), B, Cin, Cout, D, D, D, 0.01, None))):
+            fn(); torch.cuda.synchronize()
+            ts = []
+            for _ in range(REPS):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            gb = 4.0 * B * D ** 3 * (Cin + 8 * Cout) / 1e9
+            print('%-4s %s Cin %3d Cout %3d in %2d^3: %7.3f ms  %6.2f GB -> %5.2f TB/s, %6.1f TFLOP/s'
+                  % (name, label, Cin, Cout, D, np.median(ts), gb, gb / np.median(ts), 2.0 * B * D ** 3 * Cin * Cout * 8 / np.median(ts) / 1e9))
