@@ -450,7 +450,8 @@ typedef ConvCfg<1, 8, 4, 4, 8, 1, 2, 1, 8, 6> Cfg4;     // stride 1, 8-wide
 typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 1, 2, 6> Cfg5;     // stride 2, 8-wide output
 typedef ConvCfg<1, 4, 4, 4, 4, 4, 2, 1, 8, 6> Cfg6;     // stride 1, 4-wide, 4 samples per workgroup
 typedef ConvCfg<2, 4, 4, 4, 4, 4, 2, 1, 2, 6> Cfg7;     // stride 2, 4-wide output
-#define WMH_NUM_CONV_CFG 8
+typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 2, 6> Cfg8;    // as Cfg0 for 1-2 input channels (first layer): one cin pair
+#define WMH_NUM_CONV_CFG 9
 
 struct CfgInfo { int S, TX, TY, TZ, TN, NT, CK, WPS, threads, lds_bytes; };
 template <class C> static CfgInfo info_of() {
@@ -458,7 +459,8 @@ template <class C> static CfgInfo info_of() {
 }
 static const CfgInfo& cfg_info(int cfg) {
     static const CfgInfo t[WMH_NUM_CONV_CFG] = {info_of<Cfg0>(), info_of<Cfg1>(), info_of<Cfg2>(), info_of<Cfg3>(),
-                                                info_of<Cfg4>(), info_of<Cfg5>(), info_of<Cfg6>(), info_of<Cfg7>()};
+                                                info_of<Cfg4>(), info_of<Cfg5>(), info_of<Cfg6>(), info_of<Cfg7>(),
+                                                info_of<Cfg8>()};
     return t[cfg];
 }
 static unsigned long long* g_conv_stamps = nullptr;
@@ -511,6 +513,7 @@ extern "C" int wmh_conv3d_k3_config(int Cin, int Cout, int D, int H, int W, int 
         return wmh_fail(WMH_EINVAL, "wmh_conv3d_k3_config: bad shape");
     const int Wo = (W - 1) / stride + 1;
     int base = Wo >= 24 ? 0 : Wo >= 12 ? 2 : Wo >= 6 ? 4 : 6;
+    if (base == 0 && stride == 1 && Cin <= 2) return 8;
     return base + (stride == 2 ? 1 : 0);
 }
 
@@ -612,6 +615,7 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
         case 5: rc = launch_conv<Cfg5>(a, (unsigned)nblk, st); break;
         case 6: rc = launch_conv<Cfg6>(a, (unsigned)nblk, st); break;
         case 7: rc = launch_conv<Cfg7>(a, (unsigned)nblk, st); break;
+        case 8: rc = launch_conv<Cfg8>(a, (unsigned)nblk, st); break;
         default: return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd: bad cfg");
     }
     if (rc != WMH_OK || a.KS == 1) return rc;

@@ -303,6 +303,80 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum_kernel(const float*
     }
 }
 
+// Same arithmetic, 4 consecutive voxels of the last axis per thread with 16-byte loads (P2 % 4 == 0, aligned x):
+// a mirrored last axis reads the mirrored quad and reverses it in registers.
+template <int K>
+__global__ __launch_bounds__(256) void seghead_softmax_accum4_kernel(const float* x, const float* ss, const float* wseg,
+                                                                     const float* gauss, float* agg, int C, int P0,
+                                                                     int P1, int P2, int A0, int A1, int A2, int g0,
+                                                                     int g1, int g2, const PatchList pl, float slope) {
+    const size_t P = (size_t)P0 * P1 * P2, A = (size_t)A0 * A1 * A2, Q = P / 4;
+    const int Q2 = P2 / 4;
+    const float wgt = 1.f / (float)pl.n;
+    for (size_t qi = (size_t)blockIdx.x * 256 + threadIdx.x; qi < Q; qi += (size_t)gridDim.x * 256) {
+        const int q2 = (int)(qi % Q2), p1 = (int)((qi / Q2) % P1), p0 = (int)(qi / ((size_t)Q2 * P1));
+        const int p2 = 4 * q2;
+        float res[K][4];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) res[k][i] = 0.f;
+        for (int b = 0; b < pl.n; ++b) {
+            const int f = pl.flip[b];
+            const bool fx = f & 1;
+            const int s0 = (f & 4) ? P0 - 1 - p0 : p0, s1 = (f & 2) ? P1 - 1 - p1 : p1, s2 = fx ? P2 - 4 - p2 : p2;
+            const size_t src = ((size_t)s0 * P1 + s1) * P2 + s2;
+            const float* xb = x + (size_t)b * C * P + src;
+            const float* ssb = ss ? ss + (size_t)b * C * 2 : nullptr;
+            float lg[K][4];
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lg[k][i] = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float4 v4 = *reinterpret_cast<const float4*>(xb + (size_t)c * P);
+                float v[4] = {fx ? v4.w : v4.x, fx ? v4.z : v4.y, fx ? v4.y : v4.z, fx ? v4.x : v4.w};
+                if (ssb) {
+                    const float sc = ssb[2 * c], sh = ssb[2 * c + 1];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = wmh_lrelu(fmaf(v[i], sc, sh), slope);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float wk = wseg[k * C + c];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lg[k][i] = fmaf(v[i], wk, lg[k][i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float mx = lg[0][i];
+#pragma unroll
+                for (int k = 1; k < K; ++k) mx = fmaxf(mx, lg[k][i]);
+                float e[K], den = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) { e[k] = expf(lg[k][i] - mx); den += e[k]; }
+#pragma unroll
+                for (int k = 0; k < K; ++k) res[k][i] += wgt * (e[k] / den);
+            }
+        }
+        const size_t p = ((size_t)p0 * P1 + p1) * P2 + p2;
+        float gw[4] = {1.f, 1.f, 1.f, 1.f};
+        if (gauss) { const float4 g4 = *reinterpret_cast<const float4*>(gauss + p); gw[0] = g4.x; gw[1] = g4.y; gw[2] = g4.z; gw[3] = g4.w; }
+        const size_t dst = ((size_t)(g0 + p0) * A1 + (g1 + p1)) * A2 + (g2 + p2);
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = res[k][i] * gw[i];
+                    agg[(size_t)k * A + dst + i] = agg[(size_t)k * A + dst + i] + t;
+                }
+        }
+    }
+}
+
 extern "C" int wmh_seghead_softmax_accumulate(const float* x, const float* ss, const float* wseg, int K,
                                               const float* gauss, float* agg, int C, int P0, int P1, int P2, int A0,
                                               int A1, int A2, const int* origin, int n, const int* flips,
@@ -313,11 +387,15 @@ extern "C" int wmh_seghead_softmax_accumulate(const float* x, const float* ss, c
     if (origin[0] < 0 || origin[1] < 0 || origin[2] < 0 || origin[0] + P0 > A0 || origin[1] + P1 > A1 || origin[2] + P2 > A2)
         return wmh_fail(WMH_EINVAL, "seghead_softmax_accumulate: patch window outside the accumulator");
     const size_t P = (size_t)P0 * P1 * P2;
-    unsigned gx = cdivu(P, 256);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_HEAD(KK)                                                                                             \
-    hipLaunchKernelGGL((seghead_softmax_accum_kernel<KK>), dim3(gx), dim3(256), 0, st, x, ss, wseg, gauss, agg, C, P0, \
-                       P1, P2, A0, A1, A2, origin[0], origin[1], origin[2], pl, lrelu_slope)
+    // 16-byte path: quads along the last axis must not straddle rows and every base must be 16-byte aligned
+    const bool quad = (P2 % 4 == 0) && !(reinterpret_cast<uintptr_t>(x) & 15) && (!gauss || !(reinterpret_cast<uintptr_t>(gauss) & 15));
+    unsigned gx = cdivu(quad ? P / 4 : P, 256);
+#define LAUNCH_HEAD(KK)                                                                                                  \
+    if (quad) hipLaunchKernelGGL((seghead_softmax_accum4_kernel<KK>), dim3(gx), dim3(256), 0, st, x, ss, wseg, gauss, agg, \
+                                 C, P0, P1, P2, A0, A1, A2, origin[0], origin[1], origin[2], pl, lrelu_slope);            \
+    else hipLaunchKernelGGL((seghead_softmax_accum_kernel<KK>), dim3(gx), dim3(256), 0, st, x, ss, wseg, gauss, agg, C,    \
+                            P0, P1, P2, A0, A1, A2, origin[0], origin[1], origin[2], pl, lrelu_slope)
     switch (K) {
         case 2: LAUNCH_HEAD(2); break;
         case 3: LAUNCH_HEAD(3); break;

@@ -57,7 +57,8 @@ def _lrelu_affine(x, ss):
 
 CONV_CASES = [
     # N, C0, C1, Cout, D, H, W, stride, ss0, ss1, expected cfg
-    (1, 1, 0, 8, 32, 32, 32, 1, False, False, 0),
+    (1, 1, 0, 8, 32, 32, 32, 1, False, False, 8),
+    (2, 2, 0, 40, 12, 16, 40, 1, True, False, 8),
     (2, 8, 0, 8, 16, 24, 40, 1, True, False, 0),
     (1, 32, 0, 32, 8, 16, 64, 1, True, False, 0),
     (1, 6, 0, 40, 9, 17, 33, 1, False, False, 0),
