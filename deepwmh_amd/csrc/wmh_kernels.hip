@@ -333,8 +333,10 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum4_kernel(const float
             for (int k = 0; k < K; ++k)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lg[k][i] = 0.f;
-            for (int c = 0; c < C; ++c) {
-                const float4 v4 = *reinterpret_cast<const float4*>(xb + (size_t)c * P);
+#pragma unroll 8
+            for (int c = 0; c < C; ++c) {       // unrolled: 8 independent 16-byte loads in flight per lane
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v v4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(xb + (size_t)c * P));   // read once
                 float v[4] = {fx ? v4.w : v4.x, fx ? v4.z : v4.y, fx ? v4.y : v4.z, fx ? v4.x : v4.w};
                 if (ssb) {
                     const float sc = ssb[2 * c], sh = ssb[2 * c + 1];
