@@ -139,9 +139,15 @@ def main():
     tot_bytes = sum(b for (_, _, _, _, b) in eng.timings)
     nl = max(1, len(eng.timings))
     achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            traffic = json.load(f)['traffic_bytes_per_launch']     # PMC counters cannot be read live: separate rocprofv3 passes
+    except Exception:
+        pass
     roofline = dict(bound='mfma', kernel='conv3d_k3_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM)',
                     achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
                     launches=len(eng.timings), avg_launch_ms=round(tot_ms / nl, 4),
                     algorithmic_gflop_per_launch=round(tot_flop / nl / 1e9, 3),
                     algorithmic_gbytes_per_launch=round(tot_bytes / nl / 1e9, 4),
