@@ -543,6 +543,44 @@ extern "C" int wmh_conv3d_k3_pack_weights(int cfg, const float* w, int Cin, int 
     return WMH_OK;
 }
 
+// Device-side repack (training: the weights change every step).  w is torch layout [Cout][Cin_total][27] in
+// HBM; input channels [ci_off, ci_off+ci_cnt) are used.  mode 0: the forward image of a conv ci_cnt -> Cout.
+// mode 1: the image of the DATA-GRADIENT conv Cout -> ci_cnt, i.e. W'[ci][co][tap] = W[co][ci][26 - tap].
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float* wf, int Cin_total, int Cout, int ci_off,
+                                                           int ci_cnt, int mode, int CK, int NT, int NCH, size_t total) {
+    const int V = CK / 2;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        size_t r = idx;
+        const int pp = (int)(r % V); r /= V;
+        const int lane = (int)(r % 64); r /= 64;
+        const int nt = (int)(r % NT); r /= NT;
+        const int tap = (int)(r % 27); r /= 27;
+        const int ch = (int)(r % NCH); r /= NCH;
+        const int g = (int)r;
+        const int eco = (g * NT + nt) * 32 + (lane & 31), eci = ch * CK + 2 * pp + (lane >> 5);   // effective conv's (cout, cin)
+        float v = 0.f;
+        if (mode == 0) {
+            if (eco < Cout && eci < ci_cnt) v = w[((size_t)eco * Cin_total + ci_off + eci) * 27 + tap];
+        } else {
+            if (eco < ci_cnt && eci < Cout) v = w[((size_t)eci * Cin_total + ci_off + eco) * 27 + (26 - tap)];
+        }
+        wf[idx] = v;
+    }
+}
+extern "C" int wmh_conv3d_k3_pack_weights_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt,
+                                                 int mode, float* wf, void* stream) {
+    if (cfg < 0 || cfg >= WMH_NUM_CONV_CFG || !w || !wf || ci_off < 0 || ci_cnt < 1 || ci_off + ci_cnt > Cin_total)
+        return wmh_fail(WMH_EINVAL, "pack_weights_device: bad args");
+    const CfgInfo& c = cfg_info(cfg);
+    const int eCin = mode == 0 ? ci_cnt : Cout, eCout = mode == 0 ? Cout : ci_cnt;
+    const int NCH = cdiv(eCin, c.CK);
+    const size_t total = (size_t)cdiv(eCout, 32 * c.NT) * NCH * 27 * c.NT * 64 * (c.CK / 2);
+    unsigned nb = (unsigned)((total + 255) / 256); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wf, Cin_total, Cout, ci_off,
+                       ci_cnt, mode, c.CK, c.NT, NCH, total);
+    return wmh_check_launch("pack_weights_kernel");
+}
+
 // split-K factor for a launch: only the small, under-filled layers split
 static int pick_ksplit(const CfgInfo& c, long long nblk, int nchunks) {
     static const int force = env_int("WMH_KSPLIT", 0);

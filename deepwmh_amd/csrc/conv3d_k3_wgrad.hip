@@ -1,0 +1,199 @@
+// conv3d_k3_wgrad.hip -- weight gradient of the 3x3x3 convolution (pad 1, stride 1|2) on the exact-fp32 MFMA.
+//
+//   dW[co][ci][tap] = sum_{n, o} dy[n, co, o] * x'[n, ci, S*o + tap - 1]
+//
+// The contraction runs over voxels, so voxels are the K dimension of v_mfma_f32_32x32x2_f32:
+//   D[co 32][tap 32(27 used)] += A[co 32][voxel pair] * B[voxel pair][tap],   one D tile per input channel.
+// A workgroup owns 32 output channels x 32 input channels (wave w owns ci = 4c + w, c = 0..7: eight
+// accumulators) and walks a strided subset of the spatial tiles, keeping dW in registers; per tile the dy tile
+// [32 co][TV voxels] is staged once and the x' halo tile 4 channels at a time (with the producer's
+// InstanceNorm+LeakyReLU applied on the way in, zero padding after it).  A lane's B address is
+// (its tap offset) + (row base) + immediate, so the inner loop has no address arithmetic.
+// Partial dW per workgroup goes to a slab; wgrad_reduce sums the slabs in fixed order (bit-reproducible).
+// Stands in for the weight half of torch.nn.Conv3d's backward [nnU-Net training, not in tree].
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "wmh_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+    const float* x0; const float* ss0; int C0;
+    const float* x1; const float* ss1; int C1;
+    const float* dy; float* part;
+    int N, D, H, W, Do, Ho, Wo, Cout, Cin;
+    int TZ, TY, IZ, IY, IX;
+    int ntx, nty, ntz, ntiles;
+    int NG, NCG, P;
+    int dys, xcs;
+    float slope;
+};
+
+template <int S, int TX>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* dyl = lds;                      // [32 co][dys]
+    float* xl = lds + 32 * a.dys;          // [4 ci][xcs]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    int bid = blockIdx.x;
+    const int p = bid % a.P; bid /= a.P;
+    const int g = bid % a.NG, cg = bid / a.NG;
+
+    const int ZS = a.IY * a.IX;
+    const int tapj = min(i, 26);
+    const int LB = wave * a.xcs + kh * S + (tapj / 9) * ZS + ((tapj / 3) % 3) * a.IX + (tapj % 3);
+    const int LA = i * a.dys + kh;
+    const int TV = a.TZ * a.TY * TX;
+    const int SPX = a.IZ * ZS;
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+    const size_t DHW = (size_t)a.D * HW, DoHoWo = (size_t)a.Do * HoWo;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    for (int t = p; t < a.ntiles; t += a.P) {
+        int b = t;
+        const int tx = b % a.ntx; b /= a.ntx;
+        const int ty = b % a.nty; b /= a.nty;
+        const int tz = b % a.ntz; b /= a.ntz;
+        const int n = b;
+        const int ox0 = tx * TX, oy0 = ty * a.TY, oz0 = tz * a.TZ;
+        const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
+        __syncthreads();                                   // previous tile fully consumed
+        for (int e = tid; e < 32 * TV; e += 256) {         // dy tile
+            const int col = e / TV, v = e - col * TV;
+            const int x = v % TX, y = (v / TX) % a.TY, z = v / (TX * a.TY);
+            const int co = g * 32 + col, oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
+            const bool ok = co < a.Cout && oz < a.Do && oy < a.Ho && ox < a.Wo;
+            const float val = ok ? a.dy[((size_t)n * a.Cout + co) * DoHoWo + (size_t)oz * HoWo + oy * a.Wo + ox] : 0.f;
+            dyl[col * a.dys + v] = val;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (cg * 32 + 4 * c >= a.Cin) continue;         // uniform: no such input channels
+            if (c > 0) __syncthreads();                    // x' chunk of the previous iteration consumed
+            for (int e = tid; e < 4 * SPX; e += 256) {     // x' halo tile, 4 input channels
+                const int cc = e / SPX, s = e - cc * SPX;
+                const int x = s % a.IX, y = (s / a.IX) % a.IY, z = s / ZS;
+                const int ci = cg * 32 + 4 * c + cc;
+                const int gx = ix0 + x, gy = iy0 + y, gz = iz0 + z;
+                const bool ok = ci < a.Cin && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
+                float v = 0.f;
+                if (ok) {
+                    const bool first = ci < a.C0;
+                    const float* xs = first ? a.x0 : a.x1;
+                    const float* ss = first ? a.ss0 : a.ss1;
+                    const int Cs = first ? a.C0 : a.C1, cl = first ? ci : ci - a.C0;
+                    v = xs[((size_t)n * Cs + cl) * DHW + (size_t)gz * HW + gy * a.W + gx];
+                    if (ss) {
+                        const float* q = ss + ((size_t)n * Cs + cl) * 2;
+                        v = fmaf(v, q[0], q[1]);
+                        v = v > 0.f ? v : v * a.slope;
+                    }
+                }
+                xl[cc * a.xcs + s] = v;
+            }
+            __syncthreads();
+            for (int z = 0; z < a.TZ; ++z)
+                for (int y = 0; y < a.TY; ++y) {
+                    const float* ap = dyl + LA + (z * a.TY + y) * TX;
+                    const float* bp = xl + LB + S * (z * ZS + y * a.IX);
+#pragma unroll
+                    for (int xp = 0; xp < TX / 2; ++xp)
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * xp], bp[S * 2 * xp], acc[c], 0, 0, 0);
+                }
+        }
+    }
+    // partial dW of this workgroup: rows = co (register index), columns = tap (lane)
+    if (i < 27) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ci = cg * 32 + 4 * c + wave;
+            if (ci >= a.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (co < a.Cout) a.part[(((size_t)p * a.Cout + co) * a.Cin + ci) * 27 + i] = acc[c][r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dW, size_t n, int P) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = part[i];
+        for (int p = 1; p < P; ++p) s += part[(size_t)p * n + i];       // fixed order
+        dW[i] = s;
+    }
+}
+
+struct WgradPlan { int TX, TY, TZ, IZ, IY, IX, ntx, nty, ntz, ntiles, NG, NCG, P, dys, xcs, lds_bytes; };
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static WgradPlan plan_wgrad(int Cin, int Cout, int N, int D, int H, int W, int S) {
+    WgradPlan q;
+    const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+    q.TX = Wo >= 24 ? 32 : Wo >= 12 ? 16 : Wo >= 6 ? 8 : 4;
+    if (q.TX == 32) { q.TY = 4; q.TZ = 2; }
+    else if (q.TX == 16) { q.TY = S == 1 ? 8 : 4; q.TZ = 2; }
+    else if (q.TX == 8) { q.TY = 8; q.TZ = S == 1 ? 4 : 2; }
+    else { q.TY = 4; q.TZ = 4; }
+    q.IX = S * (q.TX - 1) + 3; q.IY = S * (q.TY - 1) + 3; q.IZ = S * (q.TZ - 1) + 3;
+    q.ntx = cdiv(Wo, q.TX); q.nty = cdiv(Ho, q.TY); q.ntz = cdiv(Do, q.TZ);
+    q.ntiles = N * q.ntx * q.nty * q.ntz;
+    q.NG = cdiv(Cout, 32); q.NCG = cdiv(Cin, 32);
+    const int pairs = q.NG * q.NCG;
+    q.P = cdiv(512, pairs); if (q.P > q.ntiles) q.P = q.ntiles; if (q.P < 1) q.P = 1;
+    q.dys = q.TZ * q.TY * q.TX + 1;
+    q.xcs = q.IZ * q.IY * q.IX;
+    q.lds_bytes = (32 * q.dys + 4 * q.xcs) * 4;
+    return q;
+}
+
+extern "C" size_t wmh_conv3d_k3_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W, int stride) {
+    const WgradPlan q = plan_wgrad(Cin, Cout, N, D, H, W, stride);
+    return (size_t)q.P * Cout * Cin * 27;
+}
+
+template <int S, int TX>
+static int launch_wgrad(const WgradArgs& a, unsigned nblk, int lds, hipStream_t st) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_kernel<S, TX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<S, TX>), dim3(nblk), dim3(256), lds, st, a);
+    return wmh_check_launch("conv3d_k3_wgrad_kernel");
+}
+
+extern "C" int wmh_conv3d_k3_wgrad(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
+                                   const float* dy, float* dW, float* workspace, int N, int D, int H, int W, int Cout,
+                                   int stride, float lrelu_slope, void* stream) {
+    if (!x0 || !dy || !dW || !workspace || C0 < 1 || N < 1 || Cout < 1 || (stride != 1 && stride != 2))
+        return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad: bad args");
+    if (!x1) C1 = 0;
+    const int Cin = C0 + C1;
+    const WgradPlan q = plan_wgrad(Cin, Cout, N, D, H, W, stride);
+    if (q.lds_bytes > 160 * 1024) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad: tile does not fit LDS");
+    WgradArgs a;
+    a.x0 = x0; a.ss0 = ss0; a.C0 = C0; a.x1 = x1; a.ss1 = ss1; a.C1 = C1; a.dy = dy; a.part = workspace;
+    a.N = N; a.D = D; a.H = H; a.W = W;
+    a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+    a.Cout = Cout; a.Cin = Cin;
+    a.TZ = q.TZ; a.TY = q.TY; a.IZ = q.IZ; a.IY = q.IY; a.IX = q.IX;
+    a.ntx = q.ntx; a.nty = q.nty; a.ntz = q.ntz; a.ntiles = q.ntiles;
+    a.NG = q.NG; a.NCG = q.NCG; a.P = q.P; a.dys = q.dys; a.xcs = q.xcs; a.slope = lrelu_slope;
+    const unsigned nblk = (unsigned)(q.NG * q.NCG * q.P);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+#define WG(SS, TT) rc = launch_wgrad<SS, TT>(a, nblk, q.lds_bytes, st)
+    if (stride == 1) { if (q.TX == 32) WG(1, 32); else if (q.TX == 16) WG(1, 16); else if (q.TX == 8) WG(1, 8); else WG(1, 4); }
+    else             { if (q.TX == 32) WG(2, 32); else if (q.TX == 16) WG(2, 16); else if (q.TX == 8) WG(2, 8); else WG(2, 4); }
+#undef WG
+    if (rc != WMH_OK) return rc;
+    const size_t n = (size_t)Cout * Cin * 27;
+    unsigned rb = (unsigned)((n + 255) / 256); if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, workspace, dW, n, q.P);
+    return wmh_check_launch("wgrad_reduce_kernel");
+}

@@ -1,0 +1,432 @@
+// train_kernels.hip -- backward-pass and optimizer kernels of the nnU-Net training step
+// (nnUNetTrainerV2.run_iteration [nnU-Net, not in tree]; reference call sites
+// deepwmh/pipeline/DCNN_multistage.py:292-309,501-520): Dice+CE loss (deep supervision), segmentation-head and
+// InstanceNorm+LeakyReLU backward, zero-insert upsampling (stride-2 data gradient), transposed-conv backward,
+// gradient-norm clipping and SGD with Nesterov momentum.  Every reduction is a fixed-order tree (no atomics):
+// a training step is bit-reproducible.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "wmh_common.h"
+
+static inline unsigned cdivu(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 256 threads of a block in a fixed order; result valid in every thread
+__device__ __forceinline__ double block_sum_256(double v, double* sh /*[4]*/) {
+    for (int m = 1; m < 64; m <<= 1) v += shfl_xor_d(v, m);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// =================================================================================================
+// Dice + cross-entropy loss at one deep-supervision scale  (DC_and_CE_loss: batch dice, do_bg=False)
+// =================================================================================================
+// partial sums per block: [k] sum p_k*y_k, [K+k] sum p_k, [2K+k] sum y_k, [3K] sum -log p_y
+template <int K>
+__global__ __launch_bounds__(256) void loss_partials_kernel(const float* logits, const uint8_t* target, double* part,
+                                                            int N, size_t S) {
+    __shared__ double sh[4];
+    const size_t M = (size_t)N * S;
+    double acc[3 * K + 1];
+#pragma unroll
+    for (int q = 0; q < 3 * K + 1; ++q) acc[q] = 0.0;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < M; idx += (size_t)gridDim.x * 256) {
+        const size_t n = idx / S, v = idx - n * S;
+        float l[K], mx;
+#pragma unroll
+        for (int k = 0; k < K; ++k) l[k] = logits[(n * K + k) * S + v];
+        mx = l[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, l[k]);
+        float e[K], den = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { e[k] = expf(l[k] - mx); den += e[k]; }
+        const int y = target[idx];
+        const float logden = logf(den);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float p = e[k] / den;
+            acc[K + k] += p;
+            if (k == y) { acc[k] += p; acc[2 * K + k] += 1.0; acc[3 * K] += (double)(logden - (l[k] - mx)); }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3 * K + 1; ++q) {
+        const double t = block_sum_256(acc[q], sh);
+        if (threadIdx.x == 0) part[(size_t)blockIdx.x * (3 * K + 1) + q] = t;
+    }
+}
+// coef: [0] ce mean, [1] dice loss, [2+2c] num_c, [3+2c] den_c ; loss_out[0] += weight * (ce + dice)
+template <int K>
+__global__ void loss_finalize_kernel(const double* part, int nblk, double M, float smooth, double weight, double* coef,
+                                     double* loss_out) {
+    __shared__ double tot[3 * K + 1];
+    const int q = threadIdx.x;
+    if (q < 3 * K + 1) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += part[(size_t)b * (3 * K + 1) + q];     // fixed order
+        tot[q] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ce = tot[3 * K] / M;
+        double dc = 0.0;
+        for (int c = 0; c < K; ++c) {
+            const double tp = tot[c], fp = tot[K + c] - tp, fn = tot[2 * K + c] - tp;
+            const double num = 2 * tp + smooth, den = 2 * tp + fp + fn + smooth + 1e-8;
+            coef[2 + 2 * c] = num; coef[3 + 2 * c] = den;
+            if (c >= 1) dc += num / den;
+        }
+        dc = -dc / (K - 1);
+        coef[0] = ce; coef[1] = dc;
+        loss_out[0] += weight * (ce + dc);
+    }
+}
+template <int K>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* logits, const uint8_t* target, const double* coef,
+                                                       float weight, float* dlogits, int N, size_t S) {
+    const size_t M = (size_t)N * S;
+    float gc[K];      // d(dice loss)/d p_c for y_c = 0 and extra term for y_c = 1
+    float gy[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+        const double num = coef[2 + 2 * c], den = coef[3 + 2 * c];
+        // d(num/den)/dp = (2y*den - num)/den^2 ; loss = -(1/(K-1)) sum_{c>=1}
+        gc[c] = c >= 1 ? (float)(num / (den * den) / (K - 1)) : 0.f;                  // y = 0:  -( -num/den^2 )/(K-1)
+        gy[c] = c >= 1 ? (float)(-(2.0 * den - num) / (den * den) / (K - 1)) : 0.f;   // y = 1
+    }
+    const float invM = (float)(1.0 / (double)M);
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < M; idx += (size_t)gridDim.x * 256) {
+        const size_t n = idx / S, v = idx - n * S;
+        float l[K], mx;
+#pragma unroll
+        for (int k = 0; k < K; ++k) l[k] = logits[(n * K + k) * S + v];
+        mx = l[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, l[k]);
+        float p[K], den = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { p[k] = expf(l[k] - mx); den += p[k]; }
+        const int y = target[idx];
+        float g[K], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { p[k] /= den; g[k] = (k == y) ? gy[k] : gc[k]; dot += g[k] * p[k]; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float ce = (p[k] - (k == y ? 1.f : 0.f)) * invM;
+            dlogits[(n * K + k) * S + v] = weight * (ce + p[k] * (g[k] - dot));
+        }
+    }
+}
+
+extern "C" int wmh_dice_ce_loss_fwd_bwd(const float* logits, const uint8_t* target, int N, int K, size_t S, float weight,
+                                        float smooth, float* dlogits, double* loss_accum, double* workspace,
+                                        void* stream) {
+    if (!logits || !target || !loss_accum || !workspace || N < 1 || S < 1) return wmh_fail(WMH_EINVAL, "dice_ce_loss: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t M = (size_t)N * S;
+    unsigned nblk = cdivu(M, 256 * 8); if (nblk > 1024) nblk = 1024; if (nblk < 1) nblk = 1;
+    double* coef = workspace;                  // [2 + 2K]
+    double* part = workspace + 16;             // [nblk][3K+1]
+#define LOSS_K(KK)                                                                                                   \
+    hipLaunchKernelGGL((loss_partials_kernel<KK>), dim3(nblk), dim3(256), 0, st, logits, target, part, N, S);         \
+    hipLaunchKernelGGL((loss_finalize_kernel<KK>), dim3(1), dim3(64), 0, st, part, (int)nblk, (double)M, smooth,       \
+                       (double)weight, coef, loss_accum);                                                            \
+    if (dlogits) hipLaunchKernelGGL((loss_bwd_kernel<KK>), dim3(cdivu(M, 256 * 4) > 4096 ? 4096 : cdivu(M, 256 * 4)), \
+                                    dim3(256), 0, st, logits, target, coef, weight, dlogits, N, S)
+    switch (K) {
+        case 2: LOSS_K(2); break;
+        case 3: LOSS_K(3); break;
+        case 4: LOSS_K(4); break;
+        default: return wmh_fail(WMH_EINVAL, "dice_ce_loss: K must be 2, 3 or 4");
+    }
+#undef LOSS_K
+    return wmh_check_launch("dice_ce_loss kernels");
+}
+extern "C" size_t wmh_dice_ce_loss_workspace_doubles(void) { return 16 + 1024 * 13; }
+
+// =================================================================================================
+// InstanceNorm + LeakyReLU backward (with the segmentation head folded in)
+// =================================================================================================
+// Upstream gradient of the activated tensor a = lrelu(z), z = y*scale+shift:
+//   dA = g1 + g2 + sum_k wseg[k][c] * dl[k]      (any of the three sources may be absent)
+// reduce: per (n,c)  sums[0] = sum dz, sums[1] = sum dz*xhat, sums[2+k] = sum a*dl[k]   (dz = dA * lrelu'(z))
+// apply : dy = gamma*rstd * (dz - sums[0]/S - xhat * sums[1]/S)
+struct BwdSrc {
+    const float* g1; const float* g2; const float* dl; const float* wseg; int K;
+};
+__device__ __forceinline__ float upstream(const BwdSrc& s, size_t nc_off, size_t n, int c, int C, size_t S, size_t v) {
+    float d = 0.f;
+    if (s.g1) d += s.g1[nc_off + v];
+    if (s.g2) d += s.g2[nc_off + v];
+    if (s.dl) for (int k = 0; k < s.K; ++k) d = fmaf(s.wseg[k * C + c], s.dl[(n * s.K + k) * S + v], d);
+    return d;
+}
+__global__ __launch_bounds__(256) void in_lrelu_bwd_reduce_kernel(const float* y, const float* ss, const float* mr,
+                                                                  BwdSrc src, double* sums, int C, size_t S, float slope,
+                                                                  int nq) {
+    __shared__ double sh[4];
+    const size_t nc = blockIdx.x, n = nc / C;
+    const int c = (int)(nc % C);
+    const float sc = ss[2 * nc], shf = ss[2 * nc + 1], mean = mr[2 * nc], rstd = mr[2 * nc + 1];
+    const float* yp = y + nc * S;
+    double a0 = 0.0, a1 = 0.0, ak[4] = {0.0, 0.0, 0.0, 0.0};
+    for (size_t v = threadIdx.x; v < S; v += 256) {
+        const float yv = yp[v];
+        const float z = fmaf(yv, sc, shf);
+        const float dA = upstream(src, nc * S, n, c, C, S, v);
+        const float dz = z > 0.f ? dA : dA * slope;
+        const float xh = (yv - mean) * rstd;
+        a0 += dz; a1 += (double)dz * xh;
+        if (src.dl) {
+            const float act = z > 0.f ? z : z * slope;
+            for (int k = 0; k < src.K; ++k) ak[k] += (double)act * src.dl[(n * src.K + k) * S + v];
+        }
+    }
+    double t = block_sum_256(a0, sh); if (threadIdx.x == 0) sums[nc * nq + 0] = t;
+    t = block_sum_256(a1, sh);        if (threadIdx.x == 0) sums[nc * nq + 1] = t;
+    for (int k = 0; k < src.K && src.dl; ++k) { t = block_sum_256(ak[k], sh); if (threadIdx.x == 0) sums[nc * nq + 2 + k] = t; }
+}
+__global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const float* y, const float* ss, const float* mr,
+                                                                 const float* gamma, BwdSrc src, const double* sums,
+                                                                 float* dy, int C, size_t S, float slope, int nq) {
+    const size_t nc = blockIdx.y, n = nc / C;
+    const int c = (int)(nc % C);
+    const float sc = ss[2 * nc], shf = ss[2 * nc + 1], mean = mr[2 * nc], rstd = mr[2 * nc + 1];
+    const float m1 = (float)(sums[nc * nq] / (double)S), m2 = (float)(sums[nc * nq + 1] / (double)S);
+    const float gr = (gamma ? gamma[c] : 1.f) * rstd;
+    const float* yp = y + nc * S;
+    float* op = dy + nc * S;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < S; v += (size_t)gridDim.x * 256) {
+        const float yv = yp[v];
+        const float z = fmaf(yv, sc, shf);
+        const float dA = upstream(src, nc * S, n, c, C, S, v);
+        const float dz = z > 0.f ? dA : dA * slope;
+        const float xh = (yv - mean) * rstd;
+        op[v] = gr * (dz - m1 - xh * m2);
+    }
+}
+// dgamma[c] = sum_n sums[n,c,1], dbeta[c] = sum_n sums[n,c,0], dwseg[k][c] = sum_n sums[n,c,2+k]  (accumulated with +=)
+__global__ void in_param_grads_kernel(const double* sums, int N, int C, int nq, int K, float* dgamma, float* dbeta,
+                                      float* dwseg) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double g = 0.0, b = 0.0, w[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int n = 0; n < N; ++n) {
+        const double* s = sums + ((size_t)n * C + c) * nq;
+        b += s[0]; g += s[1];
+        for (int k = 0; k < K; ++k) w[k] += s[2 + k];
+    }
+    if (dgamma) dgamma[c] = (float)g;
+    if (dbeta) dbeta[c] = (float)b;
+    if (dwseg) for (int k = 0; k < K; ++k) dwseg[k * C + c] = (float)w[k];
+}
+
+extern "C" int wmh_in_lrelu_bwd(const float* y, const float* ss, const float* mean_rstd, const float* gamma,
+                                const float* g1, const float* g2, const float* dlogits, const float* wseg, int K,
+                                float* dy, float* dgamma, float* dbeta, float* dwseg, double* sums, int N, int C,
+                                size_t S, float slope, void* stream) {
+    if (!y || !ss || !mean_rstd || !dy || !sums || N < 1 || C < 1 || S < 1 || K > 4 || (!g1 && !g2 && !dlogits))
+        return wmh_fail(WMH_EINVAL, "in_lrelu_bwd: bad args");
+    if (dlogits && (!wseg || K < 1)) return wmh_fail(WMH_EINVAL, "in_lrelu_bwd: head gradient without head weights");
+    hipStream_t st = (hipStream_t)stream;
+    BwdSrc src{g1, g2, dlogits, wseg, dlogits ? K : 0};
+    const int nq = 2 + 4;
+    hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, dim3((unsigned)((size_t)N * C)), dim3(256), 0, st, y, ss, mean_rstd, src,
+                       sums, C, S, slope, nq);
+    unsigned gx = cdivu(S, 256 * 4); if (gx > 512) gx = 512; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel, dim3(gx, (unsigned)((size_t)N * C)), dim3(256), 0, st, y, ss, mean_rstd,
+                       gamma, src, sums, dy, C, S, slope, nq);
+    hipLaunchKernelGGL(in_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sums, N, C, nq, src.K, dgamma, dbeta,
+                       dlogits ? dwseg : nullptr);
+    return wmh_check_launch("in_lrelu_bwd kernels");
+}
+
+// per-channel sum over (n, spatial): the conv bias gradient  db[c] = sum_{n,v} dy[n,c,v]
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* x, float* out, int N, int C, size_t S) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    double a = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const float* p = x + ((size_t)n * C + c) * S;
+        for (size_t v = threadIdx.x; v < S; v += 256) a += p[v];
+    }
+    const double t = block_sum_256(a, sh);
+    if (threadIdx.x == 0) out[c] = (float)t;
+}
+extern "C" int wmh_channel_sum(const float* x, float* out, int N, int C, size_t S, void* stream) {
+    if (!x || !out || N < 1 || C < 1 || S < 1) return wmh_fail(WMH_EINVAL, "channel_sum: bad args");
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, S);
+    return wmh_check_launch("channel_sum_kernel");
+}
+
+// =================================================================================================
+// zero-insert upsampling: up[n,c,2z,2y,2x] = dy[n,c,z,y,x], 0 elsewhere; up has the stride-2 conv's INPUT size
+// (data gradient of a stride-2 3x3x3 conv = stride-1 conv of `up` with the flipped, transposed kernel)
+// =================================================================================================
+__global__ __launch_bounds__(256) void upsample_zero2_kernel(const float* dy, float* up, int Do, int Ho, int Wo, int D,
+                                                             int H, int W) {
+    const size_t nc = blockIdx.y, S = (size_t)D * H * W;
+    const float* ip = dy + nc * Do * Ho * Wo;
+    float* op = up + nc * S;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < S; v += (size_t)gridDim.x * 256) {
+        const int x = (int)(v % W), yy = (int)((v / W) % H), z = (int)(v / ((size_t)W * H));
+        const bool on = !((x | yy | z) & 1);
+        op[v] = on ? ip[((size_t)(z >> 1) * Ho + (yy >> 1)) * Wo + (x >> 1)] : 0.f;
+    }
+}
+extern "C" int wmh_upsample_zero2(const float* dy, float* up, int N, int C, int Do, int Ho, int Wo, int D, int H, int W,
+                                  void* stream) {
+    if (!dy || !up || (D - 1) / 2 + 1 != Do || (H - 1) / 2 + 1 != Ho || (W - 1) / 2 + 1 != Wo)
+        return wmh_fail(WMH_EINVAL, "upsample_zero2: bad args");
+    const size_t S = (size_t)D * H * W;
+    unsigned gx = cdivu(S, 256 * 4); if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(upsample_zero2_kernel, dim3(gx, (unsigned)((size_t)N * C)), dim3(256), 0, (hipStream_t)stream, dy, up,
+                       Do, Ho, Wo, D, H, W);
+    return wmh_check_launch("upsample_zero2_kernel");
+}
+
+// =================================================================================================
+// ConvTranspose3d(k2,s2) backward (vector ALU v1; the forward is on the matrix cores)
+//   dX'[n,ci,d,h,w] = sum_{co,t} dY[n,co,2d+i,2h+j,2w+k] * W[ci,co,t]       (gradient of the ACTIVATED input x')
+//   dW[ci,co,t]     = sum_{n,d,h,w} x'[n,ci,d,h,w] * dY[n,co,2d+i,2h+j,2w+k]
+// =================================================================================================
+template <int CIT>
+__global__ __launch_bounds__(256) void convT_bwd_data_kernel(const float* dY, const float* w, float* dX, int Cin, int Cout,
+                                                             int D, int H, int W) {
+    const int n = blockIdx.z, ci0 = blockIdx.y * CIT;
+    const size_t DHW = (size_t)D * H * W, v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= DHW) return;
+    const int wq = (int)(v % W), hq = (int)((v / W) % H), dq = (int)(v / ((size_t)W * H));
+    const int H2 = 2 * H, W2 = 2 * W;
+    float acc[CIT];
+#pragma unroll
+    for (int c = 0; c < CIT; ++c) acc[c] = 0.f;
+    for (int co = 0; co < Cout; ++co) {
+        const float* yp = dY + ((size_t)n * Cout + co) * 8 * DHW + ((size_t)(2 * dq) * H2 + 2 * hq) * W2 + 2 * wq;
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const float2 t = *reinterpret_cast<const float2*>(yp + ((size_t)i * H2 + jj) * W2);
+                g[i * 4 + jj * 2] = t.x; g[i * 4 + jj * 2 + 1] = t.y;
+            }
+#pragma unroll
+        for (int c = 0; c < CIT; ++c) {
+            if (ci0 + c < Cin) {
+                const float* wp = w + ((size_t)(ci0 + c) * Cout + co) * 8;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[c] = fmaf(g[t], wp[t], acc[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CIT; ++c)
+        if (ci0 + c < Cin) dX[((size_t)n * Cin + ci0 + c) * DHW + v] = acc[c];
+}
+// one block per (ci, co): reduces over n and space in a fixed order
+__global__ __launch_bounds__(256) void convT_bwd_weight_kernel(const float* x, const float* ss, const float* dY, float* dW,
+                                                               int N, int Cin, int Cout, int D, int H, int W,
+                                                               float slope) {
+    __shared__ double sh[4];
+    const int co = blockIdx.x, ci = blockIdx.y;
+    const size_t DHW = (size_t)D * H * W;
+    const int H2 = 2 * H, W2 = 2 * W;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int n = 0; n < N; ++n) {
+        const float* xp = x + ((size_t)n * Cin + ci) * DHW;
+        const float sc = ss ? ss[2 * ((size_t)n * Cin + ci)] : 1.f, shf = ss ? ss[2 * ((size_t)n * Cin + ci) + 1] : 0.f;
+        const float* yb = dY + ((size_t)n * Cout + co) * 8 * DHW;
+        for (size_t v = threadIdx.x; v < DHW; v += 256) {
+            const int wq = (int)(v % W), hq = (int)((v / W) % H), dq = (int)(v / ((size_t)W * H));
+            float xv = xp[v];
+            if (ss) xv = wmh_lrelu(fmaf(xv, sc, shf), slope);
+            const float* yp = yb + ((size_t)(2 * dq) * H2 + 2 * hq) * W2 + 2 * wq;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float2 t = *reinterpret_cast<const float2*>(yp + ((size_t)i * H2 + jj) * W2);
+                    acc[i * 4 + jj * 2] += (double)xv * t.x; acc[i * 4 + jj * 2 + 1] += (double)xv * t.y;
+                }
+        }
+    }
+    for (int t = 0; t < 8; ++t) {
+        const double s = block_sum_256(acc[t], sh);
+        if (threadIdx.x == 0) dW[((size_t)ci * Cout + co) * 8 + t] = (float)s;
+    }
+}
+extern "C" int wmh_convtranspose3d_k2s2_bwd(const float* x, const float* ss, const float* w, const float* dY, float* dX,
+                                            float* dW, int N, int Cin, int Cout, int D, int H, int W, float slope,
+                                            void* stream) {
+    if (!w || !dY || N < 1 || Cin < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "convtranspose3d_k2s2_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t DHW = (size_t)D * H * W;
+    if (dX) {
+        constexpr int CIT = 8;
+        hipLaunchKernelGGL((convT_bwd_data_kernel<CIT>), dim3(cdivu(DHW, 256), (Cin + CIT - 1) / CIT, N), dim3(256), 0, st, dY,
+                           w, dX, Cin, Cout, D, H, W);
+    }
+    if (dW) {
+        if (!x) return wmh_fail(WMH_EINVAL, "convtranspose3d_k2s2_bwd: dW needs x");
+        hipLaunchKernelGGL(convT_bwd_weight_kernel, dim3(Cout, Cin), dim3(256), 0, st, x, ss, dY, dW, N, Cin, Cout, D, H, W, slope);
+    }
+    return wmh_check_launch("convT_bwd kernels");
+}
+
+// =================================================================================================
+// gradient-norm clipping (torch.nn.utils.clip_grad_norm_) and SGD with Nesterov momentum + weight decay
+// =================================================================================================
+__global__ __launch_bounds__(256) void sqnorm_partials_kernel(const float* g, size_t n, double* part) {
+    __shared__ double sh[4];
+    double a = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a += (double)g[i] * g[i];
+    const double t = block_sum_256(a, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+// out[0] = total norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))
+__global__ void clip_coef_kernel(const double* part, int nblk, float max_norm, float* out) {
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += part[b];
+        const double norm = sqrt(s);
+        const double coef = max_norm / (norm + 1e-6);
+        out[0] = (float)norm;
+        out[1] = (float)(coef < 1.0 ? coef : 1.0);
+    }
+}
+extern "C" int wmh_grad_clip_coef(const float* grads, size_t n, float max_norm, float* out2, double* workspace, void* stream) {
+    if (!grads || !out2 || !workspace || n < 1) return wmh_fail(WMH_EINVAL, "grad_clip_coef: bad args");
+    unsigned nblk = cdivu(n, 256 * 16); if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(sqnorm_partials_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, grads, n, workspace);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, (int)nblk, max_norm, out2);
+    return wmh_check_launch("grad_clip kernels");
+}
+// torch.optim.SGD(nesterov=True): g = clip*grad + wd*p ; buf = first ? g : mom*buf + g ; p -= lr * (g + mom*buf)
+__global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* p, const float* g, float* m, size_t n, float lr, float mom,
+                                                           float wd, const float* clip, int first) {
+    const float cs = clip ? clip[1] : 1.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float pv = p[i];
+        float gv = g[i] * cs;
+        gv = fmaf(wd, pv, gv);
+        const float b = first ? gv : fmaf(mom, m[i], gv);
+        m[i] = b;
+        p[i] = pv - lr * fmaf(mom, b, gv);
+    }
+}
+extern "C" int wmh_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, size_t n, float lr,
+                                     float momentum, float weight_decay, const float* clip, int first_step, void* stream) {
+    if (!params || !grads || !momentum_buf || n < 1) return wmh_fail(WMH_EINVAL, "sgd_nesterov_step: bad args");
+    unsigned nblk = cdivu(n, 256 * 4); if (nblk > 4096) nblk = 4096;
+    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, n, lr,
+                       momentum, weight_decay, clip, first_step);
+    return wmh_check_launch("sgd_nesterov_kernel");
+}

@@ -146,6 +146,47 @@ int wmh_finalize_argmax(const float* agg, const float* cnt, float* prob, uint8_t
                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training step [nnU-Net nnUNetTrainerV2.run_iteration, loss_functions/dice_loss.py DC_and_CE_loss,
+ * deep_supervision.py MultipleOutputLoss2; torch.optim.SGD(nesterov), clip_grad_norm_; not in tree].
+ * Reference call sites: deepwmh/pipeline/DCNN_multistage.py:292-309,501-520 (`nnUNet_train ...`).
+ * All reductions are fixed-order trees (no atomics): a step is bit-reproducible.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Device-side weight repack (weights change every step): w = torch layout [Cout][Cin_total][27] in HBM, input
+ * channels [ci_off, ci_off+ci_cnt).  mode 0: forward image (ci_cnt -> Cout).  mode 1: image of the data-gradient
+ * convolution (Cout -> ci_cnt; transposed, taps flipped), to be run through wmh_conv3d_k3_fwd on dy. */
+int wmh_conv3d_k3_pack_weights_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt,
+                                      int mode, float* wf, void* stream);
+/* dW[Cout][C0+C1][27] = sum over (n, voxel) of dy * lrelu(instnorm(x)) (transform on load as in the forward). */
+size_t wmh_conv3d_k3_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W, int stride);
+int wmh_conv3d_k3_wgrad(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
+                        const float* dy, float* dW, float* workspace, int N, int D, int H, int W, int Cout,
+                        int stride, float lrelu_slope, void* stream);
+/* up[n,c,2z,2y,2x] = dy[n,c,z,y,x], zero elsewhere (up has the stride-2 conv's input size D,H,W). */
+int wmh_upsample_zero2(const float* dy, float* up, int N, int C, int Do, int Ho, int Wo, int D, int H, int W,
+                       void* stream);
+/* Dice+CE at one deep-supervision scale: loss_accum[0] += weight*(CE + Dice); dlogits (optional) = weight * dLoss/dlogits.
+ * target = uint8 labels [N,S]; workspace = wmh_dice_ce_loss_workspace_doubles() doubles. */
+size_t wmh_dice_ce_loss_workspace_doubles(void);
+int wmh_dice_ce_loss_fwd_bwd(const float* logits, const uint8_t* target, int N, int K, size_t S, float weight,
+                             float smooth, float* dlogits, double* loss_accum, double* workspace, void* stream);
+/* Backward of a = lrelu(instnorm(y)) given dA = g1 + g2 + wseg^T dlogits (any subset): writes dy and the parameter
+ * gradients dgamma[C], dbeta[C], dwseg[K][C].  sums = scratch of N*C*6 doubles. */
+int wmh_in_lrelu_bwd(const float* y, const float* ss, const float* mean_rstd, const float* gamma, const float* g1,
+                     const float* g2, const float* dlogits, const float* wseg, int K, float* dy, float* dgamma,
+                     float* dbeta, float* dwseg, double* sums, int N, int C, size_t S, float slope, void* stream);
+/* out[c] = sum over (n, voxels) of x[n,c,:] (conv bias gradient). */
+int wmh_channel_sum(const float* x, float* out, int N, int C, size_t S, void* stream);
+/* ConvTranspose3d(k2,s2) backward: dX (gradient of the activated input; may be NULL) and dW (may be NULL). */
+int wmh_convtranspose3d_k2s2_bwd(const float* x, const float* ss, const float* w, const float* dY, float* dX,
+                                 float* dW, int N, int Cin, int Cout, int D, int H, int W, float slope, void* stream);
+/* out2[0] = ||grads||_2, out2[1] = min(1, max_norm/(norm+1e-6)); workspace = 1024 doubles. */
+int wmh_grad_clip_coef(const float* grads, size_t n, float max_norm, float* out2, double* workspace, void* stream);
+/* torch.optim.SGD(momentum, nesterov=True, weight_decay) on a flat arena; clip = out2 of wmh_grad_clip_coef or NULL. */
+int wmh_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, size_t n, float lr, float momentum,
+                          float weight_decay, const float* clip, int first_step, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Self-test helper: D = A(32x2) * B(2x32) through one v_mfma_f32_32x32x2_f32, used by the GPU
  * tests to pin the fragment layout this library assumes (a: [32][2], b: [2][32], d: [32][32]).
  * ------------------------------------------------------------------------------------------- */

@@ -1,0 +1,218 @@
+"""GPU parity tests of the training-step kernels against torch autograd (CPU fp32) of the same ops."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+SLOPE = 0.01
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from deepwmh_amd import _lib
+    return _lib.load()
+
+
+def P(t):
+    from deepwmh_amd import _lib
+    return _lib.ptr(t)
+
+
+def check(rc, what=''):
+    from deepwmh_amd import _lib
+    return _lib.check(rc, what)
+
+
+def _act(x, ss):
+    if ss is None:
+        return x
+    return F.leaky_relu(x * ss[..., 0][:, :, None, None, None] + ss[..., 1][:, :, None, None, None], SLOPE)
+
+
+def _run_conv(lib, cfg, x, ss, wf, Cout, stride, N, D, H, W):
+    Cin = x.shape[1]
+    Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.full((N, Cout, Do, Ho, Wo), float('nan'), device='cuda')
+    nws = lib.wmh_conv3d_k3_workspace_floats(cfg, Cin, N, D, H, W, Cout, stride)
+    ws = torch.empty(nws, device='cuda') if nws else None
+    check(lib.wmh_conv3d_k3_fwd(cfg, P(x), P(ss), Cin, None, None, 0, P(wf), None, P(y), None, P(ws), N, D, H, W, Cout, stride,
+                                SLOPE, None), 'conv fwd')
+    return y
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 16, 8, 8, 32, 1), (1, 6, 40, 5, 9, 33, 1), (2, 16, 8, 8, 8, 8, 1), (1, 32, 32, 4, 4, 4, 1),
+                                   (1, 8, 16, 16, 16, 32, 2), (2, 16, 32, 8, 8, 16, 2), (1, 12, 8, 9, 7, 13, 2)])
+def test_device_pack_and_data_gradient(lib, shape):
+    # forward image packed on the device == host pack; data gradient = forward kernel on dy with the mode-1 image
+    N, Cin, Cout, D, H, W, s = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, Cin, D, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.1
+    y = F.conv3d(x, w, None, stride=s, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    cfg = lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, s)
+    wd = w.cuda()
+    nf = lib.wmh_conv3d_k3_packed_floats(cfg, Cin, Cout)
+    wf_dev = torch.full((nf,), float('nan'), device='cuda')
+    check(lib.wmh_conv3d_k3_pack_weights_device(cfg, P(wd), Cin, Cout, 0, Cin, 0, P(wf_dev), None), 'pack0')
+    wf_host = np.empty(nf, np.float32)
+    wn = w.numpy()
+    lib.wmh_conv3d_k3_pack_weights(cfg, wn.ctypes.data_as(C.c_void_p), Cin, Cout, wf_host.ctypes.data_as(C.c_void_p))
+    torch.cuda.synchronize()
+    assert np.array_equal(wf_dev.cpu().numpy(), wf_host)
+    # data gradient
+    dyd = dy.cuda()
+    Do, Ho, Wo = y.shape[2:]
+    if s == 2:
+        up = torch.full((N, Cout, D, H, W), float('nan'), device='cuda')
+        check(lib.wmh_upsample_zero2(P(dyd), P(up), N, Cout, Do, Ho, Wo, D, H, W, None), 'up')
+        src = up
+    else:
+        src = dyd
+    cfgb = lib.wmh_conv3d_k3_config(Cout, Cin, D, H, W, 1)
+    wfb = torch.full((lib.wmh_conv3d_k3_packed_floats(cfgb, Cout, Cin),), float('nan'), device='cuda')
+    check(lib.wmh_conv3d_k3_pack_weights_device(cfgb, P(wd), Cin, Cout, 0, Cin, 1, P(wfb), None), 'pack1')
+    dx = _run_conv(lib, cfgb, src, None, wfb, Cin, 1, N, D, H, W)
+    torch.cuda.synchronize()
+    err = float((dx.cpu() - x.grad).abs().max())
+    assert err <= 1e-5 * (1 + float(x.grad.abs().max())), err
+
+
+WG_CASES = [(2, 8, 0, 16, 8, 8, 32, 1, True, False), (1, 6, 0, 40, 5, 9, 33, 1, False, False), (2, 4, 12, 8, 4, 8, 32, 1, True, True),
+            (2, 16, 0, 8, 8, 8, 16, 1, True, False), (3, 32, 0, 32, 8, 8, 8, 1, True, False), (5, 40, 0, 36, 4, 4, 4, 1, True, False),
+            (1, 8, 0, 16, 16, 16, 64, 2, True, False), (2, 16, 0, 32, 8, 8, 32, 2, False, False), (1, 12, 0, 8, 9, 7, 13, 2, True, False),
+            (1, 1, 0, 8, 8, 8, 32, 1, False, False), (1, 64, 0, 64, 4, 8, 32, 1, True, False)]
+
+
+@pytest.mark.parametrize('case', WG_CASES, ids=[str(c) for c in WG_CASES])
+def test_conv3d_wgrad(lib, case):
+    N, C0, C1, Cout, D, H, W, s, use0, use1 = case
+    g = torch.Generator().manual_seed(31)
+    Cin = C0 + C1
+    x0 = torch.randn(N, C0, D, H, W, generator=g)
+    x1 = torch.randn(N, C1, D, H, W, generator=g) if C1 else None
+    ss0 = torch.stack([0.5 + torch.rand(N, C0, generator=g), 0.3 * torch.randn(N, C0, generator=g)], -1) if use0 else None
+    ss1 = torch.stack([0.5 + torch.rand(N, C1, generator=g), 0.3 * torch.randn(N, C1, generator=g)], -1) if use1 else None
+    xin = _act(x0, ss0)
+    if C1:
+        xin = torch.cat((xin, _act(x1, ss1)), 1)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.1).requires_grad_()
+    y = F.conv3d(xin, w, None, stride=s, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    d = [t.cuda() if t is not None else None for t in (x0, ss0, x1, ss1)]
+    dyd = dy.cuda()
+    dW = torch.full((Cout, Cin, 27), float('nan'), device='cuda')
+    ws = torch.empty(lib.wmh_conv3d_k3_wgrad_workspace_floats(Cin, Cout, N, D, H, W, s), device='cuda')
+    check(lib.wmh_conv3d_k3_wgrad(P(d[0]), P(d[1]), C0, P(d[2]), P(d[3]), C1, P(dyd), P(dW), P(ws), N, D, H, W, Cout, s, SLOPE, None), 'wgrad')
+    torch.cuda.synchronize()
+    got = dW.cpu().view(Cout, Cin, 3, 3, 3)
+    assert not torch.isnan(got).any()
+    err = float((got - w.grad).abs().max())
+    assert err <= 2e-5 * (1 + float(w.grad.abs().max())), err
+
+
+@pytest.mark.parametrize('K,shape', [(2, (2, 9, 10, 11)), (3, (1, 16, 16, 16)), (2, (3, 4, 4, 4))])
+def test_dice_ce_loss(lib, K, shape):
+    from oracle.training import dc_and_ce_loss
+    g = torch.Generator().manual_seed(41)
+    N = shape[0]
+    sp = shape[1:]
+    logits = (torch.randn(N, K, *sp, generator=g) * 2).requires_grad_()
+    target = torch.randint(0, K, (N, 1) + tuple(sp), generator=g)
+    wgt = 0.2667
+    loss = wgt * dc_and_ce_loss(logits, target.float())
+    loss.backward()
+    S = int(np.prod(sp))
+    ld, td = logits.detach().cuda(), target.to(torch.uint8).cuda()
+    dl = torch.full((N, K, S), float('nan'), device='cuda')
+    acc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    ws = torch.empty(lib.wmh_dice_ce_loss_workspace_doubles(), dtype=torch.float64, device='cuda')
+    check(lib.wmh_dice_ce_loss_fwd_bwd(P(ld), P(td), N, K, S, wgt, 1e-5, P(dl), P(acc), P(ws), None), 'loss')
+    torch.cuda.synchronize()
+    assert abs(float(acc.cpu()) - float(loss)) <= 1e-5 * (1 + abs(float(loss)))
+    err = float((dl.cpu().view_as(logits) - logits.grad).abs().max())
+    assert err <= 1e-6 + 1e-4 * float(logits.grad.abs().max()), err
+
+
+@pytest.mark.parametrize('with_g1,with_g2,with_head', [(True, False, False), (True, True, False), (False, False, True), (True, False, True)])
+def test_in_lrelu_bwd(lib, with_g1, with_g2, with_head):
+    g = torch.Generator().manual_seed(51)
+    N, Cc, K, sp = 2, 6, 2, (6, 7, 8)
+    S = int(np.prod(sp))
+    y = (torch.randn(N, Cc, *sp, generator=g) * 2 + 0.5).requires_grad_()
+    gamma = (1 + 0.2 * torch.randn(Cc, generator=g)).requires_grad_()
+    beta = (0.1 * torch.randn(Cc, generator=g)).requires_grad_()
+    wseg = torch.randn(K, Cc, generator=g).requires_grad_()
+    a = F.leaky_relu(F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5), SLOPE)
+    g1 = torch.randn(a.shape, generator=g) if with_g1 else None
+    g2 = torch.randn(a.shape, generator=g) if with_g2 else None
+    dl = torch.randn(N, K, *sp, generator=g) if with_head else None
+    obj = 0
+    if with_g1: obj = obj + (a * g1).sum()
+    if with_g2: obj = obj + (a * g2).sum()
+    if with_head: obj = obj + (torch.einsum('kc,ncxyz->nkxyz', wseg, a) * dl).sum()
+    obj.backward()
+    yd = y.detach().cuda()
+    ss = torch.empty(N, Cc, 2, device='cuda'); mr = torch.empty(N, Cc, 2, device='cuda')
+    gd, bd = gamma.detach().cuda(), beta.detach().cuda()
+    check(lib.wmh_instnorm_stats(P(yd), P(gd), P(bd), 1e-5, P(ss), P(mr), N, Cc, S, None), 'stats')
+    dy = torch.full((N, Cc, S), float('nan'), device='cuda')
+    dgam = torch.full((Cc,), float('nan'), device='cuda'); dbet = torch.full((Cc,), float('nan'), device='cuda')
+    dws = torch.full((K, Cc), float('nan'), device='cuda')
+    sums = torch.empty(N * Cc * 6, dtype=torch.float64, device='cuda')
+    g1d = g1.cuda() if with_g1 else None; g2d = g2.cuda() if with_g2 else None
+    dld = dl.cuda() if with_head else None; wd = wseg.detach().cuda()
+    check(lib.wmh_in_lrelu_bwd(P(yd), P(ss), P(mr), P(gd), P(g1d), P(g2d), P(dld), P(wd), K, P(dy), P(dgam), P(dbet), P(dws), P(sums),
+                               N, Cc, S, SLOPE, None), 'in bwd')
+    torch.cuda.synchronize()
+    sc = float(y.grad.abs().max())
+    assert float((dy.cpu().view_as(y) - y.grad).abs().max()) <= 2e-5 * (1 + sc)
+    assert float((dgam.cpu() - gamma.grad).abs().max()) <= 1e-4 * (1 + float(gamma.grad.abs().max()))
+    assert float((dbet.cpu() - beta.grad).abs().max()) <= 1e-4 * (1 + float(beta.grad.abs().max()))
+    if with_head:
+        assert float((dws.cpu() - wseg.grad).abs().max()) <= 1e-4 * (1 + float(wseg.grad.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 8, 4, 4, 4, True), (1, 8, 12, 3, 6, 5, False)])
+def test_convtranspose3d_bwd(lib, shape):
+    N, Cin, Cout, D, H, W, use_ss = shape
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    ss = torch.stack([0.5 + torch.rand(N, Cin, generator=g), 0.3 * torch.randn(N, Cin, generator=g)], -1) if use_ss else None
+    a = _act(x, ss).requires_grad_()
+    w = (torch.randn(Cin, Cout, 2, 2, 2, generator=g) * 0.2).requires_grad_()
+    out = F.conv_transpose3d(a, w, None, stride=2)
+    dY = torch.randn(out.shape, generator=g)
+    out.backward(dY)
+    xd, ssd, wd, dYd = x.cuda(), (ss.cuda() if use_ss else None), w.detach().cuda(), dY.cuda()
+    dX = torch.full((N, Cin, D, H, W), float('nan'), device='cuda'); dW = torch.full((Cin, Cout, 8), float('nan'), device='cuda')
+    check(lib.wmh_convtranspose3d_k2s2_bwd(P(xd), P(ssd), P(wd), P(dYd), P(dX), P(dW), N, Cin, Cout, D, H, W, SLOPE, None), 'convT bwd')
+    torch.cuda.synchronize()
+    assert float((dX.cpu() - a.grad).abs().max()) <= 1e-5 * (1 + float(a.grad.abs().max()))
+    assert float((dW.cpu().view_as(w) - w.grad).abs().max()) <= 2e-5 * (1 + float(w.grad.abs().max()))
+
+
+def test_clip_and_sgd_nesterov(lib):
+    g = torch.Generator().manual_seed(71)
+    n = 100003
+    p = torch.randn(n, generator=g).requires_grad_()
+    opt = torch.optim.SGD([p], 0.01, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    pd = p.detach().clone().cuda(); m = torch.zeros(n, device='cuda')
+    clip = torch.empty(2, device='cuda'); ws = torch.empty(1024, dtype=torch.float64, device='cuda')
+    for step in range(3):
+        gr = torch.randn(n, generator=g) * (0.2 if step == 1 else 0.01)     # step 1 exceeds the clip norm of 12
+        p.grad = gr.clone()
+        norm = float(torch.nn.utils.clip_grad_norm_([p], 12))
+        opt.step()
+        gd = gr.cuda()
+        check(lib.wmh_grad_clip_coef(P(gd), n, 12.0, P(clip), P(ws), None), 'clip')
+        check(lib.wmh_sgd_nesterov_step(P(pd), P(gd), P(m), n, 0.01, 0.99, 3e-5, P(clip), 1 if step == 0 else 0, None), 'sgd')
+        torch.cuda.synchronize()
+        assert abs(float(clip[0].cpu()) - norm) <= 1e-4 * norm
+        assert float((pd.cpu() - p.detach()).abs().max()) <= 1e-6
+    assert float(clip[1].cpu()) == 1.0
