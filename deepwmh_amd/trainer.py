@@ -1,0 +1,348 @@
+"""The nnU-Net training step on the HIP kernels: forward with deep supervision, Dice+CE loss, backward,
+gradient clipping, SGD with Nesterov momentum.
+
+Host-side mirror of `nnUNetTrainerV2.run_iteration` / `initialize_optimizer_and_scheduler` / `maybe_update_lr`
+[nnU-Net, not in tree], i.e. what `nnUNet_train 3d_fullres nnUNetTrainerV2 <id> all ...` runs
+(/root/reference/deepwmh/pipeline/DCNN_multistage.py:292-309,501-520), in fp32 (the reference runs AMP fp16).
+Parameters, gradients and momentum live in three flat HBM arenas (one kernel launch each for clipping and
+the optimizer; one RCCL all-reduce for data parallelism).  Nothing here falls back to torch autograd.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .network import IN_EPS, LRELU_SLOPE
+from .plan import UNetPlan
+
+
+def deep_supervision_weights(num_pool):
+    """nnUNetTrainerV2.initialize: 1/2^i per scale, the lowest resolution masked out, normalised."""
+    w = np.array([1 / (2 ** i) for i in range(num_pool)], dtype=np.float64)
+    if num_pool > 1:
+        w[-1] = 0
+    return w / w.sum()
+
+
+def poly_lr(epoch, max_epochs, initial_lr=1e-2, exponent=0.9):
+    return initial_lr * (1 - epoch / max_epochs) ** exponent
+
+
+class _Conv:
+    def __init__(self, name, cin, cout, stride):
+        self.name, self.cin, self.cout, self.stride = name, cin, cout, stride
+
+
+class UNetTrainer:
+    def __init__(self, plan: UNetPlan, state_dict, device='cuda:0', momentum=0.99, weight_decay=3e-5, clip=12.0):
+        plan.check_supported()
+        self.plan, self.device = plan, torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('UNetTrainer needs a HIP device; there is no CPU path')
+        self.lib = _lib.load()
+        _lib.check(self.lib.wmh_device_check(self.device.index or 0), 'wmh_device_check')
+        self.momentum, self.weight_decay, self.clip = momentum, weight_decay, clip
+        self.K = plan.num_classes
+        self.ds_weights = deep_supervision_weights(plan.num_pool)
+        self.enc = [_Conv(s.name, s.cin, s.cout, s.stride) for s in plan.encoder_convs()]
+        self.dec = []
+        for st in plan.decoder_stages():
+            name, cdown, cskip = st['tu']
+            self.dec.append(dict(tu=name, cdown=cdown, cskip=cskip, seg=st['seg'],
+                                 convs=[_Conv(c.name, c.cin, c.cout, 1) for c in st['convs']]))
+        # ---- flat arenas: upstream parameter order (localization, context, tu, seg_outputs) ------------------
+        order = []
+        for st in self.dec:
+            for c in st['convs']:
+                order += [(c.name + '.conv.weight', (c.cout, c.cin, 3, 3, 3)), (c.name + '.conv.bias', (c.cout,)),
+                          (c.name + '.instnorm.weight', (c.cout,)), (c.name + '.instnorm.bias', (c.cout,))]
+        for c in self.enc:
+            order += [(c.name + '.conv.weight', (c.cout, c.cin, 3, 3, 3)), (c.name + '.conv.bias', (c.cout,)),
+                      (c.name + '.instnorm.weight', (c.cout,)), (c.name + '.instnorm.bias', (c.cout,))]
+        for st in self.dec:
+            order.append((st['tu'] + '.weight', (st['cdown'], st['cskip'], 2, 2, 2)))
+        for st in self.dec:
+            order.append((st['seg'] + '.weight', (self.K, st['cskip'], 1, 1, 1)))
+        self.param_order = order
+        sizes = [int(np.prod(s)) for _, s in order]
+        offs = np.concatenate([[0], np.cumsum([(n + 3) // 4 * 4 for n in sizes])])       # 16-byte aligned views
+        self.nparams = int(offs[-1])
+        dev = self.device
+        self.params = torch.zeros(self.nparams, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.nparams, dtype=torch.float32, device=dev)
+        self.mom = torch.zeros(self.nparams, dtype=torch.float32, device=dev)
+        self.p, self.g = {}, {}
+        for (name, shape), o, n in zip(order, offs[:-1], sizes):
+            self.p[name] = self.params[int(o):int(o) + n].view(*shape)
+            self.g[name] = self.grads[int(o):int(o) + n].view(*shape)
+        self.load_state_dict(state_dict)
+        self.first_step = True
+        self._bufs, self._packed, self._version = {}, {}, 0
+        self.clip_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.loss_acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.ws_d = torch.empty(max(self.lib.wmh_dice_ce_loss_workspace_doubles(), 1024), dtype=torch.float64, device=dev)
+
+    # ---- parameters --------------------------------------------------------------------------------------------
+    def load_state_dict(self, sd):
+        for name, shape in self.param_order:
+            v = sd[name]
+            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            assert tuple(v.shape) == tuple(shape), (name, v.shape, shape)
+            self.p[name].copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)))
+        self._version = getattr(self, '_version', 0) + 1
+
+    def state_dict(self):
+        return OrderedDict((name, self.p[name].detach().cpu().numpy().copy()) for name, _ in self.param_order)
+
+    def momentum_state(self):
+        return self.mom.detach().cpu().numpy().copy()
+
+    # ---- plumbing -----------------------------------------------------------------------------------------------
+    def _buf(self, key, shape, dtype=torch.float32):
+        n = int(np.prod(shape))
+        t = self._bufs.get(key)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t[:n].view(*shape)
+
+    @staticmethod
+    def _st():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _pack(self, conv, cfg, mode, ci_off, ci_cnt):
+        """Fragment-major weight image for the current parameters (repacked on the device once per step)."""
+        key = (conv.name, cfg, mode, ci_off, ci_cnt)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == self._version:
+            return hit[1]
+        ecin, ecout = (ci_cnt, conv.cout) if mode == 0 else (conv.cout, ci_cnt)
+        n = self.lib.wmh_conv3d_k3_packed_floats(cfg, ecin, ecout)
+        wf = hit[1] if hit is not None else torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.wmh_conv3d_k3_pack_weights_device(cfg, _lib.ptr(self.p[conv.name + '.conv.weight']), conv.cin,
+                                                              conv.cout, ci_off, ci_cnt, mode, _lib.ptr(wf), self._st()),
+                   'wmh_conv3d_k3_pack_weights_device')
+        self._packed[key] = (self._version, wf)
+        return wf
+
+    def _run_conv(self, key, cfg, x0, ss0, x1, ss1, wf, bias, cout, stride, want_stats):
+        N, C0, D, H, W = x0.shape
+        C1 = 0 if x1 is None else x1.shape[1]
+        Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = self._buf(key + '.y', (N, cout, Do, Ho, Wo))
+        part, npart = None, 0
+        if want_stats:
+            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials(cfg, N, Do, Ho, Wo), 'num_partials')
+            part = self._buf(key + '.part', (N, cout, npart, 4))
+        nws = self.lib.wmh_conv3d_k3_workspace_floats(cfg, C0 + C1, N, D, H, W, cout, stride)
+        ws = self._buf('splitk.ws', (nws,)) if nws else None
+        _lib.check(self.lib.wmh_conv3d_k3_fwd(cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wf),
+                                              _lib.ptr(bias), _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws), N, D, H, W, cout, stride,
+                                              LRELU_SLOPE, self._st()), 'wmh_conv3d_k3_fwd')
+        return y, part, npart
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def _conv_fwd(self, key, conv, x0, ss0, x1=None, ss1=None):
+        N, _, D, H, W = x0.shape
+        cfg = _lib.check(self.lib.wmh_conv3d_k3_config(conv.cin, conv.cout, D, H, W, conv.stride), 'config')
+        wf = self._pack(conv, cfg, 0, 0, conv.cin)
+        y, part, npart = self._run_conv(key, cfg, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout,
+                                        conv.stride, True)
+        ss = self._buf(key + '.ss', (N, conv.cout, 2))
+        mr = self._buf(key + '.mr', (N, conv.cout, 2))
+        _lib.check(self.lib.wmh_instnorm_finalize(_lib.ptr(part), npart, _lib.ptr(self.p[conv.name + '.instnorm.weight']),
+                                                  _lib.ptr(self.p[conv.name + '.instnorm.bias']), IN_EPS, _lib.ptr(ss),
+                                                  _lib.ptr(mr), N, conv.cout, self._st()), 'instnorm_finalize')
+        return dict(key=key, conv=conv, x0=x0, ss0=ss0, x1=x1, ss1=ss1, y=y, ss=ss, mr=mr)
+
+    def forward(self, x):
+        """x [N,Cin,P0,P1,P2] on the device.  Returns the deep-supervision logits (full resolution first) and keeps
+        the tape for backward()."""
+        assert x.is_contiguous() and x.dtype == torch.float32
+        tape = dict(enc=[], dec=[])
+        cur, cur_ss, skips = x, None, []
+        nenc = len(self.enc)
+        for i, conv in enumerate(self.enc):
+            rec = self._conv_fwd('t.enc%d' % i, conv, cur, cur_ss)
+            tape['enc'].append(rec)
+            cur, cur_ss = rec['y'], rec['ss']
+            if i % 2 == 1 and i < nenc - 2:
+                skips.append((cur, cur_ss))
+        logits = []
+        for u, st in enumerate(self.dec):
+            N, Cin, D, H, W = cur.shape
+            up = self._buf('t.tu%d.y' % u, (N, st['cskip'], 2 * D, 2 * H, 2 * W))
+            wtu = self.p[st['tu'] + '.weight']
+            if (D * H * W) % 4 == 0:
+                wf = self._pack_tu(u, wtu, st)
+                _lib.check(self.lib.wmh_convtranspose3d_k2s2_mfma_fwd(_lib.ptr(cur), _lib.ptr(cur_ss), _lib.ptr(wf), _lib.ptr(up), N,
+                                                                      Cin, st['cskip'], D, H, W, LRELU_SLOPE, self._st()), 'convT fwd')
+            else:
+                _lib.check(self.lib.wmh_convtranspose3d_k2s2_fwd(_lib.ptr(cur), _lib.ptr(cur_ss), _lib.ptr(wtu), _lib.ptr(up), N, Cin,
+                                                                 st['cskip'], D, H, W, LRELU_SLOPE, self._st()), 'convT fwd')
+            skip, skip_ss = skips[-(u + 1)]
+            r0 = self._conv_fwd('t.dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss)
+            r1 = self._conv_fwd('t.dec%d.1' % u, st['convs'][1], r0['y'], r0['ss'])
+            lg = self._buf('t.logits%d' % u, (N, self.K) + tuple(r1['y'].shape[2:]))
+            sp = int(np.prod(r1['y'].shape[2:]))
+            _lib.check(self.lib.wmh_seghead_logits(_lib.ptr(r1['y']), _lib.ptr(r1['ss']), _lib.ptr(self.p[st['seg'] + '.weight']),
+                                                   self.K, _lib.ptr(lg), N, st['cskip'], sp, LRELU_SLOPE, self._st()), 'seghead')
+            tape['dec'].append(dict(tu_in=(cur, cur_ss), up=up, r0=r0, r1=r1, logits=lg))
+            logits.append(lg)
+            cur, cur_ss = r1['y'], r1['ss']
+        self.tape = tape
+        return logits[::-1]
+
+    def _pack_tu(self, u, wtu, st):
+        key = ('tu', u)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == self._version:
+            return hit[1]
+        n = self.lib.wmh_convtranspose3d_k2s2_packed_floats(st['cdown'], st['cskip'])
+        host = np.empty(n, dtype=np.float32)
+        w_h = wtu.detach().cpu().numpy()
+        _lib.check(self.lib.wmh_convtranspose3d_k2s2_pack_weights(w_h.ctypes.data_as(C.c_void_p), st['cdown'], st['cskip'],
+                                                                  host.ctypes.data_as(C.c_void_p)), 'convT pack')
+        wf = torch.from_numpy(host).to(self.device)
+        self._packed[key] = (self._version, wf)
+        return wf
+
+    # ---- backward ------------------------------------------------------------------------------------------------
+    def _block_bwd(self, rec, g1, g2, dl, wseg_name, need_dx):
+        """Backward of one Conv-IN-LReLU block given the upstream gradient of its activated output
+        (g1 + g2 + head).  Returns the gradient(s) of the block's activated input(s)."""
+        lib, st = self.lib, self._st()
+        conv, y = rec['conv'], rec['y']
+        N, Cc = y.shape[:2]
+        S = int(np.prod(y.shape[2:]))
+        dy = self._buf('b.dy.%s' % rec['key'], y.shape)
+        sums = self._buf('b.sums', (N * Cc * 6,), torch.float64)
+        _lib.check(lib.wmh_in_lrelu_bwd(_lib.ptr(y), _lib.ptr(rec['ss']), _lib.ptr(rec['mr']), _lib.ptr(self.p[conv.name + '.instnorm.weight']),
+                                        _lib.ptr(g1), _lib.ptr(g2), _lib.ptr(dl), _lib.ptr(self.p[wseg_name]) if wseg_name else None,
+                                        self.K, _lib.ptr(dy), _lib.ptr(self.g[conv.name + '.instnorm.weight']),
+                                        _lib.ptr(self.g[conv.name + '.instnorm.bias']),
+                                        _lib.ptr(self.g[wseg_name]) if (wseg_name and dl is not None) else None, _lib.ptr(sums),
+                                        N, Cc, S, LRELU_SLOPE, st), 'wmh_in_lrelu_bwd')
+        _lib.check(lib.wmh_channel_sum(_lib.ptr(dy), _lib.ptr(self.g[conv.name + '.conv.bias']), N, Cc, S, st), 'channel_sum')
+        x0, x1 = rec['x0'], rec['x1']
+        _, C0, D, H, W = x0.shape
+        C1 = 0 if x1 is None else x1.shape[1]
+        nws = lib.wmh_conv3d_k3_wgrad_workspace_floats(C0 + C1, Cc, N, D, H, W, conv.stride)
+        ws = self._buf('b.wgrad.ws', (nws,))
+        _lib.check(lib.wmh_conv3d_k3_wgrad(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
+                                           _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, conv.stride,
+                                           LRELU_SLOPE, st), 'wmh_conv3d_k3_wgrad')
+        if not need_dx:
+            return None
+        src = dy
+        if conv.stride == 2:
+            src = self._buf('b.up.%s' % rec['key'], (N, Cc, D, H, W))
+            Do, Ho, Wo = y.shape[2:]
+            _lib.check(lib.wmh_upsample_zero2(_lib.ptr(dy), _lib.ptr(src), N, Cc, Do, Ho, Wo, D, H, W, st), 'upsample_zero2')
+        outs = []
+        for part, (off, cnt) in enumerate([(0, C0)] + ([(C0, C1)] if C1 else [])):
+            cfg = _lib.check(lib.wmh_conv3d_k3_config(Cc, cnt, D, H, W, 1), 'config')
+            wf = self._pack(conv, cfg, 1, off, cnt)
+            dx, _, _ = self._run_conv('b.dx%d.%s' % (part, rec['key']), cfg, src, None, None, None, wf, None, cnt, 1, False)
+            outs.append(dx)
+        return outs
+
+    def backward(self, targets):
+        """targets: list of uint8 device tensors [N, spatial] per scale (full resolution first).  Fills the
+        gradient arena and returns the device scalar holding the loss."""
+        lib, st, tape = self.lib, self._st(), self.tape
+        nd = len(self.dec)
+        self.loss_acc.zero_()
+        dls = [None] * nd
+        for s in range(nd):                                  # scale s <-> decoder stage u = nd-1-s
+            u = nd - 1 - s
+            w = float(self.ds_weights[s])
+            lg = tape['dec'][u]['logits']
+            N = lg.shape[0]
+            S = int(np.prod(lg.shape[2:]))
+            if w == 0.0:
+                self.g[self.dec[u]['seg'] + '.weight'].zero_()
+                continue
+            dl = self._buf('b.dl%d' % u, lg.shape)
+            _lib.check(lib.wmh_dice_ce_loss_fwd_bwd(_lib.ptr(lg), _lib.ptr(targets[s]), N, self.K, S, w, 1e-5, _lib.ptr(dl),
+                                                    _lib.ptr(self.loss_acc), _lib.ptr(self.ws_d), st), 'wmh_dice_ce_loss_fwd_bwd')
+            dls[u] = dl
+        g_next = None                                        # gradient arriving from the stage above (via its convT)
+        gskip = {}
+        for u in range(nd - 1, -1, -1):
+            rec = tape['dec'][u]
+            seg = self.dec[u]['seg'] + '.weight'
+            (gA0,) = self._block_bwd(rec['r1'], g_next, None, dls[u], seg if dls[u] is not None else None, True)
+            d_up, d_skip = self._block_bwd(rec['r0'], gA0, None, None, None, True)
+            gskip[u] = d_skip
+            x_in, ss_in = rec['tu_in']
+            N, Cin, D, H, W = x_in.shape
+            g_in = self._buf('b.tu%d.dx' % u, x_in.shape)
+            tu = self.dec[u]['tu'] + '.weight'
+            _lib.check(lib.wmh_convtranspose3d_k2s2_bwd(_lib.ptr(x_in), _lib.ptr(ss_in), _lib.ptr(self.p[tu]), _lib.ptr(d_up), _lib.ptr(g_in),
+                                                        _lib.ptr(self.g[tu]), N, Cin, self.dec[u]['cskip'], D, H, W, LRELU_SLOPE, st),
+                       'wmh_convtranspose3d_k2s2_bwd')
+            g_next = g_in
+        # encoder: bottleneck back to the first layer; stage outputs also receive the decoder's skip gradient
+        nenc = len(self.enc)
+        g = g_next
+        for i in range(nenc - 1, -1, -1):
+            g2 = None
+            if i % 2 == 1 and i < nenc - 2:                  # output of encoder stage d = i//2 -> skip of decoder u = nd-1-d
+                g2 = gskip[nd - 1 - i // 2]
+            outs = self._block_bwd(tape['enc'][i], g, g2, None, None, i > 0)
+            g = outs[0] if outs else None
+        return self.loss_acc
+
+    # ---- optimizer -----------------------------------------------------------------------------------------------
+    def optimizer_step(self, lr):
+        st = self._st()
+        _lib.check(self.lib.wmh_grad_clip_coef(_lib.ptr(self.grads), self.nparams, self.clip, _lib.ptr(self.clip_out), _lib.ptr(self.ws_d),
+                                               st), 'wmh_grad_clip_coef')
+        _lib.check(self.lib.wmh_sgd_nesterov_step(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.mom), self.nparams, lr,
+                                                  self.momentum, self.weight_decay, _lib.ptr(self.clip_out), 1 if self.first_step else 0,
+                                                  st), 'wmh_sgd_nesterov_step')
+        self.first_step = False
+        self._version += 1                                   # packed weight images are stale
+
+    def allreduce_grads(self, group=None):
+        """Data parallelism (new design: the reference is single-GPU): one RCCL all-reduce of the flat gradient
+        arena, then the mean.  Batch-dice statistics stay per rank."""
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
+            self.grads.div_(dist.get_world_size(group))
+
+    def run_iteration(self, data, targets, lr, do_backprop=True, group=None):
+        """nnUNetTrainerV2.run_iteration.  data [N,C,...] device fp32, targets = per-scale uint8 label tensors."""
+        self.forward(data)
+        loss = self.backward(targets) if do_backprop else self.loss_only(targets)
+        if do_backprop:
+            self.allreduce_grads(group)
+            self.optimizer_step(lr)
+        return loss
+
+    def loss_only(self, targets):
+        nd = len(self.dec)
+        self.loss_acc.zero_()
+        for s in range(nd):
+            w = float(self.ds_weights[s])
+            if w == 0.0:
+                continue
+            lg = self.tape['dec'][nd - 1 - s]['logits']
+            _lib.check(self.lib.wmh_dice_ce_loss_fwd_bwd(_lib.ptr(lg), _lib.ptr(targets[s]), lg.shape[0], self.K,
+                                                         int(np.prod(lg.shape[2:])), w, 1e-5, None, _lib.ptr(self.loss_acc),
+                                                         _lib.ptr(self.ws_d), self._st()), 'loss')
+        return self.loss_acc
+
+
+def downsample_targets(seg, num_scales):
+    """Deep-supervision targets: nearest-neighbour picks at strides 1, 2, 4, ...  seg: uint8 tensor [N, X, Y, Z]."""
+    out = []
+    for s in range(num_scales):
+        k = 2 ** s
+        t = seg[:, ::k, ::k, ::k] if k > 1 else seg
+        out.append(t.contiguous().view(seg.shape[0], -1))
+    return out

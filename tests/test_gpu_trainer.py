@@ -1,0 +1,88 @@
+"""GPU parity test of the whole training step (forward with deep supervision, Dice+CE, backward, clip, SGD) against
+the torch-autograd oracle restatement of nnUNetTrainerV2.run_iteration."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(tiny_net, tiny_io, N=2):
+    from deepwmh_amd.trainer import UNetTrainer, downsample_targets
+    plan, net, sd = tiny_net
+    rng = np.random.default_rng(5)
+    vol = tiny_io['volume'][0]
+    data = np.stack([vol[4:36, 8:40, 4:36], vol[8:40, 0:32, 2:34][::-1].copy()])[:N, None].astype(np.float32)
+    seg = (tiny_io['seg_tta'][4:36, 8:40, 4:36] > 0).astype(np.uint8)
+    seg2 = (rng.random((32, 32, 32)) < 0.2).astype(np.uint8)
+    labels = np.stack([seg, seg2])[:N]
+    tr = UNetTrainer(plan, sd, 'cuda:0')
+    return plan, net, tr, data, labels, downsample_targets
+
+
+def test_training_step_matches_autograd_oracle(tiny_net, tiny_io):
+    from oracle import training as ot
+    plan, net, tr, data, labels, downsample_targets = _setup(tiny_net, tiny_io)
+    import copy
+    net = copy.deepcopy(net).train()
+    weights = ot.deep_supervision_weights(plan.num_pool)
+    assert np.allclose(weights, tr.ds_weights)
+    opt = ot.make_optimizer(net, 1e-2)
+    x = torch.from_numpy(data)
+    tgt = ot.downsample_targets(torch.from_numpy(labels[:, None].astype(np.float32)), plan.num_pool)
+    xd = x.cuda()
+    td = downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
+
+    # --- gradients of the first step ---
+    net.do_ds = True
+    opt.zero_grad()
+    out = net(x)
+    loss = ot.multiple_output_loss(out, tgt, weights)
+    loss.backward()
+    lg = tr.forward(xd)
+    for i, (a, b) in enumerate(zip(lg, out)):
+        assert float((a.cpu() - b.detach()).abs().max()) <= 1e-4, 'logits scale %d' % i
+    l = tr.backward(td)
+    torch.cuda.synchronize()
+    assert abs(float(l.cpu()) - float(loss.detach())) <= 1e-5 * (1 + abs(float(loss.detach())))
+    worst = 0.0
+    for name, p in net.named_parameters():
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        got = tr.g[name].cpu()
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        rel = err / (scale + 1e-6)
+        worst = max(worst, rel if scale > 1e-5 else 0.0)
+        tol = 3e-3 * scale + 2e-6
+        assert err <= tol, 'grad %s: err %.3g scale %.3g' % (name, err, scale)
+    print('largest relative gradient error over all parameters: %.3g' % worst)
+
+    # --- two full iterations: parameters after the optimizer steps ---
+    net2 = __import__('copy').deepcopy(tiny_net[1]).train()
+    opt2 = ot.make_optimizer(net2, 1e-2)
+    from deepwmh_amd.trainer import UNetTrainer
+    tr2 = UNetTrainer(plan, tiny_net[2], 'cuda:0')
+    for it in range(2):
+        lo = ot.run_iteration(net2, opt2, x, tgt, weights)
+        lh = tr2.run_iteration(xd, td, 1e-2)
+        torch.cuda.synchronize()
+        assert abs(float(lh.cpu()) - lo) <= 1e-4 * (1 + abs(lo)), (it, float(lh.cpu()), lo)
+    sd2 = tr2.state_dict()
+    for name, p in net2.named_parameters():
+        err = float(np.abs(sd2[name] - p.detach().numpy()).max())
+        assert err <= 2e-5, 'param %s after 2 steps: %.3g' % (name, err)
+
+
+def test_training_step_is_bit_reproducible(tiny_net, tiny_io):
+    from deepwmh_amd.trainer import UNetTrainer
+    plan, net, tr, data, labels, downsample_targets = _setup(tiny_net, tiny_io)
+    xd = torch.from_numpy(data).cuda()
+    td = downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
+    res = []
+    for _ in range(2):
+        t = UNetTrainer(plan, tiny_net[2], 'cuda:0')
+        for it in range(2):
+            t.run_iteration(xd, td, 1e-2)
+        torch.cuda.synchronize()
+        res.append(t.params.cpu().numpy().copy())
+    assert np.array_equal(res[0], res[1])
