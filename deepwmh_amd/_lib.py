@@ -38,7 +38,8 @@ SIGNATURES = {
     'wmh_upsample_zero2': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'wmh_dice_ce_loss_workspace_doubles': (_sz, []),
     'wmh_dice_ce_loss_fwd_bwd': (_i, [_vp, _vp, _i, _i, _sz, _f, _f, _vp, _vp, _vp, _vp]),
-    'wmh_in_lrelu_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _sz, _f, _vp]),
+    'wmh_in_lrelu_bwd_scratch_doubles': (_sz, [_i, _i, _sz]),
+    'wmh_in_lrelu_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _sz, _f, _vp]),
     'wmh_channel_sum': (_i, [_vp, _vp, _i, _i, _sz, _vp]),
     'wmh_convtranspose3d_k2s2_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_grad_clip_coef': (_i, [_vp, _sz, _f, _vp, _vp, _vp]),

@@ -168,16 +168,19 @@ __device__ __forceinline__ float upstream(const BwdSrc& s, size_t nc_off, size_t
     if (s.dl) for (int k = 0; k < s.K; ++k) d = fmaf(s.wseg[k * C + c], s.dl[(n * s.K + k) * S + v], d);
     return d;
 }
+// grid (SPLIT, N*C): block (sp, nc) reduces the sp-th slice of the spatial range; partial sums per block
 __global__ __launch_bounds__(256) void in_lrelu_bwd_reduce_kernel(const float* y, const float* ss, const float* mr,
-                                                                  BwdSrc src, double* sums, int C, size_t S, float slope,
+                                                                  BwdSrc src, double* psums, int C, size_t S, float slope,
                                                                   int nq) {
     __shared__ double sh[4];
-    const size_t nc = blockIdx.x, n = nc / C;
+    const size_t nc = blockIdx.y, n = nc / C;
     const int c = (int)(nc % C);
+    const size_t chunk = (S + gridDim.x - 1) / gridDim.x;
+    const size_t v0 = (size_t)blockIdx.x * chunk, v1 = v0 + chunk < S ? v0 + chunk : S;
     const float sc = ss[2 * nc], shf = ss[2 * nc + 1], mean = mr[2 * nc], rstd = mr[2 * nc + 1];
     const float* yp = y + nc * S;
     double a0 = 0.0, a1 = 0.0, ak[4] = {0.0, 0.0, 0.0, 0.0};
-    for (size_t v = threadIdx.x; v < S; v += 256) {
+    for (size_t v = v0 + threadIdx.x; v < v1; v += 256) {
         const float yv = yp[v];
         const float z = fmaf(yv, sc, shf);
         const float dA = upstream(src, nc * S, n, c, C, S, v);
@@ -189,13 +192,26 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_reduce_kernel(const float* y
             for (int k = 0; k < src.K; ++k) ak[k] += (double)act * src.dl[(n * src.K + k) * S + v];
         }
     }
-    double t = block_sum_256(a0, sh); if (threadIdx.x == 0) sums[nc * nq + 0] = t;
-    t = block_sum_256(a1, sh);        if (threadIdx.x == 0) sums[nc * nq + 1] = t;
-    for (int k = 0; k < src.K && src.dl; ++k) { t = block_sum_256(ak[k], sh); if (threadIdx.x == 0) sums[nc * nq + 2 + k] = t; }
+    double* out = psums + (nc * gridDim.x + blockIdx.x) * nq;
+    double t = block_sum_256(a0, sh); if (threadIdx.x == 0) out[0] = t;
+    t = block_sum_256(a1, sh);        if (threadIdx.x == 0) out[1] = t;
+    for (int k = 0; k < src.K && src.dl; ++k) { t = block_sum_256(ak[k], sh); if (threadIdx.x == 0) out[2 + k] = t; }
 }
+// sums[nc][q] = sum over slices (fixed order)
+__global__ void in_lrelu_bwd_combine_kernel(const double* psums, double* sums, int NC, int split, int nq, int nused) {
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= NC * nused) return;
+    const int nc = idx / nused, q = idx % nused;
+    double s = 0.0;
+    for (int sp = 0; sp < split; ++sp) s += psums[((size_t)nc * split + sp) * nq + q];
+    sums[(size_t)nc * nq + q] = s;
+}
+// dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); each block also leaves sum(dy) of its slice (conv bias gradient)
 __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const float* y, const float* ss, const float* mr,
                                                                  const float* gamma, BwdSrc src, const double* sums,
-                                                                 float* dy, int C, size_t S, float slope, int nq) {
+                                                                 float* dy, double* dysum, int C, size_t S, float slope,
+                                                                 int nq) {
+    __shared__ double sh[4];
     const size_t nc = blockIdx.y, n = nc / C;
     const int c = (int)(nc % C);
     const float sc = ss[2 * nc], shf = ss[2 * nc + 1], mean = mr[2 * nc], rstd = mr[2 * nc + 1];
@@ -203,48 +219,72 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const float* y,
     const float gr = (gamma ? gamma[c] : 1.f) * rstd;
     const float* yp = y + nc * S;
     float* op = dy + nc * S;
+    double acc = 0.0;
     for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < S; v += (size_t)gridDim.x * 256) {
         const float yv = yp[v];
         const float z = fmaf(yv, sc, shf);
         const float dA = upstream(src, nc * S, n, c, C, S, v);
         const float dz = z > 0.f ? dA : dA * slope;
         const float xh = (yv - mean) * rstd;
-        op[v] = gr * (dz - m1 - xh * m2);
+        const float o = gr * (dz - m1 - xh * m2);
+        op[v] = o;
+        acc += o;
     }
+    const double t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) dysum[nc * gridDim.x + blockIdx.x] = t;
 }
-// dgamma[c] = sum_n sums[n,c,1], dbeta[c] = sum_n sums[n,c,0], dwseg[k][c] = sum_n sums[n,c,2+k]  (accumulated with +=)
-__global__ void in_param_grads_kernel(const double* sums, int N, int C, int nq, int K, float* dgamma, float* dbeta,
-                                      float* dwseg) {
+// dgamma[c] = sum_n sums[n,c,1], dbeta[c] = sum_n sums[n,c,0], dwseg[k][c] = sum_n sums[n,c,2+k], dbias[c] = sum dysum
+__global__ void in_param_grads_kernel(const double* sums, const double* dysum, int gx, int N, int C, int nq, int K,
+                                      float* dgamma, float* dbeta, float* dwseg, float* dbias) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
-    double g = 0.0, b = 0.0, w[4] = {0.0, 0.0, 0.0, 0.0};
+    double g = 0.0, b = 0.0, w[4] = {0.0, 0.0, 0.0, 0.0}, db = 0.0;
     for (int n = 0; n < N; ++n) {
         const double* s = sums + ((size_t)n * C + c) * nq;
         b += s[0]; g += s[1];
         for (int k = 0; k < K; ++k) w[k] += s[2 + k];
+        for (int i = 0; i < gx; ++i) db += dysum[((size_t)n * C + c) * gx + i];
     }
     if (dgamma) dgamma[c] = (float)g;
     if (dbeta) dbeta[c] = (float)b;
+    if (dbias) dbias[c] = (float)db;
     if (dwseg) for (int k = 0; k < K; ++k) dwseg[k * C + c] = (float)w[k];
 }
 
+static void in_bwd_geometry(int N, int C, size_t S, unsigned& split, unsigned& gx) {
+    const size_t NC = (size_t)N * C;
+    split = (unsigned)((2048 + NC - 1) / NC);                 // ~2048 reducing blocks in total
+    const unsigned maxs = cdivu(S, 2048); if (split > maxs) split = maxs; if (split < 1) split = 1; if (split > 256) split = 256;
+    gx = cdivu(S, 256 * 4); if (gx > 512) gx = 512; if (gx < 1) gx = 1;
+    const unsigned cap = (unsigned)((8192 + NC - 1) / NC); if (gx > cap) gx = cap < 1 ? 1 : cap;
+}
+extern "C" size_t wmh_in_lrelu_bwd_scratch_doubles(int N, int C, size_t S) {
+    unsigned split, gx; in_bwd_geometry(N, C, S, split, gx);
+    return (size_t)N * C * 6 * (1 + split) + (size_t)N * C * gx;
+}
 extern "C" int wmh_in_lrelu_bwd(const float* y, const float* ss, const float* mean_rstd, const float* gamma,
                                 const float* g1, const float* g2, const float* dlogits, const float* wseg, int K,
-                                float* dy, float* dgamma, float* dbeta, float* dwseg, double* sums, int N, int C,
-                                size_t S, float slope, void* stream) {
-    if (!y || !ss || !mean_rstd || !dy || !sums || N < 1 || C < 1 || S < 1 || K > 4 || (!g1 && !g2 && !dlogits))
+                                float* dy, float* dgamma, float* dbeta, float* dwseg, float* dbias, double* scratch, int N,
+                                int C, size_t S, float slope, void* stream) {
+    if (!y || !ss || !mean_rstd || !dy || !scratch || N < 1 || C < 1 || S < 1 || K > 4 || (!g1 && !g2 && !dlogits))
         return wmh_fail(WMH_EINVAL, "in_lrelu_bwd: bad args");
     if (dlogits && (!wseg || K < 1)) return wmh_fail(WMH_EINVAL, "in_lrelu_bwd: head gradient without head weights");
     hipStream_t st = (hipStream_t)stream;
     BwdSrc src{g1, g2, dlogits, wseg, dlogits ? K : 0};
-    const int nq = 2 + 4;
-    hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, dim3((unsigned)((size_t)N * C)), dim3(256), 0, st, y, ss, mean_rstd, src,
-                       sums, C, S, slope, nq);
-    unsigned gx = cdivu(S, 256 * 4); if (gx > 512) gx = 512; if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel, dim3(gx, (unsigned)((size_t)N * C)), dim3(256), 0, st, y, ss, mean_rstd,
-                       gamma, src, sums, dy, C, S, slope, nq);
-    hipLaunchKernelGGL(in_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sums, N, C, nq, src.K, dgamma, dbeta,
-                       dlogits ? dwseg : nullptr);
+    const int nq = 6, NC = N * C;
+    unsigned split, gx; in_bwd_geometry(N, C, S, split, gx);
+    double* sums = scratch;
+    double* psums = scratch + (size_t)NC * nq;
+    double* dysum = psums + (size_t)NC * nq * split;
+    const int nused = 2 + src.K;
+    hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, dim3(split, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, src, psums, C,
+                       S, slope, nq);
+    hipLaunchKernelGGL(in_lrelu_bwd_combine_kernel, dim3((NC * nused + 63) / 64), dim3(64), 0, st, psums, sums, NC, (int)split,
+                       nq, nused);
+    hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel, dim3(gx, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, gamma, src, sums,
+                       dy, dysum, C, S, slope, nq);
+    hipLaunchKernelGGL(in_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sums, dysum, (int)gx, N, C, nq, src.K, dgamma,
+                       dbeta, dlogits ? dwseg : nullptr, dbias);
     return wmh_check_launch("in_lrelu_bwd kernels");
 }
 

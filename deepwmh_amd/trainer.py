@@ -218,14 +218,14 @@ class UNetTrainer:
         N, Cc = y.shape[:2]
         S = int(np.prod(y.shape[2:]))
         dy = self._buf('b.dy.%s' % rec['key'], y.shape)
-        sums = self._buf('b.sums', (N * Cc * 6,), torch.float64)
+        sums = self._buf('b.sums', (lib.wmh_in_lrelu_bwd_scratch_doubles(N, Cc, S),), torch.float64)
         _lib.check(lib.wmh_in_lrelu_bwd(_lib.ptr(y), _lib.ptr(rec['ss']), _lib.ptr(rec['mr']), _lib.ptr(self.p[conv.name + '.instnorm.weight']),
                                         _lib.ptr(g1), _lib.ptr(g2), _lib.ptr(dl), _lib.ptr(self.p[wseg_name]) if wseg_name else None,
                                         self.K, _lib.ptr(dy), _lib.ptr(self.g[conv.name + '.instnorm.weight']),
                                         _lib.ptr(self.g[conv.name + '.instnorm.bias']),
-                                        _lib.ptr(self.g[wseg_name]) if (wseg_name and dl is not None) else None, _lib.ptr(sums),
+                                        _lib.ptr(self.g[wseg_name]) if (wseg_name and dl is not None) else None,
+                                        _lib.ptr(self.g[conv.name + '.conv.bias']), _lib.ptr(sums),
                                         N, Cc, S, LRELU_SLOPE, st), 'wmh_in_lrelu_bwd')
-        _lib.check(lib.wmh_channel_sum(_lib.ptr(dy), _lib.ptr(self.g[conv.name + '.conv.bias']), N, Cc, S, st), 'channel_sum')
         x0, x1 = rec['x0'], rec['x1']
         _, C0, D, H, W = x0.shape
         C1 = 0 if x1 is None else x1.shape[1]

@@ -170,11 +170,14 @@ int wmh_upsample_zero2(const float* dy, float* up, int N, int C, int Do, int Ho,
 size_t wmh_dice_ce_loss_workspace_doubles(void);
 int wmh_dice_ce_loss_fwd_bwd(const float* logits, const uint8_t* target, int N, int K, size_t S, float weight,
                              float smooth, float* dlogits, double* loss_accum, double* workspace, void* stream);
-/* Backward of a = lrelu(instnorm(y)) given dA = g1 + g2 + wseg^T dlogits (any subset): writes dy and the parameter
- * gradients dgamma[C], dbeta[C], dwseg[K][C].  sums = scratch of N*C*6 doubles. */
+/* Backward of a = lrelu(instnorm(y)) given dA = g1 + g2 + wseg^T dlogits (any subset): writes dy (the gradient of
+ * the raw conv output) and the parameter gradients dgamma[C], dbeta[C], dwseg[K][C] and dbias[C] = sum dy (any may
+ * be NULL).  scratch = wmh_in_lrelu_bwd_scratch_doubles(N, C, S) doubles. */
+size_t wmh_in_lrelu_bwd_scratch_doubles(int N, int C, size_t S);
 int wmh_in_lrelu_bwd(const float* y, const float* ss, const float* mean_rstd, const float* gamma, const float* g1,
                      const float* g2, const float* dlogits, const float* wseg, int K, float* dy, float* dgamma,
-                     float* dbeta, float* dwseg, double* sums, int N, int C, size_t S, float slope, void* stream);
+                     float* dbeta, float* dwseg, float* dbias, double* scratch, int N, int C, size_t S, float slope,
+                     void* stream);
 /* out[c] = sum over (n, voxels) of x[n,c,:] (conv bias gradient). */
 int wmh_channel_sum(const float* x, float* out, int N, int C, size_t S, void* stream);
 /* ConvTranspose3d(k2,s2) backward: dX (gradient of the activated input; may be NULL) and dW (may be NULL). */

@@ -164,14 +164,16 @@ def test_in_lrelu_bwd(lib, with_g1, with_g2, with_head):
     dy = torch.full((N, Cc, S), float('nan'), device='cuda')
     dgam = torch.full((Cc,), float('nan'), device='cuda'); dbet = torch.full((Cc,), float('nan'), device='cuda')
     dws = torch.full((K, Cc), float('nan'), device='cuda')
-    sums = torch.empty(N * Cc * 6, dtype=torch.float64, device='cuda')
+    sums = torch.empty(lib.wmh_in_lrelu_bwd_scratch_doubles(N, Cc, S), dtype=torch.float64, device='cuda')
+    dbias = torch.full((Cc,), float('nan'), device='cuda')
     g1d = g1.cuda() if with_g1 else None; g2d = g2.cuda() if with_g2 else None
     dld = dl.cuda() if with_head else None; wd = wseg.detach().cuda()
-    check(lib.wmh_in_lrelu_bwd(P(yd), P(ss), P(mr), P(gd), P(g1d), P(g2d), P(dld), P(wd), K, P(dy), P(dgam), P(dbet), P(dws), P(sums),
+    check(lib.wmh_in_lrelu_bwd(P(yd), P(ss), P(mr), P(gd), P(g1d), P(g2d), P(dld), P(wd), K, P(dy), P(dgam), P(dbet), P(dws), P(dbias), P(sums),
                                N, Cc, S, SLOPE, None), 'in bwd')
     torch.cuda.synchronize()
     sc = float(y.grad.abs().max())
     assert float((dy.cpu().view_as(y) - y.grad).abs().max()) <= 2e-5 * (1 + sc)
+    assert float((dbias.cpu() - y.grad.sum((0, 2, 3, 4))).abs().max()) <= 1e-3 * (1 + sc)
     assert float((dgam.cpu() - gamma.grad).abs().max()) <= 1e-4 * (1 + float(gamma.grad.abs().max()))
     assert float((dbet.cpu() - beta.grad).abs().max()) <= 1e-4 * (1 + float(beta.grad.abs().max()))
     if with_head:
