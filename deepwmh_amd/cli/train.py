@@ -1,0 +1,143 @@
+"""`nnUNet_train` drop-in for the command lines DeepWMH emits
+(/root/reference/deepwmh/pipeline/DCNN_multistage.py:292-309,501-520,693-713):
+  nnUNet_train 3d_fullres nnUNetTrainerV2 <task id> all -e E -b B [--noval] [--save_every_epoch]
+               [--disable_postprocessing_on_folds] [--custom_val_cases v1 v2 ...] [-c]
+Writes model_latest / model_best / model_ep_NNNN (+ .pkl) and plans.pkl where the reference looks for them
+(DCNN_multistage.py:300,321,510,608-631).  Launched under torch.distributed.run it is data parallel (one RCCL
+all-reduce of the gradient arena per iteration); the reference itself passes one GPU id."""
+import argparse
+import os
+import pickle
+import sys
+import time
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(prog='nnUNet_train')
+    ap.add_argument('network')
+    ap.add_argument('network_trainer')
+    ap.add_argument('task')
+    ap.add_argument('fold')
+    ap.add_argument('-e', '--epochs', type=int, default=1000)                 # fork-only
+    ap.add_argument('-b', '--batches_per_epoch', type=int, default=250)       # fork-only
+    ap.add_argument('-val', '--validation_only', action='store_true')
+    ap.add_argument('-c', '--continue_training', action='store_true')
+    ap.add_argument('-p', default='nnUNetPlansv2.1')
+    ap.add_argument('--noval', action='store_true')                           # fork-only
+    ap.add_argument('--save_every_epoch', action='store_true')                # fork-only
+    ap.add_argument('--disable_postprocessing_on_folds', action='store_true')
+    ap.add_argument('--custom_val_cases', nargs='*', default=None)            # fork-only
+    ap.add_argument('--npz', action='store_true')
+    ap.add_argument('--fp32', action='store_true')
+    ap.add_argument('--val_batches', type=int, default=None)
+    ap.add_argument('--seed', type=int, default=12345)
+    return ap
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.network != '3d_fullres' or args.network_trainer != 'nnUNetTrainerV2':
+        sys.exit('nnUNet_train (deepwmh_amd): only "3d_fullres nnUNetTrainerV2" is implemented (DeepWMH uses nothing else)')
+    results, pre = os.environ.get('RESULTS_FOLDER'), os.environ.get('nnUNet_preprocessed')
+    if not results or not pre:
+        sys.exit('RESULTS_FOLDER / nnUNet_preprocessed are not set')
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from .. import checkpoint as ck
+    from ..data import DATA_ID, PatchLoader
+    from ..plan import UNetPlan
+    from ..synthetic import he_init_state_dict
+    from ..trainer import UNetTrainer, downsample_targets, poly_lr
+
+    world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        sys.exit('nnUNet_train (deepwmh_amd): no HIP device visible')
+    torch.cuda.set_device(local)
+    device = 'cuda:%d' % local
+
+    tasks = [d for d in sorted(os.listdir(pre)) if d.startswith('Task%03d_' % int(args.task))] if args.task.isdigit() else [args.task]
+    if len(tasks) != 1 or not os.path.isdir(os.path.join(pre, tasks[0])):
+        sys.exit('task %s not found under %s (run nnUNet_plan_and_preprocess first)' % (args.task, pre))
+    task = tasks[0]
+    with open(os.path.join(pre, task, '%s_plans_3D.pkl' % args.p), 'rb') as f:
+        plans = pickle.load(f)
+    plan = UNetPlan.from_nnunet_plans(plans)
+    stage_dir = os.path.join(pre, task, DATA_ID + '_stage0')
+    cases = sorted(f[:-4] for f in os.listdir(stage_dir) if f.endswith('.npz'))
+    val_cases = [c for c in (args.custom_val_cases or []) if c]
+    missing = [c for c in val_cases if c not in cases]
+    if missing:
+        sys.exit('custom validation cases not in the dataset: %s' % ' '.join(missing))
+    train_cases = [c for c in cases if c not in val_cases] if val_cases else cases     # fold "all": train on everything
+    val_cases = val_cases or cases
+    folder = ck.trainer_folder(results, task, args.network, args.network_trainer, args.p)
+    fdir = os.path.join(folder, ck.fold_folder(args.fold))
+    os.makedirs(fdir, exist_ok=True)
+
+    bs = int(plans['plans_per_stage'][max(plans['plans_per_stage'].keys())]['batch_size'])
+    start_epoch, best = 0, None
+    latest = os.path.join(fdir, 'model_latest.model')
+    if args.continue_training and os.path.isfile(latest):
+        _, _, sd, info = ck.load_checkpoint(folder, args.fold, 'model_latest')
+        start_epoch = int(info['epoch'])
+        tr = UNetTrainer(plan, sd, device)
+        mom = info['checkpoint'].get('deepwmh_amd_momentum')
+        if mom is not None:
+            tr.mom.copy_(torch.as_tensor(np.asarray(mom)).to(tr.mom.device))
+            tr.first_step = False
+        best = info['checkpoint'].get('deepwmh_amd_best')
+        if rank == 0:
+            print('continuing from %s (epoch %d)' % (latest, start_epoch), flush=True)
+    else:
+        tr = UNetTrainer(plan, he_init_state_dict(plan, seed=args.seed, trained_like=False), device)
+    if world > 1:                                       # identical start on every rank
+        dist.broadcast(tr.params, 0); dist.broadcast(tr.mom, 0)
+    loader = PatchLoader(stage_dir, train_cases, plan.patch_size, bs, seed=args.seed + 1000 * rank + start_epoch)
+    vloader = PatchLoader(stage_dir, val_cases, plan.patch_size, bs, seed=args.seed + 77, mirror=False)
+    nval = args.val_batches if args.val_batches is not None else max(1, min(50, args.batches_per_epoch // 5))
+    ma = None
+
+    def save(name, epoch):
+        if rank != 0:
+            return
+        extra = dict(deepwmh_amd_momentum=tr.momentum_state(), deepwmh_amd_best=best)
+        ck.save_checkpoint(folder, tr.state_dict(), plans, args.fold, name, epoch=epoch, extra=extra)
+
+    for epoch in range(start_epoch, args.epochs):
+        lr = poly_lr(epoch, args.epochs, 1e-2, 0.9)
+        t0, losses = time.time(), []
+        for _ in range(args.batches_per_epoch):
+            data, seg = loader.next_batch()
+            x = torch.from_numpy(data).to(device)
+            tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool)
+            losses.append(float(tr.run_iteration(x, tg, lr).cpu()))
+        vl = []
+        for _ in range(nval):
+            data, seg = vloader.next_batch()
+            x = torch.from_numpy(data).to(device)
+            tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool)
+            vl.append(float(tr.run_iteration(x, tg, lr, do_backprop=False).cpu()))
+        v = float(np.mean(vl))
+        ma = -v if ma is None else 0.9 * ma + 0.1 * (-v)           # moving-average criterion (higher is better)
+        if rank == 0:
+            print('epoch %d/%d: lr %.6f train loss %.4f val loss %.4f (%.1f s)'
+                  % (epoch + 1, args.epochs, lr, float(np.mean(losses)), v, time.time() - t0), flush=True)
+        save('model_latest', epoch + 1)
+        if best is None or ma > best:
+            best = ma
+            save('model_best', epoch + 1)
+        if args.save_every_epoch:
+            save('model_ep_%04d' % (epoch + 1), epoch + 1)
+    save('model_final_checkpoint', args.epochs)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,0 +1,171 @@
+"""Training data side of `nnUNet_plan_and_preprocess` / `nnUNet_train`: dataset fingerprint and plan, preprocessed
+case storage, random patch sampling with foreground oversampling [nnU-Net, not in tree:
+experiment_planning/experiment_planner_baseline_3DUNet_v21.py, preprocessing/, training/dataloading/dataset_loading.py
+DataLoader3D].  Host CPU numpy: the reference's data path is host code too; only the patches go to the GPU.
+Directory contract: /root/reference/deepwmh/pipeline/DCNN_multistage.py:50-93 (raw), :620-631 (preprocessed)."""
+import json
+import os
+import pickle
+from collections import OrderedDict
+
+import numpy as np
+
+from . import nifti, preprocess
+from .checkpoint import PLANS_ID, make_plans
+from .plan import UNetPlan
+
+DATA_ID = 'nnUNetData_plans_v2.1'
+
+
+def find_task(raw_base, task):
+    base = os.path.join(raw_base, 'nnUNet_raw_data')
+    try:
+        tid = int(task)
+        hits = [d for d in sorted(os.listdir(base)) if d.startswith('Task%03d_' % tid)]
+    except ValueError:
+        hits = [task] if os.path.isdir(os.path.join(base, str(task))) else []
+    if len(hits) != 1:
+        raise FileNotFoundError('task %s: %d matching folders under %s' % (task, len(hits), base))
+    return hits[0]
+
+
+def plan_patch(median_shape):
+    """Fixed-architecture planner: isotropic 2x pooling, 3x3x3 kernels (what the HIP path implements).  Patch =
+    median shape rounded down to a multiple of 2^num_pool, at most 128 per axis; up to 5 poolings while the
+    bottleneck keeps >= 4 voxels per axis (ExperimentPlanner3D_v21's stopping rule)."""
+    shp = [int(s) for s in median_shape]
+    num_pool = 5
+    while num_pool > 1 and min(shp) < 4 * 2 ** num_pool:
+        num_pool -= 1
+    div = 2 ** num_pool
+    patch = [max(div, min(128, s // div * div)) for s in shp]
+    return patch, num_pool
+
+
+def plan_and_preprocess(raw_base, preprocessed_base, task, verify=True, log=print):
+    task = find_task(raw_base, task)
+    raw = os.path.join(raw_base, 'nnUNet_raw_data', task)
+    with open(os.path.join(raw, 'dataset.json')) as f:
+        ds = json.load(f)
+    nmod = len(ds['modality'])
+    nclass = len(ds['labels'])
+    cases = [os.path.basename(t['image'])[:-len('.nii.gz')] for t in ds['training']]
+    out = os.path.join(preprocessed_base, task)
+    stage_dir = os.path.join(out, DATA_ID + '_stage0')
+    os.makedirs(stage_dir, exist_ok=True)
+    loaded, spacings, shapes = [], [], []
+    for c in cases:
+        imgs = []
+        meta = None
+        for m in range(nmod):
+            p = os.path.join(raw, 'imagesTr', '%s_%04d.nii.gz' % (c, m))
+            if not os.path.isfile(p):
+                raise FileNotFoundError('dataset integrity: missing %s' % p)
+            arr, mt = nifti.read(p)
+            imgs.append(arr)
+            meta = meta or mt
+        lab, lmeta = nifti.read(os.path.join(raw, 'labelsTr', c + '.nii.gz'))
+        if verify:
+            if lab.shape != imgs[0].shape:
+                raise ValueError('dataset integrity: %s image %s vs label %s' % (c, imgs[0].shape, lab.shape))
+            if not np.allclose(lmeta['spacing'], meta['spacing'], atol=1e-3):
+                raise ValueError('dataset integrity: %s spacing differs between image and label' % c)
+            u = np.unique(lab)
+            if not set(u.astype(int).tolist()) <= set(range(nclass)):
+                raise ValueError('dataset integrity: %s has labels %s outside dataset.json' % (c, u))
+        data = np.stack(imgs).astype(np.float32)
+        cropped, nz, bbox = preprocess.crop_to_nonzero(data)
+        sl = tuple(slice(a, b) for a, b in bbox)
+        seg = lab[sl].astype(np.int8)
+        seg[~nz] = -1                                    # nnU-Net marks outside-of-body voxels with -1
+        loaded.append((c, cropped, seg, nz, bbox, meta, data.shape[1:]))
+        spacings.append(meta['spacing'])
+        shapes.append(cropped.shape[1:])
+    target_spacing = np.median(np.array(spacings), 0)
+    new_shapes = [np.round(np.array(sp) / target_spacing * np.array(sh)).astype(int) for sp, sh in zip(spacings, shapes)]
+    median_shape = np.median(np.array(new_shapes), 0).astype(int)
+    patch, num_pool = plan_patch(median_shape)
+    crop_frac = np.median([np.prod(sh) / np.prod(full) for (_, _, _, _, _, _, full), sh in zip(loaded, shapes)])
+    plan = UNetPlan(nmod, 32, nclass, [[2, 2, 2]] * num_pool, [[3, 3, 3]] * (num_pool + 1), 2, 320, patch)
+    plans = make_plans(plan, tuple(float(v) for v in target_spacing), use_mask_for_norm=bool(crop_frac < 0.75), batch_size=2)
+    plans['original_spacings'] = [np.array(s) for s in spacings]
+    plans['original_sizes'] = [np.array(s) for s in shapes]
+    plans['preprocessed_data_folder'] = out
+    plans['plans_per_stage'][0]['median_patient_size_in_voxels'] = median_shape
+    use_mask = plans['use_mask_for_norm'][0]
+    for (c, cropped, seg, nz, bbox, meta, full), nshape in zip(loaded, new_shapes):
+        res = preprocess.resample_to_spacing(cropped, meta['spacing'], target_spacing, 3)
+        if res.shape[1:] != seg.shape:
+            seg_r = preprocess._resize(seg.astype(np.float64), res.shape[1:], 0).astype(np.int8)
+            nz_r = seg_r >= 0
+        else:
+            seg_r, nz_r = seg, nz
+        norm = preprocess.normalize_noncT(res, nz_r, use_mask)
+        allc = np.concatenate([norm, seg_r[None].astype(np.float32)], 0)
+        np.savez_compressed(os.path.join(stage_dir, c + '.npz'), data=allc)
+        fg = np.argwhere(seg_r > 0)
+        if len(fg) > 10000:
+            fg = fg[np.random.default_rng(1234).choice(len(fg), 10000, replace=False)]
+        with open(os.path.join(stage_dir, c + '.pkl'), 'wb') as f:
+            pickle.dump(OrderedDict(original_size_of_raw_data=np.array(full), original_spacing=np.array(meta['spacing']),
+                                    crop_bbox=bbox, size_after_cropping=cropped.shape[1:], size_after_resampling=res.shape[1:],
+                                    spacing_after_resampling=target_spacing, class_locations={1: fg}), f)
+    for name in ('%s_plans_3D.pkl' % PLANS_ID, '%s_plans_2D.pkl' % PLANS_ID):
+        with open(os.path.join(out, name), 'wb') as f:
+            pickle.dump(plans, f)
+    with open(os.path.join(out, 'dataset_properties.pkl'), 'wb') as f:
+        pickle.dump(OrderedDict(all_sizes=shapes, all_spacings=spacings, all_classes=list(range(1, nclass)),
+                                modalities=ds['modality'], size_reductions=OrderedDict()), f)
+    with open(os.path.join(out, 'dataset.json'), 'w') as f:
+        json.dump(ds, f, indent=4)
+    log('planned %s: %d cases, median shape %s, target spacing %s, patch %s, %d poolings, use_mask_for_norm %s'
+        % (task, len(cases), median_shape.tolist(), np.round(target_spacing, 3).tolist(), patch, num_pool, use_mask))
+    return task, plans
+
+
+class PatchLoader:
+    """DataLoader3D: random patches, a third of each batch forced onto foreground, zero-padding when a case is
+    smaller than the patch; mirroring along random axes (the one augmentation done here; nnU-Net's rotation /
+    scaling / gamma / noise transforms are host-side batchgenerators code and are not reproduced)."""
+
+    def __init__(self, stage_dir, cases, patch, batch_size=2, oversample_fg=0.33, seed=0, mirror=True):
+        self.patch, self.bs, self.ofg, self.mirror = tuple(patch), batch_size, oversample_fg, mirror
+        self.rng = np.random.default_rng(seed)
+        self.cases = []
+        for c in cases:
+            d = np.load(os.path.join(stage_dir, c + '.npz'))['data']
+            with open(os.path.join(stage_dir, c + '.pkl'), 'rb') as f:
+                props = pickle.load(f)
+            self.cases.append((c, d, props.get('class_locations', {}).get(1, np.zeros((0, 3), int))))
+        if not self.cases:
+            raise ValueError('no training cases')
+
+    def next_batch(self):
+        P = self.patch
+        data = np.zeros((self.bs, self.cases[0][1].shape[0] - 1) + P, np.float32)
+        seg = np.zeros((self.bs,) + P, np.uint8)
+        for b in range(self.bs):
+            _, d, fg = self.cases[int(self.rng.integers(len(self.cases)))]
+            shp = d.shape[1:]
+            force_fg = b >= round(self.bs * (1 - self.ofg)) and len(fg) > 0
+            lo = []
+            if force_fg:
+                ctr = fg[int(self.rng.integers(len(fg)))]
+            for ax in range(3):
+                room = shp[ax] - P[ax]
+                if force_fg:
+                    start = int(np.clip(ctr[ax] - P[ax] // 2, min(0, room), max(0, room)))
+                else:
+                    start = int(self.rng.integers(min(0, room), max(0, room) + 1)) if room != 0 else 0
+                lo.append(start)
+            src = tuple(slice(max(0, l), min(s, l + p)) for l, s, p in zip(lo, shp, P))
+            dst = tuple(slice(max(0, -l), max(0, -l) + (sl.stop - sl.start)) for l, sl in zip(lo, src))
+            data[(b, slice(None)) + dst] = d[(slice(None, -1),) + src]
+            s = d[(-1,) + src]
+            seg[(b,) + dst] = np.maximum(s, 0).astype(np.uint8)
+            if self.mirror:
+                for ax in range(3):
+                    if self.rng.random() < 0.5:
+                        data[b] = np.flip(data[b], ax + 1)
+                        seg[b] = np.flip(seg[b], ax)
+        return np.ascontiguousarray(data), np.ascontiguousarray(seg)

@@ -19,6 +19,25 @@ def shard_cases(cases, rank, world):
     return list(cases)[rank::world]
 
 
+def average_gradients(flat_grads, group=None, bucket_elems=None):
+    """Data-parallel gradient exchange (config 5; new design, the reference is single-GPU): all-reduce (sum) of the
+    flat gradient arena and division by the world size.  With `bucket_elems` the arena is reduced in buckets issued
+    back to front (the decoder's large gradients are complete first), each an async RCCL operation."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return flat_grads
+    W = dist.get_world_size(group)
+    if not bucket_elems or bucket_elems >= flat_grads.numel():
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    else:
+        works, n = [], flat_grads.numel()
+        for end in range(n, 0, -bucket_elems):
+            works.append(dist.all_reduce(flat_grads[max(0, end - bucket_elems):end], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        for w in works:
+            w.wait()
+    flat_grads.div_(W)
+    return flat_grads
+
+
 class PatchShardedPredictor:
     """Host logic of the patch-sharded mode, independent of where the arithmetic runs.
 

@@ -310,10 +310,8 @@ class UNetTrainer:
     def allreduce_grads(self, group=None):
         """Data parallelism (new design: the reference is single-GPU): one RCCL all-reduce of the flat gradient
         arena, then the mean.  Batch-dice statistics stay per rank."""
-        import torch.distributed as dist
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
-            self.grads.div_(dist.get_world_size(group))
+        from .distributed import average_gradients
+        average_gradients(self.grads, group, bucket_elems=8 * 1024 * 1024)    # 32 MB buckets over xGMI
 
     def run_iteration(self, data, targets, lr, do_backprop=True, group=None):
         """nnUNetTrainerV2.run_iteration.  data [N,C,...] device fp32, targets = per-scale uint8 label tensors."""

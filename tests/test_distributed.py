@@ -93,3 +93,23 @@ def test_patch_sharded_predict_gloo(world, golden_dir, tmp_path, tiny_io):
     prob = np.load(out)
     # 8 patches over 2 (even) or 3 (ragged last round) ranks == the serial oracle, bit for bit
     assert np.array_equal(prob, tiny_io['prob_notta']) or float(np.abs(prob - tiny_io['prob_notta']).max()) <= 2e-6
+
+
+def _grad_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from deepwmh_amd.distributed import average_gradients
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    a = average_gradients(g.clone(), None)
+    b = average_gradients(g.clone(), None, bucket_elems=96)            # ragged buckets, issued back to front
+    assert torch.equal(a, b)
+    if rank == 0:
+        np.save(out, a.numpy())
+    dist.destroy_process_group()
+
+
+def test_gradient_averaging_gloo(tmp_path):
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'g.npy')
+    mp.spawn(_grad_worker, args=(2, port, out), nprocs=2, join=True)
+    assert np.array_equal(np.load(out), np.arange(1000, dtype=np.float32) * 1.5)

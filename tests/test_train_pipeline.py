@@ -1,0 +1,125 @@
+"""Training-side boundary: `nnUNet_plan_and_preprocess` / `nnUNet_train` command lines of the reference, the raw /
+preprocessed directory contract and the patch loader (CPU), and the full plan -> train -> continue -> predict
+chain through the drop-in executables on the GPU."""
+import json
+import os
+import pickle
+import shlex
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_raw_dataset(raw_base, task='Task001_LabelDenoising', n=4, shape=(40, 48, 44), seed=0):
+    """What reference _prepare_nnunet_training_data writes (DCNN_multistage.py:39-93)."""
+    from deepwmh_amd import nifti
+    from deepwmh_amd.synthetic import synthetic_flair
+    root = os.path.join(raw_base, 'nnUNet_raw_data', task)
+    os.makedirs(os.path.join(root, 'imagesTr')); os.makedirs(os.path.join(root, 'labelsTr'))
+    training = []
+    for i in range(n):
+        name = 'case_%02d' % i
+        vol = synthetic_flair(shape, seed=seed + i)[0]
+        img = vol * 40 + 200 * (vol != 0)
+        lab = (vol > 1.6).astype(np.float32)
+        nifti.write(os.path.join(root, 'imagesTr', name + '_0000.nii.gz'), img, spacing=(1.0, 1.0, 1.0))
+        nifti.write(os.path.join(root, 'labelsTr', name + '.nii.gz'), lab, spacing=(1.0, 1.0, 1.0))
+        training.append({'image': os.path.join(root, 'imagesTr', name + '.nii.gz'), 'label': os.path.join(root, 'labelsTr', name + '.nii.gz')})
+    js = {'name': '', 'description': '', 'reference': '', 'license': '', 'release': 'v1.0', 'tensorImageSize': '3D',
+          'modality': {'0': 'Modality_01'}, 'labels': {'0': 'background', '1': 'lesion'}, 'numTraining': n, 'numTest': 0,
+          'training': training, 'test': []}
+    json.dump(js, open(os.path.join(root, 'dataset.json'), 'w'), indent=4)
+    return task
+
+
+def test_cli_accepts_reference_training_commands():
+    from deepwmh_amd.cli.plan_and_preprocess import build_parser as pp
+    from deepwmh_amd.cli.train import build_parser as tp
+    a = pp().parse_args(shlex.split('nnUNet_plan_and_preprocess -t %d --verify_dataset_integrity' % 1)[1:])
+    assert a.task_ids == ['1'] and a.verify_dataset_integrity
+    cmd = 'nnUNet_train %s %s %d %s -e %d -b %d --noval --save_every_epoch --disable_postprocessing_on_folds' % \
+        ('3d_fullres', 'nnUNetTrainerV2', 1, 'all', 50, 150) + ' -c'
+    a = tp().parse_args(shlex.split(cmd)[1:])
+    assert (a.network, a.network_trainer, a.task, a.fold) == ('3d_fullres', 'nnUNetTrainerV2', '1', 'all')
+    assert a.epochs == 50 and a.batches_per_epoch == 150 and a.noval and a.save_every_epoch and a.continue_training
+    cmd = 'nnUNet_train %s %s %d %s -e %d -b %d --disable_postprocessing_on_folds --custom_val_cases %s ' % \
+        ('3d_fullres', 'nnUNetTrainerV2', 2, 'all', 100, 150, ' v1  v_2 ')
+    a = tp().parse_args(shlex.split(cmd)[1:])
+    assert a.custom_val_cases == ['v1', 'v_2'] and a.epochs == 100 and not a.continue_training
+    with pytest.raises(SystemExit) as e:
+        tp().parse_args(['-h'])
+    assert e.value.code == 0
+
+
+def test_plan_and_preprocess_and_loader(tmp_path):
+    from deepwmh_amd.data import DATA_ID, PatchLoader, plan_and_preprocess, plan_patch
+    assert plan_patch((160, 192, 160)) == ([128, 128, 128], 5)
+    assert plan_patch((40, 48, 44)) == ([40, 48, 40], 3)            # >= 4 voxels per axis at the bottleneck
+    assert plan_patch((20, 100, 70)) == ([20, 100, 68], 2)
+    assert plan_patch((300, 300, 300)) == ([128, 128, 128], 5)
+    raw, pre = str(tmp_path / 'raw'), str(tmp_path / 'pre')
+    task = make_raw_dataset(raw)
+    t, plans = plan_and_preprocess(raw, pre, '1', True, log=lambda *a: None)
+    assert t == task
+    out = os.path.join(pre, task)
+    for f in ('nnUNetPlansv2.1_plans_3D.pkl', 'nnUNetPlansv2.1_plans_2D.pkl', 'dataset_properties.pkl', 'dataset.json'):
+        assert os.path.isfile(os.path.join(out, f)), f             # release_model copies these (DCNN_multistage.py:620-631)
+    st = plans['plans_per_stage'][0]
+    patch = [int(v) for v in st['patch_size']]
+    npool = len(st['pool_op_kernel_sizes'])
+    assert npool == 3 and all(p % 8 == 0 and 32 <= p <= 48 for p in patch) and plans['num_classes'] == 1
+    d = np.load(os.path.join(out, DATA_ID + '_stage0', 'case_00.npz'))['data']
+    assert d.shape[0] == 2 and set(np.unique(d[-1]).tolist()) <= {-1.0, 0.0, 1.0}
+    body = d[-1] >= 0
+    assert abs(float(d[0][body].mean())) < 1e-3 and abs(float(d[0][body].std()) - 1) < 1e-2
+    ld = PatchLoader(os.path.join(out, DATA_ID + '_stage0'), ['case_00', 'case_01'], (32, 32, 32), 2, seed=3)
+    big = PatchLoader(os.path.join(out, DATA_ID + '_stage0'), ['case_00'], (48, 56, 48), 2, seed=4)     # patch > case: zero pad
+    xb, sb = big.next_batch()
+    assert xb.shape == (2, 1, 48, 56, 48) and float(np.abs(xb).sum()) > 0
+    fg_hits = 0
+    for _ in range(6):
+        x, s = ld.next_batch()
+        assert x.shape == (2, 1, 32, 32, 32) and s.shape == (2, 32, 32, 32) and s.dtype == np.uint8 and s.max() <= 1
+        fg_hits += int(s[1].sum() > 0)
+    assert fg_hits == 6                                             # the forced-foreground half of every batch
+    # integrity check fails loudly on a shape mismatch
+    from deepwmh_amd import nifti
+    nifti.write(os.path.join(raw, 'nnUNet_raw_data', task, 'labelsTr', 'case_01.nii.gz'), np.zeros((4, 4, 4), np.float32), spacing=(1, 1, 1))
+    with pytest.raises(ValueError):
+        plan_and_preprocess(raw, pre, '1', True, log=lambda *a: None)
+
+
+@pytest.mark.gpu
+def test_plan_train_continue_predict_through_the_executables(tmp_path):
+    raw, pre, res = str(tmp_path / 'raw'), str(tmp_path / 'pre'), str(tmp_path / 'results')
+    task = make_raw_dataset(raw, n=3)
+    env = dict(os.environ, nnUNet_raw_data_base=raw, nnUNet_preprocessed=pre, RESULTS_FOLDER=res, CUDA_VISIBLE_DEVICES='0',
+               PATH=os.path.join(ROOT, 'bin') + os.pathsep + os.environ['PATH'])
+
+    def run(cmd):
+        p = subprocess.run(shlex.split(cmd), env=env, capture_output=True, text=True)
+        print(p.stdout[-1500:], p.stderr[-1500:])
+        return p
+    assert run('nnUNet_plan_and_preprocess -t 1 --verify_dataset_integrity').returncode == 0
+    train = 'nnUNet_train 3d_fullres nnUNetTrainerV2 1 all -e 2 -b 3 --noval --save_every_epoch --disable_postprocessing_on_folds'
+    p = run(train)
+    assert p.returncode == 0 and 'epoch 2/2' in p.stdout
+    fdir = os.path.join(res, 'nnUNet', '3d_fullres', task, 'nnUNetTrainerV2__nnUNetPlansv2.1', 'all')
+    have = set(os.listdir(fdir))
+    for f in ('model_latest.model', 'model_latest.model.pkl', 'model_best.model', 'model_best.model.pkl', 'model_ep_0001.model',
+              'model_ep_0002.model', 'model_ep_0002.model.pkl'):
+        assert f in have, f
+    assert os.path.isfile(os.path.join(os.path.dirname(fdir), 'plans.pkl'))
+    p = run(train.replace('-e 2', '-e 3') + ' -c')                  # the reference appends -c when model_latest exists
+    assert p.returncode == 0 and 'continuing from' in p.stdout and 'epoch 3/3' in p.stdout and 'epoch 1/3' not in p.stdout
+    out = str(tmp_path / 'softmax')
+    pr = run('nnUNet_predict -i %s -o %s -tr nnUNetTrainerV2 -m 3d_fullres -p nnUNetPlansv2.1 -t %s -f all -chk model_ep_0002 '
+             '--selected_cases case_00 --save_softmax --disable_post_processing --disable_tta'
+             % (os.path.join(raw, 'nnUNet_raw_data', task, 'imagesTr'), out, task))
+    assert pr.returncode == 0 and sorted(os.listdir(out)) == ['case_00.nii.gz', 'case_00_0.nii.gz']
+    from deepwmh_amd import nifti
+    p0, _ = nifti.read(os.path.join(out, 'case_00_0.nii.gz'))
+    assert p0.shape == (40, 48, 44) and 0.0 <= float(p0.min()) and float(p0.max()) <= 1.0 + 1e-6
