@@ -75,6 +75,8 @@ def main():
     ap.add_argument('--tta', type=int, default=1, help='1: 8-fold mirroring as DeepWMH_predict; 0: --disable_tta')
     ap.add_argument('--shape', type=int, nargs=3, default=[160, 192, 160])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
+                    help='bf16 = BASELINE.json config 3 (bf16 matrix-core operands, fp32 accumulate/storage); not the headline number')
     ap.add_argument('--shard', choices=['volumes', 'patches'], default='volumes',
                     help='volumes: one volume per rank per step (weak scaling, no collective); patches: ONE volume per '
                          'step, its patches split over the ranks with an RCCL all-gather of the weighted tiles (strong)')
@@ -99,7 +101,7 @@ def main():
 
     plan = baseline_plan()
     sd = he_init_state_dict(plan, seed=0)
-    eng = UNetEngine(plan, sd, device)
+    eng = UNetEngine(plan, sd, device, precision=args.precision)
     tta = bool(args.tta)
     pred = SlidingWindowPredictor(eng, do_mirroring=tta, batch=8)
     by_patch = args.shard == 'patches'
@@ -159,7 +161,7 @@ def main():
         res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=nvol / dt,
                    unit='volumes/s', n_gpus=args.gpus, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='strong' if by_patch else 'weak', vs_baseline=None,
-                   dtype='f32', data='synthetic',
+                   dtype='f32' if args.precision == 'fp32' else 'bf16 operands / f32 accumulate+storage', data='synthetic',
                    config=dict(workload='configs[1]: one %dx%dx%d FLAIR volume per GPU, 128^3 patches, step 0.5, fp32, '
                                         'Gaussian aggregation, mirroring (TTA x8) %s; %d patch forwards per volume'
                                         % (args.shape[0], args.shape[1], args.shape[2], 'on' if tta else 'off', forwards),

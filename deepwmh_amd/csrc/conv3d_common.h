@@ -1,0 +1,166 @@
+// conv3d_common.h -- definitions shared by the fp32 and bf16-operand forms of the 3x3x3 convolution kernel:
+// launch arguments, the tile-geometry template, and the epilogue (bias is already in the accumulators; stores
+// and one-pass InstanceNorm moments).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "wmh_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float* x0; const float* ss0; int C0;
+    const float* x1; const float* ss1; int C1;
+    const float* wf; const float* bias; float* y; float* part;
+    int N, D, H, W, Do, Ho, Wo, Cout;
+    int nchunks, ntx, nty, ntz, npart;
+    int G, KS, xcd_swizzle;
+    float slope;
+    unsigned long long* stamps;     // diagnostics only (NULL in production): per-workgroup cycle counts
+};
+
+template <int S_, int LX_, int LY_, int TZ_, int TY_, int TN_, int MT_, int NT_, int CK_, int APF_>
+struct ConvCfg {
+    static constexpr int S = S_, LX = LX_, LY = LY_, LZ = 32 / (LX_ * LY_);
+    static constexpr int TX = LX_, TY = TY_, TZ = TZ_, TN = TN_, MT = MT_, NT = NT_, CK = CK_, APF = APF_;
+    static constexpr int MY = TY / LY, MZ = TZ / LZ, MPS = MY * MZ;  // M-tiles per sample
+    static constexpr int NMT = TN * MPS;                             // M-tiles per workgroup
+    static constexpr int WM = NMT / MT;                              // waves per workgroup
+    static constexpr int THREADS = WM * 64;
+    static constexpr int WPS = MPS / MT;                             // waves per sample
+    static constexpr int IX = S * (TX - 1) + 3, IY = S * (TY - 1) + 3, IZ = S * (TZ - 1) + 3;
+    static constexpr int YS = IX, ZS = IY * YS, NS = IZ * ZS;
+    static constexpr int SP = TN * NS;                               // staged elements per channel
+    static constexpr int NIT = (SP + THREADS - 1) / THREADS;
+    static constexpr int CS = NIT * THREADS;                         // channel stride in LDS: padded so that every
+                                                                     // thread's every store is in range (no branches)
+    static constexpr int TILE = CK * CS;                             // floats per LDS buffer
+    static constexpr int LDS_FLOATS = 2 * TILE;
+    static constexpr int WT0 = (NIT >= 27) ? 0 : 27 - NIT;           // tap at which the staged writes start
+    static constexpr int WPT = (NIT + 26) / 27;                      // write slices per tap
+    static_assert(LX * LY * LZ == 32, "lane map must cover 32 voxels");
+    static_assert(TY % LY == 0 && TZ % LZ == 0, "tile must be whole M-tiles");
+    static_assert(MPS % MT == 0, "a wave's M-tiles must belong to one sample");
+    static_assert(NMT % MT == 0 && WM >= 1 && WM <= 4, "1..4 waves");
+    static_assert(NIT <= 32, "validity mask is 32 bits");
+    static_assert(CK % 2 == 0, "k step is a cin pair");
+    static_assert(((2 * ZS + 2 * YS + 2) + (CK - 2) * CS + TILE) * 4 < 65536, "ds_read immediate range");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
+};
+
+template <int V> struct AVec;
+template <> struct AVec<1> { typedef float T; };
+template <> struct AVec<2> { typedef float2 T; };
+template <> struct AVec<4> { typedef float4 T; };
+__device__ __forceinline__ float avec_get(float v, int) { return v; }
+__device__ __forceinline__ float avec_get(float2 v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ float avec_get(float4 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+__device__ __forceinline__ float sum32(float v) {   // sum over the 32 lanes of this half-wave
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);  v += __shfl_xor(v, 1);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue of one workgroup tile.  acc[nt][m][r]: row (r&3)+8*(r>>2)+4*kh of cout tile nt, voxel j of M-tile m.
+// ------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C::NT][C::MT], int g, int ks, int n,
+                                              int wave, int j, int kh, int dx, int dy, int dz, int ts0, int oz0,
+                                              int oy0, int ox0, int tile_sp) {
+    constexpr int MT = C::MT, NT = C::NT;
+    const int HoWo = a.Ho * a.Wo;
+    const size_t DoHoWo = (size_t)a.Do * HoWo;
+    const bool split = a.KS > 1;
+    // split-K: raw partial sums into slab ks of y ([KS][N][Cout][Do][Ho][Wo]); bias/statistics come later
+    float* ybase = a.y + (split ? (size_t)ks * a.N * a.Cout * DoHoWo : 0);
+
+    unsigned vmask = 0;
+    int cnt = 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int ts = ts0 + m;
+        const int oz = oz0 + (ts / C::MY) * C::LZ + dz, oy = oy0 + (ts % C::MY) * C::LY + dy, ox = ox0 + dx;
+        const bool valid = (n < a.N) && oz < a.Do && oy < a.Ho && ox < a.Wo;
+        vmask |= valid ? (1u << m) : 0u;
+        cnt += __popcll(__ballot(valid) & 0xffffffffull);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cob = (g * NT + nt) * 32;           // first output channel of this 32-row tile
+        if (cob >= a.Cout) continue;                  // uniform over the workgroup
+        const int nrows = min(32, a.Cout - cob);
+        // ---- bias; InstanceNorm moments in ONE pass about a per-row shift K (one sample of the row) ----
+        float vals[32];                               // [2r] = sum(v-K), [2r+1] = sum((v-K)^2) over this lane's voxels
+        float kshift[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v0 = acc[nt][0][r];
+            const float k0 = __builtin_amdgcn_readlane(v0, 0), k1 = __builtin_amdgcn_readlane(v0, 32);
+            const float K = kh ? k1 : k0;
+            kshift[r] = K;
+            float sd = 0.f, sq = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float v = acc[nt][m][r];
+                const float d = ((vmask >> m) & 1u) ? v - K : 0.f;
+                sd += d;
+                sq = fmaf(d, d, sq);
+            }
+            vals[2 * r] = sd; vals[2 * r + 1] = sq;
+        }
+        if (a.part != nullptr && !split) {
+            // recursive halving over the 32 lanes of each half-wave: 16+8+4+2+1 shuffles; lane j ends with vals[j]
+#pragma unroll
+            for (int M = 16, K2 = 16; M >= 1; M >>= 1, K2 >>= 1) {
+                const bool up = (j & M) != 0;
+#pragma unroll
+                for (int i = 0; i < K2; ++i) {
+                    const float keep = up ? vals[i + K2] : vals[i];
+                    const float send = up ? vals[i] : vals[i + K2];
+                    vals[i] = keep + __shfl_xor(send, M);
+                }
+            }
+            const float mine = vals[0];                       // lane j: (j&1) ? sum d^2 : sum d, of row j>>1
+            const float other = __shfl_xor(mine, 1);
+            float Kr = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Kr = ((j >> 1) == r) ? kshift[r] : Kr;
+            if ((j & 1) == 0 && n < a.N) {
+                const int r = j >> 1;
+                const int co = cob + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (co < a.Cout) {
+                    const float fc = (float)cnt;
+                    const float sd = mine, sq = other;
+                    const float m2 = cnt > 0 ? fmaxf(sq - sd * sd / fc, 0.f) : 0.f;
+                    const int pidx = tile_sp * C::WPS + (wave % C::WPS);
+                    float4* pp = reinterpret_cast<float4*>(a.part) + ((size_t)n * a.Cout + co) * a.npart + pidx;
+                    *pp = make_float4(fc, fmaf(fc, Kr, sd), m2, 0.f);
+                }
+            }
+        }
+        // ---- stores: one acc register = two 128-B row segments (two output channels) per wave-instruction.
+        // (An LDS-transposed 16-byte-store variant measured slower: the epilogue is bound by the store path,
+        // ~16 B/clk/CU, not by instruction count.)
+        float* ych = ybase + ((size_t)n * a.Cout + cob) * DoHoWo;          // channel cob of sample n
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int ts = ts0 + m;
+            const int oz = oz0 + (ts / C::MY) * C::LZ + dz, oy = oy0 + (ts % C::MY) * C::LY + dy, ox = ox0 + dx;
+            if ((vmask >> m) & 1u) {
+                float* yp = ych + (size_t)(4 * kh) * DoHoWo + (size_t)oz * HoWo + oy * a.Wo + ox;
+                if (nrows == 32) {                  // uniform: all 32 output channels of this tile exist
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * DoHoWo] = acc[nt][m][r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2);
+                        if (4 * kh + row < nrows) yp[(size_t)row * DoHoWo] = acc[nt][m][r];
+                    }
+                }
+            }
+        }
+    }
+}

@@ -1,0 +1,254 @@
+// conv3d_k3_bf16.hip -- the 3x3x3 convolution with bf16 matrix-core operands (BASELINE.json config 3,
+// "bf16 forward"): storage stays fp32 NCDHW and the epilogue (bias, fp32 InstanceNorm moments, stores) is the
+// fp32 kernel's, but the operands are rounded to bf16 on their way into LDS and the product runs on
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate; 8x the fp32 instruction's rate per k):
+//
+//   D[cout 32][voxel 32] += A[cout 32][16 cin of one tap] * B[16 cin][voxel 32]
+//
+// * LDS tile is channel-interleaved, [voxel][16 cin] bf16 = two 16-byte halves per voxel, so a lane's B operand
+//   (8 consecutive cin of its voxel) is ONE ds_read_b128.  The half index is XOR-ed with bit 3 of the voxel's x
+//   so that the 16 lanes of a ds_read_b128 group hit 16 different 16-byte slots (conflict-free for all three kw).
+// * Staging gathers a voxel's 16 channels (16 coalesced dword loads across the wave), applies the producer's
+//   InstanceNorm+LeakyReLU in fp32, converts with round-to-nearest-even and writes two 16-byte pieces.
+// * Weights: fragment-major bf16 image [G][cin/16][tap][NT][lane][8], one 16-byte load per lane per tap.
+// The kernel is latency/bandwidth bound, not MFMA bound (the matrix work is 1/8 of the fp32 kernel's).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include "conv3d_common.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {     // round to nearest even
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a = (a + 0x7FFFu + ((a >> 16) & 1u)) >> 16;
+    b = (b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u;
+    return a | b;
+}
+
+template <class C, int RIT>
+__global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_bf16_kernel(const ConvArgs a) {
+    constexpr int S = C::S, MT = C::MT, NT = C::NT, NIT = C::NIT, THREADS = C::THREADS, APF = 4, CKB = 16;
+    static_assert(C::TN == 1, "one sample per workgroup");
+    extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];      // [CS voxels][2]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kh = lane >> 5;
+    const int dx = j % C::LX, dy = (j / C::LX) % C::LY, dz = j / (C::LX * C::LY);
+    int bid = blockIdx.x;
+    if (a.xcd_swizzle) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int ks = bid % a.KS; bid /= a.KS;
+    const int g = bid % a.G;
+    int b = bid / a.G;
+    const int tx = b % a.ntx; b /= a.ntx;
+    const int ty = b % a.nty; b /= a.nty;
+    const int tz = b % a.ntz; b /= a.ntz;
+    const int n0 = b;
+    const int ox0 = tx * C::TX, oy0 = ty * C::TY, oz0 = tz * C::TZ;
+    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
+    const int HW = a.H * a.W;
+    const size_t DHW = (size_t)a.D * HW;
+    const int ch_lo = (int)(((long long)a.nchunks * ks) / a.KS);
+    const int ch_hi = (int)(((long long)a.nchunks * (ks + 1)) / a.KS);
+
+    int sp_off[NIT];
+    unsigned okmask = 0, keymask = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * THREADS;
+        const int x = e % C::IX, y = (e / C::IX) % C::IY, z = (e / (C::IX * C::IY)) % C::IZ;
+        const int gx = ix0 + x, gy = iy0 + y, gz = iz0 + z;
+        const bool ok = (e < C::SP) && (n0 < a.N) && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
+        sp_off[it] = ok ? gz * HW + gy * a.W + gx : 0;
+        okmask |= ok ? (1u << it) : 0u;
+        keymask |= ((x >> 3) & 1) ? (1u << it) : 0u;
+    }
+    const int ts0 = (wave * MT) % C::MPS;
+    // byte address of this lane's B operand for (m, kw) at tap row (kd, kh_) = badr[kw][m] + (kd*ZS + kh_*YS)*32
+    int badr[3][MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int ts = ts0 + m;
+        const int tyi = ts % C::MY, tzi = ts / C::MY;
+        const int e0 = S * ((tzi * C::LZ + dz) * C::ZS + (tyi * C::LY + dy) * C::YS + dx);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) badr[kw][m] = (e0 + kw) * 32 + 16 * (kh ^ (((S * dx + kw) >> 3) & 1));
+    }
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (g * NT + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const float bv = (a.KS == 1 && a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[nt][m][r] = bv;
+        }
+
+    const bf16x8* wl = reinterpret_cast<const bf16x8*>(a.wf) + (size_t)g * a.nchunks * 27 * NT * 64 + lane;
+    const int Tlast = ch_hi * 27 - 1;
+    bf16x8 aring[APF][NT];
+    auto loadA = [&](int T, bf16x8 (&dst)[NT]) {
+        T = min(T, Tlast);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dst[nt] = wl[((size_t)T * NT + nt) * 64];
+    };
+#pragma unroll
+    for (int d = 0; d < APF; ++d) loadA(ch_lo * 27 + d, aring[d]);
+
+    const char* ldsb = reinterpret_cast<const char*>(ldsq);
+    for (int ch = ch_lo; ch < ch_hi; ++ch) {
+        // ---- stage 16 input channels of the halo tile -------------------------------------------------------
+        const int cb = ch * CKB;
+        const float* xs; const float* ss; int Cs, c0;
+        if (cb < a.C0) { xs = a.x0; ss = a.ss0; Cs = a.C0; c0 = cb; }
+        else           { xs = a.x1; ss = a.ss1; Cs = a.C1; c0 = cb - a.C0; }
+        const bool has_ss = ss != nullptr;
+        const float slope_eff = has_ss ? a.slope : 1.f;
+        if (ch != ch_lo) __syncthreads();                 // every wave is done reading the previous chunk
+#pragma unroll
+        for (int r0 = 0; r0 < NIT; r0 += RIT) {
+            float v[RIT][CKB];
+#pragma unroll
+            for (int ii = 0; ii < RIT; ++ii)
+#pragma unroll
+                for (int c = 0; c < CKB; ++c) {
+                    const int it = r0 + ii;
+                    if (it < NIT) v[ii][c] = xs[((size_t)n0 * Cs + min(c0 + c, Cs - 1)) * DHW + sp_off[it]];
+                }
+#pragma unroll
+            for (int ii = 0; ii < RIT; ++ii) {
+                const int it = r0 + ii;
+                if (it >= NIT) continue;
+                const bool sok = (okmask >> it) & 1u;
+                unsigned w[8];
+#pragma unroll
+                for (int c = 0; c < CKB; c += 2) {
+                    float f[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int cc = min(c0 + c + u, Cs - 1);
+                        const float sc = has_ss ? ss[((size_t)n0 * Cs + cc) * 2] : 1.f;
+                        const float sh = has_ss ? ss[((size_t)n0 * Cs + cc) * 2 + 1] : 0.f;
+                        float t = fmaf(v[ii][c + u], sc, sh);
+                        t = t > 0.f ? t : t * slope_eff;
+                        f[u] = (sok && (c0 + c + u) < Cs) ? t : 0.f;
+                    }
+                    w[c >> 1] = pack_bf16x2(f[0], f[1]);
+                }
+                const int e = tid + it * THREADS;
+                const int key = (keymask >> it) & 1u;
+                ldsq[e * 2 + (0 ^ key)] = make_uint4(w[0], w[1], w[2], w[3]);
+                ldsq[e * 2 + (1 ^ key)] = make_uint4(w[4], w[5], w[6], w[7]);
+            }
+        }
+        __syncthreads();
+        // ---- 27 taps x MT x NT MFMAs -----------------------------------------------------------------------------
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int kw = tap % 3;
+            const int rowoff = ((tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS) * 32;
+            bf16x8 anew[NT];
+            loadA(ch * 27 + tap + APF, anew);
+            __builtin_amdgcn_sched_barrier(0x38F);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(ldsb + badr[kw][m] + rowoff);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[0][nt], bv, acc[nt][m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int d = 0; d + 1 < APF; ++d)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) aring[d][nt] = aring[d + 1][nt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) aring[APF - 1][nt] = anew[nt];
+        }
+    }
+    conv_epilogue<C>(a, acc, g, ks, n0, wave, j, kh, dx, dy, dz, ts0, oz0, oy0, ox0, (tz * a.nty + ty) * a.ntx + tx);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> BCfg0;      // same tile geometry as the fp32 Cfg0 / Cfg2
+typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> BCfg2;
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+
+static inline unsigned short f2bf(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static int bf16_nt(int cfg) { return cfg == 0 ? 1 : cfg == 2 ? 2 : 0; }
+
+extern "C" int wmh_conv3d_k3_bf16_supported(int cfg) { return bf16_nt(cfg) > 0; }
+extern "C" size_t wmh_conv3d_k3_packed_halfs_bf16(int cfg, int Cin, int Cout) {
+    const int NT = bf16_nt(cfg);
+    if (!NT) return 0;
+    return (size_t)cdiv(Cout, 32 * NT) * cdiv(Cin, 16) * 27 * NT * 64 * 8;
+}
+// w: host fp32 torch layout [Cout][Cin][27]; wf: host uint16 out, [G][cin/16][tap][NT][lane][8]
+extern "C" int wmh_conv3d_k3_pack_weights_bf16(int cfg, const float* w, int Cin, int Cout, uint16_t* wf) {
+    const int NT = bf16_nt(cfg);
+    if (!NT || !w || !wf) return wmh_fail(WMH_EINVAL, "pack_weights_bf16: unsupported cfg or null");
+    const int G = cdiv(Cout, 32 * NT), NCH = cdiv(Cin, 16);
+    for (int g = 0; g < G; ++g)
+        for (int ch = 0; ch < NCH; ++ch)
+            for (int tap = 0; tap < 27; ++tap)
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = (g * NT + nt) * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + e;
+                            float v = 0.f;
+                            if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 27 + tap];
+                            wf[(((((size_t)g * NCH + ch) * 27 + tap) * NT + nt) * 64 + lane) * 8 + e] = f2bf(v);
+                        }
+    return WMH_OK;
+}
+
+template <class C, int RIT>
+static int launch_bf16(const ConvArgs& a, unsigned nblk, hipStream_t st) {
+    const int lds = C::CS * 32;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_kernel<C, RIT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((conv3d_k3_bf16_kernel<C, RIT>), dim3(nblk), dim3(C::THREADS), lds, st, a);
+    return wmh_check_launch("conv3d_k3_bf16_kernel");
+}
+
+extern "C" int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1,
+                                      const float* ss1, int C1, const uint16_t* wf, const float* bias, float* y,
+                                      float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope,
+                                      void* stream) {
+    const int NT = bf16_nt(cfg);
+    if (!NT) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: configuration has no bf16 kernel");
+    if (!x0 || !wf || !y || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: null/empty argument");
+    if (x1 == nullptr) C1 = 0;
+    if (C1 > 0 && (C0 % 16) != 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: C0 must be a multiple of 16 with two sources");
+    ConvArgs a;
+    a.x0 = x0; a.ss0 = ss0; a.C0 = C0; a.x1 = x1; a.ss1 = ss1; a.C1 = C1;
+    a.wf = reinterpret_cast<const float*>(wf); a.bias = bias; a.y = y; a.part = partials;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Do = D; a.Ho = H; a.Wo = W; a.Cout = Cout;
+    a.nchunks = (C1 > 0) ? (C0 / 16 + cdiv(C1, 16)) : cdiv(C0, 16);
+    const int TX = cfg == 0 ? BCfg0::TX : BCfg2::TX, TY = cfg == 0 ? BCfg0::TY : BCfg2::TY, TZ = cfg == 0 ? BCfg0::TZ : BCfg2::TZ;
+    const int WPS = cfg == 0 ? BCfg0::WPS : BCfg2::WPS;
+    a.ntx = cdiv(W, TX); a.nty = cdiv(H, TY); a.ntz = cdiv(D, TZ);
+    a.npart = a.ntx * a.nty * a.ntz * WPS;
+    a.slope = lrelu_slope;
+    a.G = cdiv(Cout, 32 * NT);
+    a.KS = 1;
+    static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
+    a.xcd_swizzle = swz_env;
+    a.stamps = nullptr;
+    const long long nblk = (long long)a.ntx * a.nty * a.ntz * N * a.G;
+    if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (cfg == 0) return launch_bf16<BCfg0, 4>(a, (unsigned)nblk, st);
+    return launch_bf16<BCfg2, 3>(a, (unsigned)nblk, st);
+}

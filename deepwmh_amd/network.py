@@ -37,6 +37,17 @@ class _ConvLayer:
         self.gamma = torch.from_numpy(_np(sd[prefix + '.instnorm.weight'])).to(device)
         self.beta = torch.from_numpy(_np(sd[prefix + '.instnorm.bias'])).to(device)
         self._packed = {}
+        self._packed_bf16 = {}
+
+    def packed_bf16(self, cfg):
+        if cfg not in self._packed_bf16:
+            n = self.lib.wmh_conv3d_k3_packed_halfs_bf16(cfg, self.cin, self.cout)
+            wf = np.empty(n, dtype=np.uint16)
+            _lib.check(self.lib.wmh_conv3d_k3_pack_weights_bf16(
+                cfg, self.w_host.ctypes.data_as(C.c_void_p), self.cin, self.cout,
+                wf.ctypes.data_as(C.c_void_p)), 'wmh_conv3d_k3_pack_weights_bf16')
+            self._packed_bf16[cfg] = torch.from_numpy(wf.view(np.int16)).to(self.device)
+        return self._packed_bf16[cfg]
 
     def packed(self, cfg):
         if cfg not in self._packed:
@@ -52,7 +63,13 @@ class _ConvLayer:
 class UNetEngine:
     """Holds the weights in HBM and runs the forward graph on a HIP stream."""
 
-    def __init__(self, plan: UNetPlan, state_dict, device='cuda:0'):
+    def __init__(self, plan: UNetPlan, state_dict, device='cuda:0', precision='fp32'):
+        """precision 'fp32' (exact-fp32 matrix instruction everywhere) or 'bf16' (BASELINE.json config 3: the
+        stride-1 convolutions of the >= 16-wide levels multiply bf16-rounded operands with fp32 accumulation;
+        storage, InstanceNorm statistics, heads and softmax stay fp32)."""
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError('precision must be fp32 or bf16')
+        self.precision = precision
         plan.check_supported()
         self.plan = plan
         self.device = torch.device(device)
@@ -109,15 +126,23 @@ class UNetEngine:
         nws = self.lib.wmh_conv3d_k3_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout, s)
         ws = self._buf('splitk.ws', (nws,)) if nws else None      # shared: layers run one after another
         st = self._stream()
-        wf = layer.packed(cfg)
+        use_bf16 = (self.precision == 'bf16' and s == 1 and self.lib.wmh_conv3d_k3_bf16_supported(cfg)
+                    and (C1 == 0 or C0 % 16 == 0))
+        wf = layer.packed_bf16(cfg) if use_bf16 else layer.packed(cfg)
         timed = cfg in self.timed_cfgs
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(self.lib.wmh_conv3d_k3_fwd(
-            cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
-            _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws),
-            N, D, H, W, layer.cout, s, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd')
+        if use_bf16:
+            _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16(
+                cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
+                _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part),
+                N, D, H, W, layer.cout, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd_bf16')
+        else:
+            _lib.check(self.lib.wmh_conv3d_k3_fwd(
+                cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
+                _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws),
+                N, D, H, W, layer.cout, s, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd')
         if timed:
             e1.record()
             vox = N * Do * Ho * Wo

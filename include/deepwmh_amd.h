@@ -75,6 +75,18 @@ int wmh_conv3d_k3_fwd(int cfg,
                       int N, int D, int H, int W, int Cout, int stride,
                       float lrelu_slope, void* stream);
 
+/* The same convolution with bf16 matrix-core operands (BASELINE.json config 3): storage, bias, statistics and
+ * outputs stay fp32; inputs (after the on-load InstanceNorm+LeakyReLU) and weights are rounded to bf16
+ * (nearest even) and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Stride 1 only, for the
+ * configurations wmh_conv3d_k3_bf16_supported() accepts (the layers holding ~90 % of the FLOPs); wf is the bf16
+ * fragment-major image from wmh_conv3d_k3_pack_weights_bf16 (packed_halfs_bf16() uint16 values). */
+int wmh_conv3d_k3_bf16_supported(int cfg);
+size_t wmh_conv3d_k3_packed_halfs_bf16(int cfg, int Cin, int Cout);
+int wmh_conv3d_k3_pack_weights_bf16(int cfg, const float* w, int Cin, int Cout, uint16_t* wf);
+int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1,
+                           int C1, const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D,
+                           int H, int W, int Cout, float lrelu_slope, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * InstanceNorm3d(eps, affine) statistics -> per-(n,c) {scale, shift} so that
  * instnorm(x) = x*scale + shift.  Merges the conv epilogue's partial (count, sum, M2) records

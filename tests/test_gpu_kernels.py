@@ -142,6 +142,56 @@ def test_conv3d_k3_and_instnorm_partials(lib, case):
     assert float((mine - full).abs().max()) <= 2e-5
 
 
+BF16_CASES = [(1, 32, 0, 32, 8, 16, 64, True, False), (2, 16, 16, 8, 8, 8, 32, False, True), (1, 6, 0, 40, 5, 9, 33, True, False),
+              (2, 64, 0, 64, 8, 8, 16, True, False), (1, 16, 32, 24, 6, 20, 13, True, True)]
+
+
+@pytest.mark.parametrize('case', BF16_CASES, ids=[str(c) for c in BF16_CASES])
+def test_conv3d_k3_bf16_operands(lib, case):
+    # reference: the same convolution on operands rounded to bf16 (torch's round-to-nearest-even cast), fp32 accumulate
+    from deepwmh_amd import _lib
+    N, C0, C1, Cout, D, H, W, use_ss0, use_ss1 = case
+    g = torch.Generator().manual_seed(97)
+    Cin = C0 + C1
+    x0 = torch.randn(N, C0, D, H, W, generator=g) * 1.5 + 0.3
+    x1 = torch.randn(N, C1, D, H, W, generator=g) if C1 else None
+    ss0 = torch.stack([0.5 + torch.rand(N, C0, generator=g), 0.3 * torch.randn(N, C0, generator=g)], -1) if use_ss0 else None
+    ss1 = torch.stack([0.5 + torch.rand(N, C1, generator=g), 0.3 * torch.randn(N, C1, generator=g)], -1) if use_ss1 else None
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (27 * Cin)) ** 0.5
+    b = 0.1 * torch.randn(Cout, generator=g)
+    xin = _lrelu_affine(x0, ss0)
+    if C1:
+        xin = torch.cat((xin, _lrelu_affine(x1, ss1)), 1)
+    r = lambda t: t.to(torch.bfloat16).float()
+    ref = F.conv3d(r(xin), r(w), b, padding=1)
+    full = F.conv3d(xin, w, b, padding=1)
+    cfg = lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, 1)
+    assert lib.wmh_conv3d_k3_bf16_supported(cfg)
+    wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_bf16(cfg, Cin, Cout), np.uint16)
+    wn = w.numpy()
+    assert lib.wmh_conv3d_k3_pack_weights_bf16(cfg, wn.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)) == 0
+    npart = lib.wmh_conv3d_k3_num_partials(cfg, N, D, H, W)
+    y = torch.full((N, Cout, D, H, W), float('nan'), device='cuda')
+    part = torch.full((N, Cout, npart, 4), float('nan'), device='cuda')
+    mr = torch.full((N, Cout, 2), float('nan'), device='cuda'); ss_out = torch.empty(N, Cout, 2, device='cuda')
+    d = [t.cuda() if t is not None else None for t in (x0, ss0, x1, ss1)]
+    wfd, bd = dev(wf.view(np.int16)), b.cuda()
+    _lib.check(lib.wmh_conv3d_k3_fwd_bf16(cfg, P(d[0]), P(d[1]), C0, P(d[2]), P(d[3]), C1, P(wfd), P(bd), P(y), P(part),
+                                          N, D, H, W, Cout, SLOPE, None), 'conv bf16')
+    _lib.check(lib.wmh_instnorm_finalize(P(part), npart, None, None, 1e-5, P(ss_out), P(mr), N, Cout, None), 'fin')
+    torch.cuda.synchronize()
+    yh = y.cpu()
+    assert not torch.isnan(yh).any()
+    scale = float(ref.abs().max())
+    err = float((yh - ref).abs().max())
+    # fmaf(x, scale, shift) vs torch's x*scale+shift can land on the other side of a bf16 rounding boundary for a few
+    # inputs (one bf16 ulp = 2^-8 relative on one operand): allow a handful of such flips, nothing larger
+    assert err <= 5e-4 * scale + 1e-5, 'vs bf16-rounded reference: %.3g (scale %.3g)' % (err, scale)
+    print('bf16 operands vs full fp32: max abs %.3g (scale %.3g)' % (float((yh - full).abs().max()), scale))
+    mean = yh.mean((2, 3, 4)).double()
+    assert float((mr.cpu().double()[..., 0] - mean).abs().max()) <= 1e-5 * (1 + float(mean.abs().max()))
+
+
 def test_instnorm_stats_and_apply(lib):
     from deepwmh_amd import _lib
     g = torch.Generator().manual_seed(5)

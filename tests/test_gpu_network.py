@@ -148,3 +148,17 @@ def test_full_size_patch_forward_vs_oracle():
           'GPU %.3f s (incl. D2H), CPU oracle %.1f s on %d threads'
           % (err, perr, np.abs(ref).max(), mism, t_gpu, t_cpu, torch.get_num_threads()))
     assert perr <= TOL and mism == 0
+
+
+def test_bf16_forward_config3(tiny_net, tiny_io):
+    """BASELINE.json config 3: bf16 matrix-core operands.  Not a 1e-4 path: report the distance to fp32 and the Dice."""
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    from oracle.sliding_window import hard_dice_binary
+    plan, net, sd = tiny_net
+    eng = UNetEngine(plan, sd, 'cuda:0', precision='bf16')
+    seg, prob = SlidingWindowPredictor(eng, do_mirroring=False).predict(tiny_io['volume'])
+    err = float(np.abs(prob - tiny_io['prob_notta']).max())
+    dice = hard_dice_binary(tiny_io['seg_notta'], seg)
+    print('bf16 operands: max|softmax - fp32 oracle| %.3g, Dice vs fp32 mask %.5f' % (err, dice))
+    assert err < 0.05 and dice > 0.98
