@@ -62,6 +62,22 @@ __device__ __forceinline__ float sum32(float v) {   // sum over the 32 lanes of 
     return v;
 }
 
+// wave-specialised persistent form for the large-layer configuration (conv3d_k3_ws.hip)
+int wmh_launch_conv_ws_cfg0(const ConvArgs& a, hipStream_t st);
+
+// one step of the recursive-halving reduction (static indices only: a runtime index into a register array
+// would be lowered to a compare/select chain per element)
+template <int M>
+__device__ __forceinline__ void halve_step(float (&vals)[32], int j) {
+    const bool up = (j & M) != 0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const float keep = up ? vals[i + M] : vals[i];
+        const float send = up ? vals[i] : vals[i + M];
+        vals[i] = keep + __shfl_xor(send, M);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Epilogue of one workgroup tile.  acc[nt][m][r]: row (r&3)+8*(r>>2)+4*kh of cout tile nt, voxel j of M-tile m.
 // ------------------------------------------------------------------------------------------------
@@ -112,16 +128,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
         }
         if (a.part != nullptr && !split) {
             // recursive halving over the 32 lanes of each half-wave: 16+8+4+2+1 shuffles; lane j ends with vals[j]
-#pragma unroll
-            for (int M = 16, K2 = 16; M >= 1; M >>= 1, K2 >>= 1) {
-                const bool up = (j & M) != 0;
-#pragma unroll
-                for (int i = 0; i < K2; ++i) {
-                    const float keep = up ? vals[i + K2] : vals[i];
-                    const float send = up ? vals[i] : vals[i + K2];
-                    vals[i] = keep + __shfl_xor(send, M);
-                }
-            }
+            halve_step<16>(vals, j); halve_step<8>(vals, j); halve_step<4>(vals, j); halve_step<2>(vals, j);
+            halve_step<1>(vals, j);
             const float mine = vals[0];                       // lane j: (j&1) ? sum d^2 : sum d, of row j>>1
             const float other = __shfl_xor(mine, 1);
             float Kr = 0.f;

@@ -502,7 +502,9 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd: grid too large");
     hipStream_t st = (hipStream_t)stream;
     if (a.KS > 1) a.y = workspace;
+    static const int use_ws = env_int("WMH_WS", 0);   // wave-specialised persistent form: measured equal
     int rc;
+    if (cfg == 0 && a.KS == 1 && use_ws && a.stamps == nullptr) return wmh_launch_conv_ws_cfg0(a, st);
 #ifdef WMH_DIAG_ABLATIONS
     static const int abl = env_int("WMH_ABL", 0);
     if (cfg == 0 && abl) return launch_cfg0_ablation(abl, a, (unsigned)nblk, st);

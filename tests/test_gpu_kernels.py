@@ -323,3 +323,37 @@ def test_seghead_softmax_mirror_accumulate_and_finalize(lib):
     pref = (agg.cpu() / (cref + 0.5))[:, 1:10, 0:6, 2:14]
     assert torch.equal(prob.cpu(), pref)
     assert torch.equal(seg.cpu(), pref.argmax(0).to(torch.uint8))
+
+
+def test_wave_specialised_form_is_bit_identical(tmp_path):
+    """The persistent loader/consumer form of the large-layer conv (WMH_WS=1) must reproduce the one-role kernel
+    bit for bit (same arithmetic, same k order).  The switch is read once per process, hence subprocesses."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, numpy as np, torch, ctypes as C\n"
+        "sys.path.insert(0, %r)\n"
+        "from deepwmh_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "N, Cin, Cout, D, H, W = 2, 12, 40, 9, 20, 70\n"
+        "x = torch.randn(N, Cin, D, H, W, generator=g).cuda(); ss = (torch.rand(N, Cin, 2, generator=g) + 0.5).cuda()\n"
+        "w = (torch.randn(Cout, Cin, 27, generator=g) * 0.1).numpy(); b = torch.randn(Cout, generator=g).cuda()\n"
+        "cfg = lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, 1)\n"
+        "wf = np.empty(lib.wmh_conv3d_k3_packed_floats(cfg, Cin, Cout), np.float32)\n"
+        "lib.wmh_conv3d_k3_pack_weights(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p))\n"
+        "wfd = torch.from_numpy(wf).cuda(); y = torch.zeros(N, Cout, D, H, W, device='cuda')\n"
+        "npart = lib.wmh_conv3d_k3_num_partials(cfg, N, D, H, W); part = torch.zeros(N, Cout, npart, 4, device='cuda')\n"
+        "_lib.check(lib.wmh_conv3d_k3_fwd(cfg, _lib.ptr(x), _lib.ptr(ss), Cin, None, None, 0, _lib.ptr(wfd), _lib.ptr(b), _lib.ptr(y),\n"
+        "           _lib.ptr(part), None, N, D, H, W, Cout, 1, 0.01, None), 'conv')\n"
+        "torch.cuda.synchronize(); np.save(sys.argv[1], y.cpu().numpy()); np.save(sys.argv[2], part.cpu().numpy())\n") % root
+    outs = []
+    for ws in ('0', '1'):
+        f1, f2 = str(tmp_path / ('y%s.npy' % ws)), str(tmp_path / ('p%s.npy' % ws))
+        r = subprocess.run([sys.executable, '-c', script, f1, f2], env=dict(os.environ, WMH_WS=ws), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((np.load(f1), np.load(f2)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert float(np.abs(outs[0][0]).max()) > 0.1
