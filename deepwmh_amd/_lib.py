@@ -68,6 +68,9 @@ def load():
             "deepwmh_amd: %s not found. The HIP library is required (there is no CPU fallback); "
             "build it with `python -c \"import __graft_entry__ as g; g.build()\"` or "
             "`python deepwmh_amd/build.py`." % LIB_PATH)
+    # torch first: its wheel bundles the HIP runtime it was built against, and the process must end up with ONE
+    # runtime -- loaded after torch, this library binds to the copy torch already mapped (same SONAME)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
