@@ -15,6 +15,7 @@ SIGNATURES = {
     'wmh_abi_version': (_i, []),
     'wmh_device_check': (_i, [_i]),
     'wmh_conv3d_k3_config': (_i, [_i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_config': (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_packed_floats': (_sz, [_i, _i, _i]),
     'wmh_conv3d_k3_pack_weights': (_i, [_i, _vp, _i, _i, _vp]),
     'wmh_conv3d_k3_num_partials': (_i, [_i, _i, _i, _i, _i]),
@@ -31,6 +32,9 @@ SIGNATURES = {
     'wmh_convtranspose3d_k2s2_packed_floats': (_sz, [_i, _i]),
     'wmh_convtranspose3d_k2s2_pack_weights': (_i, [_vp, _i, _i, _vp]),
     'wmh_convtranspose3d_k2s2_mfma_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_convtranspose3d_packed_floats': (_sz, [_i, _i, _i]),
+    'wmh_convtranspose3d_pack_weights': (_i, [_vp, _i, _i, _i, _vp]),
+    'wmh_convtranspose3d_mfma_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_extract_patches': (_i, [_vp, _vp, _i, _i, _i, _i, _ip, _i, _i, _i, _i, _ip, _ip, _vp]),
     'wmh_seghead_softmax_accumulate': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ip, _i, _ip, _f, _vp]),
     'wmh_seghead_logits': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _sz, _f, _vp]),

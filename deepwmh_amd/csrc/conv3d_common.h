@@ -19,16 +19,18 @@ struct ConvArgs {
     unsigned long long* stamps;     // diagnostics only (NULL in production): per-workgroup cycle counts
 };
 
-template <int S_, int LX_, int LY_, int TZ_, int TY_, int TN_, int MT_, int NT_, int CK_, int APF_>
+// KZ: kernel extent along the first spatial axis (3, or 1 for nnU-Net's anisotropic [1,3,3] kernels); SZ: stride
+// along that axis (differs from the in-plane stride S for [1,2,2] pooling)
+template <int S_, int LX_, int LY_, int TZ_, int TY_, int TN_, int MT_, int NT_, int CK_, int APF_, int KZ_ = 3, int SZ_ = S_>
 struct ConvCfg {
-    static constexpr int S = S_, LX = LX_, LY = LY_, LZ = 32 / (LX_ * LY_);
+    static constexpr int S = S_, LX = LX_, LY = LY_, LZ = 32 / (LX_ * LY_), KZ = KZ_, SZ = SZ_, NTAPS = KZ_ * 9, PZ = KZ_ / 2;
     static constexpr int TX = LX_, TY = TY_, TZ = TZ_, TN = TN_, MT = MT_, NT = NT_, CK = CK_, APF = APF_;
     static constexpr int MY = TY / LY, MZ = TZ / LZ, MPS = MY * MZ;  // M-tiles per sample
     static constexpr int NMT = TN * MPS;                             // M-tiles per workgroup
     static constexpr int WM = NMT / MT;                              // waves per workgroup
     static constexpr int THREADS = WM * 64;
     static constexpr int WPS = MPS / MT;                             // waves per sample
-    static constexpr int IX = S * (TX - 1) + 3, IY = S * (TY - 1) + 3, IZ = S * (TZ - 1) + 3;
+    static constexpr int IX = S * (TX - 1) + 3, IY = S * (TY - 1) + 3, IZ = SZ * (TZ - 1) + KZ;
     static constexpr int YS = IX, ZS = IY * YS, NS = IZ * ZS;
     static constexpr int SP = TN * NS;                               // staged elements per channel
     static constexpr int NIT = (SP + THREADS - 1) / THREADS;
@@ -36,15 +38,15 @@ struct ConvCfg {
                                                                      // thread's every store is in range (no branches)
     static constexpr int TILE = CK * CS;                             // floats per LDS buffer
     static constexpr int LDS_FLOATS = 2 * TILE;
-    static constexpr int WT0 = (NIT >= 27) ? 0 : 27 - NIT;           // tap at which the staged writes start
-    static constexpr int WPT = (NIT + 26) / 27;                      // write slices per tap
+    static constexpr int WT0 = (NIT >= NTAPS) ? 0 : NTAPS - NIT;           // tap at which the staged writes start
+    static constexpr int WPT = (NIT + NTAPS - 1) / NTAPS;                      // write slices per tap
     static_assert(LX * LY * LZ == 32, "lane map must cover 32 voxels");
     static_assert(TY % LY == 0 && TZ % LZ == 0, "tile must be whole M-tiles");
     static_assert(MPS % MT == 0, "a wave's M-tiles must belong to one sample");
     static_assert(NMT % MT == 0 && WM >= 1 && WM <= 4, "1..4 waves");
     static_assert(NIT <= 32, "validity mask is 32 bits");
     static_assert(CK % 2 == 0, "k step is a cin pair");
-    static_assert(((2 * ZS + 2 * YS + 2) + (CK - 2) * CS + TILE) * 4 < 65536, "ds_read immediate range");
+    static_assert((((KZ - 1) * ZS + 2 * YS + 2) + (CK - 2) * CS + TILE) * 4 < 65536, "ds_read immediate range");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 };
 

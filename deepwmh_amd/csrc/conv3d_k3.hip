@@ -58,7 +58,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
     const int tz = b % a.ntz; b /= a.ntz;
     const int n0 = b * C::TN;
     const int ox0 = tx * C::TX, oy0 = ty * C::TY, oz0 = tz * C::TZ;
-    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
+    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * C::SZ - C::PZ;
     const int HW = a.H * a.W;
     const size_t DHW = (size_t)a.D * HW;
     // this block's range of cin chunks (split-K)
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
     for (int m = 0; m < MT; ++m) {
         const int ts = ts0 + m;
         const int tyi = ts % C::MY, tzi = ts / C::MY;
-        baddr[m] = kh * C::CS + tn_w * C::NS + S * ((tzi * C::LZ + dz) * C::ZS + (tyi * C::LY + dy) * C::YS + dx);
+        baddr[m] = kh * C::CS + tn_w * C::NS + C::SZ * (tzi * C::LZ + dz) * C::ZS + S * ((tyi * C::LY + dy) * C::YS + dx);
     }
 
     // accumulators start at the bias (split-K slabs start at 0: the reduce kernel adds the bias once)
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
 
     // ---- weights: prefetch ring over the linear (chunk, tap) sequence ---------------------------
     typedef typename AVec<CK / 2>::T AV;
-    const AV* wl = reinterpret_cast<const AV*>(a.wf) + (size_t)g * a.nchunks * 27 * NT * 64 + lane;
-    const int Tlast = ch_hi * 27 - 1;
+    const AV* wl = reinterpret_cast<const AV*>(a.wf) + (size_t)g * a.nchunks * C::NTAPS * NT * 64 + lane;
+    const int Tlast = ch_hi * C::NTAPS - 1;
     AV aring[APF][NT];
     auto loadA = [&](int T, AV (&dst)[NT]) {
         T = min(T, Tlast);                           // past the end: harmless re-read of the last tap
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
     if (a.stamps) t_begin = __builtin_amdgcn_s_memtime();
     load_chunk(ch_lo);
 #pragma unroll
-    for (int d = 0; d < APF; ++d) loadA(ch_lo * 27 + d, aring[d]);
+    for (int d = 0; d < APF; ++d) loadA(ch_lo * C::NTAPS + d, aring[d]);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) write_slice(ch_lo, it, lds);
     __syncthreads();
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
         const int chn = min(ch + 1, ch_hi - 1);
         if (!(ABL & 2)) load_chunk(chn);            // global loads stay in flight under the MFMAs below
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
+        for (int tap = 0; tap < C::NTAPS; ++tap) {
             const int toff = (tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS + (tap % 3);
             AV anew[NT];
-            if (!(ABL & 4)) loadA(ch * 27 + tap + APF, anew);
+            if (!(ABL & 4)) loadA(ch * C::NTAPS + tap + APF, anew);
             else {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) anew[nt] = aring[0][nt];
@@ -301,16 +301,32 @@ typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 1, 2, 6> Cfg5;     // stride 2, 8-wide outp
 typedef ConvCfg<1, 4, 4, 4, 4, 4, 2, 1, 8, 6> Cfg6;     // stride 1, 4-wide, 4 samples per workgroup
 typedef ConvCfg<2, 4, 4, 4, 4, 4, 2, 1, 2, 6> Cfg7;     // stride 2, 4-wide output
 typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 2, 6> Cfg8;    // as Cfg0 for 1-2 input channels (first layer): one cin pair
-#define WMH_NUM_CONV_CFG 9
+// anisotropic plans (nnU-Net [1,3,3] kernels, [1,2,2] pooling): same tiles, 9 taps and/or no stride along z
+typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6, 1, 1> Cfg9;      // kernel 1x3x3, stride 1
+typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6, 1, 1> Cfg10;
+typedef ConvCfg<1, 8, 4, 4, 8, 1, 2, 1, 8, 6, 1, 1> Cfg11;
+typedef ConvCfg<1, 4, 4, 4, 4, 4, 2, 1, 8, 6, 1, 1> Cfg12;
+typedef ConvCfg<2, 32, 1, 2, 8, 1, 4, 2, 2, 6, 1, 1> Cfg13;     // kernel 1x3x3, stride (1,2,2)
+typedef ConvCfg<2, 16, 2, 2, 16, 1, 4, 2, 2, 6, 1, 1> Cfg14;
+typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 1, 2, 6, 1, 1> Cfg15;
+typedef ConvCfg<2, 4, 4, 4, 4, 4, 2, 1, 2, 6, 1, 1> Cfg16;
+typedef ConvCfg<2, 32, 1, 2, 8, 1, 4, 2, 2, 6, 3, 1> Cfg17;     // kernel 3x3x3, stride (1,2,2)
+typedef ConvCfg<2, 16, 2, 2, 16, 1, 4, 2, 2, 6, 3, 1> Cfg18;
+typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 1, 2, 6, 3, 1> Cfg19;
+typedef ConvCfg<2, 4, 4, 4, 4, 4, 2, 1, 2, 6, 3, 1> Cfg20;
+#define WMH_NUM_CONV_CFG 21
 
-struct CfgInfo { int S, TX, TY, TZ, TN, NT, CK, WPS, threads, lds_bytes; };
+struct CfgInfo { int S, TX, TY, TZ, TN, NT, CK, WPS, threads, lds_bytes, KZ, SZ; };
 template <class C> static CfgInfo info_of() {
-    return CfgInfo{C::S, C::TX, C::TY, C::TZ, C::TN, C::NT, C::CK, C::WPS, C::THREADS, C::LDS_FLOATS * 4};
+    return CfgInfo{C::S, C::TX, C::TY, C::TZ, C::TN, C::NT, C::CK, C::WPS, C::THREADS, C::LDS_FLOATS * 4, C::KZ, C::SZ};
 }
 static const CfgInfo& cfg_info(int cfg) {
     static const CfgInfo t[WMH_NUM_CONV_CFG] = {info_of<Cfg0>(), info_of<Cfg1>(), info_of<Cfg2>(), info_of<Cfg3>(),
                                                 info_of<Cfg4>(), info_of<Cfg5>(), info_of<Cfg6>(), info_of<Cfg7>(),
-                                                info_of<Cfg8>()};
+                                                info_of<Cfg8>(), info_of<Cfg9>(), info_of<Cfg10>(), info_of<Cfg11>(),
+                                                info_of<Cfg12>(), info_of<Cfg13>(), info_of<Cfg14>(), info_of<Cfg15>(),
+                                                info_of<Cfg16>(), info_of<Cfg17>(), info_of<Cfg18>(), info_of<Cfg19>(),
+                                                info_of<Cfg20>()};
     return t[cfg];
 }
 static unsigned long long* g_conv_stamps = nullptr;
@@ -371,13 +387,22 @@ static int launch_cfg0_ablation(int abl, const ConvArgs& a, unsigned nblk, hipSt
 }
 #endif
 
+// General form: kernel (kz,3,3) with kz in {1,3}; stride (sz, s, s) with sz <= s.  <0 when the combination has no kernel.
+extern "C" int wmh_conv3d_config(int Cin, int Cout, int D, int H, int W, int kz, int sz, int s) {
+    if (Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (s != 1 && s != 2) || (sz != 1 && sz != 2) || (kz != 1 && kz != 3) || sz > s)
+        return wmh_fail(WMH_EINVAL, "wmh_conv3d_config: bad shape");
+    const int Wo = (W - 1) / s + 1;
+    const int wc = Wo >= 24 ? 0 : Wo >= 12 ? 1 : Wo >= 6 ? 2 : 3;          // width class
+    if (kz == 3 && sz == s) {
+        if (wc == 0 && s == 1 && Cin <= 2) return 8;
+        return 2 * wc + (s == 2 ? 1 : 0);
+    }
+    if (kz == 1 && sz == 1) return (s == 1 ? 9 : 13) + wc;
+    if (kz == 3 && sz == 1 && s == 2) return 17 + wc;
+    return wmh_fail(WMH_EINVAL, "wmh_conv3d_config: kernel 1 with stride 2 along the same axis is not implemented");
+}
 extern "C" int wmh_conv3d_k3_config(int Cin, int Cout, int D, int H, int W, int stride) {
-    if (Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2))
-        return wmh_fail(WMH_EINVAL, "wmh_conv3d_k3_config: bad shape");
-    const int Wo = (W - 1) / stride + 1;
-    int base = Wo >= 24 ? 0 : Wo >= 12 ? 2 : Wo >= 6 ? 4 : 6;
-    if (base == 0 && stride == 1 && Cin <= 2) return 8;
-    return base + (stride == 2 ? 1 : 0);
+    return wmh_conv3d_config(Cin, Cout, D, H, W, 3, stride, stride);
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -385,23 +410,23 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 extern "C" size_t wmh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg < 0 || cfg >= WMH_NUM_CONV_CFG) return 0;
     const CfgInfo& c = cfg_info(cfg);
-    return (size_t)cdiv(Cout, 32 * c.NT) * cdiv(Cin, c.CK) * 27 * c.NT * 64 * (c.CK / 2);
+    return (size_t)cdiv(Cout, 32 * c.NT) * cdiv(Cin, c.CK) * (c.KZ * 9) * c.NT * 64 * (c.CK / 2);
 }
 
 extern "C" int wmh_conv3d_k3_pack_weights(int cfg, const float* w, int Cin, int Cout, float* wf) {
     if (cfg < 0 || cfg >= WMH_NUM_CONV_CFG || !w || !wf) return wmh_fail(WMH_EINVAL, "pack_weights: bad args");
     const CfgInfo& c = cfg_info(cfg);
-    const int CK = c.CK, NT = c.NT, G = cdiv(Cout, 32 * NT), NCH = cdiv(Cin, CK), V = CK / 2;
+    const int CK = c.CK, NT = c.NT, G = cdiv(Cout, 32 * NT), NCH = cdiv(Cin, CK), V = CK / 2, NTAPS = c.KZ * 9;
     for (int g = 0; g < G; ++g)
         for (int ch = 0; ch < NCH; ++ch)
-            for (int tap = 0; tap < 27; ++tap)
+            for (int tap = 0; tap < NTAPS; ++tap)
                 for (int nt = 0; nt < NT; ++nt)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int p = 0; p < V; ++p) {
                             const int co = (g * NT + nt) * 32 + (lane & 31), ci = ch * CK + 2 * p + (lane >> 5);
                             float v = 0.f;
-                            if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 27 + tap];
-                            wf[(((((size_t)g * NCH + ch) * 27 + tap) * NT + nt) * 64 + lane) * V + p] = v;
+                            if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * NTAPS + tap];
+                            wf[(((((size_t)g * NCH + ch) * NTAPS + tap) * NT + nt) * 64 + lane) * V + p] = v;
                         }
     return WMH_OK;
 }
@@ -410,22 +435,22 @@ extern "C" int wmh_conv3d_k3_pack_weights(int cfg, const float* w, int Cin, int 
 // HBM; input channels [ci_off, ci_off+ci_cnt) are used.  mode 0: the forward image of a conv ci_cnt -> Cout.
 // mode 1: the image of the DATA-GRADIENT conv Cout -> ci_cnt, i.e. W'[ci][co][tap] = W[co][ci][26 - tap].
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float* wf, int Cin_total, int Cout, int ci_off,
-                                                           int ci_cnt, int mode, int CK, int NT, int NCH, size_t total) {
+                                                           int ci_cnt, int mode, int CK, int NT, int NCH, int NTAPS, size_t total) {
     const int V = CK / 2;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         size_t r = idx;
         const int pp = (int)(r % V); r /= V;
         const int lane = (int)(r % 64); r /= 64;
         const int nt = (int)(r % NT); r /= NT;
-        const int tap = (int)(r % 27); r /= 27;
+        const int tap = (int)(r % NTAPS); r /= NTAPS;
         const int ch = (int)(r % NCH); r /= NCH;
         const int g = (int)r;
         const int eco = (g * NT + nt) * 32 + (lane & 31), eci = ch * CK + 2 * pp + (lane >> 5);   // effective conv's (cout, cin)
         float v = 0.f;
         if (mode == 0) {
-            if (eco < Cout && eci < ci_cnt) v = w[((size_t)eco * Cin_total + ci_off + eci) * 27 + tap];
+            if (eco < Cout && eci < ci_cnt) v = w[((size_t)eco * Cin_total + ci_off + eci) * NTAPS + tap];
         } else {
-            if (eco < ci_cnt && eci < Cout) v = w[((size_t)eci * Cin_total + ci_off + eco) * 27 + (26 - tap)];
+            if (eco < ci_cnt && eci < Cout) v = w[((size_t)eci * Cin_total + ci_off + eco) * NTAPS + (NTAPS - 1 - tap)];
         }
         wf[idx] = v;
     }
@@ -437,10 +462,10 @@ extern "C" int wmh_conv3d_k3_pack_weights_device(int cfg, const float* w, int Ci
     const CfgInfo& c = cfg_info(cfg);
     const int eCin = mode == 0 ? ci_cnt : Cout, eCout = mode == 0 ? Cout : ci_cnt;
     const int NCH = cdiv(eCin, c.CK);
-    const size_t total = (size_t)cdiv(eCout, 32 * c.NT) * NCH * 27 * c.NT * 64 * (c.CK / 2);
+    const size_t total = (size_t)cdiv(eCout, 32 * c.NT) * NCH * (c.KZ * 9) * c.NT * 64 * (c.CK / 2);
     unsigned nb = (unsigned)((total + 255) / 256); if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wf, Cin_total, Cout, ci_off,
-                       ci_cnt, mode, c.CK, c.NT, NCH, total);
+                       ci_cnt, mode, c.CK, c.NT, NCH, c.KZ * 9, total);
     return wmh_check_launch("pack_weights_kernel");
 }
 
@@ -465,7 +490,7 @@ extern "C" int wmh_conv3d_k3_num_partials(int cfg, int N, int Do, int Ho, int Wo
 extern "C" size_t wmh_conv3d_k3_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout, int stride) {
     if (cfg < 0 || cfg >= WMH_NUM_CONV_CFG) return 0;
     const CfgInfo& c = cfg_info(cfg);
-    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const int Do = (D - 1) / c.SZ + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const long long nblk = (long long)cdiv(Wo, c.TX) * cdiv(Ho, c.TY) * cdiv(Do, c.TZ) * cdiv(N, c.TN) * cdiv(Cout, 32 * c.NT);
     const int ks = pick_ksplit(c, nblk, cdiv(Cin, c.CK));
     return ks > 1 ? (size_t)ks * N * Cout * Do * Ho * Wo : 0;
@@ -485,7 +510,7 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
     a.x0 = x0; a.ss0 = ss0; a.C0 = C0; a.x1 = x1; a.ss1 = ss1; a.C1 = C1;
     a.wf = wf; a.bias = bias; a.y = y; a.part = partials;
     a.N = N; a.D = D; a.H = H; a.W = W;
-    a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+    a.Do = (D - 1) / c.SZ + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;   // stride = in-plane stride
     a.Cout = Cout;
     a.nchunks = (C1 > 0) ? (C0 / c.CK + cdiv(C1, c.CK)) : cdiv(C0, c.CK);
     a.ntx = cdiv(a.Wo, c.TX); a.nty = cdiv(a.Ho, c.TY); a.ntz = cdiv(a.Do, c.TZ);
@@ -524,6 +549,18 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
         case 6: rc = launch_conv<Cfg6>(a, (unsigned)nblk, st); break;
         case 7: rc = launch_conv<Cfg7>(a, (unsigned)nblk, st); break;
         case 8: rc = launch_conv<Cfg8>(a, (unsigned)nblk, st); break;
+        case 9: rc = launch_conv<Cfg9>(a, (unsigned)nblk, st); break;
+        case 10: rc = launch_conv<Cfg10>(a, (unsigned)nblk, st); break;
+        case 11: rc = launch_conv<Cfg11>(a, (unsigned)nblk, st); break;
+        case 12: rc = launch_conv<Cfg12>(a, (unsigned)nblk, st); break;
+        case 13: rc = launch_conv<Cfg13>(a, (unsigned)nblk, st); break;
+        case 14: rc = launch_conv<Cfg14>(a, (unsigned)nblk, st); break;
+        case 15: rc = launch_conv<Cfg15>(a, (unsigned)nblk, st); break;
+        case 16: rc = launch_conv<Cfg16>(a, (unsigned)nblk, st); break;
+        case 17: rc = launch_conv<Cfg17>(a, (unsigned)nblk, st); break;
+        case 18: rc = launch_conv<Cfg18>(a, (unsigned)nblk, st); break;
+        case 19: rc = launch_conv<Cfg19>(a, (unsigned)nblk, st); break;
+        case 20: rc = launch_conv<Cfg20>(a, (unsigned)nblk, st); break;
         default: return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd: bad cfg");
     }
     if (rc != WMH_OK || a.KS == 1) return rc;

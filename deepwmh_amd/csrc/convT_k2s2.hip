@@ -24,8 +24,10 @@ struct ConvTArgs {
     float slope;
 };
 
-template <int NT, int MT, int CKC>
+// KT: kernel/stride along the first spatial axis: 2, or 1 for nnU-Net's anisotropic (1,2,2) up-sampling
+template <int NT, int MT, int CKC, int KT>
 __global__ __launch_bounds__(256, 2) void convT_k2s2_mfma_kernel(const ConvTArgs a) {
+    constexpr int NTAP = 4 * KT;                  // rows per output channel
     constexpr int VT = MT * 32;                  // voxels per workgroup tile
     constexpr int F4 = CKC * VT / 4 / 256;       // float4 staged per thread per chunk
     static_assert(CKC * VT / 4 % 256 == 0 && CKC % 8 == 0, "staging shape");
@@ -124,9 +126,12 @@ __global__ __launch_bounds__(256, 2) void convT_k2s2_mfma_kernel(const ConvTArgs
         __syncthreads();
     }
 
-    // epilogue: rows (2t, 2t+1) = taps k = 0, 1 -> float2; lanes along w -> contiguous 256 B per half-wave
+    // epilogue: accumulator rows r and r+1 (r even) are the taps k = 0, 1 of one output position -> float2;
+    // lanes run along w -> 256 contiguous bytes per half-wave.
+    //   KT = 2: row = co_l*8 + t, t = 4*kh + (r&3) -> tap i = kh, j = (r>>1)&1 ; co_l = r>>2          (4 couts per tile)
+    //   KT = 1: row = co_l*4 + t, t = r&3          -> tap j = (r>>1)&1           ; co_l = 2*(r>>2) + kh (8 couts per tile)
     const int H2 = 2 * a.H, W2 = 2 * a.W;
-    const size_t O = (size_t)8 * DHW;
+    const size_t O = (size_t)NTAP * DHW;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const long long gv = gv0 + 32 * m + j;
@@ -134,15 +139,15 @@ __global__ __launch_bounds__(256, 2) void convT_k2s2_mfma_kernel(const ConvTArgs
         const int n = (int)(gv / DHW);
         const long long v = gv - (long long)n * DHW;
         const int wq = (int)(v % a.W), hq = (int)((v / a.W) % a.H), dq = (int)(v / ((long long)a.W * a.H));
-        // kh selects i (tap bit 2): rows 4*kh + (r&3) -> t = 4*kh + (r&3): i = kh, j = (r>>1)&1, k = r&1
-        const size_t base = ((size_t)(2 * dq + kh) * H2 + 2 * hq) * W2 + 2 * wq;
+        const size_t base = ((size_t)(KT == 2 ? 2 * dq + kh : dq) * H2 + 2 * hq) * W2 + 2 * wq;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int co0 = ((rg * 4 + wave) * NT + nt) * 4;            // 32 rows = 4 output channels x 8 taps
+            const int co0 = ((rg * 4 + wave) * NT + nt) * (32 / NTAP);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (co0 + c >= a.Cout) continue;
-                float* yp = a.y + ((size_t)n * a.Cout + co0 + c) * O + base;
+                const int co = co0 + (KT == 2 ? c : 2 * c + kh);
+                if (co >= a.Cout) continue;
+                float* yp = a.y + ((size_t)n * a.Cout + co) * O + base;
                 *reinterpret_cast<float2*>(yp) = make_float2(acc[nt][m][4 * c + 0], acc[nt][m][4 * c + 1]);
                 *reinterpret_cast<float2*>(yp + W2) = make_float2(acc[nt][m][4 * c + 2], acc[nt][m][4 * c + 3]);
             }
@@ -152,19 +157,22 @@ __global__ __launch_bounds__(256, 2) void convT_k2s2_mfma_kernel(const ConvTArgs
 
 static inline int cdivi(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-extern "C" size_t wmh_convtranspose3d_k2s2_packed_floats(int Cin, int Cout) {
-    const int RT = cdivi((long long)Cout * 8, 256) * 8, Cin8 = (Cin + 7) / 8;
+static size_t convT_packed_floats(int Cin, int Cout, int kt) {
+    const int RT = cdivi((long long)Cout * 4 * kt, 256) * 8, Cin8 = (Cin + 7) / 8;
     return (size_t)RT * Cin8 * 64 * 4;
 }
+extern "C" size_t wmh_convtranspose3d_k2s2_packed_floats(int Cin, int Cout) { return convT_packed_floats(Cin, Cout, 2); }
+extern "C" size_t wmh_convtranspose3d_packed_floats(int Cin, int Cout, int kt) { return (kt == 1 || kt == 2) ? convT_packed_floats(Cin, Cout, kt) : 0; }
 // w: host torch layout [Cin][Cout][2][2][2]; wf: host out, fragment-major [row tile][Cin/8][lane][4]
-extern "C" int wmh_convtranspose3d_k2s2_pack_weights(const float* w, int Cin, int Cout, float* wf) {
-    if (!w || !wf || Cin < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "convT pack: bad args");
-    const int R = Cout * 8, RT = cdivi(R, 256) * 8, Cin8 = (Cin + 7) / 8;
+// kt = kernel/stride along the first spatial axis (2, or 1 for (1,2,2)); w = torch layout [Cin][Cout][kt][2][2]
+extern "C" int wmh_convtranspose3d_pack_weights(const float* w, int Cin, int Cout, int kt, float* wf) {
+    if (!w || !wf || Cin < 1 || Cout < 1 || (kt != 1 && kt != 2)) return wmh_fail(WMH_EINVAL, "convT pack: bad args");
+    const int R = Cout * 4 * kt, RT = cdivi(R, 256) * 8, Cin8 = (Cin + 7) / 8;
     for (int rt = 0; rt < RT; ++rt)
         for (int q = 0; q < Cin8; ++q)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 4; ++e) {
-                    const int row = rt * 32 + (lane & 31), ci = 2 * (4 * q + e) + (lane >> 5);
+                    const int row = rt * 32 + (lane & 31), ci = 2 * (4 * q + e) + (lane >> 5);   // row = co*(4*kt) + tap
                     float v = 0.f;
                     if (row < R && ci < Cin) v = w[(size_t)ci * R + row];
                     wf[(((size_t)rt * Cin8 + q) * 64 + lane) * 4 + e] = v;
@@ -172,23 +180,32 @@ extern "C" int wmh_convtranspose3d_k2s2_pack_weights(const float* w, int Cin, in
     return WMH_OK;
 }
 
-extern "C" int wmh_convtranspose3d_k2s2_mfma_fwd(const float* x, const float* ss, const float* wf, float* y, int N,
-                                                 int Cin, int Cout, int D, int H, int W, float lrelu_slope,
-                                                 void* stream) {
-    if (!x || !wf || !y || N < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1)
-        return wmh_fail(WMH_EINVAL, "convtranspose3d_k2s2_mfma_fwd: bad args");
+extern "C" int wmh_convtranspose3d_k2s2_pack_weights(const float* w, int Cin, int Cout, float* wf) {
+    return wmh_convtranspose3d_pack_weights(w, Cin, Cout, 2, wf);
+}
+
+extern "C" int wmh_convtranspose3d_mfma_fwd(const float* x, const float* ss, const float* wf, float* y, int N, int Cin,
+                                            int Cout, int D, int H, int W, int kt, float lrelu_slope, void* stream) {
+    if (!x || !wf || !y || N < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (kt != 1 && kt != 2))
+        return wmh_fail(WMH_EINVAL, "convtranspose3d_mfma_fwd: bad args");
     const long long DHW = (long long)D * H * W;
     if (DHW % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 7))
         return wmh_fail(WMH_EINVAL, "convtranspose3d_k2s2_mfma_fwd: needs D*H*W % 4 == 0 and 16-byte aligned x");
     constexpr int NT = 2, MT = 4, CKC = 32;
     ConvTArgs a;
     a.x = x; a.ss = ss; a.wf = wf; a.y = y; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
-    a.nrg = cdivi((long long)Cout * 8, 256);
+    a.nrg = cdivi((long long)Cout * 4 * kt, 256);
     a.nvox = (long long)N * DHW;
     a.slope = lrelu_slope;
     const long long nblk = (long long)cdivi(a.nvox, MT * 32) * a.nrg;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "convtranspose3d_k2s2_mfma_fwd: grid too large");
     const int lds = 2 * CKC * MT * 32 * 4;
-    hipLaunchKernelGGL((convT_k2s2_mfma_kernel<NT, MT, CKC>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    if (kt == 2) hipLaunchKernelGGL((convT_k2s2_mfma_kernel<NT, MT, CKC, 2>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    else         hipLaunchKernelGGL((convT_k2s2_mfma_kernel<NT, MT, CKC, 1>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
     return wmh_check_launch("convT_k2s2_mfma_kernel");
+}
+extern "C" int wmh_convtranspose3d_k2s2_mfma_fwd(const float* x, const float* ss, const float* wf, float* y, int N,
+                                                 int Cin, int Cout, int D, int H, int W, float lrelu_slope,
+                                                 void* stream) {
+    return wmh_convtranspose3d_mfma_fwd(x, ss, wf, y, N, Cin, Cout, D, H, W, 2, lrelu_slope, stream);
 }

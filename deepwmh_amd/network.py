@@ -29,10 +29,11 @@ def _np(v):
 class _ConvLayer:
     """One Conv3d(3x3x3)+InstanceNorm layer: packed weights per kernel configuration."""
 
-    def __init__(self, lib, sd, prefix, cin, cout, stride, device):
+    def __init__(self, lib, sd, prefix, cin, cout, stride, device, kz=3, sz=None):
         self.lib, self.cin, self.cout, self.stride, self.device = lib, cin, cout, stride, device
+        self.kz, self.sz = kz, (stride if sz is None else sz)
         self.w_host = _np(sd[prefix + '.conv.weight'])
-        assert self.w_host.shape == (cout, cin, 3, 3, 3), (prefix, self.w_host.shape)
+        assert self.w_host.shape == (cout, cin, kz, 3, 3), (prefix, self.w_host.shape)
         self.bias = torch.from_numpy(_np(sd[prefix + '.conv.bias'])).to(device)
         self.gamma = torch.from_numpy(_np(sd[prefix + '.instnorm.weight'])).to(device)
         self.beta = torch.from_numpy(_np(sd[prefix + '.instnorm.bias'])).to(device)
@@ -79,20 +80,21 @@ class UNetEngine:
         _lib.check(self.lib.wmh_device_check(self.device.index or 0), 'wmh_device_check')
         sd = state_dict
         dev = self.device
-        self.enc = [_ConvLayer(self.lib, sd, s.name, s.cin, s.cout, s.stride, dev) for s in plan.encoder_convs()]
+        self.enc = [_ConvLayer(self.lib, sd, s.name, s.cin, s.cout, s.stride, dev, s.kz, s.sz) for s in plan.encoder_convs()]
         self.dec = []
         for st in plan.decoder_stages():
             name, cdown, cskip = st['tu']
+            kt = st['tu_kt']
             tu_host = _np(sd[name + '.weight'])
-            assert tuple(tu_host.shape) == (cdown, cskip, 2, 2, 2)
+            assert tuple(tu_host.shape) == (cdown, cskip, kt, 2, 2)
             tu_w = torch.from_numpy(tu_host).to(dev)
-            wf = np.empty(self.lib.wmh_convtranspose3d_k2s2_packed_floats(cdown, cskip), dtype=np.float32)
-            _lib.check(self.lib.wmh_convtranspose3d_k2s2_pack_weights(tu_host.ctypes.data_as(C.c_void_p), cdown, cskip,
-                                                                      wf.ctypes.data_as(C.c_void_p)), 'convT pack')
+            wf = np.empty(self.lib.wmh_convtranspose3d_packed_floats(cdown, cskip, kt), dtype=np.float32)
+            _lib.check(self.lib.wmh_convtranspose3d_pack_weights(tu_host.ctypes.data_as(C.c_void_p), cdown, cskip, kt,
+                                                                 wf.ctypes.data_as(C.c_void_p)), 'convT pack')
             tu_wf = torch.from_numpy(wf).to(dev)
-            convs = [_ConvLayer(self.lib, sd, c.name, c.cin, c.cout, 1, dev) for c in st['convs']]
+            convs = [_ConvLayer(self.lib, sd, c.name, c.cin, c.cout, 1, dev, c.kz, c.sz) for c in st['convs']]
             seg_w = torch.from_numpy(_np(sd[st['seg'] + '.weight']).reshape(plan.num_classes, cskip)).contiguous().to(dev)
-            self.dec.append(dict(tu_w=tu_w, tu_wf=tu_wf, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
+            self.dec.append(dict(tu_w=tu_w, tu_wf=tu_wf, kt=kt, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
         self._bufs = {}
         # optional live kernel timing (bench.py): conv configs to bracket with HIP events on the launch stream
         self.timed_cfgs = set()
@@ -117,8 +119,8 @@ class UNetEngine:
         C1 = 0 if x1 is None else x1.shape[1]
         assert C0 + C1 == layer.cin
         s = layer.stride
-        Do, Ho, Wo = (D - 1) // s + 1, (H - 1) // s + 1, (W - 1) // s + 1
-        cfg = _lib.check(self.lib.wmh_conv3d_k3_config(layer.cin, layer.cout, D, H, W, s), 'wmh_conv3d_k3_config')
+        Do, Ho, Wo = (D - 1) // layer.sz + 1, (H - 1) // s + 1, (W - 1) // s + 1
+        cfg = _lib.check(self.lib.wmh_conv3d_config(layer.cin, layer.cout, D, H, W, layer.kz, layer.sz, s), 'wmh_conv3d_config')
         npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials')
         y = self._buf(key + '.y', (N, layer.cout, Do, Ho, Wo))
         part = self._buf(key + '.part', (N, layer.cout, npart, 4))
@@ -154,13 +156,15 @@ class UNetEngine:
             N, layer.cout, st), 'wmh_instnorm_finalize')
         return y, ss
 
-    def _convT(self, key, w, wf, x, ss, cout):
+    def _convT(self, key, w, wf, x, ss, cout, kt=2):
         N, Cin, D, H, W = x.shape
-        y = self._buf(key + '.y', (N, cout, 2 * D, 2 * H, 2 * W))
+        y = self._buf(key + '.y', (N, cout, kt * D, 2 * H, 2 * W))
         if (D * H * W) % 4 == 0:           # matrix-core kernel (16-byte staging loads)
-            _lib.check(self.lib.wmh_convtranspose3d_k2s2_mfma_fwd(
-                _lib.ptr(x), _lib.ptr(ss), _lib.ptr(wf), _lib.ptr(y), N, Cin, cout, D, H, W, LRELU_SLOPE,
-                self._stream()), 'wmh_convtranspose3d_k2s2_mfma_fwd')
+            _lib.check(self.lib.wmh_convtranspose3d_mfma_fwd(
+                _lib.ptr(x), _lib.ptr(ss), _lib.ptr(wf), _lib.ptr(y), N, Cin, cout, D, H, W, kt, LRELU_SLOPE,
+                self._stream()), 'wmh_convtranspose3d_mfma_fwd')
+        elif kt != 2:
+            raise NotImplementedError('(1,2,2) transposed convolution needs D*H*W % 4 == 0')
         else:                              # odd-sized tensors: vector-ALU kernel
             _lib.check(self.lib.wmh_convtranspose3d_k2s2_fwd(
                 _lib.ptr(x), _lib.ptr(ss), _lib.ptr(w), _lib.ptr(y), N, Cin, cout, D, H, W, LRELU_SLOPE,
@@ -182,7 +186,7 @@ class UNetEngine:
                 skips.append((cur, cur_ss))
         outs = []
         for u, st in enumerate(self.dec):
-            up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'])
+            up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt'])
             skip, skip_ss = skips[-(u + 1)]
             cur, cur_ss = self._conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss)
             cur, cur_ss = self._conv('dec%d.1' % u, st['convs'][1], cur, cur_ss)

@@ -18,8 +18,14 @@ class ConvSpec:
     name: str          # state-dict prefix, e.g. 'conv_blocks_context.0.blocks.0'
     cin: int
     cout: int
-    stride: int
+    stride: int        # in-plane stride s (1 or 2)
     level: int         # resolution level (0 = full patch resolution)
+    kz: int = 3        # kernel extent along the first spatial axis (1 for nnU-Net's anisotropic [1,3,3])
+    sz: int = 0        # stride along the first spatial axis (0 = same as `stride`)
+
+    def __post_init__(self):
+        if self.sz == 0:
+            self.sz = self.stride
 
 
 @dataclass
@@ -47,32 +53,39 @@ class UNetPlan:
         return out
 
     def check_supported(self):
-        """The HIP path implements the isotropic 3x3x3 / 2x2x2 configuration of BASELINE.json."""
+        """The HIP path implements nnU-Net's 3-D plans: kernels [3,3,3] or [1,3,3] (anisotropic data: no convolution
+        along the thick-slice axis), pooling [2,2,2] or [1,2,2], two convolutions per stage."""
         for k in self.conv_kernel_sizes:
-            if list(k) != [3, 3, 3]:
-                raise NotImplementedError("conv_kernel_sizes %s: only [3,3,3] is implemented in HIP" % (k,))
+            if list(k) not in ([3, 3, 3], [1, 3, 3]):
+                raise NotImplementedError("conv_kernel_sizes %s: [3,3,3] and [1,3,3] are implemented in HIP" % (k,))
         for p in self.pool_op_kernel_sizes:
-            if list(p) != [2, 2, 2]:
-                raise NotImplementedError("pool_op_kernel_sizes %s: only [2,2,2] is implemented in HIP" % (p,))
+            if list(p) not in ([2, 2, 2], [1, 2, 2]):
+                raise NotImplementedError("pool_op_kernel_sizes %s: [2,2,2] and [1,2,2] are implemented in HIP" % (p,))
         if self.conv_per_stage != 2:
             raise NotImplementedError("conv_per_stage must be 2")
-        div = 2 ** self.num_pool
-        for s in self.patch_size:
+        for ax, s in enumerate(self.patch_size):
+            div = int(np.prod([p[ax] for p in self.pool_op_kernel_sizes]))
             if s % div:
-                raise ValueError("patch_size %s not divisible by 2^num_pool" % (self.patch_size,))
+                raise ValueError("patch_size %s not divisible by the pooling along axis %d" % (self.patch_size, ax))
+
+    @property
+    def isotropic(self):
+        return all(list(k) == [3, 3, 3] for k in self.conv_kernel_sizes) and all(list(p) == [2, 2, 2] for p in self.pool_op_kernel_sizes)
 
     def encoder_convs(self):
         """(stage d, conv i) -> ConvSpec in forward order, bottleneck included."""
         feats = self.features()
         specs, cin = [], self.num_input_channels
+        ks, ps = self.conv_kernel_sizes, self.pool_op_kernel_sizes
         for d in range(self.num_pool):
             pre = 'conv_blocks_context.%d.blocks' % d
-            specs.append(ConvSpec('%s.0' % pre, cin, feats[d], 1 if d == 0 else 2, d))
-            specs.append(ConvSpec('%s.1' % pre, feats[d], feats[d], 1, d))
+            s, sz = (1, 1) if d == 0 else (ps[d - 1][1], ps[d - 1][0])
+            specs.append(ConvSpec('%s.0' % pre, cin, feats[d], s, d, ks[d][0], sz))
+            specs.append(ConvSpec('%s.1' % pre, feats[d], feats[d], 1, d, ks[d][0], 1))
             cin = feats[d]
         d = self.num_pool
-        specs.append(ConvSpec('conv_blocks_context.%d.0.blocks.0' % d, cin, feats[d], 2, d))
-        specs.append(ConvSpec('conv_blocks_context.%d.1.blocks.0' % d, feats[d], feats[d], 1, d))
+        specs.append(ConvSpec('conv_blocks_context.%d.0.blocks.0' % d, cin, feats[d], ps[-1][1], d, ks[d][0], ps[-1][0]))
+        specs.append(ConvSpec('conv_blocks_context.%d.1.blocks.0' % d, feats[d], feats[d], 1, d, ks[d][0], 1))
         return specs
 
     def decoder_stages(self):
@@ -83,10 +96,11 @@ class UNetPlan:
             level = self.num_pool - 1 - u
             cskip = feats[level]
             pre = 'conv_blocks_localization.%d' % u
+            kz = self.conv_kernel_sizes[-(u + 1)][0]      # upstream: decoder u takes the kernel of the stage one deeper
             out.append(dict(
-                u=u, level=level, tu=('tu.%d' % u, cdown, cskip),
-                convs=[ConvSpec('%s.0.blocks.0' % pre, 2 * cskip, cskip, 1, level),
-                       ConvSpec('%s.1.blocks.0' % pre, cskip, cskip, 1, level)],
+                u=u, level=level, tu=('tu.%d' % u, cdown, cskip), tu_kt=self.pool_op_kernel_sizes[-(u + 1)][0],
+                convs=[ConvSpec('%s.0.blocks.0' % pre, 2 * cskip, cskip, 1, level, kz, 1),
+                       ConvSpec('%s.1.blocks.0' % pre, cskip, cskip, 1, level, kz, 1)],
                 seg='seg_outputs.%d' % u))
             cdown = cskip
         return out

@@ -38,6 +38,8 @@ class _Conv:
 class UNetTrainer:
     def __init__(self, plan: UNetPlan, state_dict, device='cuda:0', momentum=0.99, weight_decay=3e-5, clip=12.0):
         plan.check_supported()
+        if not plan.isotropic:
+            raise NotImplementedError('training implements the isotropic [3,3,3] / [2,2,2] architecture only (the planner emits nothing else)')
         self.plan, self.device = plan, torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('UNetTrainer needs a HIP device; there is no CPU path')

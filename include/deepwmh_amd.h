@@ -55,6 +55,10 @@ int wmh_device_check(int dev);
 
 /* Pick the kernel configuration for a layer shape (input spatial dims D,H,W). <0 on error. */
 int wmh_conv3d_k3_config(int Cin, int Cout, int D, int H, int W, int stride);
+/* General form for nnU-Net's anisotropic plans: kernel (kz,3,3) with kz in {1,3} (weights [Cout][Cin][kz][3][3]),
+ * stride (sz, s, s) with sz <= s (pooling [1,2,2] = sz 1, s 2).  Every wmh_conv3d_k3_* call below takes the cfg it
+ * returns; `stride` arguments are the in-plane stride s, Do = (D-1)/sz + 1. */
+int wmh_conv3d_config(int Cin, int Cout, int D, int H, int W, int kz, int sz, int s);
 /* Number of floats of the packed (MFMA fragment-major) weight image for that configuration. */
 size_t wmh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout);
 /* Host-side repack: w is host memory [Cout][Cin][3][3][3] (torch Conv3d.weight), wf host out. */
@@ -119,6 +123,12 @@ int wmh_convtranspose3d_k2s2_pack_weights(const float* w, int Cin, int Cout, flo
 int wmh_convtranspose3d_k2s2_mfma_fwd(const float* x, const float* ss, const float* wf, float* y,
                                       int N, int Cin, int Cout, int D, int H, int W,
                                       float lrelu_slope, void* stream);
+/* General form: kernel = stride = (kt,2,2), kt in {1,2} (nnU-Net's anisotropic up-sampling is kt = 1);
+ * w torch layout [Cin][Cout][kt][2][2]; output [N,Cout,kt*D,2H,2W]. */
+size_t wmh_convtranspose3d_packed_floats(int Cin, int Cout, int kt);
+int wmh_convtranspose3d_pack_weights(const float* w, int Cin, int Cout, int kt, float* wf);
+int wmh_convtranspose3d_mfma_fwd(const float* x, const float* ss, const float* wf, float* y, int N, int Cin,
+                                 int Cout, int D, int H, int W, int kt, float lrelu_slope, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sliding-window glue [nnU-Net neural_network.py::_internal_predict_3D_3Dconv_tiled and

@@ -142,6 +142,71 @@ def test_conv3d_k3_and_instnorm_partials(lib, case):
     assert float((mine - full).abs().max()) <= 2e-5
 
 
+ANISO_CASES = [
+    # N, Cin, Cout, D, H, W, kz, sz, s
+    (2, 8, 8, 6, 16, 40, 1, 1, 1), (1, 16, 24, 5, 20, 13, 1, 1, 1), (3, 32, 32, 4, 8, 8, 1, 1, 1), (5, 32, 32, 2, 4, 4, 1, 1, 1),
+    (1, 8, 16, 6, 32, 64, 1, 1, 2), (2, 16, 32, 4, 16, 32, 1, 1, 2), (1, 16, 32, 5, 16, 16, 1, 1, 2), (5, 16, 32, 3, 8, 8, 1, 1, 2),
+    (1, 8, 16, 6, 32, 64, 3, 1, 2), (2, 16, 32, 4, 17, 31, 3, 1, 2), (1, 16, 32, 5, 16, 16, 3, 1, 2), (5, 16, 32, 3, 8, 8, 3, 1, 2),
+    (1, 1, 8, 4, 32, 32, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', ANISO_CASES, ids=[str(c) for c in ANISO_CASES])
+def test_conv3d_anisotropic_kernels_and_strides(lib, case):
+    # nnU-Net's anisotropic plans: kernel (kz,3,3), stride (sz,s,s)
+    from deepwmh_amd import _lib
+    N, Cin, Cout, D, H, W, kz, sz, s = case
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    ss = torch.stack([0.5 + torch.rand(N, Cin, generator=g), 0.3 * torch.randn(N, Cin, generator=g)], -1)
+    w = torch.randn(Cout, Cin, kz, 3, 3, generator=g) * (2.0 / (9 * kz * Cin)) ** 0.5
+    b = 0.1 * torch.randn(Cout, generator=g)
+    ref = F.conv3d(_lrelu_affine(x, ss), w, b, stride=(sz, s, s), padding=(kz // 2, 1, 1))
+    Do, Ho, Wo = ref.shape[2:]
+    cfg = lib.wmh_conv3d_config(Cin, Cout, D, H, W, kz, sz, s)
+    assert cfg >= 9
+    wf = np.empty(lib.wmh_conv3d_k3_packed_floats(cfg, Cin, Cout), np.float32)
+    wn = w.numpy()
+    assert lib.wmh_conv3d_k3_pack_weights(cfg, wn.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)) == 0
+    npart = lib.wmh_conv3d_k3_num_partials(cfg, N, Do, Ho, Wo)
+    y = torch.full((N, Cout, Do, Ho, Wo), float('nan'), device='cuda')
+    part = torch.full((N, Cout, npart, 4), float('nan'), device='cuda')
+    mr = torch.full((N, Cout, 2), float('nan'), device='cuda'); sso = torch.empty(N, Cout, 2, device='cuda')
+    nws = lib.wmh_conv3d_k3_workspace_floats(cfg, Cin, N, D, H, W, Cout, s)
+    ws = torch.full((nws,), float('nan'), device='cuda') if nws else None
+    xd, ssd, wfd, bd = x.cuda(), ss.cuda(), dev(wf), b.cuda()
+    _lib.check(lib.wmh_conv3d_k3_fwd(cfg, P(xd), P(ssd), Cin, None, None, 0, P(wfd), P(bd), P(y), P(part), P(ws), N, D, H, W, Cout, s,
+                                     SLOPE, None), 'conv')
+    _lib.check(lib.wmh_instnorm_finalize(P(part), npart, None, None, 1e-5, P(sso), P(mr), N, Cout, None), 'fin')
+    torch.cuda.synchronize()
+    yh = y.cpu()
+    assert not torch.isnan(yh).any()
+    assert float((yh - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
+    mean = ref.mean((2, 3, 4)).double()
+    assert float((mr.cpu().double()[..., 0] - mean).abs().max()) <= 1e-5 * (1 + float(mean.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 8, 3, 4, 4), (1, 24, 20, 5, 8, 16), (2, 64, 32, 2, 8, 8)])
+def test_convtranspose3d_anisotropic_1x2x2(lib, shape):
+    from deepwmh_amd import _lib
+    N, Cin, Cout, D, H, W = shape
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 1, 2, 2, generator=g) * 0.2
+    ss = torch.stack([0.5 + torch.rand(N, Cin, generator=g), 0.3 * torch.randn(N, Cin, generator=g)], -1)
+    ref = F.conv_transpose3d(_lrelu_affine(x, ss), w, None, stride=(1, 2, 2))
+    wf = np.empty(lib.wmh_convtranspose3d_packed_floats(Cin, Cout, 1), np.float32)
+    wn = w.numpy()
+    assert lib.wmh_convtranspose3d_pack_weights(wn.ctypes.data_as(C.c_void_p), Cin, Cout, 1, wf.ctypes.data_as(C.c_void_p)) == 0
+    y = torch.full((N, Cout, D, 2 * H, 2 * W), float('nan'), device='cuda')
+    xd, ssd, wd = x.cuda(), ss.cuda(), dev(wf)
+    _lib.check(lib.wmh_convtranspose3d_mfma_fwd(P(xd), P(ssd), P(wd), P(y), N, Cin, Cout, D, H, W, 1, SLOPE, None), 'convT 1x2x2')
+    torch.cuda.synchronize()
+    yh = y.cpu()
+    assert not torch.isnan(yh).any()
+    assert float((yh - ref).abs().max()) <= 1e-5 * (1 + float(ref.abs().max()))
+
+
 BF16_CASES = [(1, 32, 0, 32, 8, 16, 64, True, False), (2, 16, 16, 8, 8, 8, 32, False, True), (1, 6, 0, 40, 5, 9, 33, True, False),
               (2, 64, 0, 64, 8, 8, 16, True, False), (1, 16, 32, 24, 6, 20, 13, True, True)]
 

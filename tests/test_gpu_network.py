@@ -162,3 +162,30 @@ def test_bf16_forward_config3(tiny_net, tiny_io):
     dice = hard_dice_binary(tiny_io['seg_notta'], seg)
     print('bf16 operands: max|softmax - fp32 oracle| %.3g, Dice vs fp32 mask %.5f' % (err, dice))
     assert err < 0.05 and dice > 0.98
+
+
+def test_anisotropic_plan_matches_oracle():
+    """nnU-Net plans for thick-slice data: [1,3,3] kernels and [1,2,2] pooling in the first stages."""
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.plan import UNetPlan
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    from oracle import sliding_window as osw
+    from oracle.generic_unet import unet_from_plan, perturb_like_trained, state_dict_numpy
+    torch.manual_seed(4)
+    plan = UNetPlan(1, 8, 2, [[1, 2, 2], [1, 2, 2], [2, 2, 2]], [[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3]], 2, 64, [8, 32, 48])
+    net = perturb_like_trained(unet_from_plan(plan), seed=5).eval()
+    eng = UNetEngine(plan, state_dict_numpy(net), 'cuda:0')
+    vol = osw.synthetic_flair((12, 40, 64), seed=9)
+    x = torch.from_numpy(np.ascontiguousarray(vol[None, :, 2:10, 4:36, 8:56]))
+    with torch.no_grad():
+        net.do_ds = True
+        ref = net(x)
+        net.do_ds = False
+    got = eng.forward_logits(x.cuda(), deep_supervision=True)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert tuple(a.shape) == tuple(b.shape)
+        assert float((a.cpu() - b).abs().max()) <= TOL, 'scale %d' % i
+    seg, prob = SlidingWindowPredictor(eng, do_mirroring=True).predict(vol)
+    seg_o, prob_o = osw.predict_3d_tiled(net, vol, plan.patch_size, 0.5, True, True)
+    assert float(np.abs(prob - prob_o).max()) <= TOL
+    assert _mask_check(seg, seg_o, prob_o)[0] == 0

@@ -120,6 +120,14 @@ def test_plan_from_nnunet_plans_dict():
     p = UNetPlan.from_nnunet_plans(plans)
     assert p.num_classes == 2 and p.patch_size == [128, 128, 128] and p.num_pool == 5
     import pytest
-    bad = tiny_plan(); bad.conv_kernel_sizes[0] = [1, 3, 3]
+    aniso = tiny_plan(); aniso.conv_kernel_sizes = [[1, 3, 3]] + [[3, 3, 3]] * 3; aniso.pool_op_kernel_sizes = [[1, 2, 2], [2, 2, 2], [2, 2, 2]]
+    aniso.patch_size = [8, 32, 32]
+    aniso.check_supported()
+    assert not aniso.isotropic
+    e = aniso.encoder_convs()
+    assert (e[0].kz, e[0].sz, e[0].stride) == (1, 1, 1) and (e[2].kz, e[2].sz, e[2].stride) == (3, 1, 2) and (e[4].sz, e[4].stride) == (2, 2)
+    d = aniso.decoder_stages()
+    assert d[-1]['tu_kt'] == 1 and d[0]['tu_kt'] == 2
+    bad = tiny_plan(); bad.conv_kernel_sizes = [[3, 1, 3]] + [[3, 3, 3]] * 3
     with pytest.raises(NotImplementedError):
         bad.check_supported()
