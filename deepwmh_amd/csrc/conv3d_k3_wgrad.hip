@@ -29,11 +29,13 @@ struct WgradArgs {
     float slope;
 };
 
-template <int S, int TX>
+template <int S, int TX, int TY_, int TZ_>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_kernel(const WgradArgs a) {
+    constexpr int TY = TY_, TZ = TZ_, IX = S * (TX - 1) + 3, IY = S * (TY - 1) + 3, IZ = S * (TZ - 1) + 3;   // compile time:
+    constexpr int TV = TZ * TY * TX, ZS = IY * IX, SPX = IZ * ZS, DYS = TV + 1, XCS = SPX;                 // no runtime divisions
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dyl = lds;                      // [32 co][dys]
-    float* xl = lds + 32 * a.dys;          // [4 ci][xcs]
+    float* xl = lds + 32 * DYS;            // [4 ci][XCS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
@@ -41,12 +43,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_kernel(const WgradArgs
     const int p = bid % a.P; bid /= a.P;
     const int g = bid % a.NG, cg = bid / a.NG;
 
-    const int ZS = a.IY * a.IX;
     const int tapj = min(i, 26);
-    const int LB = wave * a.xcs + kh * S + (tapj / 9) * ZS + ((tapj / 3) % 3) * a.IX + (tapj % 3);
-    const int LA = i * a.dys + kh;
-    const int TV = a.TZ * a.TY * TX;
-    const int SPX = a.IZ * ZS;
+    const int LB = wave * XCS + kh * S + (tapj / 9) * ZS + ((tapj / 3) % 3) * IX + (tapj % 3);
+    const int LA = i * DYS + kh;
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
     const size_t DHW = (size_t)a.D * HW, DoHoWo = (size_t)a.Do * HoWo;
 
@@ -62,16 +61,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_kernel(const WgradArgs
         const int ty = b % a.nty; b /= a.nty;
         const int tz = b % a.ntz; b /= a.ntz;
         const int n = b;
-        const int ox0 = tx * TX, oy0 = ty * a.TY, oz0 = tz * a.TZ;
+        const int ox0 = tx * TX, oy0 = ty * TY, oz0 = tz * TZ;
         const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
         __syncthreads();                                   // previous tile fully consumed
         for (int e = tid; e < 32 * TV; e += 256) {         // dy tile
             const int col = e / TV, v = e - col * TV;
-            const int x = v % TX, y = (v / TX) % a.TY, z = v / (TX * a.TY);
+            const int x = v % TX, y = (v / TX) % TY, z = v / (TX * TY);
             const int co = g * 32 + col, oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
             const bool ok = co < a.Cout && oz < a.Do && oy < a.Ho && ox < a.Wo;
             const float val = ok ? a.dy[((size_t)n * a.Cout + co) * DoHoWo + (size_t)oz * HoWo + oy * a.Wo + ox] : 0.f;
-            dyl[col * a.dys + v] = val;
+            dyl[col * DYS + v] = val;
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_kernel(const WgradArgs
             if (c > 0) __syncthreads();                    // x' chunk of the previous iteration consumed
             for (int e = tid; e < 4 * SPX; e += 256) {     // x' halo tile, 4 input channels
                 const int cc = e / SPX, s = e - cc * SPX;
-                const int x = s % a.IX, y = (s / a.IX) % a.IY, z = s / ZS;
+                const int x = s % IX, y = (s / IX) % IY, z = s / ZS;
                 const int ci = cg * 32 + 4 * c + cc;
                 const int gx = ix0 + x, gy = iy0 + y, gz = iz0 + z;
                 const bool ok = ci < a.Cin && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
@@ -96,13 +95,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_kernel(const WgradArgs
                         v = v > 0.f ? v : v * a.slope;
                     }
                 }
-                xl[cc * a.xcs + s] = v;
+                xl[cc * XCS + s] = v;
             }
             __syncthreads();
-            for (int z = 0; z < a.TZ; ++z)
-                for (int y = 0; y < a.TY; ++y) {
-                    const float* ap = dyl + LA + (z * a.TY + y) * TX;
-                    const float* bp = xl + LB + S * (z * ZS + y * a.IX);
+#pragma unroll
+            for (int z = 0; z < TZ; ++z)
+#pragma unroll
+                for (int y = 0; y < TY; ++y) {
+                    const float* ap = dyl + LA + (z * TY + y) * TX;
+                    const float* bp = xl + LB + S * (z * ZS + y * IX);
 #pragma unroll
                     for (int xp = 0; xp < TX / 2; ++xp)
                         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * xp], bp[S * 2 * xp], acc[c], 0, 0, 0);
@@ -138,7 +139,7 @@ static WgradPlan plan_wgrad(int Cin, int Cout, int N, int D, int H, int W, int S
     WgradPlan q;
     const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     q.TX = Wo >= 24 ? 32 : Wo >= 12 ? 16 : Wo >= 6 ? 8 : 4;
-    if (q.TX == 32) { q.TY = 4; q.TZ = 2; }
+    if (q.TX == 32) { q.TY = 4; q.TZ = 2; }                      // keep in step with the WG() table below
     else if (q.TX == 16) { q.TY = S == 1 ? 8 : 4; q.TZ = 2; }
     else if (q.TX == 8) { q.TY = 8; q.TZ = S == 1 ? 4 : 2; }
     else { q.TY = 4; q.TZ = 4; }
@@ -159,11 +160,11 @@ extern "C" size_t wmh_conv3d_k3_wgrad_workspace_floats(int Cin, int Cout, int N,
     return (size_t)q.P * Cout * Cin * 27;
 }
 
-template <int S, int TX>
+template <int S, int TX, int TY, int TZ>
 static int launch_wgrad(const WgradArgs& a, unsigned nblk, int lds, hipStream_t st) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_kernel<S, TX>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_kernel<S, TX, TY, TZ>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<S, TX>), dim3(nblk), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<S, TX, TY, TZ>), dim3(nblk), dim3(256), lds, st, a);
     return wmh_check_launch("conv3d_k3_wgrad_kernel");
 }
 
@@ -187,9 +188,9 @@ extern "C" int wmh_conv3d_k3_wgrad(const float* x0, const float* ss0, int C0, co
     const unsigned nblk = (unsigned)(q.NG * q.NCG * q.P);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-#define WG(SS, TT) rc = launch_wgrad<SS, TT>(a, nblk, q.lds_bytes, st)
-    if (stride == 1) { if (q.TX == 32) WG(1, 32); else if (q.TX == 16) WG(1, 16); else if (q.TX == 8) WG(1, 8); else WG(1, 4); }
-    else             { if (q.TX == 32) WG(2, 32); else if (q.TX == 16) WG(2, 16); else if (q.TX == 8) WG(2, 8); else WG(2, 4); }
+#define WG(SS, TT, YY, ZZ) rc = launch_wgrad<SS, TT, YY, ZZ>(a, nblk, q.lds_bytes, st)
+    if (stride == 1) { if (q.TX == 32) WG(1, 32, 4, 2); else if (q.TX == 16) WG(1, 16, 8, 2); else if (q.TX == 8) WG(1, 8, 8, 4); else WG(1, 4, 4, 4); }
+    else             { if (q.TX == 32) WG(2, 32, 4, 2); else if (q.TX == 16) WG(2, 16, 4, 2); else if (q.TX == 8) WG(2, 8, 8, 2); else WG(2, 4, 4, 4); }
 #undef WG
     if (rc != WMH_OK) return rc;
     const size_t n = (size_t)Cout * Cin * 27;
