@@ -301,11 +301,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
 
 struct WgradPlan { int TX, TY, TZ, IZ, IY, IX, ntx, nty, ntz, ntiles, NG, NCG, P, dys, xcs, lds_bytes; };
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static bool wgrad_old_form() {
+    static const bool v = getenv("WMH_WGRAD_OLD") != nullptr;      // diagnostic: the unpipelined kernel
+    return v;
+}
 static WgradPlan plan_wgrad(int Cin, int Cout, int N, int D, int H, int W, int S) {
     WgradPlan q;
     const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     q.TX = Wo >= 24 ? 32 : Wo >= 12 ? 16 : Wo >= 6 ? 8 : 4;
-    if (q.TX == 32) { q.TY = 4; q.TZ = 2; }                      // keep in step with the WG() table below
+    if (S == 2 && !wgrad_old_form()) {                           // pipelined stride 2: halo tiles small enough to prefetch
+        if (q.TX == 32) q.TX = 16;
+        if (q.TX == 16) { q.TY = 2; q.TZ = 2; } else if (q.TX == 8) { q.TY = 4; q.TZ = 2; } else { q.TY = 4; q.TZ = 4; }
+    }
+    else if (q.TX == 32) { q.TY = 4; q.TZ = 2; }                 // keep in step with the WG()/WP() tables below
     else if (q.TX == 16) { q.TY = S == 1 ? 8 : 4; q.TZ = 2; }
     else if (q.TX == 8) { q.TY = 8; q.TZ = S == 1 ? 4 : 2; }
     else { q.TY = 4; q.TZ = 4; }
@@ -369,8 +377,9 @@ extern "C" int wmh_conv3d_k3_wgrad(const float* x0, const float* ss0, int C0, co
     int rc;
 #define WG(SS, TT, YY, ZZ) rc = launch_wgrad<SS, TT, YY, ZZ>(a, nblk, q.lds_bytes, st)
 #define WP(SS, TT, YY, ZZ) rc = launch_wgrad_pipe<SS, TT, YY, ZZ>(a, nblk, st)
-    static const bool old_form = getenv("WMH_WGRAD_OLD") != nullptr;      // diagnostic: the unpipelined kernel
-    if (stride == 1 && !old_form) { if (q.TX == 32) WP(1, 32, 4, 2); else if (q.TX == 16) WP(1, 16, 8, 2); else if (q.TX == 8) WP(1, 8, 8, 4); else WP(1, 4, 4, 4); }
+    const bool old_form = wgrad_old_form();
+    if (stride == 2 && !old_form) { if (q.TX == 16) WP(2, 16, 2, 2); else if (q.TX == 8) WP(2, 8, 4, 2); else WP(2, 4, 4, 4); }
+    else if (stride == 1 && !old_form) { if (q.TX == 32) WP(1, 32, 4, 2); else if (q.TX == 16) WP(1, 16, 8, 2); else if (q.TX == 8) WP(1, 8, 8, 4); else WP(1, 4, 4, 4); }
     else if (stride == 1) { if (q.TX == 32) WG(1, 32, 4, 2); else if (q.TX == 16) WG(1, 16, 8, 2); else if (q.TX == 8) WG(1, 8, 8, 4); else WG(1, 4, 4, 4); }
     else             { if (q.TX == 32) WG(2, 32, 4, 2); else if (q.TX == 16) WG(2, 16, 4, 2); else if (q.TX == 8) WG(2, 8, 8, 2); else WG(2, 4, 4, 4); }
 #undef WG
