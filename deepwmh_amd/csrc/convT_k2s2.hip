@@ -180,6 +180,27 @@ extern "C" int wmh_convtranspose3d_pack_weights(const float* w, int Cin, int Cou
     return WMH_OK;
 }
 
+// the same image written on the device (training: the weights change every step)
+__global__ __launch_bounds__(256) void convT_pack_kernel(const float* w, float* wf, int Cin, int R, int Cin8, size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        size_t r = idx;
+        const int e = (int)(r % 4); r /= 4;
+        const int lane = (int)(r % 64); r /= 64;
+        const int q = (int)(r % Cin8);
+        const int rt = (int)(r / Cin8);
+        const int row = rt * 32 + (lane & 31), ci = 2 * (4 * q + e) + (lane >> 5);
+        wf[idx] = (row < R && ci < Cin) ? w[(size_t)ci * R + row] : 0.f;
+    }
+}
+extern "C" int wmh_convtranspose3d_pack_weights_device(const float* w, int Cin, int Cout, int kt, float* wf, void* stream) {
+    if (!w || !wf || Cin < 1 || Cout < 1 || (kt != 1 && kt != 2)) return wmh_fail(WMH_EINVAL, "convT pack (device): bad args");
+    const int R = Cout * 4 * kt, Cin8 = (Cin + 7) / 8;
+    const size_t total = convT_packed_floats(Cin, Cout, kt);
+    unsigned nb = (unsigned)((total + 255) / 256); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(convT_pack_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wf, Cin, R, Cin8, total);
+    return wmh_check_launch("convT_pack_kernel");
+}
+
 extern "C" int wmh_convtranspose3d_k2s2_pack_weights(const float* w, int Cin, int Cout, float* wf) {
     return wmh_convtranspose3d_pack_weights(w, Cin, Cout, 2, wf);
 }

@@ -203,11 +203,22 @@ class UNetTrainer:
         if hit is not None and hit[0] == self._version:
             return hit[1]
         n = self.lib.wmh_convtranspose3d_k2s2_packed_floats(st['cdown'], st['cskip'])
-        host = np.empty(n, dtype=np.float32)
-        w_h = wtu.detach().cpu().numpy()
-        _lib.check(self.lib.wmh_convtranspose3d_k2s2_pack_weights(w_h.ctypes.data_as(C.c_void_p), st['cdown'], st['cskip'],
-                                                                  host.ctypes.data_as(C.c_void_p)), 'convT pack')
-        wf = torch.from_numpy(host).to(self.device)
+        wf = hit[1] if hit is not None else torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.wmh_convtranspose3d_pack_weights_device(_lib.ptr(wtu), st['cdown'], st['cskip'], 2, _lib.ptr(wf), self._st()),
+                   'wmh_convtranspose3d_pack_weights_device')
+        self._packed[key] = (self._version, wf)
+        return wf
+
+    def _pack_tu_dgrad(self, u, wtu, cfg, cin, cout):
+        """Image of the transposed convolution's data gradient as a stride-2 convolution cout -> cin over dY (pack mode 2)."""
+        key = ('tu.dgrad', u, cfg)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == self._version:
+            return hit[1]
+        n = self.lib.wmh_conv3d_k3_packed_floats(cfg, cout, cin)
+        wf = hit[1] if hit is not None else torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.wmh_conv3d_k3_pack_weights_device(cfg, _lib.ptr(wtu), cout, cin, 0, cout, 2, _lib.ptr(wf), self._st()),
+                   'wmh_conv3d_k3_pack_weights_device')
         self._packed[key] = (self._version, wf)
         return wf
 
@@ -281,11 +292,16 @@ class UNetTrainer:
             gskip[u] = d_skip
             x_in, ss_in = rec['tu_in']
             N, Cin, D, H, W = x_in.shape
-            g_in = self._buf('b.tu%d.dx' % u, x_in.shape)
             tu = self.dec[u]['tu'] + '.weight'
-            _lib.check(lib.wmh_convtranspose3d_k2s2_bwd(_lib.ptr(x_in), _lib.ptr(ss_in), _lib.ptr(self.p[tu]), _lib.ptr(d_up), _lib.ptr(g_in),
-                                                        _lib.ptr(self.g[tu]), N, Cin, self.dec[u]['cskip'], D, H, W, LRELU_SLOPE, st),
-                       'wmh_convtranspose3d_k2s2_bwd')
+            cskip = self.dec[u]['cskip']
+            # dW on the matrix cores; dX as a stride-2 convolution of dY with the 2-window embedded in the 3-window
+            nws = lib.wmh_convtranspose3d_k2s2_wgrad_workspace_floats(Cin, cskip, N, D, H, W)
+            ws = self._buf('b.wgrad.ws', (max(nws, 1),))
+            _lib.check(lib.wmh_convtranspose3d_k2s2_wgrad(_lib.ptr(x_in), _lib.ptr(ss_in), _lib.ptr(d_up), _lib.ptr(self.g[tu]), _lib.ptr(ws),
+                                                          N, Cin, cskip, D, H, W, LRELU_SLOPE, st), 'wmh_convtranspose3d_k2s2_wgrad')
+            cfg = _lib.check(lib.wmh_conv3d_k3_config(cskip, Cin, 2 * D, 2 * H, 2 * W, 2), 'config')
+            wf = self._pack_tu_dgrad(u, self.p[tu], cfg, Cin, cskip)
+            g_in, _, _ = self._run_conv('b.tu%d.dx' % u, cfg, d_up, None, None, None, wf, None, Cin, 2, False)
             g_next = g_in
         # encoder: bottleneck back to the first layer; stage outputs also receive the decoder's skip gradient
         nenc = len(self.enc)

@@ -127,6 +127,8 @@ int wmh_convtranspose3d_k2s2_mfma_fwd(const float* x, const float* ss, const flo
  * w torch layout [Cin][Cout][kt][2][2]; output [N,Cout,kt*D,2H,2W]. */
 size_t wmh_convtranspose3d_packed_floats(int Cin, int Cout, int kt);
 int wmh_convtranspose3d_pack_weights(const float* w, int Cin, int Cout, int kt, float* wf);
+/* The same image written on the device (w, wf in HBM): training repacks every step. */
+int wmh_convtranspose3d_pack_weights_device(const float* w, int Cin, int Cout, int kt, float* wf, void* stream);
 int wmh_convtranspose3d_mfma_fwd(const float* x, const float* ss, const float* wf, float* y, int N, int Cin,
                                  int Cout, int D, int H, int W, int kt, float lrelu_slope, void* stream);
 
@@ -176,7 +178,9 @@ int wmh_finalize_argmax(const float* agg, const float* cnt, float* prob, uint8_t
 
 /* Device-side weight repack (weights change every step): w = torch layout [Cout][Cin_total][27] in HBM, input
  * channels [ci_off, ci_off+ci_cnt).  mode 0: forward image (ci_cnt -> Cout).  mode 1: image of the data-gradient
- * convolution (Cout -> ci_cnt; transposed, taps flipped), to be run through wmh_conv3d_k3_fwd on dy. */
+ * convolution (Cout -> ci_cnt; transposed, taps flipped), to be run through wmh_conv3d_k3_fwd on dy.  mode 2: w is a
+ * ConvTranspose3d(k2,s2) weight [Cout][ci_cnt][8]; the image is its data gradient as a stride-2 convolution
+ * ci_cnt -> Cout over dY (cfg from wmh_conv3d_k3_config(ci_cnt, Cout, 2D, 2H, 2W, 2)). */
 int wmh_conv3d_k3_pack_weights_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt,
                                       int mode, float* wf, void* stream);
 /* dW[Cout][C0+C1][27] = sum over (n, voxel) of dy * lrelu(instnorm(x)) (transform on load as in the forward). */
@@ -205,6 +209,11 @@ int wmh_channel_sum(const float* x, float* out, int N, int C, size_t S, void* st
 /* ConvTranspose3d(k2,s2) backward: dX (gradient of the activated input; may be NULL) and dW (may be NULL). */
 int wmh_convtranspose3d_k2s2_bwd(const float* x, const float* ss, const float* w, const float* dY, float* dX,
                                  float* dW, int N, int Cin, int Cout, int D, int H, int W, float slope, void* stream);
+/* The same dW on the matrix cores (voxels as the MFMA K dimension, fixed-order slab reduction).
+ * workspace >= wmh_convtranspose3d_k2s2_wgrad_workspace_floats(...) floats. */
+size_t wmh_convtranspose3d_k2s2_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
+int wmh_convtranspose3d_k2s2_wgrad(const float* x, const float* ss, const float* dY, float* dW, float* workspace,
+                                   int N, int Cin, int Cout, int D, int H, int W, float slope, void* stream);
 /* out2[0] = ||grads||_2, out2[1] = min(1, max_norm/(norm+1e-6)); workspace = 1024 doubles. */
 int wmh_grad_clip_coef(const float* grads, size_t n, float max_norm, float* out2, double* workspace, void* stream);
 /* torch.optim.SGD(momentum, nesterov=True, weight_decay) on a flat arena; clip = out2 of wmh_grad_clip_coef or NULL. */

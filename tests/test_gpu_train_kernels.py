@@ -199,6 +199,53 @@ def test_convtranspose3d_bwd(lib, shape):
     assert float((dW.cpu().view_as(w) - w.grad).abs().max()) <= 2e-5 * (1 + float(w.grad.abs().max()))
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 8, 4, 4, 4, True), (1, 8, 12, 3, 6, 5, False), (2, 40, 72, 4, 8, 16, True),
+                                   (1, 64, 32, 6, 10, 20, True)])
+def test_convtranspose3d_bwd_mfma(lib, shape):
+    """MFMA forms: dW with voxels as the K dimension; dX as a stride-2 convolution (pack mode 2) of dY."""
+    N, Cin, Cout, D, H, W, use_ss = shape
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    ss = torch.stack([0.5 + torch.rand(N, Cin, generator=g), 0.3 * torch.randn(N, Cin, generator=g)], -1) if use_ss else None
+    a = _act(x, ss).requires_grad_()
+    w = (torch.randn(Cin, Cout, 2, 2, 2, generator=g) * 0.2).requires_grad_()
+    out = F.conv_transpose3d(a, w, None, stride=2)
+    dY = torch.randn(out.shape, generator=g)
+    out.backward(dY)
+    xd, ssd, wd, dYd = x.cuda(), (ss.cuda() if use_ss else None), w.detach().cuda(), dY.cuda()
+    dW = torch.full((Cin, Cout, 8), float('nan'), device='cuda')
+    ws = torch.empty(max(1, lib.wmh_convtranspose3d_k2s2_wgrad_workspace_floats(Cin, Cout, N, D, H, W)), device='cuda')
+    check(lib.wmh_convtranspose3d_k2s2_wgrad(P(xd), P(ssd), P(dYd), P(dW), P(ws), N, Cin, Cout, D, H, W, SLOPE, None), 'convT wgrad')
+    torch.cuda.synchronize()
+    assert float((dW.cpu().view_as(w) - w.grad).abs().max()) <= 2e-5 * (1 + float(w.grad.abs().max()))
+    dW2 = torch.full((Cin, Cout, 8), float('nan'), device='cuda')
+    check(lib.wmh_convtranspose3d_k2s2_wgrad(P(xd), P(ssd), P(dYd), P(dW2), P(ws), N, Cin, Cout, D, H, W, SLOPE, None), 'convT wgrad')
+    assert torch.equal(dW, dW2)                                              # fixed-order reduction
+    cfg = check(lib.wmh_conv3d_k3_config(Cout, Cin, 2 * D, 2 * H, 2 * W, 2), 'config')
+    wf = torch.empty(lib.wmh_conv3d_k3_packed_floats(cfg, Cout, Cin), device='cuda')
+    check(lib.wmh_conv3d_k3_pack_weights_device(cfg, P(wd), Cout, Cin, 0, Cout, 2, P(wf), None), 'pack mode 2')
+    dX = torch.full((N, Cin, D, H, W), float('nan'), device='cuda')
+    nws = lib.wmh_conv3d_k3_workspace_floats(cfg, Cout, N, 2 * D, 2 * H, 2 * W, Cin, 2)
+    cws = torch.empty(max(1, nws), device='cuda')
+    check(lib.wmh_conv3d_k3_fwd(cfg, P(dYd), None, Cout, None, None, 0, P(wf), None, P(dX), None, P(cws), N, 2 * D, 2 * H, 2 * W, Cin, 2,
+                                SLOPE, None), 'conv fwd (convT dX)')
+    torch.cuda.synchronize()
+    assert float((dX.cpu() - a.grad).abs().max()) <= 1e-5 * (1 + float(a.grad.abs().max()))
+
+
+def test_convtranspose3d_device_pack_matches_host(lib):
+    g = torch.Generator().manual_seed(63)
+    for Cin, Cout, kt in [(16, 8, 2), (40, 24, 2), (12, 20, 1)]:
+        w = torch.randn(Cin, Cout, kt, 2, 2, generator=g)
+        n = lib.wmh_convtranspose3d_packed_floats(Cin, Cout, kt)
+        host = np.empty(n, dtype=np.float32)
+        wn = w.numpy()
+        check(lib.wmh_convtranspose3d_pack_weights(wn.ctypes.data_as(C.c_void_p), Cin, Cout, kt, host.ctypes.data_as(C.c_void_p)), 'pack')
+        wd = w.cuda(); dev = torch.empty(n, device='cuda')
+        check(lib.wmh_convtranspose3d_pack_weights_device(P(wd), Cin, Cout, kt, P(dev), None), 'pack device')
+        assert np.array_equal(dev.cpu().numpy(), host)
+
+
 def test_clip_and_sgd_nesterov(lib):
     g = torch.Generator().manual_seed(71)
     n = 100003
