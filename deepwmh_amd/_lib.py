@@ -55,6 +55,14 @@ SIGNATURES = {
     'wmh_convtranspose3d_k2s2_wgrad': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_grad_clip_coef': (_i, [_vp, _sz, _f, _vp, _vp, _vp]),
     'wmh_sgd_nesterov_step': (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _i, _vp]),
+    'wmh_cc_label': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'wmh_remove_small_components': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'wmh_fill_holes': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'wmh_nonzero_mask': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'wmh_mask_bbox': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'wmh_zscore_crop_workspace_doubles': (_sz, [_i]),
+    'wmh_zscore_crop': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'wmh_uncrop_u8': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'wmh_selftest_mfma_32x32x2': (_i, [_vp, _vp, _vp, _vp]),
 }
 
@@ -104,3 +112,9 @@ def ptr(t):
         return None
     assert t.is_contiguous(), 'tensor must be contiguous'
     return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    """torch's current HIP stream as the `void* stream` argument of the C ABI."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

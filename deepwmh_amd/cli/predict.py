@@ -85,26 +85,76 @@ def main(argv=None):
     nmod = plan.num_input_channels
     print('deepwmh_amd nnUNet_predict: task %s, checkpoint %s (epoch %s), %d case(s), mirroring %s'
           % (task, args.chk, info.get('epoch'), len(cases), 'off' if args.disable_tta else 'on'), flush=True)
+    # Host work (gunzip + NIfTI parse before, gzip + write after) runs in worker threads around the GPU, as nnU-Net's
+    # --num_threads_preprocessing / --num_threads_nifti_save processes do; zlib and numpy release the GIL.
+    from concurrent.futures import ThreadPoolExecutor
+    from ..preprocess import export_segmentation_device, needs_resampling, preprocess_case_device
+    stage = info['init'][5] if info.get('init') else None
+    todo = []
     for case in cases:
         out = os.path.join(args.output_folder, case + '.nii.gz')
         if os.path.isfile(out) and not args.overwrite_existing and not args.save_softmax:
             continue
+        todo.append((case, out))
+
+    def load(case):
         t0 = time.time()
         vols, meta = [], None
         for m in range(nmod):
             arr, mt = nifti.read(os.path.join(args.input_folder, '%s_%04d.nii.gz' % (case, m)))
             vols.append(arr)
             meta = meta or mt
-        data, props = preprocess_case(np.stack(vols), meta['spacing'], plans, info['init'][5] if info.get('init') else None)
-        t1 = time.time()
-        seg, prob = pred.predict(data, return_prob=True)
-        t2 = time.time()
-        seg_full, prob_full = export_prediction(prob, props)
+        vol = np.stack(vols)
+        host = None
+        if needs_resampling(vol.shape[1:], meta['spacing'], plans, stage) or list(plans.get('transpose_forward', [0, 1, 2])) != [0, 1, 2]:
+            host = preprocess_case(vol, meta['spacing'], plans, stage)      # resampling stays on the host (scipy splines)
+        return vol, meta, host, time.time() - t0
+
+    def save(out, case, seg_full, prob0, meta, host_export=None):
+        if host_export is not None:                                          # resampled case: export (order-1 resample) off the GPU thread
+            seg_full, prob_full = export_prediction(*host_export)
+            prob0 = prob_full[0] if args.save_softmax else None
         nifti.write(out, seg_full, like=meta, dtype=np.uint8)
-        if args.save_softmax:
-            nifti.write(os.path.join(args.output_folder, case + '_0.nii.gz'), prob_full[0], like=meta, dtype=np.float32)
-        print('  %s: shape %s, load+preprocess %.2f s, predict %.2f s, export %.2f s'
-              % (case, tuple(data.shape[1:]), t1 - t0, t2 - t1, time.time() - t2), flush=True)
+        if prob0 is not None:
+            nifti.write(os.path.join(args.output_folder, case + '_0.nii.gz'), prob0, like=meta, dtype=np.float32)
+
+    nread = max(1, min(args.num_threads_preprocessing, 4))
+    t_all = time.time()
+    with ThreadPoolExecutor(nread) as readers, ThreadPoolExecutor(max(1, args.num_threads_nifti_save)) as writers:
+        ahead = nread + 1
+        loads = [readers.submit(load, c) for c, _ in todo[:ahead]]
+        saves = []
+        for i, (case, out) in enumerate(todo):
+            t0 = time.time()
+            vol, meta, host, t_load = loads[i].result()
+            loads[i] = None
+            if i + ahead < len(todo):
+                loads.append(readers.submit(load, todo[i + ahead][0]))
+            t1 = time.time()
+            if host is None:
+                data_d, props = preprocess_case_device(vol, plans, 'cuda:0')
+                seg_d, prob_d = pred.predict_device(data_d, return_prob=args.save_softmax)
+                seg_full = export_segmentation_device(seg_d, props)          # synchronises: the label map is on the host
+                prob0 = None
+                if args.save_softmax:
+                    prob0 = export_prediction(prob_d.cpu().numpy(), props)[1][0]
+                shape = tuple(data_d.shape[1:])
+            else:
+                data, props = host
+                seg, prob = pred.predict(data, return_prob=True)
+                shape = tuple(data.shape[1:])
+            t2 = time.time()
+            if host is None:
+                saves.append(writers.submit(save, out, case, seg_full, prob0, meta))
+            else:
+                saves.append(writers.submit(save, out, case, None, None, meta, (prob, props)))
+            print('  %s: shape %s, read%s %.2f s (waited %.2f s), gpu %.2f s'
+                  % (case, shape, '+resample' if host is not None else '', t_load, t1 - t0, t2 - t1), flush=True)
+        for f in saves:
+            f.result()                                                       # re-raises a failed write
+    if todo:
+        dt = time.time() - t_all
+        print('  %d case(s) in %.2f s (%.2f cases/s)' % (len(todo), dt, len(todo) / dt), flush=True)
     return 0
 
 

@@ -98,3 +98,67 @@ def export_prediction(prob, props):
     pfull[0] = 1.0                                  # outside the crop everything is background
     pfull[(slice(None),) + sl] = prob
     return full, pfull
+
+
+# ---- device path: crop-to-nonzero + z-score on the GPU (no resampling: volumes already at the plan's spacing) ----------
+def needs_resampling(shape_zyx, spacing, plans, stage=None):
+    stages = plans['plans_per_stage']
+    st = stages[stage if stage is not None else (max(stages.keys()) if isinstance(stages, dict) else len(stages) - 1)]
+    tf = list(plans.get('transpose_forward', [0, 1, 2]))
+    target = np.asarray(st['current_spacing'], float)
+    sp = np.asarray(spacing, float)[tf]
+    shp = np.asarray(shape_zyx)[tf]
+    return bool(np.any(np.round(sp / target * shp).astype(int) != shp))
+
+
+def preprocess_case_device(volume_zyx, plans, device='cuda:0'):
+    """Same result as preprocess_case for a volume that needs no resampling and no axis transpose, computed by
+    libdeepwmh_amd.so: non-zero mask -> fill holes (6-connected background components that do not reach the border) ->
+    bounding box -> masked z-score fused with the crop.  Returns (device tensor [C, ...] fp32, props); the only
+    host round trip is the 6-int box (the crop's shape decides the sliding-window geometry)."""
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    tf = list(plans.get('transpose_forward', [0, 1, 2]))
+    if tf != [0, 1, 2]:
+        raise NotImplementedError('preprocess_case_device: transpose_forward %s (use preprocess_case)' % (tf,))
+    data = volume_zyx[None] if volume_zyx.ndim == 3 else volume_zyx
+    x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(device)
+    Cn, D, H, W = (int(v) for v in x.shape)
+    n = D * H * W
+    st = _lib.current_stream()
+    raw = torch.empty(n, dtype=torch.uint8, device=device)
+    mask = torch.empty(n, dtype=torch.uint8, device=device)
+    labels = torch.empty(n, dtype=torch.int32, device=device)
+    flags = torch.empty(n, dtype=torch.int32, device=device)
+    bbox_d = torch.empty(6, dtype=torch.int32, device=device)
+    _lib.check(lib.wmh_nonzero_mask(_lib.ptr(x), _lib.ptr(raw), Cn, D, H, W, st), 'wmh_nonzero_mask')
+    _lib.check(lib.wmh_fill_holes(_lib.ptr(raw), _lib.ptr(mask), _lib.ptr(labels), _lib.ptr(flags), D, H, W, st), 'wmh_fill_holes')
+    _lib.check(lib.wmh_mask_bbox(_lib.ptr(mask), _lib.ptr(bbox_d), D, H, W, st), 'wmh_mask_bbox')
+    bb = [int(v) for v in bbox_d.cpu().tolist()]
+    bbox = [[bb[0], bb[1]], [bb[2], bb[3]], [bb[4], bb[5]]]
+    shape = tuple(b - a for a, b in bbox)
+    umn = plans.get('use_mask_for_norm', {0: False})
+    use_mask = bool(umn[0] if isinstance(umn, dict) else umn)
+    out = torch.empty((Cn,) + shape, dtype=torch.float32, device=device)
+    stats = torch.empty(Cn, 2, dtype=torch.float32, device=device)
+    ws = torch.empty(max(1, lib.wmh_zscore_crop_workspace_doubles(Cn)), dtype=torch.float64, device=device)
+    _lib.check(lib.wmh_zscore_crop(_lib.ptr(x), _lib.ptr(mask), _lib.ptr(bbox_d), _lib.ptr(out), None, _lib.ptr(stats), _lib.ptr(ws),
+                                   Cn, D, H, W, int(use_mask), st), 'wmh_zscore_crop')
+    props = dict(original_shape=(D, H, W), bbox=bbox, shape_after_crop=shape, transpose_forward=tf,
+                 transpose_backward=list(plans.get('transpose_backward', [0, 1, 2])), bbox_device=bbox_d)
+    return out, props
+
+
+def export_segmentation_device(seg_crop, props):
+    """seg_crop: uint8 device tensor in network geometry (no resampling / transpose case) -> uint8 numpy label map in the
+    input's geometry (un-crop into zeros on the device, one D2H copy of the label map)."""
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    D, H, W = props['original_shape']
+    assert tuple(seg_crop.shape) == tuple(props['shape_after_crop']) and seg_crop.dtype == torch.uint8
+    full = torch.empty((D, H, W), dtype=torch.uint8, device=seg_crop.device)
+    _lib.check(lib.wmh_uncrop_u8(_lib.ptr(seg_crop.contiguous()), _lib.ptr(props['bbox_device']), _lib.ptr(full), D, H, W, 0,
+                                 _lib.current_stream()), 'wmh_uncrop_u8')
+    return full.cpu().numpy()

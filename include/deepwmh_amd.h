@@ -221,6 +221,34 @@ int wmh_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf
                           float weight_decay, const float* clip, int first_step, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Whole-volume passes either side of the network.  Volumes are [D][H][W] (C order), masks uint8.
+ * Integer results (labels, masks, boxes) are exact and independent of scheduling.
+ * ------------------------------------------------------------------------------------------- */
+
+/* 6-connected components of mask != 0: labels[v] = smallest voxel index of v's component, -1 for background.
+ * Stands in for scipy.ndimage.label as used by deepwmh/analysis/image_ops.py:8,333 (same partition; label ids differ). */
+int wmh_cc_label(const uint8_t* mask, int32_t* labels, int D, int H, int W, void* stream);
+/* out = mask with every component of fewer than min_volume voxels removed: remove_sparks,
+ * deepwmh/analysis/image_ops.py:325-345 (remove_3mm_sparks :347-367 picks min_volume).  labels, counts: D*H*W int32 scratch. */
+int wmh_remove_small_components(const uint8_t* mask, uint8_t* out, int32_t* labels, int32_t* counts, int D, int H, int W,
+                                int min_volume, void* stream);
+/* scipy.ndimage.binary_fill_holes (default cross structure): background that cannot reach the border becomes 1
+ * [nnU-Net cropping.create_nonzero_mask].  labels, flags: D*H*W int32 scratch. */
+int wmh_fill_holes(const uint8_t* mask, uint8_t* out, int32_t* labels, int32_t* flags, int D, int H, int W, void* stream);
+/* mask[v] = any channel of data[C][D][H][W] is non-zero at v. */
+int wmh_nonzero_mask(const float* data, uint8_t* mask, int C, int D, int H, int W, void* stream);
+/* bbox6 (device) = {z0, z1, y0, y1, x0, x1}, half-open box of mask != 0; the whole volume if the mask is empty. */
+int wmh_mask_bbox(const uint8_t* mask, int32_t* bbox6, int D, int H, int W, void* stream);
+/* nnU-Net non-CT normalisation fused with the crop: per channel, (x - mean) / (std + 1e-8) over the box (inside mask
+ * when use_mask, 0 outside it); out = [C][box], mask_out = [box] (may be NULL), stats = [C][2] {mean, std}.
+ * Moments accumulate in double in a fixed order.  workspace >= wmh_zscore_crop_workspace_doubles(C). */
+size_t wmh_zscore_crop_workspace_doubles(int C);
+int wmh_zscore_crop(const float* data, const uint8_t* mask, const int32_t* bbox6, float* out, uint8_t* mask_out, float* stats,
+                    double* workspace, int C, int D, int H, int W, int use_mask, void* stream);
+/* full[box] = crop, `fill` elsewhere (segmentation export un-crop). */
+int wmh_uncrop_u8(const uint8_t* crop, const int32_t* bbox6, uint8_t* full, int D, int H, int W, int fill, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Self-test helper: D = A(32x2) * B(2x32) through one v_mfma_f32_32x32x2_f32, used by the GPU
  * tests to pin the fragment layout this library assumes (a: [32][2], b: [2][32], d: [32][32]).
  * ------------------------------------------------------------------------------------------- */

@@ -1,0 +1,133 @@
+"""GPU parity of the whole-volume passes either side of the network against the oracle:
+connected components / remove_sparks (reference deepwmh/analysis/image_ops.py:325-367), fill-holes, crop + z-score,
+un-crop.  Integer results must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from deepwmh_amd import _lib
+    return _lib.load()
+
+
+def P(t):
+    from deepwmh_amd import _lib
+    return _lib.ptr(t)
+
+
+def check(rc, what=''):
+    from deepwmh_amd import _lib
+    return _lib.check(rc, what)
+
+
+def _masks():
+    rng = np.random.default_rng(5)
+    out = []
+    for shape, dens in [((7, 9, 11), 0.3), ((1, 1, 1), 1.0), ((1, 17, 5), 0.5), ((16, 16, 16), 0.05), ((33, 20, 27), 0.55),
+                        ((40, 48, 40), 0.15), ((5, 1, 64), 0.7)]:
+        out.append((rng.random(shape) < dens).astype(np.uint8))
+    out.append(np.zeros((6, 5, 4), np.uint8))
+    out.append(np.ones((6, 5, 4), np.uint8))
+    snake = np.zeros((12, 12, 12), np.uint8)            # one long winding component: deep union-find chains
+    for z in range(12):
+        snake[z, :, 0 if z % 2 else 11] = 1
+        snake[z, 0 if (z // 2) % 2 else 11, :] = 1
+    out.append(snake)
+    return out
+
+
+def test_cc_label_partition_matches_scipy(lib):
+    from oracle import postprocess as opp
+    for m in _masks():
+        md = torch.from_numpy(m).cuda()
+        lab = torch.full(m.shape, -7, dtype=torch.int32, device='cuda')
+        check(lib.wmh_cc_label(P(md), P(lab), *m.shape, None), 'cc_label')
+        torch.cuda.synchronize()
+        assert np.array_equal(lab.cpu().numpy().astype(np.int64), opp.components_partition(m)), m.shape
+
+
+@pytest.mark.parametrize('min_volume', [2, 3, 5, 27])
+def test_remove_sparks_matches_reference_semantics(lib, min_volume):
+    from deepwmh_amd import postprocess as pp
+    from oracle import postprocess as opp
+    for m in _masks():
+        got = pp.remove_sparks(m.astype(np.float32), min_volume=min_volume)
+        ref = opp.remove_sparks(m.astype(np.float32), min_volume=min_volume)
+        assert got.dtype == ref.dtype and np.array_equal(got, ref), (m.shape, min_volume)
+
+
+def test_remove_3mm_sparks_voxel_size_rules(lib):
+    from deepwmh_amd import postprocess as pp
+    from oracle import postprocess as opp
+    m = _masks()[5]
+    for vs in ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.9, 0.9, 3.0], [2.0, 2.0, 2.0], [0.43, 0.43, 1.2]):
+        assert np.array_equal(pp.remove_3mm_sparks(m, vs), opp.remove_3mm_sparks(m, vs)), vs
+    with pytest.raises(RuntimeError):
+        pp.remove_3mm_sparks(m, (1.0, 1.0, 1.0))          # the reference insists on a list (image_ops.py:351-352)
+
+
+def test_fill_holes_matches_scipy(lib):
+    from oracle import postprocess as opp
+    rng = np.random.default_rng(9)
+    cases = _masks()
+    shell = np.zeros((20, 22, 24), np.uint8); shell[3:17, 4:18, 5:19] = 1; shell[6:14, 7:15, 8:16] = 0      # closed cavity
+    leak = shell.copy(); leak[10, 10, 16:24] = 0                                                            # cavity with a tunnel out
+    cases += [shell, leak, (rng.random((30, 30, 30)) < 0.8).astype(np.uint8)]
+    for m in cases:
+        md = torch.from_numpy(m).cuda()
+        out = torch.empty_like(md)
+        lab = torch.empty(m.size, dtype=torch.int32, device='cuda'); fl = torch.empty_like(lab)
+        check(lib.wmh_fill_holes(P(md), P(out), P(lab), P(fl), *m.shape, None), 'fill_holes')
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().astype(bool), opp.fill_holes(m)), m.shape
+
+
+def test_full_size_volume_remove_sparks_exact(lib):
+    from deepwmh_amd import postprocess as pp
+    from deepwmh_amd.synthetic import synthetic_flair
+    from oracle import postprocess as opp
+    v = synthetic_flair((160, 192, 160), 3)[0]
+    m = (v > 1.2).astype(np.float32)
+    got = pp.remove_3mm_sparks(m, [1.0, 1.0, 1.0])
+    ref = opp.remove_3mm_sparks(m, [1.0, 1.0, 1.0])
+    assert np.array_equal(got, ref) and 0 < ref.sum() < m.sum()
+    # idempotent, and a checksum independent of scheduling
+    assert np.array_equal(pp.remove_3mm_sparks(got, [1.0, 1.0, 1.0]), got)
+
+
+@pytest.mark.parametrize('use_mask', [True, False])
+def test_preprocess_case_device_matches_host(lib, use_mask):
+    from deepwmh_amd import checkpoint as ck, preprocess
+    from deepwmh_amd.plan import tiny_plan
+    plans = ck.make_plans(tiny_plan(), spacing=(1.0, 1.0, 1.0), use_mask_for_norm=use_mask)
+    rng = np.random.default_rng(3)
+    vol = np.zeros((46, 52, 44), np.float32)
+    vol[3:43, 2:50, 5:42] = rng.standard_normal((40, 48, 37)).astype(np.float32) * 40 + 200
+    vol[10:14, 20:25, 20:26] = 0                             # a hole inside the head: filled by the mask, kept in the statistics
+    vol[0, 0, 0] = 0
+    ref, props_ref = preprocess.preprocess_case(vol, (1.0, 1.0, 1.0), plans)
+    got, props = preprocess.preprocess_case_device(vol, plans)
+    torch.cuda.synchronize()
+    assert props['bbox'] == props_ref['bbox'] and tuple(props['shape_after_crop']) == tuple(props_ref['shape_after_crop'])
+    assert tuple(got.shape) == ref.shape
+    assert float(np.abs(got.cpu().numpy() - ref).max()) <= 2e-5 * (1 + float(np.abs(ref).max()))
+    # un-crop: label map back in the input's geometry
+    seg = (torch.rand(props['shape_after_crop'], device='cuda') < 0.3).to(torch.uint8)
+    full = preprocess.export_segmentation_device(seg, props)
+    prob = np.stack([1 - seg.cpu().numpy().astype(np.float32), seg.cpu().numpy().astype(np.float32)])
+    full_ref, _ = preprocess.export_prediction(prob, props_ref)
+    assert np.array_equal(full, full_ref)
+
+
+def test_preprocess_device_all_zero_volume(lib):
+    from deepwmh_amd import checkpoint as ck, preprocess
+    from deepwmh_amd.plan import tiny_plan
+    plans = ck.make_plans(tiny_plan(), spacing=(1.0, 1.0, 1.0), use_mask_for_norm=True)
+    vol = np.zeros((8, 9, 10), np.float32)
+    got, props = preprocess.preprocess_case_device(vol, plans)
+    ref, props_ref = preprocess.preprocess_case(vol, (1.0, 1.0, 1.0), plans)
+    assert props['bbox'] == props_ref['bbox'] and np.array_equal(got.cpu().numpy(), ref)
