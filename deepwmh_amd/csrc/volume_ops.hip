@@ -238,3 +238,54 @@ extern "C" int wmh_uncrop_u8(const uint8_t* crop, const int32_t* bbox6, uint8_t*
     hipLaunchKernelGGL(uncrop_u8_kernel, dim3(vgrid((size_t)D * H * W)), dim3(256), 0, (hipStream_t)stream, crop, bbox6, full, D, H, W, fill);
     return wmh_check_launch("uncrop_u8_kernel");
 }
+
+// ---- Stage-II glue of the self-training loop (reference deepwmh/pipeline/DCNN_multistage.py:102-125) ----------------
+// Element-wise fp32 in numpy's operation order, no fused multiply-add: results are bit-identical to the reference's.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void softmax_mask_kernel(const float* x, const float* m, float* y, size_t n) {
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
+        const float t = 1.0f - x[v];
+        const float u = m[v] * t;
+        y[v] = 1.0f - u;                                        // y = 1-(m*(1-x)), DCNN_multistage.py:108
+    }
+}
+__global__ __launch_bounds__(256) void ensemble_kernel(const float* stack, int E, float* field, uint8_t* label, size_t n) {
+    const float fe = (float)E;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) s = s + stack[(size_t)e * n + v];    // scalar_field += ..., in file order (:115-117)
+        s = s / fe;                                                    // :118
+        if (field) field[v] = s;
+        label[v] = s < 0.5f ? 1 : 0;                                   // inverted softmax: < 0.5 is lesion (:119)
+    }
+}
+__global__ __launch_bounds__(256) void overlap_kernel(const float* a, const float* b, unsigned long long* out3, size_t n) {
+    __shared__ unsigned int sh[3];
+    if (threadIdx.x < 3) sh[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int tp = 0, sa = 0, sb = 0;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
+        const bool pa = a[v] > 0.5f, pb = b[v] > 0.5f;
+        tp += (pa && pb) ? 1u : 0u; sa += pa ? 1u : 0u; sb += pb ? 1u : 0u;
+    }
+    atomicAdd(&sh[0], tp); atomicAdd(&sh[1], sa); atomicAdd(&sh[2], sb);
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(out3 + threadIdx.x, (unsigned long long)sh[threadIdx.x]);
+}
+extern "C" int wmh_softmax_mask(const float* x, const float* m, float* y, size_t n, void* stream) {
+    if (!x || !m || !y) return wmh_fail(WMH_EINVAL, "softmax_mask: bad args");
+    if (n) hipLaunchKernelGGL(softmax_mask_kernel, dim3(vgrid(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, m, y, n);
+    return wmh_check_launch("softmax_mask_kernel");
+}
+extern "C" int wmh_ensemble_softmax(const float* stack, int E, float* field, uint8_t* label, size_t n, void* stream) {
+    if (!stack || !label || E < 1) return wmh_fail(WMH_EINVAL, "ensemble_softmax: bad args");
+    if (n) hipLaunchKernelGGL(ensemble_kernel, dim3(vgrid(n, 1024)), dim3(256), 0, (hipStream_t)stream, stack, E, field, label, n);
+    return wmh_check_launch("ensemble_kernel");
+}
+extern "C" int wmh_binary_overlap(const float* a, const float* b, unsigned long long* out3, size_t n, void* stream) {
+    if (!a || !b || !out3) return wmh_fail(WMH_EINVAL, "binary_overlap: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out3, 0, 3 * sizeof(unsigned long long), st) != hipSuccess) return wmh_fail(WMH_ELAUNCH, "binary_overlap: memset");
+    if (n) hipLaunchKernelGGL(overlap_kernel, dim3(vgrid(n, 256 * 16, 2048)), dim3(256), 0, st, a, b, out3, n);
+    return wmh_check_launch("overlap_kernel");
+}

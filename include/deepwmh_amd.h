@@ -249,6 +249,19 @@ int wmh_zscore_crop(const float* data, const uint8_t* mask, const int32_t* bbox6
 int wmh_uncrop_u8(const uint8_t* crop, const int32_t* bbox6, uint8_t* full, int D, int H, int W, int fill, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Stage-II glue of DeepWMH's self-training loop.  fp32 in numpy's operation order without
+ * fused multiply-add: bit-identical to the reference expressions cited.
+ * ------------------------------------------------------------------------------------------- */
+
+/* y = 1 - (m * (1 - x)): valid-mask the inverted (background) softmax -- DCNN_multistage.py:102-109. */
+int wmh_softmax_mask(const float* x, const float* m, float* y, size_t n, void* stream);
+/* field = (stack[0] + stack[1] + ... + stack[E-1]) / E in that order; label = field < 0.5 (lesion where the averaged
+ * background probability is below one half) -- DCNN_multistage.py:115-119.  stack = [E][n]; field may be NULL. */
+int wmh_ensemble_softmax(const float* stack, int E, float* field, uint8_t* label, size_t n, void* stream);
+/* out3 = {|a>.5 & b>.5|, |a>.5|, |b>.5|}: the three counts hard_dice_binary needs (deepwmh/analysis/metrics.py:26-32). */
+int wmh_binary_overlap(const float* a, const float* b, unsigned long long* out3, size_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Self-test helper: D = A(32x2) * B(2x32) through one v_mfma_f32_32x32x2_f32, used by the GPU
  * tests to pin the fragment layout this library assumes (a: [32][2], b: [2][32], d: [32][32]).
  * ------------------------------------------------------------------------------------------- */
