@@ -32,28 +32,60 @@ __device__ __forceinline__ void cc_union(int* L, int a, int b) {
     }
 }
 
-// fg(v) = (mask[v] != 0) ^ invert
-__global__ __launch_bounds__(256) void cc_init_kernel(const uint8_t* mask, int* L, size_t n, int invert) {
-    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256)
-        L[v] = (((mask[v] != 0) ? 1 : 0) ^ invert) ? (int)v : -1;
+// fg(v) = (mask[v] != 0) ^ invert.  Labels start as the first voxel of the x-run a voxel sits in (found with one ballot per
+// wave: a wave covers 64 consecutive voxels), so the union-find only ever sees one node per run segment.
+__global__ __launch_bounds__(256) void cc_init_kernel(const uint8_t* mask, int* L, unsigned n, int W, int invert) {
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned nround = (n + 255u) & ~255u;                 // whole waves iterate together (ballots need all lanes)
+    for (unsigned v = blockIdx.x * 256u + threadIdx.x; v < nround; v += gridDim.x * 256u) {
+        const bool fg = v < n && ((((mask[v] != 0) ? 1 : 0) ^ invert) != 0);
+        const unsigned x = v % (unsigned)W;
+        const unsigned long long fgm = __ballot(fg);
+        const bool prev_fg = lane > 0 && ((fgm >> (lane - 1)) & 1ull);
+        const unsigned long long starts = __ballot(fg && (!prev_fg || x == 0));
+        if (v < n) {
+            int lab = -1;
+            if (fg) {
+                const unsigned long long below = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+                const unsigned first = 63u - (unsigned)__builtin_clzll(below);     // this lane's run start (always exists)
+                lab = (int)(v - (lane - first));
+            }
+            L[v] = lab;
+        }
+    }
 }
+// One union per place where two runs START touching: a voxel links to its y/z neighbour only if the pair to its left is
+// not linked already (both left voxels foreground and in the same rows), and to its x neighbour only across a wave boundary.
 __global__ __launch_bounds__(256) void cc_merge_kernel(int* L, int D, int H, int W) {
-    const size_t n = (size_t)D * H * W; const int HW = H * W;
-    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
+    const unsigned n = (unsigned)D * H * W, HW = (unsigned)H * W;
+    for (unsigned v = blockIdx.x * 256u + threadIdx.x; v < n; v += gridDim.x * 256u) {
         if (L[v] < 0) continue;                                 // sign never changes after init
-        const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / HW);
-        if (x > 0 && L[v - 1] >= 0) cc_union(L, (int)v, (int)v - 1);
-        if (y > 0 && L[v - W] >= 0) cc_union(L, (int)v, (int)v - W);
-        if (z > 0 && L[v - HW] >= 0) cc_union(L, (int)v, (int)v - HW);
+        const unsigned x = v % (unsigned)W, y = (v / (unsigned)W) % (unsigned)H, z = v / HW;
+        const bool left = x > 0 && L[v - 1] >= 0;
+        if (left && (v & 63u) == 0) cc_union(L, (int)v, (int)v - 1);
+        if (y > 0 && L[v - W] >= 0 && !(left && L[v - W - 1] >= 0)) cc_union(L, (int)v, (int)(v - W));
+        if (z > 0 && L[v - HW] >= 0 && !(left && L[v - HW - 1] >= 0)) cc_union(L, (int)v, (int)(v - HW));
     }
 }
 __global__ __launch_bounds__(256) void cc_compress_kernel(int* L, size_t n) {
     for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256)
         if (L[v] >= 0) L[v] = cc_find(L, (int)v);               // racing writers store ancestors only: still valid
 }
-__global__ __launch_bounds__(256) void cc_count_kernel(const int* L, int* cnt, size_t n) {
-    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256)
-        if (L[v] >= 0) atomicAdd(cnt + L[v], 1);
+// component sizes: lanes that follow each other with the same root add once (one atomic per run segment, integer: exact)
+__global__ __launch_bounds__(256) void cc_count_kernel(const int* L, int* cnt, unsigned n) {
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned nround = (n + 255u) & ~255u;
+    for (unsigned v = blockIdx.x * 256u + threadIdx.x; v < nround; v += gridDim.x * 256u) {
+        const int r = v < n ? L[v] : -1;
+        const int rp = __shfl_up(r, 1, 64);
+        const bool lead = r >= 0 && (lane == 0 || rp != r);
+        const unsigned long long brk = __ballot(lead || r < 0);          // positions where a new segment (or background) begins
+        if (lead) {
+            const unsigned long long after = lane == 63 ? 0ull : (brk >> (lane + 1));
+            const unsigned len = after ? (unsigned)__builtin_ctzll(after) + 1u : 64u - lane;
+            atomicAdd(cnt + r, (int)len);
+        }
+    }
 }
 __global__ __launch_bounds__(256) void cc_filter_kernel(const int* L, const int* cnt, uint8_t* out, size_t n, int min_volume) {
     for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256)
@@ -74,7 +106,7 @@ __global__ __launch_bounds__(256) void cc_fill_kernel(const int* L, const int* f
 
 static int cc_label(const uint8_t* mask, int* labels, int D, int H, int W, int invert, hipStream_t st) {
     const size_t n = (size_t)D * H * W;
-    hipLaunchKernelGGL(cc_init_kernel, dim3(vgrid(n)), dim3(256), 0, st, mask, labels, n, invert);
+    hipLaunchKernelGGL(cc_init_kernel, dim3(vgrid(n)), dim3(256), 0, st, mask, labels, (unsigned)n, W, invert);
     hipLaunchKernelGGL(cc_merge_kernel, dim3(vgrid(n)), dim3(256), 0, st, labels, D, H, W);
     hipLaunchKernelGGL(cc_compress_kernel, dim3(vgrid(n)), dim3(256), 0, st, labels, n);
     return wmh_check_launch("cc_label kernels");
@@ -93,7 +125,7 @@ extern "C" int wmh_remove_small_components(const uint8_t* mask, uint8_t* out, in
     int rc = cc_label(mask, labels, D, H, W, 0, st);
     if (rc != WMH_OK) return rc;
     if (hipMemsetAsync(counts, 0, n * sizeof(int), st) != hipSuccess) return wmh_fail(WMH_ELAUNCH, "remove_small_components: memset");
-    hipLaunchKernelGGL(cc_count_kernel, dim3(vgrid(n)), dim3(256), 0, st, labels, counts, n);
+    hipLaunchKernelGGL(cc_count_kernel, dim3(vgrid(n)), dim3(256), 0, st, labels, counts, (unsigned)n);
     hipLaunchKernelGGL(cc_filter_kernel, dim3(vgrid(n)), dim3(256), 0, st, labels, counts, out, n, min_volume);
     return wmh_check_launch("remove_small_components kernels");
 }
@@ -188,8 +220,9 @@ __global__ __launch_bounds__(256) void zscore_partial_kernel(const float* data, 
 __global__ __launch_bounds__(64) void zscore_final_kernel(const double* part, float* stats) {     // stats[c] = {mean, std}
     const int c = blockIdx.x;
     double s = 0, q = 0, k = 0;
+    for (int b = threadIdx.x; b < ZS_BLOCKS; b += 64) { const double* o = part + ((size_t)c * ZS_BLOCKS + b) * 3; s += o[0]; q += o[1]; k += o[2]; }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); k += __shfl_down(k, off, 64); }
     if (threadIdx.x == 0) {
-        for (int b = 0; b < ZS_BLOCKS; ++b) { const double* o = part + ((size_t)c * ZS_BLOCKS + b) * 3; s += o[0]; q += o[1]; k += o[2]; }
         const double mean = k > 0 ? s / k : 0.0;
         double var = k > 0 ? q / k - mean * mean : 0.0; if (var < 0) var = 0;
         stats[2 * c] = (float)mean; stats[2 * c + 1] = (float)sqrt(var);
