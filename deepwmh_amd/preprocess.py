@@ -1,8 +1,10 @@
 """Host-side pre/post steps either side of the network inside `nnUNet_predict`
 [nnU-Net, not in tree: preprocessing.GenericPreprocessor.preprocess_test_case, cropping.crop_to_nonzero,
-inference.segmentation_export.save_segmentation_nifti_from_softmax].  CPU numpy/scipy (SURVEY.md 8f row 1:
-"next" after the network path); with volumes already at the plan's spacing (the synthetic benchmark and
-1 mm FLAIR) crop / z-score / uncrop are all that run.  Parity unpinned: restated from upstream nnU-Net v1."""
+inference.segmentation_export.save_segmentation_nifti_from_softmax].
+Two forms: `preprocess_case` / `export_prediction` are the numpy/scipy restatement (used when a case needs resampling
+or an axis transpose, and as the checker of the device form in the tests); `preprocess_case_device` /
+`export_segmentation_device` run crop / z-score / un-crop in libdeepwmh_amd.so and are what `nnUNet_predict` uses for
+volumes already at the plan's spacing.  Parity unpinned: restated from upstream nnU-Net v1."""
 import numpy as np
 from scipy.ndimage import binary_fill_holes, zoom
 
