@@ -249,11 +249,21 @@ class UNetTrainer:
                                            LRELU_SLOPE, st), 'wmh_conv3d_k3_wgrad')
         if not need_dx:
             return None
+        if conv.stride == 2:                                 # gather form: 27 MFMAs per channel pair for the 8 output parities
+            assert C1 == 0
+            key = ('dgrad.s2', conv.name)
+            hit = self._packed.get(key)
+            if hit is None or hit[0] != self._version:
+                wp = hit[1] if hit is not None else torch.empty(lib.wmh_conv3d_k3s2_dgrad_packed_floats(C0, Cc), dtype=torch.float32,
+                                                                device=self.device)
+                _lib.check(lib.wmh_conv3d_k3s2_dgrad_pack_weights_device(_lib.ptr(self.p[conv.name + '.conv.weight']), C0, Cc, _lib.ptr(wp), st),
+                           'wmh_conv3d_k3s2_dgrad_pack_weights_device')
+                self._packed[key] = (self._version, wp)
+            wp = self._packed[key][1]
+            dx = self._buf('b.dx0.%s.y' % rec['key'], (N, C0, D, H, W))
+            _lib.check(lib.wmh_conv3d_k3s2_dgrad(_lib.ptr(dy), _lib.ptr(wp), _lib.ptr(dx), N, C0, Cc, D, H, W, st), 'wmh_conv3d_k3s2_dgrad')
+            return [dx]
         src = dy
-        if conv.stride == 2:
-            src = self._buf('b.up.%s' % rec['key'], (N, Cc, D, H, W))
-            Do, Ho, Wo = y.shape[2:]
-            _lib.check(lib.wmh_upsample_zero2(_lib.ptr(dy), _lib.ptr(src), N, Cc, Do, Ho, Wo, D, H, W, st), 'upsample_zero2')
         outs = []
         for part, (off, cnt) in enumerate([(0, C0)] + ([(C0, C1)] if C1 else [])):
             cfg = _lib.check(lib.wmh_conv3d_k3_config(Cc, cnt, D, H, W, 1), 'config')

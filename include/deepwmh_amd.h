@@ -188,6 +188,13 @@ size_t wmh_conv3d_k3_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int
 int wmh_conv3d_k3_wgrad(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
                         const float* dy, float* dW, float* workspace, int N, int D, int H, int W, int Cout,
                         int stride, float lrelu_slope, void* stream);
+/* Data gradient of the stride-2 3x3x3 convolution in gather form (each of the 27 taps feeds exactly one of the 8 output
+ * parity classes: the ideal MFMA count, 1/8 of the zero-insert route below).  w = torch layout [Cout][Cin][27] in HBM;
+ * wp = its image, wmh_conv3d_k3s2_dgrad_packed_floats(Cin, Cout) floats; dy = [N][Cout][Do][Ho][Wo] with Do = (D-1)/2+1;
+ * dx = [N][Cin][D][H][W], every element written. */
+size_t wmh_conv3d_k3s2_dgrad_packed_floats(int Cin, int Cout);
+int wmh_conv3d_k3s2_dgrad_pack_weights_device(const float* w, int Cin, int Cout, float* wp, void* stream);
+int wmh_conv3d_k3s2_dgrad(const float* dy, const float* wp, float* dx, int N, int Cin, int Cout, int D, int H, int W, void* stream);
 /* up[n,c,2z,2y,2x] = dy[n,c,z,y,x], zero elsewhere (up has the stride-2 conv's input size D,H,W). */
 int wmh_upsample_zero2(const float* dy, float* up, int N, int C, int Do, int Ho, int Wo, int D, int H, int W,
                        void* stream);

@@ -246,6 +246,25 @@ def test_convtranspose3d_device_pack_matches_host(lib):
         assert np.array_equal(dev.cpu().numpy(), host)
 
 
+@pytest.mark.parametrize('shape', [(2, 8, 16, 8, 8, 8), (1, 40, 20, 9, 11, 13), (1, 32, 64, 12, 10, 70), (2, 3, 5, 4, 6, 5)])
+def test_conv3d_stride2_dgrad_gather(lib, shape):
+    """dx of Conv3d(k3, s2, p1) in gather form against autograd (even and odd extents, channel tails, several x tiles)."""
+    N, Cin, Cout, D, H, W = shape
+    g = torch.Generator().manual_seed(81)
+    x = torch.randn(N, Cin, D, H, W, generator=g).requires_grad_()
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.1
+    y = F.conv3d(x, w, None, stride=2, padding=1)
+    dY = torch.randn(y.shape, generator=g)
+    y.backward(dY)
+    wd, dYd = w.cuda(), dY.cuda()
+    wp = torch.empty(lib.wmh_conv3d_k3s2_dgrad_packed_floats(Cin, Cout), device='cuda')
+    check(lib.wmh_conv3d_k3s2_dgrad_pack_weights_device(P(wd), Cin, Cout, P(wp), None), 'dgrad pack')
+    dX = torch.full((N, Cin, D, H, W), float('nan'), device='cuda')
+    check(lib.wmh_conv3d_k3s2_dgrad(P(dYd), P(wp), P(dX), N, Cin, Cout, D, H, W, None), 'k3s2 dgrad')
+    torch.cuda.synchronize()
+    assert float((dX.cpu() - x.grad).abs().max()) <= 1e-5 * (1 + float(x.grad.abs().max()))
+
+
 def test_clip_and_sgd_nesterov(lib):
     g = torch.Generator().manual_seed(71)
     n = 100003
