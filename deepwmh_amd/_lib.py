@@ -66,6 +66,9 @@ SIGNATURES = {
     'wmh_zscore_crop_workspace_doubles': (_sz, [_i]),
     'wmh_zscore_crop': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'wmh_uncrop_u8': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'wmh_resample_workspace_doubles': (_sz, [_i, _i, _i, _i]),
+    'wmh_resample': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'wmh_resample_nearest_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'wmh_softmax_mask': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'wmh_ensemble_softmax': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     'wmh_binary_overlap': (_i, [_vp, _vp, _vp, _sz, _vp]),

@@ -60,7 +60,6 @@ def main(argv=None):
     from .. import nifti
     from ..checkpoint import load_checkpoint, resolve_task, trainer_folder
     from ..network import UNetEngine
-    from ..preprocess import export_prediction, preprocess_case
     from ..sliding_window import SlidingWindowPredictor
 
     task = resolve_task(results, args.task_name, args.model)
@@ -88,7 +87,7 @@ def main(argv=None):
     # Host work (gunzip + NIfTI parse before, gzip + write after) runs in worker threads around the GPU, as nnU-Net's
     # --num_threads_preprocessing / --num_threads_nifti_save processes do; zlib and numpy release the GIL.
     from concurrent.futures import ThreadPoolExecutor
-    from ..preprocess import export_segmentation_device, needs_resampling, preprocess_case_device
+    from ..preprocess import export_prediction_device, preprocess_case_device
     stage = info['init'][5] if info.get('init') else None
     todo = []
     for case in cases:
@@ -104,16 +103,9 @@ def main(argv=None):
             arr, mt = nifti.read(os.path.join(args.input_folder, '%s_%04d.nii.gz' % (case, m)))
             vols.append(arr)
             meta = meta or mt
-        vol = np.stack(vols)
-        host = None
-        if needs_resampling(vol.shape[1:], meta['spacing'], plans, stage) or list(plans.get('transpose_forward', [0, 1, 2])) != [0, 1, 2]:
-            host = preprocess_case(vol, meta['spacing'], plans, stage)      # resampling stays on the host (scipy splines)
-        return vol, meta, host, time.time() - t0
+        return np.stack(vols), meta, time.time() - t0
 
-    def save(out, case, seg_full, prob0, meta, host_export=None):
-        if host_export is not None:                                          # resampled case: export (order-1 resample) off the GPU thread
-            seg_full, prob_full = export_prediction(*host_export)
-            prob0 = prob_full[0] if args.save_softmax else None
+    def save(out, case, seg_full, prob0, meta):
         nifti.write(out, seg_full, like=meta, dtype=np.uint8)
         if prob0 is not None:
             nifti.write(os.path.join(args.output_folder, case + '_0.nii.gz'), prob0, like=meta, dtype=np.float32)
@@ -126,30 +118,20 @@ def main(argv=None):
         saves = []
         for i, (case, out) in enumerate(todo):
             t0 = time.time()
-            vol, meta, host, t_load = loads[i].result()
+            vol, meta, t_load = loads[i].result()
             loads[i] = None
             if i + ahead < len(todo):
                 loads.append(readers.submit(load, todo[i + ahead][0]))
             t1 = time.time()
-            if host is None:
-                data_d, props = preprocess_case_device(vol, plans, 'cuda:0')
-                seg_d, prob_d = pred.predict_device(data_d, return_prob=args.save_softmax)
-                seg_full = export_segmentation_device(seg_d, props)          # synchronises: the label map is on the host
-                prob0 = None
-                if args.save_softmax:
-                    prob0 = export_prediction(prob_d.cpu().numpy(), props)[1][0]
-                shape = tuple(data_d.shape[1:])
-            else:
-                data, props = host
-                seg, prob = pred.predict(data, return_prob=True)
-                shape = tuple(data.shape[1:])
+            # crop, (resample,) z-score, sliding window, (resample,) argmax, un-crop: all on the device
+            data_d, props = preprocess_case_device(vol, meta['spacing'], plans, stage, 'cuda:0')
+            resampled = tuple(data_d.shape[1:]) != tuple(props['shape_after_crop'])
+            seg_d, prob_d = pred.predict_device(data_d, return_prob=args.save_softmax or resampled)
+            seg_full, prob0 = export_prediction_device(seg_d, prob_d, props, args.save_softmax)     # synchronises
             t2 = time.time()
-            if host is None:
-                saves.append(writers.submit(save, out, case, seg_full, prob0, meta))
-            else:
-                saves.append(writers.submit(save, out, case, None, None, meta, (prob, props)))
-            print('  %s: shape %s, read%s %.2f s (waited %.2f s), gpu %.2f s'
-                  % (case, shape, '+resample' if host is not None else '', t_load, t1 - t0, t2 - t1), flush=True)
+            saves.append(writers.submit(save, out, case, seg_full, prob0, meta))
+            print('  %s: shape %s%s, read %.2f s (waited %.2f s), gpu %.2f s'
+                  % (case, tuple(data_d.shape[1:]), ' (resampled)' if resampled else '', t_load, t1 - t0, t2 - t1), flush=True)
         for f in saves:
             f.result()                                                       # re-raises a failed write
     if todo:

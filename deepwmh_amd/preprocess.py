@@ -113,24 +113,39 @@ def needs_resampling(shape_zyx, spacing, plans, stage=None):
     return bool(np.any(np.round(sp / target * shp).astype(int) != shp))
 
 
-def preprocess_case_device(volume_zyx, plans, device='cuda:0'):
-    """Same result as preprocess_case for a volume that needs no resampling and no axis transpose, computed by
-    libdeepwmh_amd.so: non-zero mask -> fill holes (6-connected background components that do not reach the border) ->
-    bounding box -> masked z-score fused with the crop.  Returns (device tensor [C, ...] fp32, props); the only
-    host round trip is the 6-int box (the crop's shape decides the sliding-window geometry)."""
+def _resample_device(x, new_shape, order):
+    """x: device float32 [C,D,H,W] -> [C,*new_shape] through wmh_resample (double arithmetic, scipy's tap order)."""
     import torch
     from . import _lib
     lib = _lib.load()
+    Cn, D, H, W = (int(v) for v in x.shape)
+    Do, Ho, Wo = (int(v) for v in new_shape)
+    out = torch.empty((Cn, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+    nws = lib.wmh_resample_workspace_doubles(D, H, W, order)
+    ws = torch.empty(max(1, nws), dtype=torch.float64, device=x.device)
+    _lib.check(lib.wmh_resample(_lib.ptr(x), _lib.ptr(out), _lib.ptr(ws), Cn, D, H, W, Do, Ho, Wo, order, _lib.current_stream()),
+               'wmh_resample')
+    return out
+
+
+def preprocess_case_device(volume_zyx, spacing, plans, stage=None, device='cuda:0'):
+    """preprocess_case on the GPU (libdeepwmh_amd.so): non-zero mask -> fill holes (6-connected background components
+    that do not reach the border) -> bounding box -> [transpose, order-3 resampling of the data and order-0 of the mask
+    when the case is not at the plan's spacing] -> masked z-score (fused with the crop when nothing is resampled).
+    Returns (device tensor [C, ...] fp32, props); the only host round trip is the 6-int box."""
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    stages = plans['plans_per_stage']
+    st_plan = stages[stage if stage is not None else (max(stages.keys()) if isinstance(stages, dict) else len(stages) - 1)]
     tf = list(plans.get('transpose_forward', [0, 1, 2]))
-    if tf != [0, 1, 2]:
-        raise NotImplementedError('preprocess_case_device: transpose_forward %s (use preprocess_case)' % (tf,))
     data = volume_zyx[None] if volume_zyx.ndim == 3 else volume_zyx
     x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(device)
     Cn, D, H, W = (int(v) for v in x.shape)
     n = D * H * W
     st = _lib.current_stream()
     raw = torch.empty(n, dtype=torch.uint8, device=device)
-    mask = torch.empty(n, dtype=torch.uint8, device=device)
+    mask = torch.empty((D, H, W), dtype=torch.uint8, device=device)
     labels = torch.empty(n, dtype=torch.int32, device=device)
     flags = torch.empty(n, dtype=torch.int32, device=device)
     bbox_d = torch.empty(6, dtype=torch.int32, device=device)
@@ -139,28 +154,72 @@ def preprocess_case_device(volume_zyx, plans, device='cuda:0'):
     _lib.check(lib.wmh_mask_bbox(_lib.ptr(mask), _lib.ptr(bbox_d), D, H, W, st), 'wmh_mask_bbox')
     bb = [int(v) for v in bbox_d.cpu().tolist()]
     bbox = [[bb[0], bb[1]], [bb[2], bb[3]], [bb[4], bb[5]]]
-    shape = tuple(b - a for a, b in bbox)
+    crop_shape = tuple(b - a for a, b in bbox)
     umn = plans.get('use_mask_for_norm', {0: False})
     use_mask = bool(umn[0] if isinstance(umn, dict) else umn)
-    out = torch.empty((Cn,) + shape, dtype=torch.float32, device=device)
+    shape_t = tuple(crop_shape[i] for i in tf)                     # crop in network axis order
+    sp = np.asarray(spacing, float)[tf]
+    target = np.asarray(st_plan['current_spacing'], float)
+    new_shape = tuple(int(v) for v in np.round(sp / target * np.array(shape_t)).astype(int))
     stats = torch.empty(Cn, 2, dtype=torch.float32, device=device)
     ws = torch.empty(max(1, lib.wmh_zscore_crop_workspace_doubles(Cn)), dtype=torch.float64, device=device)
-    _lib.check(lib.wmh_zscore_crop(_lib.ptr(x), _lib.ptr(mask), _lib.ptr(bbox_d), _lib.ptr(out), None, _lib.ptr(stats), _lib.ptr(ws),
-                                   Cn, D, H, W, int(use_mask), st), 'wmh_zscore_crop')
-    props = dict(original_shape=(D, H, W), bbox=bbox, shape_after_crop=shape, transpose_forward=tf,
+    props = dict(original_shape=(D, H, W), bbox=bbox, shape_after_crop=shape_t, transpose_forward=tf,
                  transpose_backward=list(plans.get('transpose_backward', [0, 1, 2])), bbox_device=bbox_d)
+    if tf == [0, 1, 2] and new_shape == shape_t:
+        out = torch.empty((Cn,) + crop_shape, dtype=torch.float32, device=device)
+        _lib.check(lib.wmh_zscore_crop(_lib.ptr(x), _lib.ptr(mask), _lib.ptr(bbox_d), _lib.ptr(out), None, _lib.ptr(stats), _lib.ptr(ws),
+                                       Cn, D, H, W, int(use_mask), st), 'wmh_zscore_crop')
+        return out, props
+    sl = tuple(slice(a, b) for a, b in bbox)
+    xc = x[(slice(None),) + sl].permute([0] + [i + 1 for i in tf]).contiguous()
+    mc = mask[sl].permute(tf).contiguous()
+    if new_shape != shape_t:
+        xc = _resample_device(xc, new_shape, 3)
+        m2 = torch.empty(new_shape, dtype=torch.uint8, device=device)
+        _lib.check(lib.wmh_resample_nearest_u8(_lib.ptr(mc), _lib.ptr(m2), shape_t[0], shape_t[1], shape_t[2], new_shape[0], new_shape[1],
+                                               new_shape[2], st), 'wmh_resample_nearest_u8')
+        mc = m2
+    full = torch.tensor([0, new_shape[0], 0, new_shape[1], 0, new_shape[2]], dtype=torch.int32, device=device)
+    out = torch.empty((Cn,) + new_shape, dtype=torch.float32, device=device)
+    _lib.check(lib.wmh_zscore_crop(_lib.ptr(xc), _lib.ptr(mc), _lib.ptr(full), _lib.ptr(out), None, _lib.ptr(stats), _lib.ptr(ws),
+                                   Cn, new_shape[0], new_shape[1], new_shape[2], int(use_mask), st), 'wmh_zscore_crop')
     return out, props
 
 
-def export_segmentation_device(seg_crop, props):
-    """seg_crop: uint8 device tensor in network geometry (no resampling / transpose case) -> uint8 numpy label map in the
-    input's geometry (un-crop into zeros on the device, one D2H copy of the label map)."""
+def export_prediction_device(seg_d, prob_d, props, want_prob0=False):
+    """(seg uint8, prob fp32 [K,...]) device tensors in network geometry -> (uint8 numpy label map, P(background) numpy or
+    None) in the input's geometry: transpose back, order-1 resampling of the probabilities to the cropped shape when it
+    differs (then argmax), un-crop into zeros on the device; one D2H copy of the label map."""
     import torch
     from . import _lib
     lib = _lib.load()
     D, H, W = props['original_shape']
-    assert tuple(seg_crop.shape) == tuple(props['shape_after_crop']) and seg_crop.dtype == torch.uint8
-    full = torch.empty((D, H, W), dtype=torch.uint8, device=seg_crop.device)
-    _lib.check(lib.wmh_uncrop_u8(_lib.ptr(seg_crop.contiguous()), _lib.ptr(props['bbox_device']), _lib.ptr(full), D, H, W, 0,
-                                 _lib.current_stream()), 'wmh_uncrop_u8')
-    return full.cpu().numpy()
+    tf, tb = props['transpose_forward'], props['transpose_backward']
+    tgt = tuple(int(props['shape_after_crop'][tf.index(i)]) for i in range(3))       # cropped shape in the input's axis order
+    need_prob = want_prob0 or tuple(seg_d.shape) != tuple(props['shape_after_crop'])
+    if need_prob:
+        assert prob_d is not None, 'export_prediction_device: probabilities needed (resampled case or --save_softmax)'
+        prob = prob_d.permute([0] + [i + 1 for i in tb]).contiguous()
+        if tuple(prob.shape[1:]) != tgt:
+            prob = _resample_device(prob, tgt, 1)
+            seg_c = prob.argmax(0).to(torch.uint8)
+        else:
+            seg_c = seg_d.permute(tb).contiguous()
+    else:
+        prob = None
+        seg_c = seg_d.permute(tb).contiguous()
+    full = torch.empty((D, H, W), dtype=torch.uint8, device=seg_c.device)
+    _lib.check(lib.wmh_uncrop_u8(_lib.ptr(seg_c), _lib.ptr(props['bbox_device']), _lib.ptr(full), D, H, W, 0, _lib.current_stream()),
+               'wmh_uncrop_u8')
+    p0 = None
+    if want_prob0:
+        p0 = torch.ones((D, H, W), dtype=torch.float32, device=seg_c.device)   # outside the crop everything is background
+        sl = tuple(slice(a, b) for a, b in props['bbox'])
+        p0[sl] = prob[0]
+        p0 = p0.cpu().numpy()
+    return full.cpu().numpy(), p0
+
+
+def export_segmentation_device(seg_crop, props):
+    """Label map only (no resampling / transpose case)."""
+    return export_prediction_device(seg_crop, None, props, False)[0]

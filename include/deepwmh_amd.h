@@ -255,6 +255,15 @@ int wmh_zscore_crop(const float* data, const uint8_t* mask, const int32_t* bbox6
 /* full[box] = crop, `fill` elsewhere (segmentation export un-crop). */
 int wmh_uncrop_u8(const uint8_t* crop, const int32_t* bbox6, uint8_t* full, int D, int H, int W, int fill, void* stream);
 
+/* Spline resampling between voxel grids: skimage.transform.resize(order, mode='edge', anti_aliasing=False) as nnU-Net's
+ * preprocessing (order 3 data, order 0 mask) and export (order 1 softmax) use it [not in tree]; same arithmetic as
+ * scipy.ndimage.zoom(order, mode='nearest', grid_mode=True) in double (u = (o + 0.5) * in/out - 0.5).  in = [C][D][H][W],
+ * out = [C][Do][Ho][Wo]; orders 0, 1, 3.  workspace >= wmh_resample_workspace_doubles(...) doubles (order 3 only). */
+size_t wmh_resample_workspace_doubles(int D, int H, int W, int order);
+int wmh_resample(const float* in, float* out, double* workspace, int C, int D, int H, int W, int Do, int Ho, int Wo, int order,
+                 void* stream);
+int wmh_resample_nearest_u8(const uint8_t* in, uint8_t* out, int D, int H, int W, int Do, int Ho, int Wo, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Stage-II glue of DeepWMH's self-training loop.  fp32 in numpy's operation order without
  * fused multiply-add: bit-identical to the reference expressions cited.

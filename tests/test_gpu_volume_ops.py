@@ -110,7 +110,7 @@ def test_preprocess_case_device_matches_host(lib, use_mask):
     vol[10:14, 20:25, 20:26] = 0                             # a hole inside the head: filled by the mask, kept in the statistics
     vol[0, 0, 0] = 0
     ref, props_ref = preprocess.preprocess_case(vol, (1.0, 1.0, 1.0), plans)
-    got, props = preprocess.preprocess_case_device(vol, plans)
+    got, props = preprocess.preprocess_case_device(vol, (1.0, 1.0, 1.0), plans)
     torch.cuda.synchronize()
     assert props['bbox'] == props_ref['bbox'] and tuple(props['shape_after_crop']) == tuple(props_ref['shape_after_crop'])
     assert tuple(got.shape) == ref.shape
@@ -128,6 +128,55 @@ def test_preprocess_device_all_zero_volume(lib):
     from deepwmh_amd.plan import tiny_plan
     plans = ck.make_plans(tiny_plan(), spacing=(1.0, 1.0, 1.0), use_mask_for_norm=True)
     vol = np.zeros((8, 9, 10), np.float32)
-    got, props = preprocess.preprocess_case_device(vol, plans)
+    got, props = preprocess.preprocess_case_device(vol, (1.0, 1.0, 1.0), plans)
     ref, props_ref = preprocess.preprocess_case(vol, (1.0, 1.0, 1.0), plans)
     assert props['bbox'] == props_ref['bbox'] and np.array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('order', [0, 1, 3])
+def test_resample_matches_scipy_zoom(lib, order):
+    """wmh_resample against the host restatement of skimage's resize (scipy zoom, float64): up- and down-sampling,
+    anisotropic factors, an axis left untouched, tiny extents."""
+    from deepwmh_amd import preprocess
+    rng = np.random.default_rng(11)
+    for shp, new in [((20, 24, 18), (31, 24, 13)), ((9, 10, 11), (18, 25, 7)), ((3, 40, 5), (4, 33, 5)), ((16, 16, 16), (16, 16, 16)),
+                     ((2, 3, 30), (5, 2, 41))]:
+        x = (rng.standard_normal((2,) + shp) * 30 + 100).astype(np.float32)
+        got = preprocess._resample_device(torch.from_numpy(x).cuda(), new, order).cpu().numpy()
+        ref = np.stack([preprocess._resize(x[c].astype(np.float64), new, order).astype(np.float32) for c in range(2)]) \
+            if tuple(new) != shp else x
+        if tuple(new) == shp and order == 3:
+            tol = 2e-5 * float(np.abs(x).max())          # identity zoom still runs the spline round trip on the device
+        else:
+            tol = 2e-6 * float(np.abs(ref).max()) if order else 0.0
+        assert got.shape == ref.shape and float(np.abs(got - ref).max()) <= tol, (shp, new, order, float(np.abs(got - ref).max()))
+
+
+@pytest.mark.parametrize('spacing,tf', [((0.9, 0.9, 1.2), [0, 1, 2]), ((1.3, 0.8, 1.0), [0, 1, 2]), ((3.0, 0.9, 0.9), [0, 1, 2]),
+                                        ((1.0, 1.0, 1.0), [1, 2, 0])])
+def test_preprocess_and_export_device_with_resampling(lib, spacing, tf):
+    from deepwmh_amd import checkpoint as ck, preprocess
+    from deepwmh_amd.plan import tiny_plan
+    plans = ck.make_plans(tiny_plan(), spacing=(1.0, 1.0, 1.0), use_mask_for_norm=True)
+    plans['transpose_forward'] = tf
+    plans['transpose_backward'] = [tf.index(i) for i in range(3)]
+    rng = np.random.default_rng(13)
+    from scipy.ndimage import gaussian_filter
+    vol = np.zeros((40, 46, 38), np.float32)
+    vol[4:37, 3:44, 5:35] = (gaussian_filter(rng.standard_normal((33, 41, 30)), 1.5) * 200 + 300).astype(np.float32)
+    vol[15:18, 20:24, 18:22] = 0
+    ref, props_ref = preprocess.preprocess_case(vol, spacing, plans)
+    got, props = preprocess.preprocess_case_device(vol, spacing, plans)
+    assert props['bbox'] == props_ref['bbox'] and tuple(props['shape_after_crop']) == tuple(props_ref['shape_after_crop'])
+    assert tuple(got.shape) == ref.shape
+    assert float(np.abs(got.cpu().numpy() - ref).max()) <= 5e-5 * (1 + float(np.abs(ref).max()))
+    # export: probabilities in network geometry -> label map + P(background) in the input's geometry
+    K = 2
+    logits = torch.from_numpy(gaussian_filter(rng.standard_normal((K,) + ref.shape[1:]), (0, 2, 2, 2)).astype(np.float32) * 8).cuda()
+    prob = torch.softmax(logits, 0).contiguous()
+    seg = prob.argmax(0).to(torch.uint8)
+    full, p0 = preprocess.export_prediction_device(seg, prob, props, True)
+    full_ref, pfull_ref = preprocess.export_prediction(prob.cpu().numpy(), props_ref)
+    assert float(np.abs(p0 - pfull_ref[0]).max()) <= 2e-6
+    sure = np.abs(pfull_ref[1] - pfull_ref[0]) > 1e-5
+    assert full.shape == full_ref.shape and int((full != full_ref)[sure].sum()) == 0

@@ -88,3 +88,16 @@ row('softmax masking', ms, n * 12, cpu_time(lambda: o2.softmax_masking(sm[0], mm
 o3 = torch.zeros(3, dtype=torch.int64, device='cuda')
 ms = timed(lambda: _lib.check(lib.wmh_binary_overlap(P(stack[0]), P(stack[1]), P(o3), n, st)))
 row('hard Dice counts', ms, n * 8, cpu_time(lambda: o2.hard_dice_binary(sm[0], sm[1])))
+
+from deepwmh_amd import preprocess as pre
+new = (144, 173, 192)
+xr = torch.from_numpy(raw[None]).cuda()
+ws = torch.empty(lib.wmh_resample_workspace_doubles(*shape, 3), dtype=torch.float64, device='cuda'); outr = torch.empty((1,) + new, device='cuda')
+ms = timed(lambda: _lib.check(lib.wmh_resample(P(xr), P(outr), P(ws), 1, *shape, *new, 3, st)), reps=5)
+nn_ = int(np.prod(new)); npad = int(np.prod([v + 24 for v in shape]))
+# algorithmic bytes: read the volume, write + 3x (read, write) the double coefficients, read them once more, write the output
+row('resample order 3 (spline)', ms, n * 4 + npad * 8 * 8 + nn_ * 4, cpu_time(lambda: pre._resize(raw.astype(np.float64), new, 3), reps=1))
+pr = torch.rand((2,) + new, device='cuda'); outp = torch.empty((2,) + shape, device='cuda')
+ms = timed(lambda: _lib.check(lib.wmh_resample(P(pr), P(outp), None, 2, *new, *shape, 1, st)), reps=5)
+prh = pr.cpu().numpy()
+row('resample order 1 (2 softmax ch.)', ms, 2 * (nn_ + n) * 4, cpu_time(lambda: [pre._resize(prh[k].astype(np.float64), shape, 1) for k in range(2)], reps=1))
