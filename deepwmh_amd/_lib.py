@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('WMH_LIB_PATH', os.path.join(_HERE, 'lib', 'libdeepwmh_amd.so'))   # override: diagnostic builds
 
-_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_vp, _i, _f, _sz, _d = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_double
 _ip = C.POINTER(C.c_int)
 
 # name -> (restype, argtypes); mirrors include/deepwmh_amd.h one to one
@@ -72,6 +72,22 @@ SIGNATURES = {
     'wmh_softmax_mask': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'wmh_ensemble_softmax': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     'wmh_binary_overlap': (_i, [_vp, _vp, _vp, _sz, _vp]),
+    'wmh_moments_workspace_doubles': (_sz, []),
+    'wmh_masked_moments_f32': (_i, [_vp, _vp, _sz, _d, _vp, _vp, _vp]),
+    'wmh_masked_moments_f64': (_i, [_vp, _vp, _sz, _d, _vp, _vp, _vp]),
+    'wmh_zscore_f64': (_i, [_vp, _d, _d, _vp, _vp, _vp, _sz, _vp]),
+    'wmh_mask_fill_f64': (_i, [_vp, _vp, _vp, _sz, _vp]),
+    'wmh_vote_mask': (_i, [_vp, _i, _vp, _sz, _vp]),
+    'wmh_label_vote': (_i, [_vp, _i, _i, _vp, _sz, _vp]),
+    'wmh_histogram_f64': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp]),
+    'wmh_block_stats': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'wmh_zoom_linear_window': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'wmh_sub_add_f64': (_i, [_vp, _vp, _vp, _sz, _vp]),
+    'wmh_mul_mask_f64': (_i, [_vp, _vp, _sz, _vp]),
+    'wmh_select_f64': (_i, [_vp, _vp, _vp, _sz, _vp]),
+    'wmh_nll': (_i, [_vp, _vp, _i, _sz, _d, _i, _vp, _vp, _vp, _vp, _vp]),
+    'wmh_median_filter_f64': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'wmh_component_filtering': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'wmh_selftest_mfma_32x32x2': (_i, [_vp, _vp, _vp, _vp]),
 }
 

@@ -278,6 +278,52 @@ int wmh_ensemble_softmax(const float* stack, int E, float* field, uint8_t* label
 int wmh_binary_overlap(const float* a, const float* b, unsigned long long* out3, size_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Stage I: negative-log-likelihood initial segmentation.  The reference is float64 numpy
+ * (deepwmh/analysis/lesion_analysis.py:84-278 and the image_ops.py helpers cited per entry); volumes are flat [n] or
+ * [D][H][W], stacks [R][n], masks uint8.  Scalars a later kernel consumes stay on the device (`*_dev` arguments).
+ * ------------------------------------------------------------------------------------------- */
+
+/* out7 (device) = {count, mean, population std, min inside mask, min over everything, max inside, max over everything};
+ * mask NULL = all voxels.
+ * Sums run about `shift`.  masked_mean / masked_std (image_ops.py:13-21), np.ma(...).min() (lesion_analysis.py:155). */
+size_t wmh_moments_workspace_doubles(void);
+int wmh_masked_moments_f32(const float* x, const uint8_t* mask, size_t n, double shift, double* out7, double* workspace, void* stream);
+int wmh_masked_moments_f64(const double* x, const uint8_t* mask, size_t n, double shift, double* out7, double* workspace, void* stream);
+/* z_score (image_ops.py:172-179): out = (x - mean) / std in double; with fill_mask, voxels outside it become *fill_value_dev
+ * (lesion_analysis.py:156,166). */
+int wmh_zscore_f64(const float* x, double mean, double stdv, const uint8_t* fill_mask, const double* fill_value_dev, double* out, size_t n,
+                   void* stream);
+int wmh_mask_fill_f64(double* x, const uint8_t* mask, const double* fill_value_dev, size_t n, void* stream);
+/* out = more than half of the R maps are > 0.5 at v (group_mean(m_i) > 0.5, lesion_analysis.py:139-141; tissue vote :239-242). */
+int wmh_vote_mask(const float* labels, int R, uint8_t* out, size_t n, void* stream);
+/* average_contiguous_labels (image_ops.py:23-38): per-voxel argmax of the votes for ids 0..K-1, first maximum wins. */
+int wmh_label_vote(const float* labels, int R, int K, uint8_t* out, size_t n, void* stream);
+/* numpy.histogram(x[mask], bins=edges): edges_dev = nbins+1 increasing doubles, last bin closed, outside ignored.  With
+ * replace_mask, voxels outside it count as *replace_value_dev (np.where(m < 0.5, x.min(), x), lesion_analysis.py:145). */
+int wmh_histogram_f64(const double* x, const uint8_t* mask, const uint8_t* replace_mask, const double* replace_value_dev, size_t n,
+                      const double* edges_dev, int nbins, unsigned long long* counts, void* stream);
+/* mean_std_grid (image_ops.py:56-170), in two steps: block statistics of the float32-rounded, zero-padded data on the
+ * coarse grid, then scipy.ndimage.zoom(order=1) of the zero-surrounded grid evaluated on the window the reference keeps. */
+int wmh_block_stats(const double* x, const uint8_t* mask, int D, int H, int W, const int* patch3, const int* step3, const int* grid3,
+                    double* mean_grid, double* std_grid, void* stream);
+int wmh_zoom_linear_window(const double* grid, const int* grid3, const int* zoomed3, const int* offset3, int D, int H, int W, double* out,
+                           void* stream);
+int wmh_sub_add_f64(double* x, const double* a, const double* b, size_t n, void* stream);       /* x = x - a + b */
+int wmh_mul_mask_f64(double* x, const uint8_t* mask, size_t n, void* stream);                  /* x *= (mask != 0) */
+int wmh_select_f64(double* x, const double* y, const uint8_t* mask, size_t n, void* stream);   /* x = mask ? y : x */
+/* nll (lesion_analysis.py:84-113) with unmasked group statistics: mu, sigma over the R references (sigma floored at
+ * min_std, or + 1e-6 when min_std < 0), anomaly of x_prime and (optionally) of every reference; side = +1 / -1 / 0. */
+int wmh_nll(const double* x_prime, const double* refs, int R, size_t n, double min_std, int side, double* anomaly, double* mu, double* sigma,
+            double* anomaly_refs, void* stream);
+/* scipy.ndimage.median_filter(size=(kz,ky,kx), mode='constant', cval=0) (image_ops.py:181-183 via median_3mm :379-421);
+ * windows up to 27 voxels. */
+int wmh_median_filter_f64(const double* in, double* out, int D, int H, int W, int kz, int ky, int kx, void* stream);
+/* component_filtering (image_ops.py:256-308): per slice and orientation, cross erosion then the largest 4-connected
+ * component; the three orientations OR-ed.  scratch_u8: n bytes; labels, counts: n int32; best: max(D,H,W) uint64. */
+int wmh_component_filtering(const uint8_t* mask, uint8_t* out, uint8_t* scratch_u8, int32_t* labels, int32_t* counts,
+                            unsigned long long* best, int D, int H, int W, const int* do_filter3, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Self-test helper: D = A(32x2) * B(2x32) through one v_mfma_f32_32x32x2_f32, used by the GPU
  * tests to pin the fragment layout this library assumes (a: [32][2], b: [2][32], d: [32][32]).
  * ------------------------------------------------------------------------------------------- */
