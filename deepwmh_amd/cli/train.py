@@ -28,7 +28,10 @@ def build_parser():
     ap.add_argument('--disable_postprocessing_on_folds', action='store_true')
     ap.add_argument('--custom_val_cases', nargs='*', default=None)            # fork-only
     ap.add_argument('--npz', action='store_true')
-    ap.add_argument('--fp32', action='store_true')
+    ap.add_argument('--fp32', action='store_true')                            # nnU-Net: disable mixed precision (already the default here)
+    ap.add_argument('--bf16', action='store_true',
+                    help='mixed precision: bf16 operands in the forward/data-gradient convolutions of the wide levels (extension; '
+                         'also WMH_TRAIN_PRECISION=bf16).  nnU-Net itself defaults to fp16 AMP; here fp32 is the default')
     ap.add_argument('--val_batches', type=int, default=None)
     ap.add_argument('--seed', type=int, default=12345)
     return ap
@@ -80,12 +83,13 @@ def main(argv=None):
     os.makedirs(fdir, exist_ok=True)
 
     bs = int(plans['plans_per_stage'][max(plans['plans_per_stage'].keys())]['batch_size'])
+    precision = 'bf16' if (args.bf16 or os.environ.get('WMH_TRAIN_PRECISION', '') == 'bf16') and not args.fp32 else 'fp32'
     start_epoch, best = 0, None
     latest = os.path.join(fdir, 'model_latest.model')
     if args.continue_training and os.path.isfile(latest):
         _, _, sd, info = ck.load_checkpoint(folder, args.fold, 'model_latest')
         start_epoch = int(info['epoch'])
-        tr = UNetTrainer(plan, sd, device)
+        tr = UNetTrainer(plan, sd, device, precision=precision)
         mom = info['checkpoint'].get('deepwmh_amd_momentum')
         if mom is not None:
             tr.mom.copy_(torch.as_tensor(np.asarray(mom)).to(tr.mom.device))
@@ -94,7 +98,7 @@ def main(argv=None):
         if rank == 0:
             print('continuing from %s (epoch %d)' % (latest, start_epoch), flush=True)
     else:
-        tr = UNetTrainer(plan, he_init_state_dict(plan, seed=args.seed, trained_like=False), device)
+        tr = UNetTrainer(plan, he_init_state_dict(plan, seed=args.seed, trained_like=False), device, precision=precision)
     if world > 1:                                       # identical start on every rank
         dist.broadcast(tr.params, 0); dist.broadcast(tr.mom, 0)
     loader = PatchLoader(stage_dir, train_cases, plan.patch_size, bs, seed=args.seed + 1000 * rank + start_epoch)

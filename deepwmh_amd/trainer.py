@@ -36,7 +36,15 @@ class _Conv:
 
 
 class UNetTrainer:
-    def __init__(self, plan: UNetPlan, state_dict, device='cuda:0', momentum=0.99, weight_decay=3e-5, clip=12.0):
+    def __init__(self, plan: UNetPlan, state_dict, device='cuda:0', momentum=0.99, weight_decay=3e-5, clip=12.0, precision='fp32'):
+        """precision 'fp32', or 'bf16' = mixed precision in the spirit of the reference's AMP default [nnU-Net run_iteration,
+        fp16=True]: the stride-1 convolutions of the >= 16-wide levels (forward and data gradient) multiply bf16-rounded
+        operands with fp32 accumulation; weights, activations, statistics, weight gradients, loss and optimizer stay fp32
+        (bf16 keeps fp32's exponent range, so no loss scaling)."""
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError('precision must be fp32 or bf16')
+        self.precision = precision
+        self.bf16_forward = self.bf16_dgrad = precision == 'bf16'      # diagnostic switches (tools/diag_bf16_train.py)
         plan.check_supported()
         if not plan.isotropic:
             raise NotImplementedError('training implements the isotropic [3,3,3] / [2,2,2] architecture only (the planner emits nothing else)')
@@ -129,6 +137,37 @@ class UNetTrainer:
         self._packed[key] = (self._version, wf)
         return wf
 
+    def _use_bf16(self, cfg, stride, C0, C1, which='fwd'):
+        return ((self.bf16_forward if which == 'fwd' else self.bf16_dgrad) and stride == 1 and bool(self.lib.wmh_conv3d_k3_bf16_supported(cfg))
+                and (C1 == 0 or C0 % 16 == 0))
+
+    def _pack_bf16(self, conv, cfg, mode, ci_off, ci_cnt):
+        key = (conv.name, cfg, mode, ci_off, ci_cnt, 'bf16')
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == self._version:
+            return hit[1]
+        ecin, ecout = (ci_cnt, conv.cout) if mode == 0 else (conv.cout, ci_cnt)
+        n = self.lib.wmh_conv3d_k3_packed_halfs_bf16(cfg, ecin, ecout)
+        wf = hit[1] if hit is not None else torch.empty(n, dtype=torch.int16, device=self.device)
+        _lib.check(self.lib.wmh_conv3d_k3_pack_weights_bf16_device(cfg, _lib.ptr(self.p[conv.name + '.conv.weight']), conv.cin, conv.cout,
+                                                                   ci_off, ci_cnt, mode, _lib.ptr(wf), self._st()),
+                   'wmh_conv3d_k3_pack_weights_bf16_device')
+        self._packed[key] = (self._version, wf)
+        return wf
+
+    def _run_conv_bf16(self, key, cfg, x0, ss0, x1, ss1, wf, bias, cout, want_stats):
+        N, C0, D, H, W = x0.shape
+        C1 = 0 if x1 is None else x1.shape[1]
+        y = self._buf(key + '.y', (N, cout, D, H, W))
+        part, npart = None, 0
+        if want_stats:
+            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials(cfg, N, D, H, W), 'num_partials')
+            part = self._buf(key + '.part', (N, cout, npart, 4))
+        _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16(cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wf),
+                                                   _lib.ptr(bias), _lib.ptr(y), _lib.ptr(part), N, D, H, W, cout, LRELU_SLOPE, self._st()),
+                   'wmh_conv3d_k3_fwd_bf16')
+        return y, part, npart
+
     def _run_conv(self, key, cfg, x0, ss0, x1, ss1, wf, bias, cout, stride, want_stats):
         N, C0, D, H, W = x0.shape
         C1 = 0 if x1 is None else x1.shape[1]
@@ -149,9 +188,14 @@ class UNetTrainer:
     def _conv_fwd(self, key, conv, x0, ss0, x1=None, ss1=None):
         N, _, D, H, W = x0.shape
         cfg = _lib.check(self.lib.wmh_conv3d_k3_config(conv.cin, conv.cout, D, H, W, conv.stride), 'config')
-        wf = self._pack(conv, cfg, 0, 0, conv.cin)
-        y, part, npart = self._run_conv(key, cfg, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout,
-                                        conv.stride, True)
+        C1 = 0 if x1 is None else x1.shape[1]
+        if self._use_bf16(cfg, conv.stride, x0.shape[1], C1):
+            wf = self._pack_bf16(conv, cfg, 0, 0, conv.cin)
+            y, part, npart = self._run_conv_bf16(key, cfg, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout, True)
+        else:
+            wf = self._pack(conv, cfg, 0, 0, conv.cin)
+            y, part, npart = self._run_conv(key, cfg, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout,
+                                            conv.stride, True)
         ss = self._buf(key + '.ss', (N, conv.cout, 2))
         mr = self._buf(key + '.mr', (N, conv.cout, 2))
         _lib.check(self.lib.wmh_instnorm_finalize(_lib.ptr(part), npart, _lib.ptr(self.p[conv.name + '.instnorm.weight']),
@@ -267,8 +311,12 @@ class UNetTrainer:
         outs = []
         for part, (off, cnt) in enumerate([(0, C0)] + ([(C0, C1)] if C1 else [])):
             cfg = _lib.check(lib.wmh_conv3d_k3_config(Cc, cnt, D, H, W, 1), 'config')
-            wf = self._pack(conv, cfg, 1, off, cnt)
-            dx, _, _ = self._run_conv('b.dx%d.%s' % (part, rec['key']), cfg, src, None, None, None, wf, None, cnt, 1, False)
+            if self._use_bf16(cfg, 1, Cc, 0, 'dgrad'):
+                wf = self._pack_bf16(conv, cfg, 1, off, cnt)
+                dx, _, _ = self._run_conv_bf16('b.dx%d.%s' % (part, rec['key']), cfg, src, None, None, None, wf, None, cnt, False)
+            else:
+                wf = self._pack(conv, cfg, 1, off, cnt)
+                dx, _, _ = self._run_conv('b.dx%d.%s' % (part, rec['key']), cfg, src, None, None, None, wf, None, cnt, 1, False)
             outs.append(dx)
         return outs
 

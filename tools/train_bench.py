@@ -1,4 +1,5 @@
-"""Time one nnUNetTrainerV2 iteration (BASELINE plan, batch 2 of 128^3 patches) on the HIP kernels."""
+"""Time one nnUNetTrainerV2 iteration (BASELINE plan, batch 2 of 128^3 patches) on the HIP kernels.
+env: WMH_BATCH (2), WMH_ITERS (4), WMH_PRECISION (fp32 | bf16)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,7 +8,8 @@ from deepwmh_amd.synthetic import he_init_state_dict
 from deepwmh_amd.trainer import UNetTrainer, downsample_targets
 plan = baseline_plan()
 B = int(os.environ.get('WMH_BATCH', '2'))
-tr = UNetTrainer(plan, he_init_state_dict(plan, 0), 'cuda:0')
+tr = UNetTrainer(plan, he_init_state_dict(plan, 0), 'cuda:0', precision=os.environ.get('WMH_PRECISION', 'fp32'))
+torch.manual_seed(0)
 x = torch.randn(B, 1, 128, 128, 128, device='cuda')
 lab = (torch.rand(B, 128, 128, 128, device='cuda') < 0.05).to(torch.uint8)
 td = downsample_targets(lab, plan.num_pool)
