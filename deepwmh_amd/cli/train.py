@@ -49,7 +49,7 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     from .. import checkpoint as ck
-    from ..data import DATA_ID, PatchLoader
+    from ..data import DATA_ID, PatchLoader, PrefetchLoader
     from ..plan import UNetPlan
     from ..synthetic import he_init_state_dict
     from ..trainer import UNetTrainer, downsample_targets, poly_lr
@@ -101,7 +101,7 @@ def main(argv=None):
         tr = UNetTrainer(plan, he_init_state_dict(plan, seed=args.seed, trained_like=False), device, precision=precision)
     if world > 1:                                       # identical start on every rank
         dist.broadcast(tr.params, 0); dist.broadcast(tr.mom, 0)
-    loader = PatchLoader(stage_dir, train_cases, plan.patch_size, bs, seed=args.seed + 1000 * rank + start_epoch)
+    loader = PrefetchLoader(PatchLoader(stage_dir, train_cases, plan.patch_size, bs, seed=args.seed + 1000 * rank + start_epoch))
     vloader = PatchLoader(stage_dir, val_cases, plan.patch_size, bs, seed=args.seed + 77, mirror=False)
     nval = args.val_batches if args.val_batches is not None else max(1, min(50, args.batches_per_epoch // 5))
     ma = None
@@ -119,7 +119,8 @@ def main(argv=None):
             data, seg = loader.next_batch()
             x = torch.from_numpy(data).to(device)
             tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool)
-            losses.append(float(tr.run_iteration(x, tg, lr).cpu()))
+            losses.append(tr.run_iteration(x, tg, lr).clone())           # stays on the device: no per-iteration sync
+        losses = [float(v) for v in torch.stack(losses).cpu()]
         vl = []
         for _ in range(nval):
             data, seg = vloader.next_batch()
@@ -138,6 +139,7 @@ def main(argv=None):
         if args.save_every_epoch:
             save('model_ep_%04d' % (epoch + 1), epoch + 1)
     save('model_final_checkpoint', args.epochs)
+    loader.close()
     if world > 1:
         dist.destroy_process_group()
     return 0

@@ -169,3 +169,43 @@ class PatchLoader:
                         data[b] = np.flip(data[b], ax + 1)
                         seg[b] = np.flip(seg[b], ax)
         return np.ascontiguousarray(data), np.ascontiguousarray(seg)
+
+
+class PrefetchLoader:
+    """Runs a PatchLoader in a background thread (nnU-Net's MultiThreadedAugmenter does this with worker processes):
+    batches are produced `depth` ahead so that host-side sampling overlaps the GPU step.  Order and content are exactly
+    the wrapped loader's (one producer, FIFO queue), so seeded runs stay reproducible."""
+
+    def __init__(self, loader, depth=3):
+        import queue
+        import threading
+        self.loader = loader
+        self.q = queue.Queue(maxsize=depth)
+        self._stop = False
+        self._err = None
+
+        def work():
+            try:
+                while not self._stop:
+                    item = loader.next_batch()
+                    while not self._stop:
+                        try:
+                            self.q.put(item, timeout=0.2)
+                            break
+                        except queue.Full:
+                            continue
+            except BaseException as e:           # surfaced on the consumer side
+                self._err = e
+                self.q.put(None)
+
+        self.t = threading.Thread(target=work, daemon=True)
+        self.t.start()
+
+    def next_batch(self):
+        item = self.q.get()
+        if item is None:
+            raise RuntimeError('patch loader thread failed') from self._err
+        return item
+
+    def close(self):
+        self._stop = True
