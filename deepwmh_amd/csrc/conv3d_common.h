@@ -43,7 +43,7 @@ struct ConvCfg {
     static_assert(LX * LY * LZ == 32, "lane map must cover 32 voxels");
     static_assert(TY % LY == 0 && TZ % LZ == 0, "tile must be whole M-tiles");
     static_assert(MPS % MT == 0, "a wave's M-tiles must belong to one sample");
-    static_assert(NMT % MT == 0 && WM >= 1 && WM <= 4, "1..4 waves");
+    static_assert(NMT % MT == 0 && WM >= 1 && WM <= 8, "1..8 waves");
     static_assert(NIT <= 32, "validity mask is 32 bits");
     static_assert(CK % 2 == 0, "k step is a cin pair");
     static_assert((((KZ - 1) * ZS + 2 * YS + 2) + (CK - 2) * CS + TILE) * 4 < 65536, "ds_read immediate range");

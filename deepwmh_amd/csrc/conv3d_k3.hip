@@ -329,7 +329,7 @@ static const CfgInfo& cfg_info(int cfg) {
                                                 info_of<Cfg20>()};
     return t[cfg];
 }
-static unsigned long long* g_conv_stamps = nullptr;
+unsigned long long* g_conv_stamps = nullptr;       // diagnostics: also read by the bf16 launcher
 // diagnostics: device buffer of 4 x uint64 per workgroup that the next conv launches fill (NULL = off)
 extern "C" void wmh_debug_set_conv_stamps(void* p) { g_conv_stamps = (unsigned long long*)p; }
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }

@@ -21,15 +21,16 @@
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {     // round to nearest even
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a = (a + 0x7FFFu + ((a >> 16) & 1u)) >> 16;
-    b = (b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u;
-    return a | b;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {     // v_cvt_pk_bf16_f32: round to nearest even
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(unsigned, b);
 }
 
 template <class C, int RIT>
-__global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_bf16_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d_k3_bf16_kernel(const ConvArgs a) {
     constexpr int S = C::S, MT = C::MT, NT = C::NT, NIT = C::NIT, THREADS = C::THREADS, APF = 4, CKB = 16;
     static_assert(C::TN == 1, "one sample per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];      // [CS voxels][2]
@@ -39,7 +40,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_bf16_kernel(const Con
     const int j = lane & 31, kh = lane >> 5;
     const int dx = j % C::LX, dy = (j / C::LX) % C::LY, dz = j / (C::LX * C::LY);
     int bid = blockIdx.x;
-    if (a.xcd_swizzle) {
+    const int abl = a.xcd_swizzle >> 4;             // diagnostics: 1 skip MFMA phase, 2 skip epilogue, 4 all channels read plane 0
+    if (a.xcd_swizzle & 1) {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
@@ -104,7 +106,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_bf16_kernel(const Con
     for (int d = 0; d < APF; ++d) loadA(ch_lo * 27 + d, aring[d]);
 
     const char* ldsb = reinterpret_cast<const char*>(ldsq);
+    unsigned long long t_stage = 0, t_mfma = 0, t_mark = 0;          // diagnostics (a.stamps != NULL only)
     for (int ch = ch_lo; ch < ch_hi; ++ch) {
+        if (a.stamps) t_mark = __builtin_amdgcn_s_memtime();
         // ---- stage 16 input channels of the halo tile -------------------------------------------------------
         const int cb = ch * CKB;
         const float* xs; const float* ss; int Cs, c0;
@@ -112,6 +116,16 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_bf16_kernel(const Con
         else           { xs = a.x1; ss = a.ss1; Cs = a.C1; c0 = cb - a.C0; }
         const bool has_ss = ss != nullptr;
         const float slope_eff = has_ss ? a.slope : 1.f;
+        // per-channel scale / shift of the producer's InstanceNorm (1, 0 without one; 0, 0 for channels past the source's
+        // end: they stage zeros).  Uniform over the workgroup: scalar registers.
+        float scv[CKB], shv[CKB];
+#pragma unroll
+        for (int c = 0; c < CKB; ++c) {
+            const bool cok = (c0 + c) < Cs;
+            const int cc = min(c0 + c, Cs - 1);
+            scv[c] = cok ? (has_ss ? ss[((size_t)n0 * Cs + cc) * 2] : 1.f) : 0.f;
+            shv[c] = (cok && has_ss) ? ss[((size_t)n0 * Cs + cc) * 2 + 1] : 0.f;
+        }
         if (ch != ch_lo) __syncthreads();                 // every wave is done reading the previous chunk
 #pragma unroll
         for (int r0 = 0; r0 < NIT; r0 += RIT) {
@@ -121,27 +135,22 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_bf16_kernel(const Con
 #pragma unroll
                 for (int c = 0; c < CKB; ++c) {
                     const int it = r0 + ii;
-                    if (it < NIT) v[ii][c] = xs[((size_t)n0 * Cs + min(c0 + c, Cs - 1)) * DHW + sp_off[it]];
+                    if (it < NIT) v[ii][c] = xs[((size_t)n0 * Cs + ((abl & 4) ? 0 : min(c0 + c, Cs - 1))) * DHW + sp_off[it]];
                 }
 #pragma unroll
             for (int ii = 0; ii < RIT; ++ii) {
                 const int it = r0 + ii;
                 if (it >= NIT) continue;
-                const bool sok = (okmask >> it) & 1u;
+                const unsigned keep = ((okmask >> it) & 1u) ? 0xFFFFFFFFu : 0u;      // halo voxels outside the volume: zeros
                 unsigned w[8];
 #pragma unroll
                 for (int c = 0; c < CKB; c += 2) {
-                    float f[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int cc = min(c0 + c + u, Cs - 1);
-                        const float sc = has_ss ? ss[((size_t)n0 * Cs + cc) * 2] : 1.f;
-                        const float sh = has_ss ? ss[((size_t)n0 * Cs + cc) * 2 + 1] : 0.f;
-                        float t = fmaf(v[ii][c + u], sc, sh);
-                        t = t > 0.f ? t : t * slope_eff;
-                        f[u] = (sok && (c0 + c + u) < Cs) ? t : 0.f;
-                    }
-                    w[c >> 1] = pack_bf16x2(f[0], f[1]);
+                    // LeakyReLU as max(t, slope * t) (0 <= slope <= 1, checked by the host); v_cvt_pk_bf16_f32 rounds to nearest even
+                    float t0 = fmaf(v[ii][c], scv[c], shv[c]);
+                    float t1 = fmaf(v[ii][c + 1], scv[c + 1], shv[c + 1]);
+                    t0 = fmaxf(t0, t0 * slope_eff);
+                    t1 = fmaxf(t1, t1 * slope_eff);
+                    w[c >> 1] = pack_bf16x2(t0, t1) & keep;
                 }
                 const int e = tid + it * THREADS;
                 const int key = (keymask >> it) & 1u;
@@ -150,7 +159,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_bf16_kernel(const Con
             }
         }
         __syncthreads();
+        if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
         // ---- 27 taps x MT x NT MFMAs -----------------------------------------------------------------------------
+        if (!(abl & 1))
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int kw = tap % 3;
@@ -172,15 +183,28 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_bf16_kernel(const Con
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) aring[APF - 1][nt] = anew[nt];
         }
+        if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mfma += t - t_mark; }
     }
-    conv_epilogue<C>(a, acc, g, ks, n0, wave, j, kh, dx, dy, dz, ts0, oz0, oy0, ox0, (tz * a.nty + ty) * a.ntx + tx);
+    if (a.stamps) t_mark = __builtin_amdgcn_s_memtime();
+    if (!(abl & 2)) conv_epilogue<C>(a, acc, g, ks, n0, wave, j, kh, dx, dy, dz, ts0, oz0, oy0, ox0, (tz * a.nty + ty) * a.ntx + tx);
+    if (a.stamps && tid == 0) {
+        unsigned long long* o = a.stamps + (size_t)blockIdx.x * 4;
+        o[0] = t_stage; o[1] = t_mfma; o[2] = __builtin_amdgcn_s_memtime() - t_mark; o[3] = (unsigned long long)(ch_hi - ch_lo);
+    }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> BCfg0;      // same tile geometry as the fp32 Cfg0 / Cfg2
-typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> BCfg2;
+extern unsigned long long* g_conv_stamps;
+int wmh_launch_conv_bf16_ws(int cfg, const ConvArgs& a, hipStream_t st);      // conv3d_k3_bf16_ws.hip
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> BCfg0;      // same tile geometry as the fp32 Cfg0 / Cfg2
+typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> BCfg2;
+// The kernel is bound by memory latency, not by the matrix cores: the same tiles cut into 8 waves of 4 (cfg 0) / 2 (cfg 2)
+// M-tiles halve the accumulator registers, so two workgroups = 16 waves fit a CU and twice as many loads are in flight.
+typedef ConvCfg<1, 32, 1, 4, 8, 1, 4, 1, 4, 6> BCfg0w;
+typedef ConvCfg<1, 16, 2, 2, 16, 1, 2, 2, 4, 6> BCfg2w;
+static int bf16_variant() { static const int v = env_int("WMH_BF16_WAVES8", 0); return v; }
 
 static inline unsigned short f2bf(float f) {
     unsigned u; memcpy(&u, &f, 4);
@@ -189,6 +213,15 @@ static inline unsigned short f2bf(float f) {
 static int bf16_nt(int cfg) { return cfg == 0 ? 1 : cfg == 2 ? 2 : 0; }
 
 extern "C" int wmh_conv3d_k3_bf16_supported(int cfg) { return bf16_nt(cfg) > 0; }
+// InstanceNorm partial records per (n, c) row the bf16 kernel writes (its wave split differs from the fp32 kernel's)
+extern "C" int wmh_conv3d_k3_num_partials_bf16(int cfg, int N, int Do, int Ho, int Wo) {
+    if (!bf16_nt(cfg)) return wmh_fail(WMH_EINVAL, "num_partials_bf16: configuration has no bf16 kernel");
+    (void)N;
+    const bool w8 = bf16_variant() != 0;
+    const int TX = cfg == 0 ? BCfg0::TX : BCfg2::TX, TY = cfg == 0 ? BCfg0::TY : BCfg2::TY, TZ = cfg == 0 ? BCfg0::TZ : BCfg2::TZ;
+    const int WPS = cfg == 0 ? (w8 ? BCfg0w::WPS : BCfg0::WPS) : (w8 ? BCfg2w::WPS : BCfg2::WPS);
+    return cdiv(Wo, TX) * cdiv(Ho, TY) * cdiv(Do, TZ) * WPS;
+}
 extern "C" size_t wmh_conv3d_k3_packed_halfs_bf16(int cfg, int Cin, int Cout) {
     const int NT = bf16_nt(cfg);
     if (!NT) return 0;
@@ -264,6 +297,7 @@ extern "C" int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0
     if (!NT) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: configuration has no bf16 kernel");
     if (!x0 || !wf || !y || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: null/empty argument");
     if (x1 == nullptr) C1 = 0;
+    if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: LeakyReLU slope must be in [0, 1]");
     if (C1 > 0 && (C0 % 16) != 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: C0 must be a multiple of 16 with two sources");
     ConvArgs a;
     a.x0 = x0; a.ss0 = ss0; a.C0 = C0; a.x1 = x1; a.ss1 = ss1; a.C1 = C1;
@@ -271,18 +305,32 @@ extern "C" int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0
     a.N = N; a.D = D; a.H = H; a.W = W; a.Do = D; a.Ho = H; a.Wo = W; a.Cout = Cout;
     a.nchunks = (C1 > 0) ? (C0 / 16 + cdiv(C1, 16)) : cdiv(C0, 16);
     const int TX = cfg == 0 ? BCfg0::TX : BCfg2::TX, TY = cfg == 0 ? BCfg0::TY : BCfg2::TY, TZ = cfg == 0 ? BCfg0::TZ : BCfg2::TZ;
-    const int WPS = cfg == 0 ? BCfg0::WPS : BCfg2::WPS;
+    const bool w8 = bf16_variant() != 0;
+    const int WPS = cfg == 0 ? (w8 ? BCfg0w::WPS : BCfg0::WPS) : (w8 ? BCfg2w::WPS : BCfg2::WPS);
     a.ntx = cdiv(W, TX); a.nty = cdiv(H, TY); a.ntz = cdiv(D, TZ);
     a.npart = a.ntx * a.nty * a.ntz * WPS;
     a.slope = lrelu_slope;
     a.G = cdiv(Cout, 32 * NT);
     a.KS = 1;
     static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
-    a.xcd_swizzle = swz_env;
-    a.stamps = nullptr;
+    static const int abl_env = env_int("WMH_BF16_ABL", 0);
+    a.xcd_swizzle = (swz_env & 1) | (abl_env << 4);
+    a.stamps = g_conv_stamps;
     const long long nblk = (long long)a.ntx * a.nty * a.ntz * N * a.G;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: grid too large");
     hipStream_t st = (hipStream_t)stream;
+    static const int use_ws = env_int("WMH_BF16_WS", 1);
+    // the wave-specialised form loads aligned 16-byte quads: rows must start 16-byte aligned
+    const bool quad_ok = (W % 4) == 0 && (size_t)16 * D * H * W * 4 < ((size_t)1 << 32) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && (!x1 || (reinterpret_cast<uintptr_t>(x1) & 15) == 0);
+    if (use_ws && abl_env == 0 && !w8 && quad_ok) return wmh_launch_conv_bf16_ws(cfg, a, st);
+    if (bf16_variant() == 2) {
+        if (cfg == 0) return launch_bf16<BCfg0w, 1>(a, (unsigned)nblk, st);
+        return launch_bf16<BCfg2w, 1>(a, (unsigned)nblk, st);
+    }
+    if (w8) {
+        if (cfg == 0) return launch_bf16<BCfg0w, 2>(a, (unsigned)nblk, st);
+        return launch_bf16<BCfg2w, 2>(a, (unsigned)nblk, st);
+    }
     if (cfg == 0) return launch_bf16<BCfg0, 4>(a, (unsigned)nblk, st);
     return launch_bf16<BCfg2, 3>(a, (unsigned)nblk, st);
 }

@@ -1,0 +1,321 @@
+// conv3d_k3_bf16_ws.hip -- wave-specialised, persistent form of the bf16-operand 3x3x3 convolution.
+//
+// The one-role bf16 kernel (conv3d_k3_bf16.hip) runs its phases one after another -- stage a chunk (global loads,
+// InstanceNorm+LeakyReLU, bf16 pack, LDS writes), then 27 taps of MFMA, then the stores -- and measured additive:
+// 0.64 ms of staging instructions + 0.63 ms of exposed HBM latency + 0.6 ms of MFMA + 0.43 ms of stores for the
+// 32->32 layer at 128^3 x 8 (tools/conv_bf16_bench.py, WMH_BF16_ABL).  Here the roles are split inside one
+// 512-thread workgroup per CU so that they overlap:
+//   waves 0-3  consumers: B operand = one ds_read_b128 per (tap, M-tile), A operand (weights) = one ds_read_b128 per
+//              (tap, cout tile) -- 16-byte GLOBAL loads inside the MFMA loop cost ~13 cycles per MFMA even from cache
+//              (tools/micro/bf16_inner.hip: 47-49 against 35.8 cycles per MFMA with the weights in LDS) --
+//              v_mfma_f32_32x32x16_bf16, epilogue (bias, fp32 IN moments, stores);
+//   waves 4-7  loaders: the next chunk's halo tile in two register halves, so that 64+ loads per lane stay in flight
+//              while the other half is normalised, packed (v_cvt_pk_bf16_f32) and written to LDS.
+// LDS: activations [2][halo voxels][16 cin] bf16 (channel-interleaved and XOR-swizzled as in the one-role kernel) and ONE
+// buffer of the chunk's weight fragments (two do not fit in 160 KB): the loaders hold the next chunk's weights in
+// registers and drop them into LDS between two barriers at the end of a chunk (~300 cycles of a ~7000-cycle chunk).  Persistent (grid = number of CUs): loaders run one chunk ahead across tile boundaries and the
+// weight ring continues into the next tile, so a tile has no prologue.  Same arithmetic and k order as the one-role
+// kernel: bit-identical results.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "conv3d_common.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned ws_pack_bf16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(unsigned, b);
+}
+
+// Uniform read of a value no kernel in flight writes (InstanceNorm scale/shift come from the previous launch): through the
+// constant address space, so that it is a scalar-cache load on its own counter instead of a vector load queued behind the
+// activation prefetch on the in-order vmcnt.
+__device__ __forceinline__ float ld_uniform(const float* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<unsigned long long>(p));
+}
+
+template <class C>
+__global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArgs a, const int T /*tiles*/) {
+    constexpr int S = C::S, MT = C::MT, NT = C::NT, CKB = 16;
+    constexpr int LTH = 256;                                   // loader threads
+    constexpr int NIT = (C::SP + LTH - 1) / LTH;
+    constexpr int CS = NIT * LTH;                              // padded voxel count: every loader store in range
+    constexpr int WQ = 27 * NT * 64;                           // 16-byte weight pieces per chunk
+    constexpr int WIT = (WQ + LTH - 1) / LTH;
+    static_assert(C::TN == 1 && C::WM == 4 && S == 1, "four consumer waves, stride 1");
+    extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];      // [2][CS voxels][2] activations, then [27][NT][64] weights
+    uint4* wlds = ldsq + 2 * CS * 2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int HW = a.H * a.W;
+    const size_t DHW = (size_t)a.D * HW;
+    const int nch = a.nchunks;
+
+    auto tile_of = [&](int v, int& g, int& tx, int& ty, int& tz, int& n0) {
+        const int q = T >> 3, r = T & 7, xcd = v & 7;
+        int t = (a.xcd_swizzle & 1) ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3) : v;
+        g = t % a.G; t /= a.G;
+        tx = t % a.ntx; t /= a.ntx;
+        ty = t % a.nty; t /= a.nty;
+        tz = t % a.ntz; t /= a.ntz;
+        n0 = t;
+    };
+    int ntiles_mine = 0;
+    for (int v = blockIdx.x; v < T; v += gridDim.x) ++ntiles_mine;
+    const int total = ntiles_mine * nch;                    // chunk iterations of this workgroup
+
+    if (loader) {
+        // ================================ loader waves =====================================================
+        const int lt = tid - 256;
+        // Staging unit = an aligned quad of 4 consecutive x voxels of one halo row (one 16-byte load per channel): the row
+        // [ox0-1, ox0+TX] is covered by the aligned span [ox0-4, ox0+TX+4), QPR quads; quads are wholly inside or wholly
+        // outside the volume (W % 4 == 0, checked by the host).  Voxels of the span outside the halo row are dropped.
+        constexpr int ROWS = C::IY * C::IZ, QPR = (C::TX + 8) / 4, NQ = ROWS * QPR;
+        constexpr int NSL = (NQ + LTH - 1) / LTH;                 // quad slots per loader thread (3 / 2)
+        static_assert(NSL >= 2 && NSL <= 3, "slot pipeline");
+        int q_off[NSL]; unsigned q_ok = 0;                        // of the tile the NEXT issue() reads
+        int n0_cur = 0;
+        auto setup = [&](int v) __attribute__((always_inline)) {
+            int g, tx, ty, tz, n0;
+            tile_of(v, g, tx, ty, tz, n0);
+            // the tile coordinates come out of VALU divisions: make them scalar again, or everything indexed with them
+            // (the InstanceNorm scale/shift reads above all) turns into vector loads on the in-order vmcnt queue
+            n0_cur = __builtin_amdgcn_readfirstlane(n0);
+            tx = __builtin_amdgcn_readfirstlane(tx); ty = __builtin_amdgcn_readfirstlane(ty); tz = __builtin_amdgcn_readfirstlane(tz);
+            const int ix0 = tx * C::TX - 4, iy0 = ty * C::TY - 1, iz0 = tz * C::TZ - 1;
+            q_ok = 0;
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) {
+                const int sidx = lt + i * LTH;
+                const int row = sidx / QPR, q = sidx - row * QPR;
+                const int gx = ix0 + 4 * q, gy = iy0 + row % C::IY, gz = iz0 + row / C::IY;
+                const bool ok = sidx < NQ && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
+                q_off[i] = ok ? gz * HW + gy * a.W + gx : 0;
+                q_ok |= ok ? (1u << i) : 0u;
+            }
+        };
+        uint4 wst[WIT];                                       // next chunk's weight fragments (this thread's pieces)
+        auto issue_w = [&](int q) __attribute__((always_inline)) {                           // chunk q of this workgroup
+            int g, tx, ty, tz, n0;
+            tile_of(blockIdx.x + (q / nch) * gridDim.x, g, tx, ty, tz, n0);
+            g = __builtin_amdgcn_readfirstlane(g);
+            const uint4* wsrc = reinterpret_cast<const uint4*>(a.wf) + ((size_t)g * nch + __builtin_amdgcn_readfirstlane(q % nch)) * WQ;
+#pragma unroll
+            for (int i = 0; i < WIT; ++i) wst[i] = wsrc[min(lt + i * LTH, WQ - 1)];
+        };
+        auto write_w = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < WIT; ++i) { const int k = lt + i * LTH; if (WIT * LTH == WQ || k < WQ) wlds[k] = wst[i]; }
+        };
+        // A half-slot = 8 channels of one quad (8 loads of 16 bytes, one 16-byte LDS piece per voxel).  The NHS half-slots of a
+        // chunk go through a ring of RS register sets: while one set is normalised, packed and written, RS-1 are in flight.
+        constexpr int NHS = 2 * NSL, RS = (NHS % 3 == 0) ? 3 : 2;
+        f32x4_t v[RS][8];
+        unsigned okh[RS];
+        auto src_of = [&](int ch, const float*& xs, const float*& ss, int& Cs, int& c0) {
+            const int cb = ch * CKB;
+            if (cb < a.C0) { xs = a.x0; ss = a.ss0; Cs = a.C0; c0 = cb; }
+            else           { xs = a.x1; ss = a.ss1; Cs = a.C1; c0 = cb - a.C0; }
+        };
+        // One scalar base per (tile, chunk) and a 32-bit lane offset per load (quad offset + channel * plane stride, host
+        // checks the range): the loads are `global_load_dwordx4 v, v_off, s[base]`, no 64-bit arithmetic per channel.
+        const unsigned pstride = 4u * (unsigned)DHW;
+        auto issue = [&](auto hc, int ch) __attribute__((always_inline)) {                   // half-slot h of chunk ch of the tile set up last
+            constexpr int h = decltype(hc)::value, i = h / 2, half = h % 2, r = h % RS;
+            ch = __builtin_amdgcn_readfirstlane(ch);          // q % nch ran on the VALU
+            const float* xs; const float* ss; int Cs, c0;
+            src_of(ch, xs, ss, Cs, c0);
+            const char* base = reinterpret_cast<const char*>(xs + ((size_t)n0_cur * Cs + c0) * DHW);
+            const int cmax = Cs - 1 - c0;                     // channels past the source's end re-read its last one (zeroed later)
+            const unsigned qo = 4u * (unsigned)q_off[i];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                v[r][c] = *reinterpret_cast<const f32x4_t*>(base + (qo + (unsigned)min(8 * half + c, cmax) * pstride));
+            okh[r] = (q_ok >> i) & 1u;
+        };
+        // InstanceNorm scale / shift of the chunk being converted: 16 channels, scalar, read once per chunk.  Without a
+        // pending normalisation the reads go to {1, 0} (index multiplier 0); channels past the end get scale = shift = 0.
+        float scv[CKB], shv[CKB], slope_eff = 1.f;
+        static __device__ const float ident2[2] = {1.f, 0.f};
+        auto load_ss = [&](int q) __attribute__((always_inline)) {
+            const int ch = __builtin_amdgcn_readfirstlane(q % nch);
+            const float* xs; const float* ss; int Cs, c0;
+            src_of(ch, xs, ss, Cs, c0);
+            const bool has_ss = ss != nullptr;
+            slope_eff = has_ss ? a.slope : 1.f;
+            const float* tab = has_ss ? ss + ((size_t)n0_cur * Cs + c0) * 2 : ident2;
+            const int mul = has_ss ? 2 : 0;
+            const int cmax = Cs - 1 - c0;
+#pragma unroll
+            for (int c = 0; c < CKB; ++c) {
+                const float sc = ld_uniform(tab + mul * min(c, cmax)), sh = ld_uniform(tab + mul * min(c, cmax) + 1);
+                scv[c] = c <= cmax ? sc : 0.f;
+                shv[c] = c <= cmax ? sh : 0.f;
+            }
+        };
+        auto convert = [&](auto hc, int buf) __attribute__((always_inline)) {
+            constexpr int h = decltype(hc)::value, i = h / 2, half = h % 2, r = h % RS;
+            uint4* dst = ldsq + (size_t)buf * CS * 2;
+            const int sidx = lt + i * LTH;
+            const int row = sidx / QPR, q = sidx - row * QPR;
+            const unsigned keep = okh[r] ? 0xFFFFFFFFu : 0u;      // quad outside the volume: zeros
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = 4 * q - 3 + k;                       // position in the halo row
+                unsigned w[4];
+#pragma unroll
+                for (int c = 0; c < 8; c += 2) {
+                    float t0 = fmaf(v[r][c][k], scv[8 * half + c], shv[8 * half + c]);
+                    float t1 = fmaf(v[r][c + 1][k], scv[8 * half + c + 1], shv[8 * half + c + 1]);
+                    t0 = fmaxf(t0, t0 * slope_eff);
+                    t1 = fmaxf(t1, t1 * slope_eff);
+                    w[c >> 1] = ws_pack_bf16x2(t0, t1) & keep;
+                }
+                if (sidx < NQ && x >= 0 && x < C::IX) {
+                    const int e = row * C::IX + x;
+                    dst[e * 2 + (half ^ ((x >> 3) & 1))] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+        };
+        // chunk q of this workgroup: tile blockIdx.x + (q / nch) * gridDim.x, channel chunk q % nch
+        auto enter = [&](int q) __attribute__((always_inline)) { if (q % nch == 0) setup(blockIdx.x + (q / nch) * gridDim.x); };
+        // one step: put half-slot (h + RS - 1) of the running sequence in flight, then convert half-slot h of chunk q
+        auto step = [&](auto hc, int q) __attribute__((always_inline)) {
+            constexpr int h = decltype(hc)::value, hn = h + RS - 1;
+            if constexpr (hn < NHS) {
+                issue(std::integral_constant<int, hn>{}, q % nch);
+            } else {
+                if (q + 1 < total) {
+                    if constexpr (hn == NHS) enter(q + 1);        // first half-slot of the next chunk: maybe a new tile
+                    issue(std::integral_constant<int, hn - NHS>{}, (q + 1) % nch);
+                }
+            }
+            convert(hc, q & 1);
+        };
+        auto produce = [&](int q) __attribute__((always_inline)) {
+            load_ss(q);                                       // before any enter(q + 1): n0_cur is still this chunk's
+            issue_w(q);
+            step(std::integral_constant<int, 0>{}, q); step(std::integral_constant<int, 1>{}, q);
+            step(std::integral_constant<int, 2>{}, q); step(std::integral_constant<int, 3>{}, q);
+            if constexpr (NHS > 4) { step(std::integral_constant<int, 4>{}, q); step(std::integral_constant<int, 5>{}, q); }
+        };
+        if (total > 0) {
+            enter(0);
+            issue(std::integral_constant<int, 0>{}, 0);
+            if constexpr (RS == 3) issue(std::integral_constant<int, 1>{}, 0);
+            produce(0);
+            write_w();
+        }
+        __syncthreads();
+        unsigned long long tw = 0, tb = 0, t0 = 0;           // diagnostics (a.stamps != NULL): work / barrier wait
+        for (int it = 0; it < total; ++it) {
+            const int nx = it + 1;                           // the chunk written during this iteration
+            if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+            if (nx < total) produce(nx);
+            if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; t0 = t; }
+            __syncthreads();                                 // consumers are done with chunk `it`: its weights may go
+            if (nx < total) write_w();
+            __syncthreads();
+            if (a.stamps) tb += __builtin_amdgcn_s_memtime() - t0;
+        }
+        if (a.stamps && tid == 256) { a.stamps[(size_t)blockIdx.x * 8 + 4] = tw; a.stamps[(size_t)blockIdx.x * 8 + 5] = tb; }
+    } else {
+        // ================================ consumer waves ===================================================
+        const int j = lane & 31, kh = lane >> 5;
+        const int dx = j % C::LX, dy = (j / C::LX) % C::LY, dz = j / (C::LX * C::LY);
+        const int ts0 = (wave * MT) % C::MPS;
+        int badr[3][MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int ts = ts0 + m;
+            const int tyi = ts % C::MY, tzi = ts / C::MY;
+            const int e0 = (tzi * C::LZ + dz) * C::ZS + (tyi * C::LY + dy) * C::YS + dx;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) badr[kw][m] = (e0 + kw) * 32 + 16 * (kh ^ (((dx + kw) >> 3) & 1));
+        }
+        const char* ldsb = reinterpret_cast<const char*>(ldsq);
+        const bf16x8* wl = reinterpret_cast<const bf16x8*>(wlds) + lane;
+        int g, tx, ty, tz, n0;
+        __syncthreads();
+        int it = 0;
+        unsigned long long tm = 0, tb = 0, te = 0, t0 = 0;
+        for (int vb = blockIdx.x; vb < T; vb += gridDim.x) {
+            tile_of(vb, g, tx, ty, tz, n0);
+            f32x16 acc[NT][MT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = (g * NT + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[nt][m][r] = bv;
+                }
+            for (int ch = 0; ch < nch; ++ch, ++it) {
+                const char* cur = ldsb + (size_t)(it & 1) * CS * 32;
+                if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+                for (int tap = 0; tap < 27; ++tap) {
+                    const int kw = tap % 3;
+                    const int rowoff = ((tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS) * 32;
+                    bf16x8 av[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) av[nt] = wl[(tap * NT + nt) * 64];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(cur + badr[kw][m] + rowoff);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[nt], bv, acc[nt][m], 0, 0, 0);
+                    }
+                }
+                if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
+                __syncthreads();
+                __syncthreads();                             // the loaders swap the weight fragments in between
+                if (a.stamps) tb += __builtin_amdgcn_s_memtime() - t0;
+            }
+            if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+            conv_epilogue<C>(a, acc, g, 0, n0, wave, j, kh, dx, dy, dz, ts0, tz * C::TZ, ty * C::TY, tx * C::TX,
+                             (tz * a.nty + ty) * a.ntx + tx);
+            if (a.stamps) te += __builtin_amdgcn_s_memtime() - t0;
+        }
+        if (a.stamps && tid == 0) {
+            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+            o[0] = tm; o[1] = tb; o[2] = te; o[3] = (unsigned long long)total;
+        }
+    }
+}
+
+typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> WBCfg0;
+typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> WBCfg2;
+
+template <class C>
+static int launch_bf16_ws(const ConvArgs& a, hipStream_t st) {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu < 8) ncu = 8;
+        ncu &= ~7;
+    }
+    constexpr int NITL = (C::SP + 255) / 256;
+    constexpr int lds = 2 * NITL * 256 * 32 + 27 * C::NT * 64 * 16;
+    static_assert(lds <= 160 * 1024, "LDS");
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_ws_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const long long T = (long long)a.ntx * a.nty * a.ntz * a.N * a.G;
+    if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 bf16 (wave-specialised): too many tiles");
+    const int grid = T < ncu ? (int)T : ncu;
+    hipLaunchKernelGGL((conv3d_k3_bf16_ws_kernel<C>), dim3(grid), dim3(512), lds, st, a, (int)T);
+    return wmh_check_launch("conv3d_k3_bf16_ws_kernel");
+}
+// a: fully prepared by wmh_conv3d_k3_fwd_bf16 (one-role geometry: npart, nchunks, G ... are the same)
+int wmh_launch_conv_bf16_ws(int cfg, const ConvArgs& a, hipStream_t st) {
+    return cfg == 0 ? launch_bf16_ws<WBCfg0>(a, st) : launch_bf16_ws<WBCfg2>(a, st);
+}

@@ -121,15 +121,18 @@ class UNetEngine:
         s = layer.stride
         Do, Ho, Wo = (D - 1) // layer.sz + 1, (H - 1) // s + 1, (W - 1) // s + 1
         cfg = _lib.check(self.lib.wmh_conv3d_config(layer.cin, layer.cout, D, H, W, layer.kz, layer.sz, s), 'wmh_conv3d_config')
-        npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials')
+        use_bf16 = (self.precision == 'bf16' and s == 1 and layer.sz == 1 and layer.kz == 3 and self.lib.wmh_conv3d_k3_bf16_supported(cfg)
+                    and (C1 == 0 or C0 % 16 == 0))
+        if use_bf16:
+            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials_bf16')
+        else:
+            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials')
         y = self._buf(key + '.y', (N, layer.cout, Do, Ho, Wo))
         part = self._buf(key + '.part', (N, layer.cout, npart, 4))
         ss = self._buf(key + '.ss', (N, layer.cout, 2))
         nws = self.lib.wmh_conv3d_k3_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout, s)
         ws = self._buf('splitk.ws', (nws,)) if nws else None      # shared: layers run one after another
         st = self._stream()
-        use_bf16 = (self.precision == 'bf16' and s == 1 and self.lib.wmh_conv3d_k3_bf16_supported(cfg)
-                    and (C1 == 0 or C0 % 16 == 0))
         wf = layer.packed_bf16(cfg) if use_bf16 else layer.packed(cfg)
         timed = cfg in self.timed_cfgs
         if timed:

@@ -161,7 +161,7 @@ class UNetTrainer:
         y = self._buf(key + '.y', (N, cout, D, H, W))
         part, npart = None, 0
         if want_stats:
-            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials(cfg, N, D, H, W), 'num_partials')
+            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, D, H, W), 'num_partials_bf16')
             part = self._buf(key + '.part', (N, cout, npart, 4))
         _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16(cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wf),
                                                    _lib.ptr(bias), _lib.ptr(y), _lib.ptr(part), N, D, H, W, cout, LRELU_SLOPE, self._st()),

@@ -235,7 +235,7 @@ def test_conv3d_k3_bf16_operands(lib, case):
     wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_bf16(cfg, Cin, Cout), np.uint16)
     wn = w.numpy()
     assert lib.wmh_conv3d_k3_pack_weights_bf16(cfg, wn.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)) == 0
-    npart = lib.wmh_conv3d_k3_num_partials(cfg, N, D, H, W)
+    npart = lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, D, H, W)
     y = torch.full((N, Cout, D, H, W), float('nan'), device='cuda')
     part = torch.full((N, Cout, npart, 4), float('nan'), device='cuda')
     mr = torch.full((N, Cout, 2), float('nan'), device='cuda'); ss_out = torch.empty(N, Cout, 2, device='cuda')
@@ -422,3 +422,42 @@ def test_wave_specialised_form_is_bit_identical(tmp_path):
         outs.append((np.load(f1), np.load(f2)))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert float(np.abs(outs[0][0]).max()) > 0.1
+
+
+def test_bf16_wave_specialised_form_is_bit_identical(tmp_path):
+    """conv3d_k3_bf16_ws.hip (loader / consumer waves, persistent, default) against the one-role bf16 kernel (WMH_BF16_WS=0):
+    same arithmetic and k order, so outputs and InstanceNorm partials must agree bit for bit.  Two sources, channel tails,
+    ragged tiles, both tile geometries (32-wide rows and 16-wide rows); the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from deepwmh_amd import _lib\n"
+        "lib = _lib.load(); P = _lib.ptr\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "outs = []\n"
+        "for (N, C0, C1, Cout, D, H, W) in [(2, 12, 0, 40, 9, 20, 70), (3, 32, 24, 32, 8, 16, 33), (2, 48, 0, 72, 6, 18, 16), (5, 16, 16, 64, 2, 33, 12)]:\n"
+        "    Cin = C0 + C1\n"
+        "    x0 = torch.randn(N, C0, D, H, W, generator=g).cuda(); s0 = (torch.rand(N, C0, 2, generator=g) + 0.5).cuda()\n"
+        "    x1 = torch.randn(N, C1, D, H, W, generator=g).cuda() if C1 else None; s1 = (torch.rand(N, C1, 2, generator=g) + 0.5).cuda() if C1 else None\n"
+        "    w = (torch.randn(Cout, Cin, 27, generator=g) * 0.1).cuda(); b = torch.randn(Cout, generator=g).cuda()\n"
+        "    cfg = lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, 1)\n"
+        "    assert lib.wmh_conv3d_k3_bf16_supported(cfg), cfg\n"
+        "    wf = torch.empty(lib.wmh_conv3d_k3_packed_halfs_bf16(cfg, Cin, Cout), dtype=torch.int16, device='cuda')\n"
+        "    _lib.check(lib.wmh_conv3d_k3_pack_weights_bf16_device(cfg, P(w), Cin, Cout, 0, Cin, 0, P(wf), None))\n"
+        "    y = torch.zeros(N, Cout, D, H, W, device='cuda')\n"
+        "    npart = lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, D, H, W); part = torch.zeros(N, Cout, npart, 4, device='cuda')\n"
+        "    _lib.check(lib.wmh_conv3d_k3_fwd_bf16(cfg, P(x0), P(s0), C0, P(x1), P(s1), C1, P(wf), P(b), P(y), P(part), N, D, H, W, Cout, 0.01, None), 'conv')\n"
+        "    torch.cuda.synchronize(); outs += [y.cpu().numpy().ravel(), part.cpu().numpy().ravel(), np.array([cfg], np.float32)]\n"
+        "np.save(sys.argv[1], np.concatenate(outs))\n") % root
+    res = []
+    for ws in ('0', '1'):
+        f1 = str(tmp_path / ('y%s.npy' % ws))
+        r = subprocess.run([sys.executable, '-c', script, f1], env=dict(os.environ, WMH_BF16_WS=ws), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(f1))
+    assert res[0].shape == res[1].shape and np.array_equal(res[0], res[1])
+    assert float(np.abs(res[0]).max()) > 0.1
