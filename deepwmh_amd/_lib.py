@@ -52,6 +52,9 @@ SIGNATURES = {
     'wmh_in_lrelu_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _sz, _f, _vp]),
     'wmh_channel_sum': (_i, [_vp, _vp, _i, _i, _sz, _vp]),
     'wmh_convtranspose3d_k2s2_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_conv3d_k3_wgrad_bf16_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_wgrad_bf16_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_wgrad_bf16': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3s2_dgrad_packed_floats': (_sz, [_i, _i]),
     'wmh_conv3d_k3s2_dgrad_pack_weights_device': (_i, [_vp, _i, _i, _vp, _vp]),
     'wmh_conv3d_k3s2_dgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

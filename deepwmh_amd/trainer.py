@@ -44,7 +44,7 @@ class UNetTrainer:
         if precision not in ('fp32', 'bf16'):
             raise ValueError('precision must be fp32 or bf16')
         self.precision = precision
-        self.bf16_forward = self.bf16_dgrad = precision == 'bf16'      # diagnostic switches (tools/diag_bf16_train.py)
+        self.bf16_forward = self.bf16_dgrad = self.bf16_wgrad = precision == 'bf16'      # diagnostic switches (tools/diag_bf16_train.py)
         plan.check_supported()
         if not plan.isotropic:
             raise NotImplementedError('training implements the isotropic [3,3,3] / [2,2,2] architecture only (the planner emits nothing else)')
@@ -286,11 +286,18 @@ class UNetTrainer:
         x0, x1 = rec['x0'], rec['x1']
         _, C0, D, H, W = x0.shape
         C1 = 0 if x1 is None else x1.shape[1]
-        nws = lib.wmh_conv3d_k3_wgrad_workspace_floats(C0 + C1, Cc, N, D, H, W, conv.stride)
-        ws = self._buf('b.wgrad.ws', (nws,))
-        _lib.check(lib.wmh_conv3d_k3_wgrad(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
-                                           _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, conv.stride,
-                                           LRELU_SLOPE, st), 'wmh_conv3d_k3_wgrad')
+        if self.bf16_wgrad and lib.wmh_conv3d_k3_wgrad_bf16_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
+            nws = lib.wmh_conv3d_k3_wgrad_bf16_workspace_floats(C0 + C1, Cc, N, D, H, W)
+            ws = self._buf('b.wgrad.ws', (nws,))
+            _lib.check(lib.wmh_conv3d_k3_wgrad_bf16(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
+                                                    _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, LRELU_SLOPE, st),
+                       'wmh_conv3d_k3_wgrad_bf16')
+        else:
+            nws = lib.wmh_conv3d_k3_wgrad_workspace_floats(C0 + C1, Cc, N, D, H, W, conv.stride)
+            ws = self._buf('b.wgrad.ws', (nws,))
+            _lib.check(lib.wmh_conv3d_k3_wgrad(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
+                                             _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, conv.stride,
+                                             LRELU_SLOPE, st), 'wmh_conv3d_k3_wgrad')
         if not need_dx:
             return None
         if conv.stride == 2:                                 # gather form: 27 MFMAs per channel pair for the 8 output parities

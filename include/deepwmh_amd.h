@@ -195,6 +195,13 @@ size_t wmh_conv3d_k3_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int
 int wmh_conv3d_k3_wgrad(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
                         const float* dy, float* dW, float* workspace, int N, int D, int H, int W, int Cout,
                         int stride, float lrelu_slope, void* stream);
+/* The same weight gradient with bf16 matrix-core operands (mixed-precision training): dy and the activated input are rounded
+ * to bf16 on their way into LDS, products accumulate in fp32, slabs / reduction / dW stay fp32.  Stride 1, rows of >= 12
+ * voxels (wmh_conv3d_k3_wgrad_bf16_supported); workspace >= wmh_conv3d_k3_wgrad_bf16_workspace_floats(...) floats. */
+int wmh_conv3d_k3_wgrad_bf16_supported(int Cin, int Cout, int N, int D, int H, int W, int stride);
+size_t wmh_conv3d_k3_wgrad_bf16_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
+int wmh_conv3d_k3_wgrad_bf16(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
+                             float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
 /* Data gradient of the stride-2 3x3x3 convolution in gather form (each of the 27 taps feeds exactly one of the 8 output
  * parity classes: the ideal MFMA count, 1/8 of the zero-insert route below).  w = torch layout [Cout][Cin][27] in HBM;
  * wp = its image, wmh_conv3d_k3s2_dgrad_packed_floats(Cin, Cout) floats; dy = [N][Cout][Do][Ho][Wo] with Do = (D-1)/2+1;

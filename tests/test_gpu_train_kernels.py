@@ -265,6 +265,41 @@ def test_conv3d_stride2_dgrad_gather(lib, shape):
     assert float((dX.cpu() - x.grad).abs().max()) <= 1e-5 * (1 + float(x.grad.abs().max()))
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 0, 8, 8, 8, 32), (1, 32, 24, 40, 5, 9, 45), (2, 20, 0, 36, 6, 16, 16), (1, 8, 8, 72, 3, 17, 20)])
+def test_conv3d_wgrad_bf16_operands(lib, shape):
+    """bf16-operand weight gradient: against autograd on bf16-rounded dy and x' (tight: only the summation order differs) and
+    against the fp32 kernel (bf16 rounding of the operands); two sources, channel tails, ragged tiles, both tile geometries."""
+    N, C0, C1, Cout, D, H, W = shape
+    Cin = C0 + C1
+    g = torch.Generator().manual_seed(91)
+    x0 = torch.randn(N, C0, D, H, W, generator=g); s0 = torch.stack([0.5 + torch.rand(N, C0, generator=g), 0.3 * torch.randn(N, C0, generator=g)], -1)
+    x1 = torch.randn(N, C1, D, H, W, generator=g) if C1 else None
+    s1 = torch.stack([0.5 + torch.rand(N, C1, generator=g), 0.3 * torch.randn(N, C1, generator=g)], -1) if C1 else None
+    dy = torch.randn(N, Cout, D, H, W, generator=g)
+    act = torch.cat([_act(x0, s0)] + ([_act(x1, s1)] if C1 else []), 1)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    w = torch.zeros(Cout, Cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(rb(act), w, None, padding=1).backward(rb(dy))
+    ref = w.grad.reshape(Cout, Cin, 27)
+    assert lib.wmh_conv3d_k3_wgrad_bf16_supported(Cin, Cout, N, D, H, W, 1) == 1
+    assert lib.wmh_conv3d_k3_wgrad_bf16_supported(Cin, Cout, N, D, H, 8, 1) == 0 and lib.wmh_conv3d_k3_wgrad_bf16_supported(Cin, Cout, N, D, H, W, 2) == 0
+    d = [t.cuda() if t is not None else None for t in (x0, s0, x1, s1, dy)]
+    ws = torch.empty(lib.wmh_conv3d_k3_wgrad_bf16_workspace_floats(Cin, Cout, N, D, H, W), device='cuda')
+    outs = []
+    for _ in range(2):
+        dW = torch.full((Cout, Cin, 27), float('nan'), device='cuda')
+        check(lib.wmh_conv3d_k3_wgrad_bf16(P(d[0]), P(d[1]), C0, P(d[2]), P(d[3]), C1, P(d[4]), P(dW), P(ws), N, D, H, W, Cout, SLOPE, None), 'wgrad bf16')
+        torch.cuda.synchronize()
+        outs.append(dW.cpu())
+    assert torch.equal(outs[0], outs[1])                                          # fixed-order reduction
+    scale = float(ref.abs().max())
+    assert float((outs[0] - ref).abs().max()) <= 2e-4 * scale + 1e-5, float((outs[0] - ref).abs().max())
+    w32 = torch.zeros(Cout, Cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(act, w32, None, padding=1).backward(dy)
+    g32 = w32.grad.reshape(Cout, Cin, 27)
+    assert float((outs[0] - g32).norm() / g32.norm()) <= 1e-2
+
+
 def test_clip_and_sgd_nesterov(lib):
     g = torch.Generator().manual_seed(71)
     n = 100003
