@@ -147,7 +147,7 @@ def main():
             traffic = json.load(f)['traffic_bytes_per_launch']     # PMC counters cannot be read live: separate rocprofv3 passes
     except Exception:
         pass
-    roofline = dict(bound='mfma', kernel='conv3d_k3_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM)',
+    roofline = dict(bound='mfma', kernel='conv3d_k3_ws_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM, wave-specialised)',
                     achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
                     launches=len(eng.timings), avg_launch_ms=round(tot_ms / nl, 4),

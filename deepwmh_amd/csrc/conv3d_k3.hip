@@ -535,9 +535,12 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd: grid too large");
     hipStream_t st = (hipStream_t)stream;
     if (a.KS > 1) a.y = workspace;
-    static const int use_ws = env_int("WMH_WS", 0);   // wave-specialised persistent form: measured equal
+    static const int use_ws = env_int("WMH_WS", 1);   // wave-specialised persistent form: +4 % on the large layers
     int rc;
-    if (cfg == 0 && a.KS == 1 && use_ws && a.stamps == nullptr) return wmh_launch_conv_ws_cfg0(a, st);
+    // the wave-specialised form moves aligned 16-byte quads on 32-bit lane offsets and writes LeakyReLU as max(t, slope t)
+    const bool ws_ok = (W % 4) == 0 && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && (!x1 || (reinterpret_cast<uintptr_t>(x1) & 15) == 0) &&
+                       (size_t)4 * D * H * W * 4 < ((size_t)1 << 32) && lrelu_slope >= 0.f && lrelu_slope <= 1.f;
+    if (cfg == 0 && a.KS == 1 && use_ws && ws_ok) return wmh_launch_conv_ws_cfg0(a, st);
 #ifdef WMH_DIAG_ABLATIONS
     static const int abl = env_int("WMH_ABL", 0);
     if (cfg == 0 && abl) return launch_cfg0_ablation(abl, a, (unsigned)nblk, st);

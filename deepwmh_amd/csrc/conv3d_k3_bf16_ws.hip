@@ -72,6 +72,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 
     if (loader) {
         // ================================ loader waves =====================================================
+        __builtin_amdgcn_s_setprio(3);                        // ahead of the MFMA-saturating consumer on the same SIMD
         const int lt = tid - 256;
         // Staging unit = an aligned quad of 4 consecutive x voxels of one halo row (one 16-byte load per channel): the row
         // [ox0-1, ox0+TX] is covered by the aligned span [ox0-4, ox0+TX+4), QPR quads; quads are wholly inside or wholly

@@ -18,16 +18,32 @@
 #include <stdlib.h>
 #include "conv3d_common.h"
 
+__device__ __forceinline__ bool getenv_dbg_perwave(int dbg) { return (dbg & 8) != 0; }
+// Uniform read of a value no kernel in flight writes (InstanceNorm scale/shift come from the previous launch): through the
+// constant address space = the scalar cache, on its own counter.  As (conditional) vector loads these reads were several
+// serialised memory round trips per chunk: the loader needed a whole consumer period for ~300 instructions.
+__device__ __forceinline__ float ws_ld_uniform(const float* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<unsigned long long>(p));
+}
+static __device__ const float ws_ident2[2] = {1.f, 0.f};
+
 template <class C>
 __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, const int T /*tiles*/, const int dbg /*timing experiments; 0 in production*/) {
     constexpr int S = C::S, MT = C::MT, NT = C::NT, CK = C::CK, V = CK / 2;
     constexpr int LTH = 256;                                   // loader threads
-    constexpr int NIT = (C::SP + LTH - 1) / LTH;
-    constexpr int CS = NIT * LTH, TILE = CK * CS;              // padded channel stride: every loader store in range
+    // LDS halo rows are the 16-byte-aligned span [ox0-4, ox0+TX+4) of the row (QPR quads; the halo row [ox0-1, ox0+TX] sits
+    // at positions 3..TX+4): a loader moves whole quads -- one 16-byte global load and one ds_write_b128 per quad and channel
+    // instead of four dword loads and stores -- because every loader instruction has to find an issue slot on a SIMD whose
+    // consumer wave always has an MFMA ready (measured: 7.7 k cycles per chunk alone, 28.6 k next to a busy consumer).
+    constexpr int ROWS = C::IY * C::IZ, QPR = (C::TX + 8) / 4, RSX = 4 * QPR, NQ = ROWS * QPR;
+    constexpr int NSL = (NQ + LTH - 1) / LTH;                  // quad slots per loader thread
+    constexpr int CS = ROWS * RSX, TILE = CK * CS;             // channel stride, floats per buffer
+    constexpr int YSL = RSX, ZSL = C::IY * RSX;                // row / plane strides of the LDS tile
     constexpr int WT = 27 * NT * 64 * V;                       // weight floats per chunk
     constexpr int WIT = (WT / 2 + LTH - 1) / LTH;              // float2 pieces per loader thread
     static_assert(C::TN == 1 && NT == 1 && C::WM == 4, "geometry of the large-layer configuration");
-    static_assert(((2 * C::ZS + 2 * C::YS + 2) + (CK - 2) * CS + TILE) * 4 < 65536, "ds_read immediate range");
+    static_assert(S == 1, "stride 1");
+    static_assert(((2 * ZSL + 2 * YSL + 2) + (CK - 2) * CS + TILE) * 4 < 65536, "ds_read immediate range");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* X = lds;                       // [2][TILE]
     float* Wl = lds + 2 * TILE;           // [2][WT]
@@ -55,49 +71,57 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
 
     if (loader) {
         // ================================ loader waves =====================================================
+        // A loader shares its SIMD with a consumer that always has an MFMA ready; left at equal priority it got to issue about
+        // one instruction per MFMA slot and needed a whole consumer period (29 k cycles) for ~300 instructions.
+        if (!(dbg & 32)) __builtin_amdgcn_s_setprio(3);
         const int lt = tid - 256;
-        int sp_off[NIT];
-        unsigned okmask = 0;
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        unsigned q_off[NSL]; unsigned q_ok = 0;               // byte offsets of this thread's quads in a channel plane
         int g = 0, n0 = 0;
-        float stg[CK][NIT];
+        f32x4_t stg[NSL][CK];
         float2 wst[WIT];
         float sc[CK], sh[CK], slope_eff = 1.f;
-        unsigned cmask = 0;
-        auto setup = [&](int v) {
+        auto setup = [&](int v) __attribute__((always_inline)) {
             int tx, ty, tz;
             tile_of(v, g, tx, ty, tz, n0);
-            const int ix0 = tx * C::TX * S - 1, iy0 = ty * C::TY * S - 1, iz0 = tz * C::TZ * S - 1;
-            okmask = 0;
+            g = __builtin_amdgcn_readfirstlane(g); n0 = __builtin_amdgcn_readfirstlane(n0);       // out of VALU divisions: scalar again
+            tx = __builtin_amdgcn_readfirstlane(tx); ty = __builtin_amdgcn_readfirstlane(ty); tz = __builtin_amdgcn_readfirstlane(tz);
+            const int ix0 = tx * C::TX - 4, iy0 = ty * C::TY - 1, iz0 = tz * C::TZ - 1;
+            q_ok = 0;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int e = lt + it * LTH;
-                const int x = e % C::IX, y = (e / C::IX) % C::IY, z = (e / (C::IX * C::IY)) % C::IZ;
-                const int gx = ix0 + x, gy = iy0 + y, gz = iz0 + z;
-                const bool ok = (e < C::SP) && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
-                sp_off[it] = ok ? gz * HW + gy * a.W + gx : 0;
-                okmask |= ok ? (1u << it) : 0u;
+            for (int i = 0; i < NSL; ++i) {
+                const int sidx = lt + i * LTH;
+                const int row = sidx / QPR, q = sidx - row * QPR;
+                const int gx = ix0 + 4 * q, gy = iy0 + row % C::IY, gz = iz0 + row / C::IY;
+                const bool ok = sidx < NQ && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
+                q_off[i] = ok ? 4u * (unsigned)(gz * HW + gy * a.W + gx) : 0u;
+                q_ok |= ok ? (1u << i) : 0u;
             }
         };
-        auto load_chunk = [&](int ch) {
+        const unsigned pstride = 4u * (unsigned)DHW;           // bytes between channel planes (host checks the 32-bit range)
+        auto load_chunk = [&](int ch) __attribute__((always_inline)) {
+            ch = __builtin_amdgcn_readfirstlane(ch);
             const int cb = ch * CK;
             const float* xs; const float* ss; int Cs, c0;
             if (cb < a.C0) { xs = a.x0; ss = a.ss0; Cs = a.C0; c0 = cb; }
             else           { xs = a.x1; ss = a.ss1; Cs = a.C1; c0 = cb - a.C0; }
-            cmask = 0;
+            const char* base = reinterpret_cast<const char*>(xs + ((size_t)n0 * Cs + c0) * DHW);
+            const int cmax = Cs - 1 - c0;                     // channels past the source's end re-read its last one (scale 0)
 #pragma unroll
-            for (int cc = 0; cc < CK; ++cc) {
-                const int c = min(c0 + cc, Cs - 1);
-                cmask |= (c0 + cc) < Cs ? (1u << cc) : 0u;
+            for (int i = 0; i < NSL; ++i)
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) stg[cc][it] = xs[((size_t)n0 * Cs + c) * DHW + sp_off[it]];
-            }
+                for (int cc = 0; cc < CK; ++cc)
+                    stg[i][cc] = *reinterpret_cast<const f32x4_t*>(base + (q_off[i] + (unsigned)min(cc, cmax) * pstride));
             const bool has_ss = ss != nullptr;
             slope_eff = has_ss ? a.slope : 1.f;
+            const float* tab = has_ss ? ss + ((size_t)n0 * Cs + c0) * 2 : ws_ident2;      // without a pending normalisation: {1, 0}
+            const int mul = has_ss ? 2 : 0;
 #pragma unroll
             for (int cc = 0; cc < CK; ++cc) {
-                const int c = min(c0 + cc, Cs - 1);
-                sc[cc] = has_ss ? ss[((size_t)n0 * Cs + c) * 2] : 1.f;
-                sh[cc] = has_ss ? ss[((size_t)n0 * Cs + c) * 2 + 1] : 0.f;
+                const int idx = mul * min(cc, cmax);
+                const float s0 = ws_ld_uniform(tab + idx), s1 = ws_ld_uniform(tab + idx + 1);
+                sc[cc] = cc <= cmax ? s0 : 0.f;                 // (x * 0 + 0 -> LeakyReLU(0) = 0: channels past the end stage zeros)
+                sh[cc] = cc <= cmax ? s1 : 0.f;
             }
             const float2* wsrc = reinterpret_cast<const float2*>(a.wf) + ((size_t)g * nch + ch) * (WT / 2);
 #pragma unroll
@@ -106,17 +130,25 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
                 wst[i] = wsrc[k];
             }
         };
-        auto write_chunk = [&](int buf) {
+        auto write_chunk = [&](int buf) __attribute__((always_inline)) {
             float* xb = X + buf * TILE;
 #pragma unroll
-            for (int cc = 0; cc < CK; ++cc)
+            for (int i = 0; i < NSL; ++i) {
+                const int sidx = lt + i * LTH;
+                // quads outside the volume: scale = shift = 0 -> zeros (the clamped address reads finite activations of this plane)
+                const bool in = (q_ok >> i) & 1u;
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    float v = fmaf(stg[cc][it], sc[cc], sh[cc]);
-                    v = v > 0.f ? v : v * slope_eff;
-                    v = (((cmask >> cc) & 1u) && ((okmask >> it) & 1u)) ? v : 0.f;
-                    xb[cc * CS + lt + it * LTH] = v;
+                for (int cc = 0; cc < CK; ++cc) {
+                    const float scl = in ? sc[cc] : 0.f, shl = in ? sh[cc] : 0.f;
+                    f32x4_t v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float t = fmaf(stg[i][cc][k], scl, shl);
+                        v[k] = fmaxf(t, t * slope_eff);         // LeakyReLU for 0 <= slope <= 1; bit-identical to the select form
+                    }
+                    if (NSL * LTH == NQ || sidx < NQ) *reinterpret_cast<f32x4_t*>(xb + cc * CS + 4 * sidx) = v;   // row * RSX + 4 q = 4 sidx
                 }
+            }
             float2* wb = reinterpret_cast<float2*>(Wl + buf * WT);
 #pragma unroll
             for (int i = 0; i < WIT; ++i) {
@@ -128,15 +160,23 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
         int vnext = blockIdx.x;
         if (total > 0) { setup(vnext); load_chunk(0); write_chunk(0); }
         __syncthreads();
+        unsigned long long lw = 0, lb = 0, l0 = 0;                 // diagnostics: loader work / barrier wait
         for (int it = 0; it < total; ++it) {
             const int nx = it + 1;
+            if (a.stamps) l0 = __builtin_amdgcn_s_memtime();
             if (nx < total && !(dbg & 1)) {
                 const int ch = nx % nch;
                 if (ch == 0) { vnext += gridDim.x; setup(vnext); }
                 load_chunk(ch);
                 write_chunk(nx & 1);
             }
+            if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); lw += t - l0; l0 = t; }
             __syncthreads();
+            if (a.stamps) lb += __builtin_amdgcn_s_memtime() - l0;
+        }
+        if (a.stamps && (dbg & 16) && tid == 256) {
+            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 4;
+            o[0] = lw; o[1] = lb; o[2] = 0; o[3] = (unsigned long long)total;
         }
     } else {
         // ================================ consumer waves ===================================================
@@ -148,10 +188,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
         for (int m = 0; m < MT; ++m) {
             const int ts = ts0 + m;
             const int tyi = ts % C::MY, tzi = ts / C::MY;
-            baddr[m] = kh * CS + S * ((tzi * C::LZ + dz) * C::ZS + (tyi * C::LY + dy) * C::YS + dx);
+            baddr[m] = kh * CS + (tzi * C::LZ + dz) * ZSL + (tyi * C::LY + dy) * YSL + dx + 3;    // halo x = 0 sits at span position 3
         }
         __syncthreads();
         int it = 0;
+        unsigned long long tm = 0, tb = 0, te = 0, t0 = 0;         // diagnostics (a.stamps != NULL)
         for (int v = blockIdx.x; v < T; v += gridDim.x) {
             int g, tx, ty, tz, n0;
             tile_of(v, g, tx, ty, tz, n0);
@@ -166,9 +207,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
             for (int ch = 0; ch < nch; ++ch, ++it) {
                 const float* cur = X + (it & 1) * TILE;
                 const float2* wcur = reinterpret_cast<const float2*>(Wl + (it & 1) * WT) + lane;
+                if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+                if (!(dbg & 64))
 #pragma unroll
                 for (int tap = 0; tap < 27; ++tap) {
-                    const int toff = (tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS + (tap % 3);
+                    const int toff = (tap / 9) * ZSL + ((tap / 3) % 3) * YSL + (tap % 3);
                     const float2 av = wcur[tap * 64];
 #pragma unroll
                     for (int p = 0; p < V; ++p) {
@@ -179,12 +222,22 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
                         }
                     }
                 }
+                if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
                 __syncthreads();
+                if (a.stamps) tb += __builtin_amdgcn_s_memtime() - t0;
             }
+            if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
             if (!(dbg & 2))
                 conv_epilogue<C>(a, acc, g, 0, n0, wave, j, kh, dx, dy, dz, ts0, tz * C::TZ, ty * C::TY, tx * C::TX,
                                  (tz * a.nty + ty) * a.ntx + tx);
             else if (acc[0][0][0] == 12345.678f) a.y[0] = acc[0][1][3];     // keep the accumulators live
+            if (a.stamps) te += __builtin_amdgcn_s_memtime() - t0;
+        }
+        if (a.stamps && getenv_dbg_perwave(dbg)) {                  // per consumer wave: its own MFMA-phase total
+            if (lane == 0) a.stamps[(size_t)blockIdx.x * 4 + wave] = wave == 3 ? (unsigned long long)total : tm;
+        } else if (a.stamps && tid == 0 && !(dbg & 16)) {            // barrier wait, MFMA phases, epilogues, chunk iterations
+            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 4;
+            o[0] = tb; o[1] = tm; o[2] = te; o[3] = (unsigned long long)total;
         }
     }
 }
@@ -201,8 +254,8 @@ int wmh_launch_conv_ws_cfg0(const ConvArgs& a, hipStream_t st) {
         if (ncu < 8) ncu = 8;
         ncu &= ~7;
     }
-    constexpr int NITL = (WCfg0::SP + 255) / 256;
-    const int lds = (2 * WCfg0::CK * NITL * 256 + 2 * 27 * 64 * (WCfg0::CK / 2)) * 4;
+    constexpr int CSL = WCfg0::IY * WCfg0::IZ * (WCfg0::TX + 8);          // channel stride of the quad-aligned LDS tile
+    const int lds = (2 * WCfg0::CK * CSL + 2 * 27 * 64 * (WCfg0::CK / 2)) * 4;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_ws_kernel<WCfg0>),
