@@ -529,6 +529,7 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
     a.xcd_swizzle = swz_env;
     a.stamps = g_conv_stamps;
     long long nblk = (long long)a.ntx * a.nty * a.ntz * cdiv(N, c.TN) * a.G;
+    const long long tiles = nblk;
     a.KS = pick_ksplit(c, nblk, a.nchunks);
     if (a.KS > 1 && workspace == nullptr) a.KS = 1;          // no slab memory given: run unsplit
     nblk *= a.KS;
@@ -540,7 +541,12 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
     // the wave-specialised form moves aligned 16-byte quads on 32-bit lane offsets and writes LeakyReLU as max(t, slope t)
     const bool ws_ok = (W % 4) == 0 && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && (!x1 || (reinterpret_cast<uintptr_t>(x1) & 15) == 0) &&
                        (size_t)4 * D * H * W * 4 < ((size_t)1 << 32) && lrelu_slope >= 0.f && lrelu_slope <= 1.f;
-    if (cfg == 0 && a.KS == 1 && use_ws && ws_ok) return wmh_launch_conv_ws_cfg0(a, st);
+    // 32-wide rows: whenever the launch is not split; 16-wide rows: when there are enough tiles for one persistent workgroup
+    // per CU -- a long cin loop is what this form likes, so it replaces split-K there (16^3 layers at batch 8)
+    if (use_ws && ws_ok && ((cfg == 0 && a.KS == 1) || (cfg == 2 && tiles >= wmh_conv_ws_min_tiles()))) {
+        a.KS = 1; a.y = y;
+        return wmh_launch_conv_ws(cfg, a, st);
+    }
 #ifdef WMH_DIAG_ABLATIONS
     static const int abl = env_int("WMH_ABL", 0);
     if (cfg == 0 && abl) return launch_cfg0_ablation(abl, a, (unsigned)nblk, st);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
     constexpr int YSL = RSX, ZSL = C::IY * RSX;                // row / plane strides of the LDS tile
     constexpr int WT = 27 * NT * 64 * V;                       // weight floats per chunk
     constexpr int WIT = (WT / 2 + LTH - 1) / LTH;              // float2 pieces per loader thread
-    static_assert(C::TN == 1 && NT == 1 && C::WM == 4, "geometry of the large-layer configuration");
+    static_assert(C::TN == 1 && C::WM == 4, "four consumer waves, one sample per workgroup");
     static_assert(S == 1, "stride 1");
     static_assert(((2 * ZSL + 2 * YSL + 2) + (CK - 2) * CS + TILE) * 4 < 65536, "ds_read immediate range");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -198,12 +198,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
             tile_of(v, g, tx, ty, tz, n0);
             f32x16 acc[NT][MT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[0][m][r] = bv;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int co = (g * NT + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[nt][m][r] = bv;
+                }
             for (int ch = 0; ch < nch; ++ch, ++it) {
                 const float* cur = X + (it & 1) * TILE;
                 const float2* wcur = reinterpret_cast<const float2*>(Wl + (it & 1) * WT) + lane;
@@ -212,13 +214,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
 #pragma unroll
                 for (int tap = 0; tap < 27; ++tap) {
                     const int toff = (tap / 9) * ZSL + ((tap / 3) % 3) * YSL + (tap % 3);
-                    const float2 av = wcur[tap * 64];
+                    float2 av[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) av[nt] = wcur[(tap * NT + nt) * 64];
 #pragma unroll
                     for (int p = 0; p < V; ++p) {
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
                             const float bv = cur[baddr[m] + toff + 2 * p * CS];
-                            acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(p == 0 ? av.x : av.y, bv, acc[0][m], 0, 0, 0);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(p == 0 ? av[nt].x : av[nt].y, bv, acc[nt][m], 0, 0, 0);
                         }
                     }
                 }
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
             if (!(dbg & 2))
                 conv_epilogue<C>(a, acc, g, 0, n0, wave, j, kh, dx, dy, dz, ts0, tz * C::TZ, ty * C::TY, tx * C::TX,
                                  (tz * a.nty + ty) * a.ntx + tx);
-            else if (acc[0][0][0] == 12345.678f) a.y[0] = acc[0][1][3];     // keep the accumulators live
+            else if (acc[0][0][0] == 12345.678f) a.y[0] = acc[NT - 1][1][3];     // keep the accumulators live
             if (a.stamps) te += __builtin_amdgcn_s_memtime() - t0;
         }
         if (a.stamps && getenv_dbg_perwave(dbg)) {                  // per consumer wave: its own MFMA-phase total
@@ -243,9 +249,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
 }
 
 typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> WCfg0;
+typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> WCfg2;
 
-// returns 1 when this form applies to the launch described by `a` (cfg0 geometry, no split-K)
-int wmh_launch_conv_ws_cfg0(const ConvArgs& a, hipStream_t st) {
+static int ws_num_cus() {
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
@@ -254,18 +260,25 @@ int wmh_launch_conv_ws_cfg0(const ConvArgs& a, hipStream_t st) {
         if (ncu < 8) ncu = 8;
         ncu &= ~7;
     }
-    constexpr int CSL = WCfg0::IY * WCfg0::IZ * (WCfg0::TX + 8);          // channel stride of the quad-aligned LDS tile
-    const int lds = (2 * WCfg0::CK * CSL + 2 * 27 * 64 * (WCfg0::CK / 2)) * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_ws_kernel<WCfg0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = true;
-    }
+    return ncu;
+}
+template <class C>
+static int launch_ws(const ConvArgs& a, hipStream_t st) {
+    constexpr int CSL = C::IY * C::IZ * (C::TX + 8);                      // channel stride of the quad-aligned LDS tile
+    constexpr int lds = (2 * C::CK * CSL + 2 * 27 * C::NT * 64 * (C::CK / 2)) * 4;
+    static_assert(lds <= 160 * 1024, "LDS");
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_ws_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const long long T = (long long)a.ntx * a.nty * a.ntz * a.N * a.G;
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 (wave-specialised): too many tiles");
+    const int ncu = ws_num_cus();
     const int grid = T < ncu ? (int)T : ncu;
     static const int dbg = getenv("WMH_WS_DBG") ? atoi(getenv("WMH_WS_DBG")) : 0;
-    hipLaunchKernelGGL((conv3d_k3_ws_kernel<WCfg0>), dim3(grid), dim3(512), lds, st, a, (int)T, dbg);
+    hipLaunchKernelGGL((conv3d_k3_ws_kernel<C>), dim3(grid), dim3(512), lds, st, a, (int)T, dbg);
     return wmh_check_launch("conv3d_k3_ws_kernel");
+}
+// tiles a launch needs before the persistent one-workgroup-per-CU form is preferred over the (split-K) one-role kernel
+int wmh_conv_ws_min_tiles() { return ws_num_cus() * 3 / 4; }
+// a: prepared by wmh_conv3d_k3_fwd with KS = 1 (no split-K: a long cin loop is what this form likes)
+int wmh_launch_conv_ws(int cfg, const ConvArgs& a, hipStream_t st) {
+    return cfg == 0 ? launch_ws<WCfg0>(a, st) : launch_ws<WCfg2>(a, st);
 }

@@ -403,21 +403,25 @@ def test_wave_specialised_form_is_bit_identical(tmp_path):
         "from deepwmh_amd import _lib\n"
         "lib = _lib.load()\n"
         "g = torch.Generator().manual_seed(3)\n"
-        "N, Cin, Cout, D, H, W = 2, 12, 40, 9, 20, 70\n"
-        "x = torch.randn(N, Cin, D, H, W, generator=g).cuda(); ss = (torch.rand(N, Cin, 2, generator=g) + 0.5).cuda()\n"
-        "w = (torch.randn(Cout, Cin, 27, generator=g) * 0.1).numpy(); b = torch.randn(Cout, generator=g).cuda()\n"
-        "cfg = lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, 1)\n"
-        "wf = np.empty(lib.wmh_conv3d_k3_packed_floats(cfg, Cin, Cout), np.float32)\n"
-        "lib.wmh_conv3d_k3_pack_weights(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p))\n"
-        "wfd = torch.from_numpy(wf).cuda(); y = torch.zeros(N, Cout, D, H, W, device='cuda')\n"
-        "npart = lib.wmh_conv3d_k3_num_partials(cfg, N, D, H, W); part = torch.zeros(N, Cout, npart, 4, device='cuda')\n"
-        "_lib.check(lib.wmh_conv3d_k3_fwd(cfg, _lib.ptr(x), _lib.ptr(ss), Cin, None, None, 0, _lib.ptr(wfd), _lib.ptr(b), _lib.ptr(y),\n"
-        "           _lib.ptr(part), None, N, D, H, W, Cout, 1, 0.01, None), 'conv')\n"
-        "torch.cuda.synchronize(); np.save(sys.argv[1], y.cpu().numpy()); np.save(sys.argv[2], part.cpu().numpy())\n") % root
+        "res_y, res_p = [], []\n"
+        "for (N, C0, C1, Cout, D, H, W) in [(2, 12, 0, 40, 9, 20, 72), (4, 24, 16, 128, 32, 32, 16), (8, 20, 0, 72, 16, 16, 16)]:\n"
+        "    Cin = C0 + C1\n"
+        "    x0 = torch.randn(N, C0, D, H, W, generator=g).cuda(); s0 = (torch.rand(N, C0, 2, generator=g) + 0.5).cuda()\n"
+        "    x1 = torch.randn(N, C1, D, H, W, generator=g).cuda() if C1 else None; s1 = (torch.rand(N, C1, 2, generator=g) + 0.5).cuda() if C1 else None\n"
+        "    w = (torch.randn(Cout, Cin, 27, generator=g) * 0.1).numpy(); b = torch.randn(Cout, generator=g).cuda()\n"
+        "    cfg = lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, 1)\n"
+        "    wf = np.empty(lib.wmh_conv3d_k3_packed_floats(cfg, Cin, Cout), np.float32)\n"
+        "    lib.wmh_conv3d_k3_pack_weights(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p))\n"
+        "    wfd = torch.from_numpy(wf).cuda(); y = torch.zeros(N, Cout, D, H, W, device='cuda')\n"
+        "    npart = lib.wmh_conv3d_k3_num_partials(cfg, N, D, H, W); part = torch.zeros(N, Cout, npart, 4, device='cuda')\n"
+        "    _lib.check(lib.wmh_conv3d_k3_fwd(cfg, _lib.ptr(x0), _lib.ptr(s0), C0, _lib.ptr(x1), _lib.ptr(s1), C1, _lib.ptr(wfd), _lib.ptr(b), _lib.ptr(y),\n"
+        "               _lib.ptr(part), None, N, D, H, W, Cout, 1, 0.01, None), 'conv')\n"
+        "    torch.cuda.synchronize(); res_y.append(y.cpu().numpy().ravel()); res_p.append(part.cpu().numpy().ravel()); res_p.append(np.array([cfg], np.float32))\n"
+        "np.save(sys.argv[1], np.concatenate(res_y)); np.save(sys.argv[2], np.concatenate(res_p))\n") % root
     outs = []
     for ws in ('0', '1'):
         f1, f2 = str(tmp_path / ('y%s.npy' % ws)), str(tmp_path / ('p%s.npy' % ws))
-        r = subprocess.run([sys.executable, '-c', script, f1, f2], env=dict(os.environ, WMH_WS=ws), capture_output=True, text=True)
+        r = subprocess.run([sys.executable, '-c', script, f1, f2], env=dict(os.environ, WMH_WS=ws, WMH_KSPLIT='1'), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append((np.load(f1), np.load(f2)))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
