@@ -65,7 +65,7 @@ __device__ __forceinline__ float sum32(float v) {   // sum over the 32 lanes of 
 }
 
 // wave-specialised persistent form for the large-layer configuration (conv3d_k3_ws.hip)
-int wmh_launch_conv_ws(int cfg, const ConvArgs& a, hipStream_t st);     // cfg 0 (32-wide rows) or 2 (16-wide rows), stride 1
+int wmh_launch_conv_ws(int cfg, const ConvArgs& a, hipStream_t st);     // cfg 0..3: 32- and 16-wide rows, stride 1 and 2
 int wmh_conv_ws_min_tiles();
 
 // one step of the recursive-halving reduction (static indices only: a runtime index into a register array

@@ -543,7 +543,7 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
                        (size_t)4 * D * H * W * 4 < ((size_t)1 << 32) && lrelu_slope >= 0.f && lrelu_slope <= 1.f;
     // 32-wide rows: whenever the launch is not split; 16-wide rows: when there are enough tiles for one persistent workgroup
     // per CU -- a long cin loop is what this form likes, so it replaces split-K there (16^3 layers at batch 8)
-    if (use_ws && ws_ok && ((cfg == 0 && a.KS == 1) || (cfg == 2 && tiles >= wmh_conv_ws_min_tiles()))) {
+    if (use_ws && ws_ok && ((cfg == 0 && a.KS == 1) || (cfg >= 1 && cfg <= 3 && tiles >= wmh_conv_ws_min_tiles()))) {
         a.KS = 1; a.y = y;
         return wmh_launch_conv_ws(cfg, a, st);
     }

@@ -35,14 +35,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
     // at positions 3..TX+4): a loader moves whole quads -- one 16-byte global load and one ds_write_b128 per quad and channel
     // instead of four dword loads and stores -- because every loader instruction has to find an issue slot on a SIMD whose
     // consumer wave always has an MFMA ready (measured: 7.7 k cycles per chunk alone, 28.6 k next to a busy consumer).
-    constexpr int ROWS = C::IY * C::IZ, QPR = (C::TX + 8) / 4, RSX = 4 * QPR, NQ = ROWS * QPR;
+    constexpr int ROWS = C::IY * C::IZ, QPR = (C::IX + 3 + 3) / 4, RSX = 4 * QPR, NQ = ROWS * QPR;   // span = 3 + IX, rounded up to quads
     constexpr int NSL = (NQ + LTH - 1) / LTH;                  // quad slots per loader thread
     constexpr int CS = ROWS * RSX, TILE = CK * CS;             // channel stride, floats per buffer
     constexpr int YSL = RSX, ZSL = C::IY * RSX;                // row / plane strides of the LDS tile
     constexpr int WT = 27 * NT * 64 * V;                       // weight floats per chunk
-    constexpr int WIT = (WT / 2 + LTH - 1) / LTH;              // float2 pieces per loader thread
+    constexpr int WIT = (WT / 2 + LTH - 1) / LTH;              // float2 pieces per loader thread (the image is copied as is)
+    typedef typename AVec<V>::T AV;                            // a lane's weights of one (tap, cout tile): V cin pairs
     static_assert(C::TN == 1 && C::WM == 4, "four consumer waves, one sample per workgroup");
-    static_assert(S == 1, "stride 1");
+    static_assert(C::SZ == S && C::KZ == 3, "isotropic 3x3x3, stride 1 or 2");
     static_assert(((2 * ZSL + 2 * YSL + 2) + (CK - 2) * CS + TILE) * 4 < 65536, "ds_read immediate range");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* X = lds;                       // [2][TILE]
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
             tile_of(v, g, tx, ty, tz, n0);
             g = __builtin_amdgcn_readfirstlane(g); n0 = __builtin_amdgcn_readfirstlane(n0);       // out of VALU divisions: scalar again
             tx = __builtin_amdgcn_readfirstlane(tx); ty = __builtin_amdgcn_readfirstlane(ty); tz = __builtin_amdgcn_readfirstlane(tz);
-            const int ix0 = tx * C::TX - 4, iy0 = ty * C::TY - 1, iz0 = tz * C::TZ - 1;
+            const int ix0 = tx * C::TX * S - 4, iy0 = ty * C::TY * S - 1, iz0 = tz * C::TZ * S - 1;
             q_ok = 0;
 #pragma unroll
             for (int i = 0; i < NSL; ++i) {
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
         for (int m = 0; m < MT; ++m) {
             const int ts = ts0 + m;
             const int tyi = ts % C::MY, tzi = ts / C::MY;
-            baddr[m] = kh * CS + (tzi * C::LZ + dz) * ZSL + (tyi * C::LY + dy) * YSL + dx + 3;    // halo x = 0 sits at span position 3
+            baddr[m] = kh * CS + S * ((tzi * C::LZ + dz) * ZSL + (tyi * C::LY + dy) * YSL + dx) + 3;    // halo x = 0 sits at span position 3
         }
         __syncthreads();
         int it = 0;
@@ -208,13 +209,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
                 }
             for (int ch = 0; ch < nch; ++ch, ++it) {
                 const float* cur = X + (it & 1) * TILE;
-                const float2* wcur = reinterpret_cast<const float2*>(Wl + (it & 1) * WT) + lane;
+                const AV* wcur = reinterpret_cast<const AV*>(Wl + (it & 1) * WT) + lane;
                 if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
                 if (!(dbg & 64))
 #pragma unroll
                 for (int tap = 0; tap < 27; ++tap) {
                     const int toff = (tap / 9) * ZSL + ((tap / 3) % 3) * YSL + (tap % 3);
-                    float2 av[NT];
+                    AV av[NT];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) av[nt] = wcur[(tap * NT + nt) * 64];
 #pragma unroll
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
                             const float bv = cur[baddr[m] + toff + 2 * p * CS];
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(p == 0 ? av[nt].x : av[nt].y, bv, acc[nt][m], 0, 0, 0);
+                                acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(avec_get(av[nt], p), bv, acc[nt][m], 0, 0, 0);
                         }
                     }
                 }
@@ -250,6 +251,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
 
 typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> WCfg0;
 typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> WCfg2;
+typedef ConvCfg<2, 32, 1, 2, 8, 1, 4, 2, 2, 6> WCfg1;       // stride 2, output rows of >= 32
+typedef ConvCfg<2, 16, 2, 2, 16, 1, 4, 2, 2, 6> WCfg3;      // stride 2, 16-wide output
 
 static int ws_num_cus() {
     static int ncu = 0;
@@ -264,7 +267,7 @@ static int ws_num_cus() {
 }
 template <class C>
 static int launch_ws(const ConvArgs& a, hipStream_t st) {
-    constexpr int CSL = C::IY * C::IZ * (C::TX + 8);                      // channel stride of the quad-aligned LDS tile
+    constexpr int CSL = C::IY * C::IZ * (4 * ((C::IX + 6) / 4));            // channel stride of the quad-aligned LDS tile
     constexpr int lds = (2 * C::CK * CSL + 2 * 27 * C::NT * 64 * (C::CK / 2)) * 4;
     static_assert(lds <= 160 * 1024, "LDS");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_ws_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -280,5 +283,11 @@ static int launch_ws(const ConvArgs& a, hipStream_t st) {
 int wmh_conv_ws_min_tiles() { return ws_num_cus() * 3 / 4; }
 // a: prepared by wmh_conv3d_k3_fwd with KS = 1 (no split-K: a long cin loop is what this form likes)
 int wmh_launch_conv_ws(int cfg, const ConvArgs& a, hipStream_t st) {
-    return cfg == 0 ? launch_ws<WCfg0>(a, st) : launch_ws<WCfg2>(a, st);
+    switch (cfg) {
+        case 0: return launch_ws<WCfg0>(a, st);
+        case 1: return launch_ws<WCfg1>(a, st);
+        case 2: return launch_ws<WCfg2>(a, st);
+        case 3: return launch_ws<WCfg3>(a, st);
+    }
+    return wmh_fail(WMH_EINVAL, "conv3d_k3 (wave-specialised): configuration not served");
 }

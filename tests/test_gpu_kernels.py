@@ -391,8 +391,9 @@ def test_seghead_softmax_mirror_accumulate_and_finalize(lib):
 
 
 def test_wave_specialised_form_is_bit_identical(tmp_path):
-    """The persistent loader/consumer form of the large-layer conv (WMH_WS=1) must reproduce the one-role kernel
-    bit for bit (same arithmetic, same k order).  The switch is read once per process, hence subprocesses."""
+    """The persistent loader/consumer form of the conv (WMH_WS=1: 32- and 16-wide rows, stride 1 and 2, given a tile per CU)
+    must reproduce the one-role kernel bit for bit (same arithmetic, same k order).  Split-K is pinned off for the
+    comparison (it changes the summation order); the switches are read once per process, hence subprocesses."""
     import os
     import subprocess
     import sys
@@ -404,18 +405,20 @@ def test_wave_specialised_form_is_bit_identical(tmp_path):
         "lib = _lib.load()\n"
         "g = torch.Generator().manual_seed(3)\n"
         "res_y, res_p = [], []\n"
-        "for (N, C0, C1, Cout, D, H, W) in [(2, 12, 0, 40, 9, 20, 72), (4, 24, 16, 128, 32, 32, 16), (8, 20, 0, 72, 16, 16, 16)]:\n"
+        "for (N, C0, C1, Cout, D, H, W, st) in [(2, 12, 0, 40, 9, 20, 72, 1), (4, 24, 16, 128, 32, 32, 16, 1), (8, 20, 0, 72, 16, 16, 16, 1),\n"
+        "                                       (8, 16, 0, 64, 32, 64, 64, 2), (8, 24, 0, 128, 32, 64, 32, 2), (3, 10, 0, 40, 11, 30, 68, 2)]:\n"
         "    Cin = C0 + C1\n"
+        "    Do, Ho, Wo = (D - 1) // st + 1, (H - 1) // st + 1, (W - 1) // st + 1\n"
         "    x0 = torch.randn(N, C0, D, H, W, generator=g).cuda(); s0 = (torch.rand(N, C0, 2, generator=g) + 0.5).cuda()\n"
         "    x1 = torch.randn(N, C1, D, H, W, generator=g).cuda() if C1 else None; s1 = (torch.rand(N, C1, 2, generator=g) + 0.5).cuda() if C1 else None\n"
         "    w = (torch.randn(Cout, Cin, 27, generator=g) * 0.1).numpy(); b = torch.randn(Cout, generator=g).cuda()\n"
-        "    cfg = lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, 1)\n"
+        "    cfg = lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, st)\n"
         "    wf = np.empty(lib.wmh_conv3d_k3_packed_floats(cfg, Cin, Cout), np.float32)\n"
         "    lib.wmh_conv3d_k3_pack_weights(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p))\n"
-        "    wfd = torch.from_numpy(wf).cuda(); y = torch.zeros(N, Cout, D, H, W, device='cuda')\n"
-        "    npart = lib.wmh_conv3d_k3_num_partials(cfg, N, D, H, W); part = torch.zeros(N, Cout, npart, 4, device='cuda')\n"
+        "    wfd = torch.from_numpy(wf).cuda(); y = torch.zeros(N, Cout, Do, Ho, Wo, device='cuda')\n"
+        "    npart = lib.wmh_conv3d_k3_num_partials(cfg, N, Do, Ho, Wo); part = torch.zeros(N, Cout, npart, 4, device='cuda')\n"
         "    _lib.check(lib.wmh_conv3d_k3_fwd(cfg, _lib.ptr(x0), _lib.ptr(s0), C0, _lib.ptr(x1), _lib.ptr(s1), C1, _lib.ptr(wfd), _lib.ptr(b), _lib.ptr(y),\n"
-        "               _lib.ptr(part), None, N, D, H, W, Cout, 1, 0.01, None), 'conv')\n"
+        "               _lib.ptr(part), None, N, D, H, W, Cout, st, 0.01, None), 'conv')\n"
         "    torch.cuda.synchronize(); res_y.append(y.cpu().numpy().ravel()); res_p.append(part.cpu().numpy().ravel()); res_p.append(np.array([cfg], np.float32))\n"
         "np.save(sys.argv[1], np.concatenate(res_y)); np.save(sys.argv[2], np.concatenate(res_p))\n") % root
     outs = []
