@@ -166,18 +166,22 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             const int sidx = lt + i * LTH;
             const int row = sidx / QPR, q = sidx - row * QPR;
             const unsigned keep = okh[r] ? 0xFFFFFFFFu : 0u;      // quad outside the volume: zeros
+            // InstanceNorm + LeakyReLU in packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: two voxels per instruction)
+            f32x4_t t[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x2_t sc2 = {scv[8 * half + c], scv[8 * half + c]}, sh2 = {shv[8 * half + c], shv[8 * half + c]};
+                const f32x2_t lo = __builtin_elementwise_fma(f32x2_t{v[r][c][0], v[r][c][1]}, sc2, sh2);
+                const f32x2_t hi = __builtin_elementwise_fma(f32x2_t{v[r][c][2], v[r][c][3]}, sc2, sh2);
+                const f32x2_t lo_s = lo * slope_eff, hi_s = hi * slope_eff;
+                t[c] = f32x4_t{fmaxf(lo[0], lo_s[0]), fmaxf(lo[1], lo_s[1]), fmaxf(hi[0], hi_s[0]), fmaxf(hi[1], hi_s[1])};
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int x = 4 * q - 3 + k;                       // position in the halo row
                 unsigned w[4];
 #pragma unroll
-                for (int c = 0; c < 8; c += 2) {
-                    float t0 = fmaf(v[r][c][k], scv[8 * half + c], shv[8 * half + c]);
-                    float t1 = fmaf(v[r][c + 1][k], scv[8 * half + c + 1], shv[8 * half + c + 1]);
-                    t0 = fmaxf(t0, t0 * slope_eff);
-                    t1 = fmaxf(t1, t1 * slope_eff);
-                    w[c >> 1] = ws_pack_bf16x2(t0, t1) & keep;
-                }
+                for (int c = 0; c < 8; c += 2) w[c >> 1] = ws_pack_bf16x2(t[c][k], t[c + 1][k]) & keep;
                 if (sidx < NQ && x >= 0 && x < C::IX) {
                     const int e = row * C::IX + x;
                     dst[e * 2 + (half ^ ((x >> 3) & 1))] = make_uint4(w[0], w[1], w[2], w[3]);

@@ -141,12 +141,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
 #pragma unroll
                 for (int cc = 0; cc < CK; ++cc) {
                     const float scl = in ? sc[cc] : 0.f, shl = in ? sh[cc] : 0.f;
-                    f32x4_t v;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float t = fmaf(stg[i][cc][k], scl, shl);
-                        v[k] = fmaxf(t, t * slope_eff);         // LeakyReLU for 0 <= slope <= 1; bit-identical to the select form
-                    }
+                    // packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: two voxels per instruction, same rounding as fmaf / *)
+                    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                    const f32x2_t sc2 = {scl, scl}, sh2 = {shl, shl};
+                    const f32x2_t lo = __builtin_elementwise_fma(f32x2_t{stg[i][cc][0], stg[i][cc][1]}, sc2, sh2);
+                    const f32x2_t hi = __builtin_elementwise_fma(f32x2_t{stg[i][cc][2], stg[i][cc][3]}, sc2, sh2);
+                    const f32x2_t lo_s = lo * slope_eff, hi_s = hi * slope_eff;
+                    // LeakyReLU as max(t, slope t) for 0 <= slope <= 1; bit-identical to the select form
+                    const f32x4_t v = {fmaxf(lo[0], lo_s[0]), fmaxf(lo[1], lo_s[1]), fmaxf(hi[0], hi_s[0]), fmaxf(hi[1], hi_s[1])};
                     if (NSL * LTH == NQ || sidx < NQ) *reinterpret_cast<f32x4_t*>(xb + cc * CS + 4 * sidx) = v;   // row * RSX + 4 q = 4 sidx
                 }
             }
