@@ -38,6 +38,10 @@ __device__ __forceinline__ float ld_uniform(const float* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<unsigned long long>(p));
 }
 
+#ifndef WMH_BF16_WS_RING
+#define WMH_BF16_WS_RING(NHS) ((NHS) % 3 == 0 ? 3 : 2)   /* register sets per lane; a full-chunk ring (6 sets) spills 257 VGPRs */
+#endif
+
 template <class C>
 __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArgs a, const int T /*tiles*/) {
     constexpr int S = C::S, MT = C::MT, NT = C::NT, CKB = 16;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         };
         // A half-slot = 8 channels of one quad (8 loads of 16 bytes, one 16-byte LDS piece per voxel).  The NHS half-slots of a
         // chunk go through a ring of RS register sets: while one set is normalised, packed and written, RS-1 are in flight.
-        constexpr int NHS = 2 * NSL, RS = (NHS % 3 == 0) ? 3 : 2;
+        constexpr int NHS = 2 * NSL, RS = WMH_BF16_WS_RING(NHS);   // RS must divide NHS (static ring indices)
         f32x4_t v[RS][8];
         unsigned okh[RS];
         auto src_of = [&](int ch, const float*& xs, const float*& ss, int& Cs, int& c0) {
@@ -213,7 +217,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         if (total > 0) {
             enter(0);
             issue(std::integral_constant<int, 0>{}, 0);
-            if constexpr (RS == 3) issue(std::integral_constant<int, 1>{}, 0);
+            if constexpr (RS > 2) issue(std::integral_constant<int, 1>{}, 0);
+            if constexpr (RS > 3) issue(std::integral_constant<int, 2>{}, 0);
+            if constexpr (RS > 4) issue(std::integral_constant<int, 3>{}, 0);
+            if constexpr (RS > 5) issue(std::integral_constant<int, 4>{}, 0);
             produce(0);
             write_w();
         }
