@@ -77,6 +77,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
                     help='bf16 = BASELINE.json config 3 (bf16 matrix-core operands, fp32 accumulate/storage); not the headline number')
+    ap.add_argument('--storage', choices=['fp32', 'bf16'], default='fp32',
+                    help='bf16 (with --precision bf16): the full-resolution activation tensors are kept as bf16; not the headline number')
     ap.add_argument('--shard', choices=['volumes', 'patches'], default='volumes',
                     help='volumes: one volume per rank per step (weak scaling, no collective); patches: ONE volume per '
                          'step, its patches split over the ranks with an RCCL all-gather of the weighted tiles (strong)')
@@ -101,7 +103,7 @@ def main():
 
     plan = baseline_plan()
     sd = he_init_state_dict(plan, seed=0)
-    eng = UNetEngine(plan, sd, device, precision=args.precision)
+    eng = UNetEngine(plan, sd, device, precision=args.precision, storage=args.storage)
     tta = bool(args.tta)
     pred = SlidingWindowPredictor(eng, do_mirroring=tta, batch=8)
     by_patch = args.shard == 'patches'
@@ -161,7 +163,8 @@ def main():
         res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=nvol / dt,
                    unit='volumes/s', n_gpus=args.gpus, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='strong' if by_patch else 'weak', vs_baseline=None,
-                   dtype='f32' if args.precision == 'fp32' else 'bf16 operands / f32 accumulate+storage', data='synthetic',
+                   dtype='f32' if args.precision == 'fp32' else ('bf16 operands / f32 accumulate+storage' if args.storage == 'fp32' else
+                                                                 'bf16 operands, bf16 full-resolution tensors / f32 accumulate'), data='synthetic',
                    config=dict(workload='configs[1]: one %dx%dx%d FLAIR volume per GPU, 128^3 patches, step 0.5, fp32, '
                                         'Gaussian aggregation, mirroring (TTA x8) %s; %d patch forwards per volume'
                                         % (args.shape[0], args.shape[1], args.shape[2], 'on' if tta else 'off', forwards),

@@ -27,6 +27,11 @@ SIGNATURES = {
     'wmh_conv3d_k3_num_partials_bf16': (_i, [_i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_pack_weights_bf16_device': (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'wmh_conv3d_k3_fwd_bf16': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_conv3d_k3_fwd_bf16_st': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    'wmh_conv3d_k3_fwd_st': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    'wmh_convtranspose3d_mfma_fwd_st': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    'wmh_seghead_softmax_accumulate_st': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ip, _i, _ip, _f, _i, _vp]),
+    'wmh_seghead_logits_st': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _sz, _f, _i, _vp]),
     'wmh_instnorm_finalize': (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]),
     'wmh_instnorm_stats': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _sz, _vp]),
     'wmh_instnorm_lrelu_apply': (_i, [_vp, _vp, _vp, _i, _i, _sz, _f, _vp]),

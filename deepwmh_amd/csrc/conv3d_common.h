@@ -65,6 +65,7 @@ __device__ __forceinline__ float sum32(float v) {   // sum over the 32 lanes of 
 }
 
 // wave-specialised persistent form for the large-layer configuration (conv3d_k3_ws.hip)
+int wmh_launch_conv_ws_in16(int cfg, const ConvArgs& a, hipStream_t st);   // config 1 with bf16 sources
 int wmh_launch_conv_ws(int cfg, const ConvArgs& a, hipStream_t st);     // cfg 0..3: 32- and 16-wide rows, stride 1 and 2
 int wmh_conv_ws_min_tiles();
 
@@ -84,7 +85,8 @@ __device__ __forceinline__ void halve_step(float (&vals)[32], int j) {
 // ------------------------------------------------------------------------------------------------
 // Epilogue of one workgroup tile.  acc[nt][m][r]: row (r&3)+8*(r>>2)+4*kh of cout tile nt, voxel j of M-tile m.
 // ------------------------------------------------------------------------------------------------
-template <class C>
+// OUT16: y is a bf16 tensor (uint16 bits, round to nearest even); the moments still come from the fp32 accumulators.
+template <class C, bool OUT16 = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C::NT][C::MT], int g, int ks, int n,
                                               int wave, int j, int kh, int dx, int dy, int dz, int ts0, int oz0,
                                               int oy0, int ox0, int tile_sp) {
@@ -154,6 +156,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
         // ---- stores: one acc register = two 128-B row segments (two output channels) per wave-instruction.
         // (An LDS-transposed 16-byte-store variant measured slower: the epilogue is bound by the store path,
         // ~16 B/clk/CU, not by instruction count.)
+        if constexpr (OUT16) {
+            unsigned short* ych = reinterpret_cast<unsigned short*>(a.y) + ((size_t)n * a.Cout + cob) * DoHoWo;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int ts = ts0 + m;
+                const int oz = oz0 + (ts / C::MY) * C::LZ + dz, oy = oy0 + (ts % C::MY) * C::LY + dy, ox = ox0 + dx;
+                if ((vmask >> m) & 1u) {
+                    unsigned short* yp = ych + (size_t)(4 * kh) * DoHoWo + (size_t)oz * HoWo + oy * a.Wo + ox;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        typedef __bf16 eb2 __attribute__((ext_vector_type(2)));
+                        typedef float ef2 __attribute__((ext_vector_type(2)));
+                        const ef2 f = {acc[nt][m][r], acc[nt][m][r + 1]};
+                        const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(f, eb2));      // v_cvt_pk_bf16_f32
+                        const int row0 = (r & 3) + 8 * (r >> 2), row1 = ((r + 1) & 3) + 8 * ((r + 1) >> 2);
+                        if (4 * kh + row0 < nrows) yp[(size_t)row0 * DoHoWo] = (unsigned short)(u & 0xFFFFu);
+                        if (4 * kh + row1 < nrows) yp[(size_t)row1 * DoHoWo] = (unsigned short)(u >> 16);
+                    }
+                }
+            }
+            continue;
+        }
         float* ych = ybase + ((size_t)n * a.Cout + cob) * DoHoWo;          // channel cob of sample n
 #pragma unroll
         for (int m = 0; m < MT; ++m) {

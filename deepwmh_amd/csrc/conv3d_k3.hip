@@ -31,7 +31,7 @@
 
 // ABL: timing-only ablations (diagnostics; results are wrong when != 0): 1 no LDS writes of the next chunk,
 // 2 no staging loads, 4 no weight loads, 8 B operand not read from LDS, 16 no per-chunk barrier
-template <class C, int ABL = 0>
+template <class C, int ABL = 0, bool OUT16 = false>
 __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs a) {
     constexpr int S = C::S, MT = C::MT, NT = C::NT, CK = C::CK, NIT = C::NIT, THREADS = C::THREADS, APF = C::APF;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
 
     // ---- epilogue ---------------------------------------------------------------------------------
     if (a.stamps) t_epi = __builtin_amdgcn_s_memtime();
-    conv_epilogue<C>(a, acc, g, ks, n0 + tn_w, wave, j, kh, dx, dy, dz, ts0, oz0, oy0, ox0, (tz * a.nty + ty) * a.ntx + tx);
+    conv_epilogue<C, OUT16>(a, acc, g, ks, n0 + tn_w, wave, j, kh, dx, dy, dz, ts0, oz0, oy0, ox0, (tz * a.nty + ty) * a.ntx + tx);
     if (a.stamps && tid == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         unsigned long long* o = a.stamps + (size_t)blockIdx.x * 4;
@@ -504,10 +504,10 @@ extern "C" size_t wmh_conv3d_k3_workspace_floats(int cfg, int Cin, int N, int D,
     return ks > 1 ? (size_t)ks * N * Cout * Do * Ho * Wo : 0;
 }
 
-extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int C0, const float* x1,
-                                 const float* ss1, int C1, const float* wf, const float* bias, float* y,
-                                 float* partials, float* workspace, int N, int D, int H, int W, int Cout, int stride,
-                                 float lrelu_slope, void* stream) {
+static int conv_fwd(int cfg, const float* x0, const float* ss0, int C0, const float* x1,
+                    const float* ss1, int C1, const float* wf, const float* bias, float* y,
+                    float* partials, float* workspace, int N, int D, int H, int W, int Cout, int stride,
+                    float lrelu_slope, int in16, int out16, void* stream) {
     if (cfg < 0 || cfg >= WMH_NUM_CONV_CFG) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd: bad cfg");
     const CfgInfo& c = cfg_info(cfg);
     if (!x0 || !wf || !y || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd: null/empty argument");
@@ -535,6 +535,7 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
     nblk *= a.KS;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd: grid too large");
     hipStream_t st = (hipStream_t)stream;
+    if (in16 || out16) a.KS = 1, nblk = tiles;               // bf16 tensors: no split-K slabs
     if (a.KS > 1) a.y = workspace;
     static const int use_ws = env_int("WMH_WS", 1);   // wave-specialised persistent form: +4 % on the large layers
     int rc;
@@ -543,6 +544,17 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
                        (size_t)4 * D * H * W * 4 < ((size_t)1 << 32) && lrelu_slope >= 0.f && lrelu_slope <= 1.f;
     // 32-wide rows: whenever the launch is not split; 16-wide rows: when there are enough tiles for one persistent workgroup
     // per CU -- a long cin loop is what this form likes, so it replaces split-K there (16^3 layers at batch 8)
+    // bf16 tensors either side are served where the full-resolution level needs them: the first layer writes them
+    // (config 8, one-role kernel), the first strided convolution reads them (config 1, wave-specialised kernel)
+    if (in16) {
+        if (cfg != 1 || out16 || !ws_ok) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_st: bf16 sources are implemented for config 1 (W % 4 == 0, aligned) only");
+        return wmh_launch_conv_ws_in16(cfg, a, st);
+    }
+    if (out16) {
+        if (cfg != 8) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_st: a bf16 output is implemented for config 8 only");
+        hipLaunchKernelGGL((conv3d_k3_kernel<Cfg8, 0, true>), dim3((unsigned)nblk), dim3(Cfg8::THREADS), Cfg8::LDS_FLOATS * 4, st, a);
+        return wmh_check_launch("conv3d_k3_kernel (bf16 out)");
+    }
     if (use_ws && ws_ok && ((cfg == 0 && a.KS == 1) || (cfg >= 1 && cfg <= 3 && tiles >= wmh_conv_ws_min_tiles()))) {
         a.KS = 1; a.y = y;
         return wmh_launch_conv_ws(cfg, a, st);
@@ -587,6 +599,21 @@ extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)NC), dim3(256), 0, st, workspace, bias, y, partials, a.npart,
                        a.KS, Cout, NC, spatial);
     return wmh_check_launch("splitk_reduce_kernel");
+}
+
+extern "C" int wmh_conv3d_k3_fwd(int cfg, const float* x0, const float* ss0, int C0, const float* x1,
+                                 const float* ss1, int C1, const float* wf, const float* bias, float* y,
+                                 float* partials, float* workspace, int N, int D, int H, int W, int Cout, int stride,
+                                 float lrelu_slope, void* stream) {
+    return conv_fwd(cfg, x0, ss0, C0, x1, ss1, C1, wf, bias, y, partials, workspace, N, D, H, W, Cout, stride, lrelu_slope, 0, 0, stream);
+}
+// The same convolution with bf16 TENSORS on one side (uint16 bit patterns, NCDHW): x_bf16 = both sources, y_bf16 = the output.
+extern "C" int wmh_conv3d_k3_fwd_st(int cfg, const void* x0, const float* ss0, int C0, const void* x1,
+                                    const float* ss1, int C1, const float* wf, const float* bias, void* y,
+                                    float* partials, int N, int D, int H, int W, int Cout, int stride,
+                                    float lrelu_slope, int x_bf16, int y_bf16, void* stream) {
+    return conv_fwd(cfg, static_cast<const float*>(x0), ss0, C0, static_cast<const float*>(x1), ss1, C1, wf, bias,
+                    static_cast<float*>(y), partials, nullptr, N, D, H, W, Cout, stride, lrelu_slope, x_bf16 != 0, y_bf16 != 0, stream);
 }
 
 // ---- MFMA layout self-test -----------------------------------------------------------------------

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 extern unsigned long long* g_conv_stamps;
-int wmh_launch_conv_bf16_ws(int cfg, const ConvArgs& a, hipStream_t st);      // conv3d_k3_bf16_ws.hip
+int wmh_launch_conv_bf16_ws(int cfg, const ConvArgs& a, hipStream_t st, int in16, int out16);      // conv3d_k3_bf16_ws.hip
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> BCfg0;      // same tile geometry as the fp32 Cfg0 / Cfg2
@@ -289,10 +289,10 @@ static int launch_bf16(const ConvArgs& a, unsigned nblk, hipStream_t st) {
     return wmh_check_launch("conv3d_k3_bf16_kernel");
 }
 
-extern "C" int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1,
-                                      const float* ss1, int C1, const uint16_t* wf, const float* bias, float* y,
-                                      float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope,
-                                      void* stream) {
+static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1,
+                         const float* ss1, int C1, const uint16_t* wf, const float* bias, float* y,
+                         float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope,
+                         int in16, int out16, void* stream) {
     const int NT = bf16_nt(cfg);
     if (!NT) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: configuration has no bf16 kernel");
     if (!x0 || !wf || !y || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: null/empty argument");
@@ -314,7 +314,8 @@ extern "C" int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0
     a.KS = 1;
     static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
     static const int abl_env = env_int("WMH_BF16_ABL", 0);
-    a.xcd_swizzle = (swz_env & 1) | (abl_env << 4);
+    static const int ws_abl_env = env_int("WMH_BF16_WS_ABL", 0);
+    a.xcd_swizzle = (swz_env & 1) | ((abl_env | ws_abl_env) << 4);
     a.stamps = g_conv_stamps;
     const long long nblk = (long long)a.ntx * a.nty * a.ntz * N * a.G;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: grid too large");
@@ -322,7 +323,11 @@ extern "C" int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0
     static const int use_ws = env_int("WMH_BF16_WS", 1);
     // the wave-specialised form loads aligned 16-byte quads: rows must start 16-byte aligned
     const bool quad_ok = (W % 4) == 0 && (size_t)16 * D * H * W * 4 < ((size_t)1 << 32) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && (!x1 || (reinterpret_cast<uintptr_t>(x1) & 15) == 0);
-    if (use_ws && abl_env == 0 && !w8 && quad_ok) return wmh_launch_conv_bf16_ws(cfg, a, st);
+    if (in16 || out16) {                          // bf16 tensors: only the wave-specialised kernel reads / writes them
+        if (!quad_ok) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16_st: bf16 storage needs W % 4 == 0 and 16-byte aligned sources");
+        return wmh_launch_conv_bf16_ws(cfg, a, st, in16, out16);
+    }
+    if (use_ws && abl_env == 0 && !w8 && quad_ok) return wmh_launch_conv_bf16_ws(cfg, a, st, 0, 0);
     if (bf16_variant() == 2) {
         if (cfg == 0) return launch_bf16<BCfg0w, 1>(a, (unsigned)nblk, st);
         return launch_bf16<BCfg2w, 1>(a, (unsigned)nblk, st);
@@ -333,4 +338,20 @@ extern "C" int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0
     }
     if (cfg == 0) return launch_bf16<BCfg0, 4>(a, (unsigned)nblk, st);
     return launch_bf16<BCfg2, 3>(a, (unsigned)nblk, st);
+}
+
+extern "C" int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1,
+                                      const float* ss1, int C1, const uint16_t* wf, const float* bias, float* y,
+                                      float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope,
+                                      void* stream) {
+    return conv_fwd_bf16(cfg, x0, ss0, C0, x1, ss1, C1, wf, bias, y, partials, N, D, H, W, Cout, lrelu_slope, 0, 0, stream);
+}
+// Same convolution with bf16 TENSORS either side (x_bf16: both sources, y_bf16: the output; uint16 bit patterns, NCDHW);
+// the InstanceNorm moments are still taken from the fp32 accumulators.
+extern "C" int wmh_conv3d_k3_fwd_bf16_st(int cfg, const void* x0, const float* ss0, int C0, const void* x1,
+                                         const float* ss1, int C1, const uint16_t* wf, const float* bias, void* y,
+                                         float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope,
+                                         int x_bf16, int y_bf16, void* stream) {
+    return conv_fwd_bf16(cfg, static_cast<const float*>(x0), ss0, C0, static_cast<const float*>(x1), ss1, C1, wf, bias,
+                         static_cast<float*>(y), partials, N, D, H, W, Cout, lrelu_slope, x_bf16 != 0, y_bf16 != 0, stream);
 }

@@ -38,11 +38,15 @@ __device__ __forceinline__ float ld_uniform(const float* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<unsigned long long>(p));
 }
 
+#ifndef WMH_BF16_WS_RING16
+#define WMH_BF16_WS_RING16(NHS) (NHS)
+#endif
 #ifndef WMH_BF16_WS_RING
 #define WMH_BF16_WS_RING(NHS) ((NHS) % 3 == 0 ? 3 : 2)   /* register sets per lane; a full-chunk ring (6 sets) spills 257 VGPRs */
 #endif
 
-template <class C>
+// IN16: both sources are bf16 tensors (a quad is one 8-byte load per channel, widened by a shift); OUT16: y is stored as bf16.
+template <class C, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArgs a, const int T /*tiles*/) {
     constexpr int S = C::S, MT = C::MT, NT = C::NT, CKB = 16;
     constexpr int LTH = 256;                                   // loader threads
@@ -60,6 +64,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
     const int HW = a.H * a.W;
     const size_t DHW = (size_t)a.D * HW;
     const int nch = a.nchunks;
+    const int abl = a.xcd_swizzle >> 4;      // timing experiments (WMH_BF16_WS_ABL; results are wrong when != 0): 1 no activation loads, 2 no convert / LDS writes, 4 no epilogue
 
     auto tile_of = [&](int v, int& g, int& tx, int& ty, int& tz, int& n0) {
         const int q = T >> 3, r = T & 7, xcd = v & 7;
@@ -120,8 +125,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         };
         // A half-slot = 8 channels of one quad (8 loads of 16 bytes, one 16-byte LDS piece per voxel).  The NHS half-slots of a
         // chunk go through a ring of RS register sets: while one set is normalised, packed and written, RS-1 are in flight.
-        constexpr int NHS = 2 * NSL, RS = WMH_BF16_WS_RING(NHS);   // RS must divide NHS (static ring indices)
-        f32x4_t v[RS][8];
+        // bf16 sources: a set is half the registers, and with half the bytes per load the same ring would keep half the bytes
+        // in flight -- the whole chunk rides in the ring instead
+        constexpr int NHS = 2 * NSL, RS = IN16 ? WMH_BF16_WS_RING16(NHS) : WMH_BF16_WS_RING(NHS);   // RS must divide NHS (static ring indices)
+        f32x4_t v[IN16 ? 1 : RS][8];
+        uint2 v16[IN16 ? RS : 1][8];
         unsigned okh[RS];
         auto src_of = [&](int ch, const float*& xs, const float*& ss, int& Cs, int& c0) {
             const int cb = ch * CKB;
@@ -136,12 +144,21 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             ch = __builtin_amdgcn_readfirstlane(ch);          // q % nch ran on the VALU
             const float* xs; const float* ss; int Cs, c0;
             src_of(ch, xs, ss, Cs, c0);
-            const char* base = reinterpret_cast<const char*>(xs + ((size_t)n0_cur * Cs + c0) * DHW);
             const int cmax = Cs - 1 - c0;                     // channels past the source's end re-read its last one (zeroed later)
-            const unsigned qo = 4u * (unsigned)q_off[i];
+            if (abl & 1) { okh[r] = (q_ok >> i) & 1u; return; }
+            if constexpr (IN16) {
+                const char* base = reinterpret_cast<const char*>(xs) + ((size_t)n0_cur * Cs + c0) * DHW * 2;
+                const unsigned qo = 2u * (unsigned)q_off[i];
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                v[r][c] = *reinterpret_cast<const f32x4_t*>(base + (qo + (unsigned)min(8 * half + c, cmax) * pstride));
+                for (int c = 0; c < 8; ++c)
+                    v16[r][c] = *reinterpret_cast<const uint2*>(base + (qo + (unsigned)min(8 * half + c, cmax) * (pstride >> 1)));
+            } else {
+                const char* base = reinterpret_cast<const char*>(xs + ((size_t)n0_cur * Cs + c0) * DHW);
+                const unsigned qo = 4u * (unsigned)q_off[i];
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    v[r][c] = *reinterpret_cast<const f32x4_t*>(base + (qo + (unsigned)min(8 * half + c, cmax) * pstride));
+            }
             okh[r] = (q_ok >> i) & 1u;
         };
         // InstanceNorm scale / shift of the chunk being converted: 16 channels, scalar, read once per chunk.  Without a
@@ -166,6 +183,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         };
         auto convert = [&](auto hc, int buf) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value, i = h / 2, half = h % 2, r = h % RS;
+            if (abl & 2) return;
             uint4* dst = ldsq + (size_t)buf * CS * 2;
             const int sidx = lt + i * LTH;
             const int row = sidx / QPR, q = sidx - row * QPR;
@@ -175,8 +193,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const f32x2_t sc2 = {scv[8 * half + c], scv[8 * half + c]}, sh2 = {shv[8 * half + c], shv[8 * half + c]};
-                const f32x2_t lo = __builtin_elementwise_fma(f32x2_t{v[r][c][0], v[r][c][1]}, sc2, sh2);
-                const f32x2_t hi = __builtin_elementwise_fma(f32x2_t{v[r][c][2], v[r][c][3]}, sc2, sh2);
+                f32x2_t xlo, xhi;
+                if constexpr (IN16) {
+                    const unsigned u0 = v16[r][c].x, u1 = v16[r][c].y;
+                    xlo = f32x2_t{__builtin_bit_cast(float, u0 << 16), __builtin_bit_cast(float, u0 & 0xFFFF0000u)};
+                    xhi = f32x2_t{__builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xFFFF0000u)};
+                } else {
+                    xlo = f32x2_t{v[r][c][0], v[r][c][1]};
+                    xhi = f32x2_t{v[r][c][2], v[r][c][3]};
+                }
+                const f32x2_t lo = __builtin_elementwise_fma(xlo, sc2, sh2);
+                const f32x2_t hi = __builtin_elementwise_fma(xhi, sc2, sh2);
                 const f32x2_t lo_s = lo * slope_eff, hi_s = hi * slope_eff;
                 t[c] = f32x4_t{fmaxf(lo[0], lo_s[0]), fmaxf(lo[1], lo_s[1]), fmaxf(hi[0], hi_s[0]), fmaxf(hi[1], hi_s[1])};
             }
@@ -293,7 +320,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 if (a.stamps) tb += __builtin_amdgcn_s_memtime() - t0;
             }
             if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
-            conv_epilogue<C>(a, acc, g, 0, n0, wave, j, kh, dx, dy, dz, ts0, tz * C::TZ, ty * C::TY, tx * C::TX,
+            if (abl & 4) { if (acc[0][0][0] == 12345.678f) a.y[0] = acc[NT - 1][1][3]; }
+            else
+            conv_epilogue<C, OUT16>(a, acc, g, 0, n0, wave, j, kh, dx, dy, dz, ts0, tz * C::TZ, ty * C::TY, tx * C::TX,
                              (tz * a.nty + ty) * a.ntx + tx);
             if (a.stamps) te += __builtin_amdgcn_s_memtime() - t0;
         }
@@ -307,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> WBCfg0;
 typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> WBCfg2;
 
-template <class C>
+template <class C, bool IN16 = false, bool OUT16 = false>
 static int launch_bf16_ws(const ConvArgs& a, hipStream_t st) {
     static int ncu = 0;
     if (!ncu) {
@@ -320,14 +349,20 @@ static int launch_bf16_ws(const ConvArgs& a, hipStream_t st) {
     constexpr int NITL = (C::SP + 255) / 256;
     constexpr int lds = 2 * NITL * 256 * 32 + 27 * C::NT * 64 * 16;
     static_assert(lds <= 160 * 1024, "LDS");
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_ws_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_ws_kernel<C, IN16, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const long long T = (long long)a.ntx * a.nty * a.ntz * a.N * a.G;
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 bf16 (wave-specialised): too many tiles");
     const int grid = T < ncu ? (int)T : ncu;
-    hipLaunchKernelGGL((conv3d_k3_bf16_ws_kernel<C>), dim3(grid), dim3(512), lds, st, a, (int)T);
+    hipLaunchKernelGGL((conv3d_k3_bf16_ws_kernel<C, IN16, OUT16>), dim3(grid), dim3(512), lds, st, a, (int)T);
     return wmh_check_launch("conv3d_k3_bf16_ws_kernel");
 }
 // a: fully prepared by wmh_conv3d_k3_fwd_bf16 (one-role geometry: npart, nchunks, G ... are the same)
-int wmh_launch_conv_bf16_ws(int cfg, const ConvArgs& a, hipStream_t st) {
+// in16 / out16: bf16 storage of the sources / of y (cfg 0 only -- the 32-wide full-resolution level, where the bytes are)
+int wmh_launch_conv_bf16_ws(int cfg, const ConvArgs& a, hipStream_t st, int in16, int out16) {
+    if (in16 || out16) {
+        if (cfg != 0) return wmh_fail(WMH_EINVAL, "conv3d_k3 bf16: bf16 storage is implemented for config 0 only");
+        return in16 ? (out16 ? launch_bf16_ws<WBCfg0, true, true>(a, st) : launch_bf16_ws<WBCfg0, true, false>(a, st))
+                    : launch_bf16_ws<WBCfg0, false, true>(a, st);
+    }
     return cfg == 0 ? launch_bf16_ws<WBCfg0>(a, st) : launch_bf16_ws<WBCfg2>(a, st);
 }

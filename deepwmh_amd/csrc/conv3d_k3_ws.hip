@@ -27,7 +27,8 @@ __device__ __forceinline__ float ws_ld_uniform(const float* p) {
 }
 static __device__ const float ws_ident2[2] = {1.f, 0.f};
 
-template <class C>
+// IN16: the sources are bf16 tensors (a quad is one 8-byte load per channel, widened by a shift in the loader)
+template <class C, bool IN16 = false>
 __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, const int T /*tiles*/, const int dbg /*timing experiments; 0 in production*/) {
     constexpr int S = C::S, MT = C::MT, NT = C::NT, CK = C::CK, V = CK / 2;
     constexpr int LTH = 256;                                   // loader threads
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
         typedef float f32x4_t __attribute__((ext_vector_type(4)));
         unsigned q_off[NSL]; unsigned q_ok = 0;               // byte offsets of this thread's quads in a channel plane
         int g = 0, n0 = 0;
-        f32x4_t stg[NSL][CK];
+        f32x4_t stg[IN16 ? 1 : NSL][CK];
+        uint2 stg16[IN16 ? NSL : 1][CK];
         float2 wst[WIT];
         float sc[CK], sh[CK], slope_eff = 1.f;
         auto setup = [&](int v) __attribute__((always_inline)) {
@@ -106,13 +108,22 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
             const float* xs; const float* ss; int Cs, c0;
             if (cb < a.C0) { xs = a.x0; ss = a.ss0; Cs = a.C0; c0 = cb; }
             else           { xs = a.x1; ss = a.ss1; Cs = a.C1; c0 = cb - a.C0; }
-            const char* base = reinterpret_cast<const char*>(xs + ((size_t)n0 * Cs + c0) * DHW);
             const int cmax = Cs - 1 - c0;                     // channels past the source's end re-read its last one (scale 0)
+            if constexpr (IN16) {
+                const char* base = reinterpret_cast<const char*>(xs) + ((size_t)n0 * Cs + c0) * DHW * 2;
 #pragma unroll
-            for (int i = 0; i < NSL; ++i)
+                for (int i = 0; i < NSL; ++i)
 #pragma unroll
-                for (int cc = 0; cc < CK; ++cc)
-                    stg[i][cc] = *reinterpret_cast<const f32x4_t*>(base + (q_off[i] + (unsigned)min(cc, cmax) * pstride));
+                    for (int cc = 0; cc < CK; ++cc)
+                        stg16[i][cc] = *reinterpret_cast<const uint2*>(base + ((q_off[i] >> 1) + (unsigned)min(cc, cmax) * (pstride >> 1)));
+            } else {
+                const char* base = reinterpret_cast<const char*>(xs + ((size_t)n0 * Cs + c0) * DHW);
+#pragma unroll
+                for (int i = 0; i < NSL; ++i)
+#pragma unroll
+                    for (int cc = 0; cc < CK; ++cc)
+                        stg[i][cc] = *reinterpret_cast<const f32x4_t*>(base + (q_off[i] + (unsigned)min(cc, cmax) * pstride));
+            }
             const bool has_ss = ss != nullptr;
             slope_eff = has_ss ? a.slope : 1.f;
             const float* tab = has_ss ? ss + ((size_t)n0 * Cs + c0) * 2 : ws_ident2;      // without a pending normalisation: {1, 0}
@@ -144,8 +155,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
                     // packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: two voxels per instruction, same rounding as fmaf / *)
                     typedef float f32x2_t __attribute__((ext_vector_type(2)));
                     const f32x2_t sc2 = {scl, scl}, sh2 = {shl, shl};
-                    const f32x2_t lo = __builtin_elementwise_fma(f32x2_t{stg[i][cc][0], stg[i][cc][1]}, sc2, sh2);
-                    const f32x2_t hi = __builtin_elementwise_fma(f32x2_t{stg[i][cc][2], stg[i][cc][3]}, sc2, sh2);
+                    f32x2_t xlo, xhi;
+                    if constexpr (IN16) {
+                        const unsigned u0 = stg16[i][cc].x, u1 = stg16[i][cc].y;
+                        xlo = f32x2_t{__builtin_bit_cast(float, u0 << 16), __builtin_bit_cast(float, u0 & 0xFFFF0000u)};
+                        xhi = f32x2_t{__builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xFFFF0000u)};
+                    } else {
+                        xlo = f32x2_t{stg[i][cc][0], stg[i][cc][1]};
+                        xhi = f32x2_t{stg[i][cc][2], stg[i][cc][3]};
+                    }
+                    const f32x2_t lo = __builtin_elementwise_fma(xlo, sc2, sh2);
+                    const f32x2_t hi = __builtin_elementwise_fma(xhi, sc2, sh2);
                     const f32x2_t lo_s = lo * slope_eff, hi_s = hi * slope_eff;
                     // LeakyReLU as max(t, slope t) for 0 <= slope <= 1; bit-identical to the select form
                     const f32x4_t v = {fmaxf(lo[0], lo_s[0]), fmaxf(lo[1], lo_s[1]), fmaxf(hi[0], hi_s[0]), fmaxf(hi[1], hi_s[1])};
@@ -267,18 +287,18 @@ static int ws_num_cus() {
     }
     return ncu;
 }
-template <class C>
+template <class C, bool IN16 = false>
 static int launch_ws(const ConvArgs& a, hipStream_t st) {
     constexpr int CSL = C::IY * C::IZ * (4 * ((C::IX + 6) / 4));            // channel stride of the quad-aligned LDS tile
     constexpr int lds = (2 * C::CK * CSL + 2 * 27 * C::NT * 64 * (C::CK / 2)) * 4;
     static_assert(lds <= 160 * 1024, "LDS");
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_ws_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_ws_kernel<C, IN16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const long long T = (long long)a.ntx * a.nty * a.ntz * a.N * a.G;
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 (wave-specialised): too many tiles");
     const int ncu = ws_num_cus();
     const int grid = T < ncu ? (int)T : ncu;
     static const int dbg = getenv("WMH_WS_DBG") ? atoi(getenv("WMH_WS_DBG")) : 0;
-    hipLaunchKernelGGL((conv3d_k3_ws_kernel<C>), dim3(grid), dim3(512), lds, st, a, (int)T, dbg);
+    hipLaunchKernelGGL((conv3d_k3_ws_kernel<C, IN16>), dim3(grid), dim3(512), lds, st, a, (int)T, dbg);
     return wmh_check_launch("conv3d_k3_ws_kernel");
 }
 // tiles a launch needs before the persistent one-workgroup-per-CU form is preferred over the (split-K) one-role kernel
@@ -292,4 +312,9 @@ int wmh_launch_conv_ws(int cfg, const ConvArgs& a, hipStream_t st) {
         case 3: return launch_ws<WCfg3>(a, st);
     }
     return wmh_fail(WMH_EINVAL, "conv3d_k3 (wave-specialised): configuration not served");
+}
+// bf16 sources (config 1: the first strided convolution reads the full-resolution level)
+int wmh_launch_conv_ws_in16(int cfg, const ConvArgs& a, hipStream_t st) {
+    if (cfg != 1) return wmh_fail(WMH_EINVAL, "conv3d_k3 (wave-specialised): bf16 sources are served for config 1 only");
+    return launch_ws<WCfg1, true>(a, st);
 }

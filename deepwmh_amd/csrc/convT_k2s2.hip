@@ -25,7 +25,8 @@ struct ConvTArgs {
 };
 
 // KT: kernel/stride along the first spatial axis: 2, or 1 for nnU-Net's anisotropic (1,2,2) up-sampling
-template <int NT, int MT, int CKC, int KT>
+// OUT16: y is a bf16 tensor (the two taps of a position become one 4-byte store)
+template <int NT, int MT, int CKC, int KT, bool OUT16 = false>
 __global__ __launch_bounds__(256, 2) void convT_k2s2_mfma_kernel(const ConvTArgs a) {
     constexpr int NTAP = 4 * KT;                  // rows per output channel
     constexpr int VT = MT * 32;                  // voxels per workgroup tile
@@ -147,6 +148,15 @@ __global__ __launch_bounds__(256, 2) void convT_k2s2_mfma_kernel(const ConvTArgs
             for (int c = 0; c < 4; ++c) {
                 const int co = co0 + (KT == 2 ? c : 2 * c + kh);
                 if (co >= a.Cout) continue;
+                if constexpr (OUT16) {
+                    typedef __bf16 eb2 __attribute__((ext_vector_type(2)));
+                    typedef float ef2 __attribute__((ext_vector_type(2)));
+                    unsigned short* yp = reinterpret_cast<unsigned short*>(a.y) + ((size_t)n * a.Cout + co) * O + base;
+                    const ef2 f0 = {acc[nt][m][4 * c + 0], acc[nt][m][4 * c + 1]}, f1 = {acc[nt][m][4 * c + 2], acc[nt][m][4 * c + 3]};
+                    *reinterpret_cast<unsigned*>(yp) = __builtin_bit_cast(unsigned, __builtin_convertvector(f0, eb2));
+                    *reinterpret_cast<unsigned*>(yp + W2) = __builtin_bit_cast(unsigned, __builtin_convertvector(f1, eb2));
+                    continue;
+                }
                 float* yp = a.y + ((size_t)n * a.Cout + co) * O + base;
                 *reinterpret_cast<float2*>(yp) = make_float2(acc[nt][m][4 * c + 0], acc[nt][m][4 * c + 1]);
                 *reinterpret_cast<float2*>(yp + W2) = make_float2(acc[nt][m][4 * c + 2], acc[nt][m][4 * c + 3]);
@@ -205,8 +215,8 @@ extern "C" int wmh_convtranspose3d_k2s2_pack_weights(const float* w, int Cin, in
     return wmh_convtranspose3d_pack_weights(w, Cin, Cout, 2, wf);
 }
 
-extern "C" int wmh_convtranspose3d_mfma_fwd(const float* x, const float* ss, const float* wf, float* y, int N, int Cin,
-                                            int Cout, int D, int H, int W, int kt, float lrelu_slope, void* stream) {
+static int convT_mfma_fwd(const float* x, const float* ss, const float* wf, float* y, int N, int Cin,
+                          int Cout, int D, int H, int W, int kt, float lrelu_slope, int out16, void* stream) {
     if (!x || !wf || !y || N < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (kt != 1 && kt != 2))
         return wmh_fail(WMH_EINVAL, "convtranspose3d_mfma_fwd: bad args");
     const long long DHW = (long long)D * H * W;
@@ -221,9 +231,20 @@ extern "C" int wmh_convtranspose3d_mfma_fwd(const float* x, const float* ss, con
     const long long nblk = (long long)cdivi(a.nvox, MT * 32) * a.nrg;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "convtranspose3d_k2s2_mfma_fwd: grid too large");
     const int lds = 2 * CKC * MT * 32 * 4;
-    if (kt == 2) hipLaunchKernelGGL((convT_k2s2_mfma_kernel<NT, MT, CKC, 2>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    if (out16 && kt == 2) hipLaunchKernelGGL((convT_k2s2_mfma_kernel<NT, MT, CKC, 2, true>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    else if (out16)       hipLaunchKernelGGL((convT_k2s2_mfma_kernel<NT, MT, CKC, 1, true>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    else if (kt == 2) hipLaunchKernelGGL((convT_k2s2_mfma_kernel<NT, MT, CKC, 2>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
     else         hipLaunchKernelGGL((convT_k2s2_mfma_kernel<NT, MT, CKC, 1>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
     return wmh_check_launch("convT_k2s2_mfma_kernel");
+}
+extern "C" int wmh_convtranspose3d_mfma_fwd(const float* x, const float* ss, const float* wf, float* y, int N, int Cin,
+                                            int Cout, int D, int H, int W, int kt, float lrelu_slope, void* stream) {
+    return convT_mfma_fwd(x, ss, wf, y, N, Cin, Cout, D, H, W, kt, lrelu_slope, 0, stream);
+}
+// the same with y stored as a bf16 tensor (uint16 bit patterns) when y_bf16 != 0
+extern "C" int wmh_convtranspose3d_mfma_fwd_st(const float* x, const float* ss, const float* wf, void* y, int N, int Cin,
+                                               int Cout, int D, int H, int W, int kt, float lrelu_slope, int y_bf16, void* stream) {
+    return convT_mfma_fwd(x, ss, wf, static_cast<float*>(y), N, Cin, Cout, D, H, W, kt, lrelu_slope, y_bf16 != 0, stream);
 }
 extern "C" int wmh_convtranspose3d_k2s2_mfma_fwd(const float* x, const float* ss, const float* wf, float* y, int N,
                                                  int Cin, int Cout, int D, int H, int W, float lrelu_slope,

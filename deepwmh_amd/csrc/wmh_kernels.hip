@@ -248,20 +248,23 @@ extern "C" int wmh_extract_patches(const float* volume, float* patches, int C, i
 }
 
 // logits_k = sum_c wseg[k][c] * lrelu(x[c]*scale[c]+shift[c]) for one voxel of item `b`
-template <int K>
+// IN16: x is a bf16 tensor (uint16 bit patterns); element offsets are the same, the bytes half
+template <int K, bool IN16 = false>
 __device__ __forceinline__ void head_logits(const float* xb, const float* ssb, const float* wseg, int C, size_t P,
                                             size_t src, float slope, float (&lg)[K]) {
 #pragma unroll
     for (int k = 0; k < K; ++k) lg[k] = 0.f;
     for (int c = 0; c < C; ++c) {
-        float v = xb[(size_t)c * P + src];
+        float v;
+        if constexpr (IN16) v = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(xb)[(size_t)c * P + src] << 16);
+        else v = xb[(size_t)c * P + src];
         if (ssb) v = wmh_lrelu(fmaf(v, ssb[2 * c], ssb[2 * c + 1]), slope);
 #pragma unroll
         for (int k = 0; k < K; ++k) lg[k] = fmaf(v, wseg[k * C + c], lg[k]);
     }
 }
 
-template <int K>
+template <int K, bool IN16 = false>
 __global__ __launch_bounds__(256) void seghead_softmax_accum_kernel(const float* x, const float* ss, const float* wseg,
                                                                     const float* gauss, float* agg, int C, int P0,
                                                                     int P1, int P2, int A0, int A1, int A2, int g0,
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum_kernel(const float*
             const int s0 = (f & 4) ? P0 - 1 - p0 : p0, s1 = (f & 2) ? P1 - 1 - p1 : p1, s2 = (f & 1) ? P2 - 1 - p2 : p2;
             const size_t src = ((size_t)s0 * P1 + s1) * P2 + s2;
             float lg[K];
-            head_logits<K>(x + (size_t)b * C * P, ss ? ss + (size_t)b * C * 2 : nullptr, wseg, C, P, src, slope, lg);
+            head_logits<K, IN16>(IN16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(x) + (size_t)b * C * P) : x + (size_t)b * C * P,
+                                 ss ? ss + (size_t)b * C * 2 : nullptr, wseg, C, P, src, slope, lg);
             float mx = lg[0];
 #pragma unroll
             for (int k = 1; k < K; ++k) mx = fmaxf(mx, lg[k]);
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum_kernel(const float*
 
 // Same arithmetic, 4 consecutive voxels of the last axis per thread with 16-byte loads (P2 % 4 == 0, aligned x):
 // a mirrored last axis reads the mirrored quad and reverses it in registers.
-template <int K>
+template <int K, bool IN16 = false>
 __global__ __launch_bounds__(256) void seghead_softmax_accum4_kernel(const float* x, const float* ss, const float* wseg,
                                                                      const float* gauss, float* agg, int C, int P0,
                                                                      int P1, int P2, int A0, int A1, int A2, int g0,
@@ -327,6 +331,7 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum4_kernel(const float
             const int s0 = (f & 4) ? P0 - 1 - p0 : p0, s1 = (f & 2) ? P1 - 1 - p1 : p1, s2 = fx ? P2 - 4 - p2 : p2;
             const size_t src = ((size_t)s0 * P1 + s1) * P2 + s2;
             const float* xb = x + (size_t)b * C * P + src;
+            const unsigned short* xb16 = reinterpret_cast<const unsigned short*>(x) + (size_t)b * C * P + src;
             const float* ssb = ss ? ss + (size_t)b * C * 2 : nullptr;
             float lg[K][4];
 #pragma unroll
@@ -336,7 +341,14 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum4_kernel(const float
 #pragma unroll 8
             for (int c = 0; c < C; ++c) {       // unrolled: 8 independent 16-byte loads in flight per lane
                 typedef float f4v __attribute__((ext_vector_type(4)));
-                const f4v v4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(xb + (size_t)c * P));   // read once
+                f4v v4;
+                if constexpr (IN16) {
+                    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                    const u2v u = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(xb16 + (size_t)c * P));
+                    v4 = f4v{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+                } else {
+                    v4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(xb + (size_t)c * P));   // read once
+                }
                 float v[4] = {fx ? v4.w : v4.x, fx ? v4.z : v4.y, fx ? v4.y : v4.z, fx ? v4.x : v4.w};
                 if (ssb) {
                     const float sc = ssb[2 * c], sh = ssb[2 * c + 1];
@@ -379,10 +391,10 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum4_kernel(const float
     }
 }
 
-extern "C" int wmh_seghead_softmax_accumulate(const float* x, const float* ss, const float* wseg, int K,
-                                              const float* gauss, float* agg, int C, int P0, int P1, int P2, int A0,
-                                              int A1, int A2, const int* origin, int n, const int* flips,
-                                              float lrelu_slope, void* stream) {
+static int seghead_softmax_accumulate(const float* x, const float* ss, const float* wseg, int K,
+                                     const float* gauss, float* agg, int C, int P0, int P1, int P2, int A0,
+                                     int A1, int A2, const int* origin, int n, const int* flips,
+                                     float lrelu_slope, int in16, void* stream) {
     PatchList pl;
     if (!x || !wseg || !agg || !origin || fill_patchlist(pl, n, origin, 1, flips))
         return wmh_fail(WMH_EINVAL, "seghead_softmax_accumulate: bad args");
@@ -393,11 +405,12 @@ extern "C" int wmh_seghead_softmax_accumulate(const float* x, const float* ss, c
     // 16-byte path: quads along the last axis must not straddle rows and every base must be 16-byte aligned
     const bool quad = (P2 % 4 == 0) && !(reinterpret_cast<uintptr_t>(x) & 15) && (!gauss || !(reinterpret_cast<uintptr_t>(gauss) & 15));
     unsigned gx = cdivu(quad ? P / 4 : P, 256);
-#define LAUNCH_HEAD(KK)                                                                                                  \
-    if (quad) hipLaunchKernelGGL((seghead_softmax_accum4_kernel<KK>), dim3(gx), dim3(256), 0, st, x, ss, wseg, gauss, agg, \
+#define LAUNCH_HEAD_F(KK, F)                                                                                             \
+    if (quad) hipLaunchKernelGGL((seghead_softmax_accum4_kernel<KK, F>), dim3(gx), dim3(256), 0, st, x, ss, wseg, gauss, agg, \
                                  C, P0, P1, P2, A0, A1, A2, origin[0], origin[1], origin[2], pl, lrelu_slope);            \
-    else hipLaunchKernelGGL((seghead_softmax_accum_kernel<KK>), dim3(gx), dim3(256), 0, st, x, ss, wseg, gauss, agg, C,    \
+    else hipLaunchKernelGGL((seghead_softmax_accum_kernel<KK, F>), dim3(gx), dim3(256), 0, st, x, ss, wseg, gauss, agg, C,    \
                             P0, P1, P2, A0, A1, A2, origin[0], origin[1], origin[2], pl, lrelu_slope)
+#define LAUNCH_HEAD(KK) do { if (in16) { LAUNCH_HEAD_F(KK, true); } else { LAUNCH_HEAD_F(KK, false); } } while (0)
     switch (K) {
         case 2: LAUNCH_HEAD(2); break;
         case 3: LAUNCH_HEAD(3); break;
@@ -405,32 +418,62 @@ extern "C" int wmh_seghead_softmax_accumulate(const float* x, const float* ss, c
         default: return wmh_fail(WMH_EINVAL, "seghead_softmax_accumulate: K must be 2, 3 or 4");
     }
 #undef LAUNCH_HEAD
+#undef LAUNCH_HEAD_F
     return wmh_check_launch("seghead_softmax_accum_kernel");
 }
+extern "C" int wmh_seghead_softmax_accumulate(const float* x, const float* ss, const float* wseg, int K,
+                                              const float* gauss, float* agg, int C, int P0, int P1, int P2, int A0,
+                                              int A1, int A2, const int* origin, int n, const int* flips,
+                                              float lrelu_slope, void* stream) {
+    return seghead_softmax_accumulate(x, ss, wseg, K, gauss, agg, C, P0, P1, P2, A0, A1, A2, origin, n, flips, lrelu_slope, 0, stream);
+}
+// the same with x a bf16 tensor (uint16 bit patterns) when x_bf16 != 0
+extern "C" int wmh_seghead_softmax_accumulate_st(const void* x, const float* ss, const float* wseg, int K,
+                                                 const float* gauss, float* agg, int C, int P0, int P1, int P2, int A0,
+                                                 int A1, int A2, const int* origin, int n, const int* flips,
+                                                 float lrelu_slope, int x_bf16, void* stream) {
+    return seghead_softmax_accumulate(static_cast<const float*>(x), ss, wseg, K, gauss, agg, C, P0, P1, P2, A0, A1, A2, origin, n, flips,
+                                      lrelu_slope, x_bf16 != 0, stream);
+}
 
-template <int K>
+template <int K, bool IN16 = false>
 __global__ __launch_bounds__(256) void seghead_logits_kernel(const float* x, const float* ss, const float* wseg,
                                                              float* out, int C, size_t P, float slope) {
     const int b = blockIdx.y;
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (size_t)gridDim.x * 256) {
         float lg[K];
-        head_logits<K>(x + (size_t)b * C * P, ss ? ss + (size_t)b * C * 2 : nullptr, wseg, C, P, p, slope, lg);
+        head_logits<K, IN16>(IN16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(x) + (size_t)b * C * P) : x + (size_t)b * C * P,
+                             ss ? ss + (size_t)b * C * 2 : nullptr, wseg, C, P, p, slope, lg);
 #pragma unroll
         for (int k = 0; k < K; ++k) out[((size_t)b * K + k) * P + p] = lg[k];
     }
 }
-extern "C" int wmh_seghead_logits(const float* x, const float* ss, const float* wseg, int K, float* out, int n, int C,
-                                  size_t spatial, float lrelu_slope, void* stream) {
+static int seghead_logits(const float* x, const float* ss, const float* wseg, int K, float* out, int n, int C,
+                          size_t spatial, float lrelu_slope, int in16, void* stream) {
     if (!x || !wseg || !out || n < 1 || C < 1 || spatial < 1) return wmh_fail(WMH_EINVAL, "seghead_logits: bad args");
     unsigned gx = cdivu(spatial, 256); if (gx > 65535) gx = 65535;
     hipStream_t st = (hipStream_t)stream;
     switch (K) {
-        case 2: hipLaunchKernelGGL((seghead_logits_kernel<2>), dim3(gx, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope); break;
-        case 3: hipLaunchKernelGGL((seghead_logits_kernel<3>), dim3(gx, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope); break;
-        case 4: hipLaunchKernelGGL((seghead_logits_kernel<4>), dim3(gx, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope); break;
+        case 2: if (in16) hipLaunchKernelGGL((seghead_logits_kernel<2, true>), dim3(gx, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+                else hipLaunchKernelGGL((seghead_logits_kernel<2>), dim3(gx, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+                break;
+        case 3: if (in16) hipLaunchKernelGGL((seghead_logits_kernel<3, true>), dim3(gx, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+                else hipLaunchKernelGGL((seghead_logits_kernel<3>), dim3(gx, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+                break;
+        case 4: if (in16) hipLaunchKernelGGL((seghead_logits_kernel<4, true>), dim3(gx, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+                else hipLaunchKernelGGL((seghead_logits_kernel<4>), dim3(gx, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+                break;
         default: return wmh_fail(WMH_EINVAL, "seghead_logits: K must be 2, 3 or 4");
     }
     return wmh_check_launch("seghead_logits_kernel");
+}
+extern "C" int wmh_seghead_logits(const float* x, const float* ss, const float* wseg, int K, float* out, int n, int C,
+                                  size_t spatial, float lrelu_slope, void* stream) {
+    return seghead_logits(x, ss, wseg, K, out, n, C, spatial, lrelu_slope, 0, stream);
+}
+extern "C" int wmh_seghead_logits_st(const void* x, const float* ss, const float* wseg, int K, float* out, int n, int C,
+                                     size_t spatial, float lrelu_slope, int x_bf16, void* stream) {
+    return seghead_logits(static_cast<const float*>(x), ss, wseg, K, out, n, C, spatial, lrelu_slope, x_bf16 != 0, stream);
 }
 
 __global__ __launch_bounds__(256) void accumulate_weight_kernel(const float* gauss, float* cnt, int P0, int P1, int P2,

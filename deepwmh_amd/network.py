@@ -64,13 +64,18 @@ class _ConvLayer:
 class UNetEngine:
     """Holds the weights in HBM and runs the forward graph on a HIP stream."""
 
-    def __init__(self, plan: UNetPlan, state_dict, device='cuda:0', precision='fp32'):
+    def __init__(self, plan: UNetPlan, state_dict, device='cuda:0', precision='fp32', storage='fp32'):
         """precision 'fp32' (exact-fp32 matrix instruction everywhere) or 'bf16' (BASELINE.json config 3: the
         stride-1 convolutions of the >= 16-wide levels multiply bf16-rounded operands with fp32 accumulation;
-        storage, InstanceNorm statistics, heads and softmax stay fp32)."""
+        InstanceNorm statistics, heads and softmax stay fp32).  storage 'bf16' (with precision 'bf16' only) also
+        keeps the five full-resolution activation tensors -- where the HBM bytes are -- as bf16, like the fp16
+        tensors of nnU-Net's autocast predict; everything below the first pooling stays fp32."""
         if precision not in ('fp32', 'bf16'):
             raise ValueError('precision must be fp32 or bf16')
+        if storage not in ('fp32', 'bf16') or (storage == 'bf16' and precision != 'bf16'):
+            raise ValueError("storage must be 'fp32', or 'bf16' together with precision='bf16'")
         self.precision = precision
+        self.storage = storage
         plan.check_supported()
         self.plan = plan
         self.device = torch.device(device)
@@ -101,11 +106,11 @@ class UNetEngine:
         self.timings = []          # (cfg, start_event, end_event, algorithmic_flop, algorithmic_bytes)
 
     # ---- buffers -------------------------------------------------------------------------------
-    def _buf(self, key, shape):
+    def _buf(self, key, shape, dtype=torch.float32):
         t = self._bufs.get(key)
         n = int(np.prod(shape))
-        if t is None or t.numel() < n:
-            t = torch.empty(n, dtype=torch.float32, device=self.device)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(n, dtype=dtype, device=self.device)
             self._bufs[key] = t
         return t[:n].view(*shape)
 
@@ -114,8 +119,13 @@ class UNetEngine:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ---- layers --------------------------------------------------------------------------------
-    def _conv(self, key, layer, x0, ss0, x1=None, ss1=None):
+    def _conv(self, key, layer, x0, ss0, x1=None, ss1=None, out16=False):
+        """out16: write y as a bf16 tensor (storage='bf16', full-resolution level).  bf16 sources are recognised by dtype.
+        Combinations the kernels do not serve fail in the library (WMH_EINVAL): there is no conversion fallback."""
         N, C0, D, H, W = x0.shape
+        in16 = x0.dtype == torch.bfloat16
+        if x1 is not None and (x1.dtype == torch.bfloat16) != in16:
+            raise ValueError('both sources of a convolution must use the same storage format')
         C1 = 0 if x1 is None else x1.shape[1]
         assert C0 + C1 == layer.cin
         s = layer.stride
@@ -127,7 +137,7 @@ class UNetEngine:
             npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials_bf16')
         else:
             npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials')
-        y = self._buf(key + '.y', (N, layer.cout, Do, Ho, Wo))
+        y = self._buf(key + ('.y16' if out16 else '.y'), (N, layer.cout, Do, Ho, Wo), torch.bfloat16 if out16 else torch.float32)
         part = self._buf(key + '.part', (N, layer.cout, npart, 4))
         ss = self._buf(key + '.ss', (N, layer.cout, 2))
         nws = self.lib.wmh_conv3d_k3_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout, s)
@@ -138,7 +148,17 @@ class UNetEngine:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if use_bf16:
+        if (in16 or out16) and use_bf16:
+            _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16_st(
+                cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
+                _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part),
+                N, D, H, W, layer.cout, LRELU_SLOPE, int(in16), int(out16), st), 'wmh_conv3d_k3_fwd_bf16_st')
+        elif in16 or out16:
+            _lib.check(self.lib.wmh_conv3d_k3_fwd_st(
+                cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
+                _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part),
+                N, D, H, W, layer.cout, s, LRELU_SLOPE, int(in16), int(out16), st), 'wmh_conv3d_k3_fwd_st')
+        elif use_bf16:
             _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16(
                 cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
                 _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part),
@@ -152,15 +172,24 @@ class UNetEngine:
             e1.record()
             vox = N * Do * Ho * Wo
             flop = 2.0 * layer.cin * layer.cout * 27 * vox
-            nbytes = 4.0 * (N * layer.cin * D * H * W + layer.cout * vox + layer.cout * layer.cin * 27)
+            nbytes = ((2.0 if in16 else 4.0) * N * layer.cin * D * H * W + (2.0 if out16 else 4.0) * layer.cout * vox
+                      + 4.0 * layer.cout * layer.cin * 27)
             self.timings.append((cfg, e0, e1, flop, nbytes))
         _lib.check(self.lib.wmh_instnorm_finalize(
             _lib.ptr(part), npart, _lib.ptr(layer.gamma), _lib.ptr(layer.beta), IN_EPS, _lib.ptr(ss), None,
             N, layer.cout, st), 'wmh_instnorm_finalize')
         return y, ss
 
-    def _convT(self, key, w, wf, x, ss, cout, kt=2):
+    def _convT(self, key, w, wf, x, ss, cout, kt=2, out16=False):
         N, Cin, D, H, W = x.shape
+        if out16:
+            if (D * H * W) % 4 != 0:
+                raise ValueError("storage='bf16' needs D*H*W % 4 == 0 below the full-resolution level")
+            y = self._buf(key + '.y16', (N, cout, kt * D, 2 * H, 2 * W), torch.bfloat16)
+            _lib.check(self.lib.wmh_convtranspose3d_mfma_fwd_st(
+                _lib.ptr(x), _lib.ptr(ss), _lib.ptr(wf), _lib.ptr(y), N, Cin, cout, D, H, W, kt, LRELU_SLOPE, 1,
+                self._stream()), 'wmh_convtranspose3d_mfma_fwd_st')
+            return y
         y = self._buf(key + '.y', (N, cout, kt * D, 2 * H, 2 * W))
         if (D * H * W) % 4 == 0:           # matrix-core kernel (16-byte staging loads)
             _lib.check(self.lib.wmh_convtranspose3d_mfma_fwd(
@@ -178,21 +207,23 @@ class UNetEngine:
     def forward_features(self, x, deep_supervision=False):
         """x: [N, Cin, P0, P1, P2] fp32 on the device.  Returns a list of (y, ss, seg_w) per decoder
         stage output that was requested (last = full resolution): y is the raw conv output whose
-        InstanceNorm+LeakyReLU is still pending as ss."""
+        InstanceNorm+LeakyReLU is still pending as ss (a torch.bfloat16 tensor at full resolution with storage='bf16')."""
         assert x.dtype == torch.float32 and x.is_contiguous() and x.device == self.device
         cur, cur_ss = x, None
         skips = []
         nenc = len(self.enc)
+        st16 = self.storage == 'bf16'              # the two encoder and two decoder convolutions + the up-sampling of level 0
         for i, layer in enumerate(self.enc):
-            cur, cur_ss = self._conv('enc%d' % i, layer, cur, cur_ss)
+            cur, cur_ss = self._conv('enc%d' % i, layer, cur, cur_ss, out16=st16 and i < 2)
             if i % 2 == 1 and i < nenc - 2:
                 skips.append((cur, cur_ss))
         outs = []
         for u, st in enumerate(self.dec):
-            up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt'])
+            o16 = st16 and u == len(self.dec) - 1
+            up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt'], out16=o16)
             skip, skip_ss = skips[-(u + 1)]
-            cur, cur_ss = self._conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss)
-            cur, cur_ss = self._conv('dec%d.1' % u, st['convs'][1], cur, cur_ss)
+            cur, cur_ss = self._conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss, out16=o16)
+            cur, cur_ss = self._conv('dec%d.1' % u, st['convs'][1], cur, cur_ss, out16=o16)
             if deep_supervision or u == len(self.dec) - 1:
                 outs.append((cur, cur_ss, st['seg_w']))
         return outs
@@ -206,7 +237,8 @@ class UNetEngine:
             N, Cc = y.shape[:2]
             sp = int(np.prod(y.shape[2:]))
             lg = torch.empty((N, K) + tuple(y.shape[2:]), dtype=torch.float32, device=self.device)
-            _lib.check(self.lib.wmh_seghead_logits(_lib.ptr(y), _lib.ptr(ss), _lib.ptr(seg_w), K, _lib.ptr(lg),
-                                                   N, Cc, sp, LRELU_SLOPE, self._stream()), 'wmh_seghead_logits')
+            _lib.check(self.lib.wmh_seghead_logits_st(_lib.ptr(y), _lib.ptr(ss), _lib.ptr(seg_w), K, _lib.ptr(lg),
+                                                      N, Cc, sp, LRELU_SLOPE, int(y.dtype == torch.bfloat16), self._stream()),
+                       'wmh_seghead_logits_st')
             res.append(lg)
         return tuple(res[::-1]) if deep_supervision else res[-1]

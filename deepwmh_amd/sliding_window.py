@@ -145,10 +145,10 @@ class SlidingWindowPredictor:
             return patches
 
         def accumulate(y, ss, seg_w, origin, n, flips):
-            _lib.check(lib.wmh_seghead_softmax_accumulate(
+            _lib.check(lib.wmh_seghead_softmax_accumulate_st(
                 _lib.ptr(y), _lib.ptr(ss), _lib.ptr(seg_w), K, _lib.ptr(gauss), _lib.ptr(agg), y.shape[1],
-                P[0], P[1], P[2], A[0], A[1], A[2], _lib.iarr(origin), n, _lib.iarr(flips), LRELU_SLOPE, st),
-                'wmh_seghead_softmax_accumulate')
+                P[0], P[1], P[2], A[0], A[1], A[2], _lib.iarr(origin), n, _lib.iarr(flips), LRELU_SLOPE,
+                int(y.dtype == torch.bfloat16), st), 'wmh_seghead_softmax_accumulate_st')
 
         if self.do_mirroring:
             for o in origins:

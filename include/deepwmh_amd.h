@@ -99,6 +99,30 @@ int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, c
                            int H, int W, int Cout, float lrelu_slope, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * bf16 TENSORS for the full-resolution level (opt-in storage mode of the bf16 inference configuration; what
+ * torch.autocast does to the convolution outputs of nnU-Net's mixed-precision predict [nnU-Net network_architecture/
+ * neural_network.py::predict_3D(mixed_precision=True), not in tree]).  The "_st" calls are the calls above with a
+ * storage flag per side: x_bf16 != 0 -> every source tensor holds bf16 bit patterns (uint16, NCDHW, same element
+ * offsets); y_bf16 != 0 -> y is written as bf16 (round to nearest even).  Arithmetic, InstanceNorm moments (from the
+ * fp32 accumulators) and every other argument are unchanged.  Served combinations (anything else fails with
+ * WMH_EINVAL, there is no fallback): wmh_conv3d_k3_fwd_bf16_st config 0 with W % 4 == 0; wmh_conv3d_k3_fwd_st
+ * y_bf16 for config 8 (first layer) and x_bf16 for config 1 (first strided convolution, W % 4 == 0). */
+int wmh_conv3d_k3_fwd_bf16_st(int cfg, const void* x0, const float* ss0, int C0, const void* x1, const float* ss1,
+                              int C1, const uint16_t* wf, const float* bias, void* y, float* partials, int N, int D,
+                              int H, int W, int Cout, float lrelu_slope, int x_bf16, int y_bf16, void* stream);
+int wmh_conv3d_k3_fwd_st(int cfg, const void* x0, const float* ss0, int C0, const void* x1, const float* ss1, int C1,
+                         const float* wf, const float* bias, void* y, float* partials, int N, int D, int H, int W,
+                         int Cout, int stride, float lrelu_slope, int x_bf16, int y_bf16, void* stream);
+int wmh_convtranspose3d_mfma_fwd_st(const float* x, const float* ss, const float* wf, void* y, int N, int Cin,
+                                    int Cout, int D, int H, int W, int kt, float lrelu_slope, int y_bf16, void* stream);
+int wmh_seghead_softmax_accumulate_st(const void* x, const float* ss, const float* wseg, int K,
+                                      const float* gauss, float* agg, int C, int P0, int P1, int P2,
+                                      int A0, int A1, int A2, const int* origin, int n,
+                                      const int* flips, float lrelu_slope, int x_bf16, void* stream);
+int wmh_seghead_logits_st(const void* x, const float* ss, const float* wseg, int K, float* out,
+                          int n, int C, size_t spatial, float lrelu_slope, int x_bf16, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * InstanceNorm3d(eps, affine) statistics -> per-(n,c) {scale, shift} so that
  * instnorm(x) = x*scale + shift.  Merges the conv epilogue's partial (count, sum, M2) records
  * with Chan's parallel-variance update in fp64, in a fixed order (bit-reproducible).

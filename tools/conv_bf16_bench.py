@@ -17,21 +17,29 @@ if os.environ.get('WMH_DIMS'):          # one custom shape: WMH_DIMS=120,128,128
     dd = [int(v) for v in os.environ['WMH_DIMS'].split(',')]
     ch = int(os.environ.get('WMH_CH', '32'))
     LAYERS = [('custom', ch, 0, ch, dd)]
+ST = int(os.environ.get('WMH_ST', '0'))        # bf16 tensors: bit 0 = sources, bit 1 = output (config 0 layers only)
+IN16, OUT16 = ST & 1, (ST >> 1) & 1
 tot = 0.0
 for name, C0, C1, Cout, D in LAYERS:
     Cin = C0 + C1
     Dz, Dy, Dx = (D, D, D) if isinstance(D, int) else D
     cfg = lib.wmh_conv3d_k3_config(Cin, Cout, Dz, Dy, Dx, 1)
-    x0 = torch.randn(B, C0, Dz, Dy, Dx, device='cuda'); x1 = torch.randn(B, C1, Dz, Dy, Dx, device='cuda') if C1 else None
+    st_layer = ST and cfg == 0
+    dt_in = torch.bfloat16 if (st_layer and IN16) else torch.float32
+    x0 = torch.randn(B, C0, Dz, Dy, Dx, device='cuda').to(dt_in); x1 = torch.randn(B, C1, Dz, Dy, Dx, device='cuda').to(dt_in) if C1 else None
     ss0 = torch.rand(B, C0, 2, device='cuda') + 0.5; ss1 = torch.rand(B, C1, 2, device='cuda') + 0.5 if C1 else None
     w = (torch.randn(Cout, Cin, 27, device='cuda') / np.sqrt(27 * Cin)).contiguous()
     wf = torch.empty(lib.wmh_conv3d_k3_packed_halfs_bf16(cfg, Cin, Cout), dtype=torch.int16, device='cuda')
     _lib.check(lib.wmh_conv3d_k3_pack_weights_bf16_device(cfg, P(w), Cin, Cout, 0, Cin, 0, P(wf), None))
-    bias = torch.zeros(Cout, device='cuda'); y = torch.empty(B, Cout, Dz, Dy, Dx, device='cuda')
+    bias = torch.zeros(Cout, device='cuda'); y = torch.empty(B, Cout, Dz, Dy, Dx, device='cuda', dtype=torch.bfloat16 if (st_layer and OUT16) else torch.float32)
     npart = lib.wmh_conv3d_k3_num_partials_bf16(cfg, B, Dz, Dy, Dx)
     part = torch.empty(B, Cout, npart, 4, device='cuda')
-    run = lambda: _lib.check(lib.wmh_conv3d_k3_fwd_bf16(cfg, P(x0), P(ss0), C0, P(x1), P(ss1), C1, P(wf), P(bias), P(y), P(part), B, Dz, Dy, Dx, Cout,
-                                                        0.01, None), 'bf16 conv')
+    if st_layer:
+        run = lambda: _lib.check(lib.wmh_conv3d_k3_fwd_bf16_st(cfg, P(x0), P(ss0), C0, P(x1), P(ss1), C1, P(wf), P(bias), P(y), P(part), B, Dz, Dy, Dx, Cout,
+                                                               0.01, IN16, OUT16, None), 'bf16 conv (bf16 tensors)')
+    else:
+        run = lambda: _lib.check(lib.wmh_conv3d_k3_fwd_bf16(cfg, P(x0), P(ss0), C0, P(x1), P(ss1), C1, P(wf), P(bias), P(y), P(part), B, Dz, Dy, Dx, Cout,
+                                                            0.01, None), 'bf16 conv')
     run(); torch.cuda.synchronize()
     ts = []
     for _ in range(5):
@@ -55,6 +63,6 @@ for name, C0, C1, Cout, D in LAYERS:
                   % (st[:, 0].mean(), st[:, 1].mean(), st[:, 2].mean(), st[0, 3], len(st)))
     vox = Dz * Dy * Dx
     fl = 2.0 * Cin * Cout * 27 * B * vox
-    gb = 4.0 * B * vox * (Cin + Cout)
+    gb = B * vox * ((2.0 if (st_layer and IN16) else 4.0) * Cin + (2.0 if (st_layer and OUT16) else 4.0) * Cout)
     print('%-7s cfg%d Cin %3d Cout %3d %s: %7.3f ms  %7.1f TFLOP/s  %6.0f GB/s algorithmic (%.2f of 8 TB/s)' % (name, cfg, Cin, Cout, 'x'.join(map(str, (Dz, Dy, Dx))), ms, fl / ms / 1e9, gb / ms / 1e6, gb / ms / 8e9))
 print('TOTAL %.3f ms' % tot)
