@@ -94,11 +94,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local_rank)                  # before the process group: RCCL binds to the current device
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    torch.cuda.set_device(local_rank)
     device = 'cuda:%d' % local_rank
 
     plan = baseline_plan()

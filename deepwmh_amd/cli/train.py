@@ -55,12 +55,12 @@ def main(argv=None):
     from ..trainer import UNetTrainer, downsample_targets, poly_lr
 
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        sys.exit('nnUNet_train (deepwmh_amd): no HIP device visible')
+    torch.cuda.set_device(local)                        # before the process group: RCCL binds to the current device
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        sys.exit('nnUNet_train (deepwmh_amd): no HIP device visible')
-    torch.cuda.set_device(local)
     device = 'cuda:%d' % local
 
     tasks = [d for d in sorted(os.listdir(pre)) if d.startswith('Task%03d_' % int(args.task))] if args.task.isdigit() else [args.task]
