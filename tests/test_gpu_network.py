@@ -150,6 +150,44 @@ def test_full_size_patch_forward_vs_oracle():
     assert perr <= TOL and mism == 0
 
 
+def test_full_size_volume_properties():
+    """BASELINE.json configs[1] at full size (160x192x160, 128^3 patches, mirroring): size-independent properties, since the
+    CPU oracle needs minutes for this volume.  (1) determinism: two runs give the same bits; (2) every voxel's class
+    probabilities sum to 1 and the label map is their argmax; (3) the patch-sharded code path on one rank (tile by tile,
+    HipTileBackend) gives the bits of the serial path; (4) without mirroring, batching the 8 patches into one forward or
+    running them one at a time agrees to rounding level (samples are independent; the launch shapes differ)."""
+    from deepwmh_amd.distributed import HipTileBackend, PatchShardedPredictor
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.plan import baseline_plan
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    from deepwmh_amd.synthetic import he_init_state_dict, synthetic_flair
+    plan = baseline_plan()
+    eng = UNetEngine(plan, he_init_state_dict(plan, seed=0), 'cuda:0')
+    vol = torch.from_numpy(synthetic_flair((160, 192, 160), seed=0)).cuda()
+    pred = SlidingWindowPredictor(eng, do_mirroring=True, batch=8)
+    seg, prob = pred.predict_device(vol)
+    seg, prob = seg.clone(), prob.clone()
+    seg2, prob2 = pred.predict_device(vol)
+    assert torch.equal(seg, seg2) and torch.equal(prob, prob2)
+    assert tuple(prob.shape) == (2, 160, 192, 160) and tuple(seg.shape) == (160, 192, 160)
+    assert float((prob.sum(0) - 1).abs().max()) <= 1e-6
+    assert float(prob.min()) >= 0.0 and float(prob.max()) <= 1.0
+    assert torch.equal(seg.long(), prob.argmax(0))
+    seg3, prob3 = PatchShardedPredictor(HipTileBackend(pred)).predict(vol)
+    assert torch.equal(seg, seg3) and torch.equal(prob, prob3)
+    p8 = SlidingWindowPredictor(eng, do_mirroring=False, batch=8)
+    p1 = SlidingWindowPredictor(eng, do_mirroring=False, batch=1)
+    s8, q8 = p8.predict_device(vol)
+    s8, q8 = s8.clone(), q8.clone()
+    s1, q1 = p1.predict_device(vol)
+    # not bit-identical: the batch size moves the small layers between the split-K and the unsplit launch (different
+    # summation order); the difference stays at rounding level
+    d = float((q8 - q1).abs().max())
+    flips = int(((s8 != s1) & ((q8[1] - 0.5).abs() > 1e-4)).sum())
+    print('full-size volume, batch 8 vs batch 1 forwards: max |dP| %.3g, label changes outside near-ties %d' % (d, flips))
+    assert d <= 2e-5 and flips == 0
+
+
 def test_bf16_forward_config3(tiny_net, tiny_io):
     """BASELINE.json config 3: bf16 matrix-core operands.  Not a 1e-4 path: report the distance to fp32 and the Dice."""
     from deepwmh_amd.network import UNetEngine
