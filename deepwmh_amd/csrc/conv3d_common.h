@@ -156,6 +156,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
         // ---- stores: one acc register = two 128-B row segments (two output channels) per wave-instruction.
         // (An LDS-transposed 16-byte-store variant measured slower: the epilogue is bound by the store path,
         // ~16 B/clk/CU, not by instruction count.)
+        // bf16 output: 2-byte stores, 32 consecutive lanes = one 64-byte segment.  Packing the two voxels of an x pair into
+        // one dword per lane (DPP swap, even lanes store row r, odd lanes row r+1) was 3x SLOWER: the address pattern across
+        // consecutive lanes is what the store path cares about, not the number of instructions or the bytes per lane.
         if constexpr (OUT16) {
             unsigned short* ych = reinterpret_cast<unsigned short*>(a.y) + ((size_t)n * a.Cout + cob) * DoHoWo;
 #pragma unroll
