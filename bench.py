@@ -24,6 +24,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 FWD_GFLOP_PER_PATCH = 954.46
+FWD_GBYTES_PER_PATCH = 4.17      # every layer reads its input once and writes its output once (fp32) + weights
+AGG_GBYTES_PER_VOLUME = 0.46     # aggregation read-modify-write + volume in / label map out
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
 
 
 def cpu_baseline(plan, sd, vol, tta, gpu_patch_logits, budget_s=30.0):
@@ -172,6 +175,12 @@ def main():
                                parallelism='patches of one volume sharded over ranks, RCCL all-gather of weighted tiles' if by_patch
                                else 'volumes sharded over ranks, no collective'),
                    end_to_end_tflops=round(forwards * FWD_GFLOP_PER_PATCH / 1e3 * nvol / dt, 2),
+                   # north_star's "fraction of the HBM roofline" for the whole path (algorithmic fp32 bytes; the fp32 path is
+                   # bound by the matrix cores, see roofline below and DESIGN.md 3.1)
+                   hbm_whole_path=dict(algorithmic_gbytes_per_volume=round(forwards * FWD_GBYTES_PER_PATCH + AGG_GBYTES_PER_VOLUME, 2),
+                                       achieved_gbs=round((forwards * FWD_GBYTES_PER_PATCH + AGG_GBYTES_PER_VOLUME) * nvol / dt, 1),
+                                       peak_gbs=HBM_PEAK_GBS,
+                                       frac=round((forwards * FWD_GBYTES_PER_PATCH + AGG_GBYTES_PER_VOLUME) * nvol / dt / HBM_PEAK_GBS, 4)),
                    roofline=roofline)
         if args.gpus == 1 and not args.no_cpu_baseline:
             # first patch, no mirroring, for the parity figure reported next to the baseline

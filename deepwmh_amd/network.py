@@ -100,10 +100,36 @@ class UNetEngine:
             convs = [_ConvLayer(self.lib, sd, c.name, c.cin, c.cout, 1, dev, c.kz, c.sz) for c in st['convs']]
             seg_w = torch.from_numpy(_np(sd[st['seg'] + '.weight']).reshape(plan.num_classes, cskip)).contiguous().to(dev)
             self.dec.append(dict(tu_w=tu_w, tu_wf=tu_wf, kt=kt, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
+        if storage == 'bf16':
+            self._check_storage_supported()
         self._bufs = {}
         # optional live kernel timing (bench.py): conv configs to bracket with HIP events on the launch stream
         self.timed_cfgs = set()
         self.timings = []          # (cfg, start_event, end_event, algorithmic_flop, algorithmic_bytes)
+
+    def _check_storage_supported(self):
+        """storage='bf16' is served by specific kernel configurations (include/deepwmh_amd.h, the *_st calls): say so
+        when the engine is built, not in the middle of a prediction."""
+        plan = self.plan
+        D, H, W = (int(v) for v in plan.patch_size)
+        e0, e1, e2 = self.enc[0], self.enc[1], self.enc[2]
+        cfg = lambda l, d, h, w: self.lib.wmh_conv3d_config(l.cin, l.cout, d, h, w, l.kz, l.sz, l.stride)
+        problems = []
+        if W % 4 != 0:
+            problems.append('the last patch axis must be a multiple of 4 (is %d)' % W)
+        if cfg(e0, D, H, W) != 8:
+            problems.append('the first layer must have 1-2 input channels, a 3x3x3 kernel and rows of >= 24 voxels')
+        if cfg(e1, D, H, W) != 0 or not self.lib.wmh_conv3d_k3_bf16_supported(0):
+            problems.append('the full-resolution level must have rows of >= 24 voxels and 3x3x3 kernels')
+        if cfg(e2, D, H, W) != 1:
+            problems.append('the first pooling must be 2x2x2 onto rows of >= 24 voxels (patch rows of >= 47)')
+        if e1.cout % 16 != 0:
+            problems.append('the full-resolution level must have a multiple of 16 feature maps (has %d)' % e1.cout)
+        last = self.dec[-1]
+        if last['kt'] != 2 or any(c.kz != 3 for c in last['convs']):
+            problems.append('the last decoder stage must be isotropic (2x2x2 up-sampling, 3x3x3 kernels)')
+        if problems:
+            raise ValueError("storage='bf16' is not available for this plan: " + '; '.join(problems))
 
     # ---- buffers -------------------------------------------------------------------------------
     def _buf(self, key, shape, dtype=torch.float32):

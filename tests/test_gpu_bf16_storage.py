@@ -248,3 +248,10 @@ def test_engine_with_bf16_storage_close_to_oracle():
     assert d_or < 5e-2 and d_st < 5e-2 and p_or < 5e-2 and dice > 0.98
     with pytest.raises(ValueError):
         UNetEngine(plan, sd, 'cuda:0', precision='fp32', storage='bf16')
+
+
+def test_storage_mode_is_refused_up_front_for_plans_it_does_not_serve(tiny_net):
+    from deepwmh_amd.network import UNetEngine
+    plan, _, sd = tiny_net                          # 4 feature maps at full resolution, 32-voxel rows
+    with pytest.raises(ValueError, match='not available for this plan'):
+        UNetEngine(plan, sd, 'cuda:0', precision='bf16', storage='bf16')
