@@ -3,8 +3,8 @@
   nnUNet_train 3d_fullres nnUNetTrainerV2 <task id> all -e E -b B [--noval] [--save_every_epoch]
                [--disable_postprocessing_on_folds] [--custom_val_cases v1 v2 ...] [-c]
 Writes model_latest / model_best / model_ep_NNNN (+ .pkl) and plans.pkl where the reference looks for them
-(DCNN_multistage.py:300,321,510,608-631).  Launched under torch.distributed.run it is data parallel (one RCCL
-all-reduce of the gradient arena per iteration); the reference itself passes one GPU id."""
+(DCNN_multistage.py:300,321,510,608-631).  Launched under torch.distributed.run it is data parallel (RCCL
+all-reduces of the gradient arena, started group by group while the backward pass is still running); the reference itself passes one GPU id."""
 import argparse
 import os
 import pickle

@@ -38,6 +38,68 @@ def average_gradients(flat_grads, group=None, bucket_elems=None):
     return flat_grads
 
 
+class OverlappedGradientAverager:
+    """The same exchange as `average_gradients`, started while the backward pass is still running.
+
+    The backward pass finishes the parameter groups one after another (loss heads and the full-resolution decoder first,
+    then the deep stages that hold most of the 31 M parameters, the first encoder layers last).  `ready(names)` is called
+    as soon as the gradients of those parameters are final on the current stream; completed neighbours in the flat arena
+    are merged, and every merged run of at least `min_elems` elements is handed to an asynchronous all-reduce (RCCL runs
+    it on its own stream, ordered after the kernels queued so far, next to the rest of the backward pass).  `finish()`
+    sends what is left, waits, checks that every parameter was sent exactly once, and divides by the world size.
+    Reduction results do not depend on how the arena was cut (an element-wise sum over ranks)."""
+
+    def __init__(self, flat_grads, ranges, group=None, min_elems=1 << 20):
+        """ranges: {parameter name: (start, end)} element ranges in flat_grads (disjoint; may include alignment padding)."""
+        self.flat, self.ranges, self.group, self.min_elems = flat_grads, dict(ranges), group, int(min_elems)
+        self.active = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.begin()
+
+    def begin(self):
+        self.seen, self.pending, self.works, self.sent = set(), [], [], 0
+
+    def _issue(self, lo, hi):
+        self.sent += hi - lo
+        if self.active:
+            self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def ready(self, names):
+        for n in names:
+            if n in self.seen:
+                raise RuntimeError('gradient of %s reported twice in one backward pass' % n)
+            self.seen.add(n)
+            self.pending.append(tuple(self.ranges[n]))
+        self.pending.sort()
+        merged = []
+        for lo, hi in self.pending:
+            if merged and merged[-1][1] == lo:
+                merged[-1] = (merged[-1][0], hi)
+            else:
+                merged.append((lo, hi))
+        self.pending = []
+        for lo, hi in merged:
+            if hi - lo >= self.min_elems:
+                self._issue(lo, hi)
+            else:
+                self.pending.append((lo, hi))
+
+    def finish(self):
+        missing = [n for n in self.ranges if n not in self.seen]
+        if missing:
+            raise RuntimeError('backward pass finished without the gradients of: %s' % ', '.join(sorted(missing)[:8]))
+        for lo, hi in self.pending:
+            self._issue(lo, hi)
+        self.pending = []
+        assert self.sent == sum(hi - lo for lo, hi in self.ranges.values())
+        for w in self.works:
+            w.wait()
+        if self.active:
+            self.flat.div_(self.world)
+        self.begin()
+        return self.flat
+
+
 class PatchShardedPredictor:
     """Host logic of the patch-sharded mode, independent of where the arithmetic runs.
 

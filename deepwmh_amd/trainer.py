@@ -87,6 +87,9 @@ class UNetTrainer:
         for (name, shape), o, n in zip(order, offs[:-1], sizes):
             self.p[name] = self.params[int(o):int(o) + n].view(*shape)
             self.g[name] = self.grads[int(o):int(o) + n].view(*shape)
+        # element range of every parameter in the arena, alignment padding included (data-parallel exchange, run_iteration)
+        self.grad_ranges = {name: (int(offs[i]), int(offs[i + 1])) for i, (name, _) in enumerate(order)}
+        self._avg = None
         self.load_state_dict(state_dict)
         self.first_step = True
         self._bufs, self._packed, self._version = {}, {}, 0
@@ -298,6 +301,8 @@ class UNetTrainer:
             _lib.check(lib.wmh_conv3d_k3_wgrad(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
                                              _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, conv.stride,
                                              LRELU_SLOPE, st), 'wmh_conv3d_k3_wgrad')
+        self._ready([conv.name + '.conv.weight', conv.name + '.conv.bias', conv.name + '.instnorm.weight', conv.name + '.instnorm.bias']
+                    + ([wseg_name] if (wseg_name and dl is not None) else []))
         if not need_dx:
             return None
         if conv.stride == 2:                                 # gather form: 27 MFMAs per channel pair for the 8 output parities
@@ -327,9 +332,21 @@ class UNetTrainer:
             outs.append(dx)
         return outs
 
-    def backward(self, targets):
+    def _ready(self, names):
+        """The gradients of these parameters are final on the launch stream: the data-parallel exchange may start."""
+        if self._avg is not None:
+            self._avg.ready(names)
+
+    def backward(self, targets, group=None):
         """targets: list of uint8 device tensors [N, spatial] per scale (full resolution first).  Fills the
-        gradient arena and returns the device scalar holding the loss."""
+        gradient arena and returns the device scalar holding the loss.  Under torch.distributed the arena is averaged
+        over the ranks on the way: each parameter group's all-reduce starts as soon as its gradient is complete and
+        runs next to the rest of the backward pass (distributed.OverlappedGradientAverager; with one process it only
+        checks that every parameter's gradient was produced exactly once)."""
+        from .distributed import OverlappedGradientAverager
+        if self._avg is None or self._avg.group is not group:
+            self._avg = OverlappedGradientAverager(self.grads, self.grad_ranges, group, min_elems=2 * 1024 * 1024)   # >= 8 MB per message
+        self._avg.begin()
         lib, st, tape = self.lib, self._st(), self.tape
         nd = len(self.dec)
         self.loss_acc.zero_()
@@ -342,6 +359,7 @@ class UNetTrainer:
             S = int(np.prod(lg.shape[2:]))
             if w == 0.0:
                 self.g[self.dec[u]['seg'] + '.weight'].zero_()
+                self._ready([self.dec[u]['seg'] + '.weight'])
                 continue
             dl = self._buf('b.dl%d' % u, lg.shape)
             _lib.check(lib.wmh_dice_ce_loss_fwd_bwd(_lib.ptr(lg), _lib.ptr(targets[s]), N, self.K, S, w, 1e-5, _lib.ptr(dl),
@@ -364,6 +382,7 @@ class UNetTrainer:
             ws = self._buf('b.wgrad.ws', (max(nws, 1),))
             _lib.check(lib.wmh_convtranspose3d_k2s2_wgrad(_lib.ptr(x_in), _lib.ptr(ss_in), _lib.ptr(d_up), _lib.ptr(self.g[tu]), _lib.ptr(ws),
                                                           N, Cin, cskip, D, H, W, LRELU_SLOPE, st), 'wmh_convtranspose3d_k2s2_wgrad')
+            self._ready([tu])
             cfg = _lib.check(lib.wmh_conv3d_k3_config(cskip, Cin, 2 * D, 2 * H, 2 * W, 2), 'config')
             wf = self._pack_tu_dgrad(u, self.p[tu], cfg, Cin, cskip)
             g_in, _, _ = self._run_conv('b.tu%d.dx' % u, cfg, d_up, None, None, None, wf, None, Cin, 2, False)
@@ -377,6 +396,7 @@ class UNetTrainer:
                 g2 = gskip[nd - 1 - i // 2]
             outs = self._block_bwd(tape['enc'][i], g, g2, None, None, i > 0)
             g = outs[0] if outs else None
+        self._avg.finish()
         return self.loss_acc
 
     # ---- optimizer -----------------------------------------------------------------------------------------------
@@ -391,17 +411,16 @@ class UNetTrainer:
         self._version += 1                                   # packed weight images are stale
 
     def allreduce_grads(self, group=None):
-        """Data parallelism (new design: the reference is single-GPU): one RCCL all-reduce of the flat gradient
-        arena, then the mean.  Batch-dice statistics stay per rank."""
+        """The exchange without overlap, for gradients that were not produced by backward(): one bucketed RCCL all-reduce
+        of the flat arena, then the mean.  backward() itself already averages (overlapped); do not call both."""
         from .distributed import average_gradients
         average_gradients(self.grads, group, bucket_elems=8 * 1024 * 1024)    # 32 MB buckets over xGMI
 
     def run_iteration(self, data, targets, lr, do_backprop=True, group=None):
         """nnUNetTrainerV2.run_iteration.  data [N,C,...] device fp32, targets = per-scale uint8 label tensors."""
         self.forward(data)
-        loss = self.backward(targets) if do_backprop else self.loss_only(targets)
+        loss = self.backward(targets, group) if do_backprop else self.loss_only(targets)   # data parallel: averaged on the way
         if do_backprop:
-            self.allreduce_grads(group)
             self.optimizer_step(lr)
         return loss
 

@@ -113,3 +113,60 @@ def test_gradient_averaging_gloo(tmp_path):
     out = str(tmp_path / 'g.npy')
     mp.spawn(_grad_worker, args=(2, port, out), nprocs=2, join=True)
     assert np.array_equal(np.load(out), np.arange(1000, dtype=np.float32) * 1.5)
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from deepwmh_amd.distributed import OverlappedGradientAverager, average_gradients
+    # an arena of 7 parameters with alignment padding inside the ranges, reported in backward order (not arena order)
+    sizes = [40, 8, 400, 12, 1000, 4, 36]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    ranges = {'p%d' % i: (int(offs[i]), int(offs[i + 1])) for i in range(len(sizes))}
+    g = torch.arange(int(offs[-1]), dtype=torch.float32) * (rank + 1) + rank
+    want = average_gradients(g.clone(), None)
+    ov = OverlappedGradientAverager(g, ranges, None, min_elems=300)
+    ov.ready(['p6', 'p5'])            # small: stays pending
+    ov.ready(['p4'])                  # merges with p5, p6 into one run >= 300 -> sent
+    ov.ready(['p1'])
+    ov.ready(['p2', 'p3'])            # p1..p3 merge -> sent
+    ov.ready(['p0'])
+    got = ov.finish()
+    assert torch.equal(got, want)
+    assert len(ov.works) == 0 and ov.sent == 0          # ready for the next iteration
+    # protocol errors are loud
+    ov.ready(['p0'])
+    try:
+        ov.ready(['p0'])
+        raise AssertionError('double report accepted')
+    except RuntimeError:
+        pass
+    ov.begin()
+    ov.ready(['p0', 'p1'])
+    try:
+        ov.finish()
+        raise AssertionError('incomplete backward accepted')
+    except RuntimeError:
+        pass
+    if rank == 0:
+        np.save(out, got.numpy())
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_averaging_gloo(tmp_path):
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'g.npy')
+    mp.spawn(_overlap_worker, args=(2, port, out), nprocs=2, join=True)
+    n = 1500
+    assert np.array_equal(np.load(out), (np.arange(n, dtype=np.float32) * 3 + 1) / 2)
+
+
+def test_overlapped_gradient_averaging_single_process_is_a_checked_no_op():
+    from deepwmh_amd.distributed import OverlappedGradientAverager
+    g = torch.arange(10, dtype=torch.float32)
+    ov = OverlappedGradientAverager(g, {'a': (0, 4), 'b': (4, 10)})
+    ov.ready(['b']); ov.ready(['a'])
+    assert torch.equal(ov.finish(), torch.arange(10, dtype=torch.float32))
+    ov.ready(['a'])
+    with pytest.raises(RuntimeError):
+        ov.finish()
