@@ -314,8 +314,7 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     a.KS = 1;
     static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
     static const int abl_env = env_int("WMH_BF16_ABL", 0);
-    static const int ws_abl_env = env_int("WMH_BF16_WS_ABL", 0);
-    a.xcd_swizzle = (swz_env & 1) | ((abl_env | ws_abl_env) << 4);
+    a.xcd_swizzle = (swz_env & 1) | (abl_env << 4);
     a.stamps = g_conv_stamps;
     const long long nblk = (long long)a.ntx * a.nty * a.ntz * N * a.G;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: grid too large");

@@ -47,7 +47,7 @@ __device__ __forceinline__ float ld_uniform(const float* p) {
 }
 
 #ifndef WMH_BF16_WS_RING16
-#define WMH_BF16_WS_RING16(NHS) (NHS)
+#define WMH_BF16_WS_RING16(NHS) ((NHS) % 3 == 0 ? 3 : 2)
 #endif
 #ifndef WMH_BF16_WS_RING
 #define WMH_BF16_WS_RING(NHS) ((NHS) % 3 == 0 ? 3 : 2)   /* register sets per lane; a full-chunk ring (6 sets) spills 257 VGPRs */
@@ -72,7 +72,6 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
     const int HW = a.H * a.W;
     const size_t DHW = (size_t)a.D * HW;
     const int nch = a.nchunks;
-    const int abl = a.xcd_swizzle >> 4;      // timing experiments (WMH_BF16_WS_ABL; results are wrong when != 0): 1 no activation loads, 2 no convert / LDS writes, 4 no epilogue
 
     auto tile_of = [&](int v, int& g, int& tx, int& ty, int& tz, int& n0) {
         const int q = T >> 3, r = T & 7, xcd = v & 7;
@@ -118,18 +117,22 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 q_ok |= ok ? (1u << i) : 0u;
             }
         };
-        uint4 wst[WIT];                                       // next chunk's weight fragments (this thread's pieces)
+        // next chunk's weight fragments (this thread's pieces).  A native vector type: an array of HIP's uint4 (a struct with
+        // a union inside) was left in scratch memory by the compiler, and its reload between the two barriers waited with
+        // vmcnt(0) for the whole prefetch ring while every wave of the workgroup stood at the barrier (~5 k ticks per chunk)
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t wst[WIT];
         auto issue_w = [&](int q) __attribute__((always_inline)) {                           // chunk q of this workgroup
             int g, tx, ty, tz, n0;
             tile_of(blockIdx.x + (q / nch) * gridDim.x, g, tx, ty, tz, n0);
             g = __builtin_amdgcn_readfirstlane(g);
-            const uint4* wsrc = reinterpret_cast<const uint4*>(a.wf) + ((size_t)g * nch + __builtin_amdgcn_readfirstlane(q % nch)) * WQ;
+            const u32x4_t* wsrc = reinterpret_cast<const u32x4_t*>(a.wf) + ((size_t)g * nch + __builtin_amdgcn_readfirstlane(q % nch)) * WQ;
 #pragma unroll
             for (int i = 0; i < WIT; ++i) wst[i] = wsrc[min(lt + i * LTH, WQ - 1)];
         };
         auto write_w = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < WIT; ++i) { const int k = lt + i * LTH; if (WIT * LTH == WQ || k < WQ) wlds[k] = wst[i]; }
+            for (int i = 0; i < WIT; ++i) { const int k = lt + i * LTH; if (WIT * LTH == WQ || k < WQ) reinterpret_cast<u32x4_t*>(wlds)[k] = wst[i]; }
         };
         // A half-slot = 8 channels of one quad (8 loads of 16 bytes, one 16-byte LDS piece per voxel).  The NHS half-slots of a
         // chunk go through a ring of RS register sets: while one set is normalised, packed and written, RS-1 are in flight.
@@ -153,7 +156,6 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             const float* xs; const float* ss; int Cs, c0;
             src_of(ch, xs, ss, Cs, c0);
             const int cmax = Cs - 1 - c0;                     // channels past the source's end re-read its last one (zeroed later)
-            if (abl & 1) { okh[r] = (q_ok >> i) & 1u; return; }
             if constexpr (IN16) {
                 const char* base = reinterpret_cast<const char*>(xs) + ((size_t)n0_cur * Cs + c0) * DHW * 2;
                 const unsigned qo = 2u * (unsigned)q_off[i];
@@ -191,63 +193,72 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         };
         auto convert = [&](auto hc, int buf) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value, i = h / 2, half = h % 2, r = h % RS;
-            if (abl & 2) return;
             uint4* dst = ldsq + (size_t)buf * CS * 2;
             const int sidx = lt + i * LTH;
             const int row = sidx / QPR, q = sidx - row * QPR;
             const unsigned keep = okh[r] ? 0xFFFFFFFFu : 0u;      // quad outside the volume: zeros
-            // InstanceNorm + LeakyReLU in packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: two voxels per instruction)
-            f32x4_t t[8];
+            // InstanceNorm + LeakyReLU in packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: two voxels per instruction), two
+            // channels at a time straight into the packed words: the staging registers of the next chunk's weights must not
+            // be pushed out to scratch (their reload sits between the two barriers, where every wave of the workgroup waits,
+            // and a scratch reload waits for ALL loads in flight -- the whole prefetch ring)
+            unsigned w[4][4];                                      // [voxel of the quad][channel pair]
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const f32x2_t sc2 = {scv[8 * half + c], scv[8 * half + c]}, sh2 = {shv[8 * half + c], shv[8 * half + c]};
-                f32x2_t xlo, xhi;
-                if constexpr (IN16) {
-                    const unsigned u0 = v16[r][c].x, u1 = v16[r][c].y;
-                    xlo = f32x2_t{__builtin_bit_cast(float, u0 << 16), __builtin_bit_cast(float, u0 & 0xFFFF0000u)};
-                    xhi = f32x2_t{__builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xFFFF0000u)};
-                } else {
-                    xlo = f32x2_t{v[r][c][0], v[r][c][1]};
-                    xhi = f32x2_t{v[r][c][2], v[r][c][3]};
+            for (int c = 0; c < 8; c += 2) {
+                f32x4_t t[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int cc = c + e;
+                    const f32x2_t sc2 = {scv[8 * half + cc], scv[8 * half + cc]}, sh2 = {shv[8 * half + cc], shv[8 * half + cc]};
+                    f32x2_t xlo, xhi;
+                    if constexpr (IN16) {
+                        const unsigned u0 = v16[r][cc].x, u1 = v16[r][cc].y;
+                        xlo = f32x2_t{__builtin_bit_cast(float, u0 << 16), __builtin_bit_cast(float, u0 & 0xFFFF0000u)};
+                        xhi = f32x2_t{__builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xFFFF0000u)};
+                    } else {
+                        xlo = f32x2_t{v[r][cc][0], v[r][cc][1]};
+                        xhi = f32x2_t{v[r][cc][2], v[r][cc][3]};
+                    }
+                    const f32x2_t lo = __builtin_elementwise_fma(xlo, sc2, sh2);
+                    const f32x2_t hi = __builtin_elementwise_fma(xhi, sc2, sh2);
+                    const f32x2_t lo_s = lo * slope_eff, hi_s = hi * slope_eff;
+                    t[e] = f32x4_t{ws_vmax(lo[0], lo_s[0]), ws_vmax(lo[1], lo_s[1]), ws_vmax(hi[0], hi_s[0]), ws_vmax(hi[1], hi_s[1])};
                 }
-                const f32x2_t lo = __builtin_elementwise_fma(xlo, sc2, sh2);
-                const f32x2_t hi = __builtin_elementwise_fma(xhi, sc2, sh2);
-                const f32x2_t lo_s = lo * slope_eff, hi_s = hi * slope_eff;
-                t[c] = f32x4_t{ws_vmax(lo[0], lo_s[0]), ws_vmax(lo[1], lo_s[1]), ws_vmax(hi[0], hi_s[0]), ws_vmax(hi[1], hi_s[1])};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k][c >> 1] = ws_pack_bf16x2(t[0][k], t[1][k]) & keep;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int x = 4 * q - 3 + k;                       // position in the halo row
-                unsigned w[4];
-#pragma unroll
-                for (int c = 0; c < 8; c += 2) w[c >> 1] = ws_pack_bf16x2(t[c][k], t[c + 1][k]) & keep;
                 if (sidx < NQ && x >= 0 && x < C::IX) {
                     const int e = row * C::IX + x;
-                    dst[e * 2 + (half ^ ((x >> 3) & 1))] = make_uint4(w[0], w[1], w[2], w[3]);
+                    dst[e * 2 + (half ^ ((x >> 3) & 1))] = make_uint4(w[k][0], w[k][1], w[k][2], w[k][3]);
                 }
             }
         };
         // chunk q of this workgroup: tile blockIdx.x + (q / nch) * gridDim.x, channel chunk q % nch
         auto enter = [&](int q) __attribute__((always_inline)) { if (q % nch == 0) setup(blockIdx.x + (q / nch) * gridDim.x); };
-        // one step: put half-slot (h + RS - 1) of the running sequence in flight, then convert half-slot h of chunk q
-        auto step = [&](auto hc, int q) __attribute__((always_inline)) {
+        // one step: put half-slot (h + RS - 1) of the running sequence in flight, then convert half-slot h of chunk q.
+        // Branch-free on purpose (past the last chunk the ring re-reads the last chunk): the weight fragments issued at the
+        // top of produce() are waited for between the two barriers, and the compiler's vmcnt for them is the minimum over all
+        // paths of the loads issued since -- with a conditional issue that minimum was 0, i.e. the whole ring had to land
+        // while every wave of the workgroup stood at the barrier (~5 k ticks per chunk).
+        auto step = [&](auto hc, int q, int buf) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value, hn = h + RS - 1;
             if constexpr (hn < NHS) {
                 issue(std::integral_constant<int, hn>{}, q % nch);
             } else {
-                if (q + 1 < total) {
-                    if constexpr (hn == NHS) enter(q + 1);        // first half-slot of the next chunk: maybe a new tile
-                    issue(std::integral_constant<int, hn - NHS>{}, (q + 1) % nch);
-                }
+                const int qn = min(q + 1, total - 1);
+                if constexpr (hn == NHS) enter(qn);               // first half-slot of the next chunk: maybe a new tile
+                issue(std::integral_constant<int, hn - NHS>{}, qn % nch);
             }
-            convert(hc, q & 1);
+            convert(hc, buf);
         };
-        auto produce = [&](int q) __attribute__((always_inline)) {
+        auto produce = [&](int q, int buf) __attribute__((always_inline)) {
             load_ss(q);                                       // before any enter(q + 1): n0_cur is still this chunk's
             issue_w(q);
-            step(std::integral_constant<int, 0>{}, q); step(std::integral_constant<int, 1>{}, q);
-            step(std::integral_constant<int, 2>{}, q); step(std::integral_constant<int, 3>{}, q);
-            if constexpr (NHS > 4) { step(std::integral_constant<int, 4>{}, q); step(std::integral_constant<int, 5>{}, q); }
+            step(std::integral_constant<int, 0>{}, q, buf); step(std::integral_constant<int, 1>{}, q, buf);
+            step(std::integral_constant<int, 2>{}, q, buf); step(std::integral_constant<int, 3>{}, q, buf);
+            if constexpr (NHS > 4) { step(std::integral_constant<int, 4>{}, q, buf); step(std::integral_constant<int, 5>{}, q, buf); }
         };
         if (total > 0) {
             enter(0);
@@ -256,22 +267,26 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             if constexpr (RS > 3) issue(std::integral_constant<int, 2>{}, 0);
             if constexpr (RS > 4) issue(std::integral_constant<int, 3>{}, 0);
             if constexpr (RS > 5) issue(std::integral_constant<int, 4>{}, 0);
-            produce(0);
+            produce(0, 0);
             write_w();
         }
         __syncthreads();
-        unsigned long long tw = 0, tb = 0, t0 = 0;           // diagnostics (a.stamps != NULL): work / barrier wait
+        unsigned long long tw = 0, tb = 0, t0 = 0, twl = 0;  // diagnostics (a.stamps != NULL): work / barrier wait / work next to an epilogue
         for (int it = 0; it < total; ++it) {
-            const int nx = it + 1;                           // the chunk written during this iteration
+            const int nx = min(it + 1, total - 1);           // the chunk written during this iteration (the last iteration repeats
+                                                             // the last chunk into the buffer nobody reads any more)
             if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
-            if (nx < total) produce(nx);
-            if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; t0 = t; }
+            produce(nx, (it + 1) & 1);
+            if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; if (it % nch == 0) twl += t - t0; t0 = t; }
             __syncthreads();                                 // consumers are done with chunk `it`: its weights may go
-            if (nx < total) write_w();
+            write_w();
             __syncthreads();
             if (a.stamps) tb += __builtin_amdgcn_s_memtime() - t0;
         }
-        if (a.stamps && tid == 256) { a.stamps[(size_t)blockIdx.x * 8 + 4] = tw; a.stamps[(size_t)blockIdx.x * 8 + 5] = tb; }
+        if (a.stamps && tid == 256) {
+            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+            o[4] = tw; o[5] = tb; o[6] = twl;               // twl: iterations whose consumers start with the previous tile's epilogue
+        }
     } else {
         // ================================ consumer waves ===================================================
         const int j = lane & 31, kh = lane >> 5;
@@ -291,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         int g, tx, ty, tz, n0;
         __syncthreads();
         int it = 0;
-        unsigned long long tm = 0, tb = 0, te = 0, t0 = 0;
+        unsigned long long tm = 0, tb = 0, te = 0, t0 = 0, tbl = 0;
         for (int vb = blockIdx.x; vb < T; vb += gridDim.x) {
             tile_of(vb, g, tx, ty, tz, n0);
             f32x16 acc[NT][MT];
@@ -325,18 +340,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
                 __syncthreads();
                 __syncthreads();                             // the loaders swap the weight fragments in between
-                if (a.stamps) tb += __builtin_amdgcn_s_memtime() - t0;
+                if (a.stamps) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; tb += d; if (ch == 0) tbl += d; }
             }
             if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
-            if (abl & 4) { if (acc[0][0][0] == 12345.678f) a.y[0] = acc[NT - 1][1][3]; }
-            else
             conv_epilogue<C, OUT16>(a, acc, g, 0, n0, wave, j, kh, dx, dy, dz, ts0, tz * C::TZ, ty * C::TY, tx * C::TX,
                              (tz * a.nty + ty) * a.ntx + tx);
             if (a.stamps) te += __builtin_amdgcn_s_memtime() - t0;
         }
         if (a.stamps && tid == 0) {
             unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
-            o[0] = tm; o[1] = tb; o[2] = te; o[3] = (unsigned long long)total;
+            o[0] = tm; o[1] = tb; o[2] = te; o[3] = (unsigned long long)total; o[7] = tbl;   // tbl: barrier wait of a tile's first chunk
         }
     }
 }

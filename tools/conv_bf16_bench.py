@@ -57,6 +57,10 @@ for name, C0, C1, Cout, D in LAYERS:
             n = st[:, 3].mean()
             print('   per chunk iteration (ticks): consumer mfma %.0f + barrier wait %.0f, epilogue %.0f per iteration; loader work %.0f + barrier wait %.0f; %d workgroups x %.0f iterations'
                   % (st[:, 0].mean() / n, st[:, 1].mean() / n, st[:, 2].mean() / n, st[:, 4].mean() / n, st[:, 5].mean() / n, len(st), n))
+            nchk = Cin // 16 if Cin % 16 == 0 else Cin // 16 + 1
+            tiles = n / max(nchk, 1)
+            print('   per tile (%d chunks): consumer barrier wait in the first chunk %.0f, in the others %.0f; loader work next to an epilogue %.0f, in the others %.0f'
+                  % (nchk, st[:, 7].mean() / tiles, (st[:, 1] - st[:, 7]).mean() / tiles, st[:, 6].mean() / tiles, (st[:, 4] - st[:, 6]).mean() / tiles))
         else:
             st = stamps.view(-1, 4).cpu().numpy(); st = st[st[:, 3] > 0]
             print('   per workgroup (s_memtime ticks): staging %.0f, mfma %.0f, epilogue %.0f over %d chunks; %d workgroups'
