@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s2_dgrad_kernel(const DgArgs 
         yoff[k] = ok ? 4u * (unsigned)((size_t)c * DoHoWo + (size_t)gz * HoWo + gy * a.Wo + gx) : 0u;
         ymask |= ok ? (1u << k) : 0u;
     }
-    float yr[NDY]; float4 wr[NW4];
+    // native vector type: an array of HIP's float4 (a struct with a union) was left in scratch memory by the compiler, and
+    // every scratch reload waits for all loads in flight
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
+    float yr[NDY]; f32x4n wr[NW4];
     auto issue = [&](int ch) {
         const int cb = ch * CK;
         const char* src = (const char*)(a.dy + ((size_t)n * a.Cout + cb) * DoHoWo);
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s2_dgrad_kernel(const DgArgs 
             const unsigned off = (whole || cb + c < a.Cout) ? yoff[k] : 0u;
             yr[k] = *(const float*)(src + off);
         }
-        const float4* wsrc = reinterpret_cast<const float4*>(a.wp + ((size_t)g * a.nchunks + ch) * WS);
+        const f32x4n* wsrc = reinterpret_cast<const f32x4n*>(a.wp + ((size_t)g * a.nchunks + ch) * WS);
 #pragma unroll
         for (int k = 0; k < NW4; ++k) {
             const int e = tid + 256 * k;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3s2_dgrad_kernel(const DgArgs 
             const int c = e / SP, s = e - c * SP;
             if (e < CK * SP) d[c * CS + s] = ((ymask >> k) & 1u) ? yr[k] : 0.f;
         }
-        float4* dw = reinterpret_cast<float4*>(d + CK * CS);
+        f32x4n* dw = reinterpret_cast<f32x4n*>(d + CK * CS);
 #pragma unroll
         for (int k = 0; k < NW4; ++k) {
             const int e = tid + 256 * k;
