@@ -210,7 +210,26 @@ static inline unsigned short f2bf(float f) {
     unsigned u; memcpy(&u, &f, 4);
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
-static int bf16_nt(int cfg) { return cfg == 0 ? 1 : cfg == 2 ? 2 : 0; }
+// Configuration 21 exists for this kernel only: the 32-wide stride-1 geometry with 64 output channels per tile
+// (4 x 4 x 32 voxels, NT = 2).  A 32-channel tile re-stages the input once per 32 output channels, and the loaders are what
+// bounds this kernel: with 64 or more output channels the wide tile halves their work per output (halo 1440 voxels per
+// 512 x 64 outputs against 2400 per 1024 x 32).  Served by the wave-specialised kernel only.
+#define WMH_BF16_CFG_WIDE 21
+typedef ConvCfg<1, 32, 1, 4, 4, 1, 4, 2, 4, 6> BCfgW;
+static int bf16_nt(int cfg) { return cfg == 0 ? 1 : (cfg == 2 || cfg == WMH_BF16_CFG_WIDE) ? 2 : 0; }
+struct BGeo { int TX, TY, TZ, WPS; };
+static BGeo bf16_geo(int cfg, bool w8) {
+    if (cfg == WMH_BF16_CFG_WIDE) return BGeo{BCfgW::TX, BCfgW::TY, BCfgW::TZ, BCfgW::WPS};
+    if (cfg == 0) return BGeo{BCfg0::TX, BCfg0::TY, BCfg0::TZ, w8 ? BCfg0w::WPS : BCfg0::WPS};
+    return BGeo{BCfg2::TX, BCfg2::TY, BCfg2::TZ, w8 ? BCfg2w::WPS : BCfg2::WPS};
+}
+// The configuration wmh_conv3d_k3_fwd_bf16 should be called with, given the one wmh_conv3d_config chose for the layer
+extern "C" int wmh_conv3d_k3_bf16_config(int cfg, int Cout, int W) {
+    static const int wide = env_int("WMH_BF16_WIDE", 1);
+    static const int use_ws = env_int("WMH_BF16_WS", 1);
+    if (cfg == 0 && wide && use_ws && bf16_variant() == 0 && Cout % 64 == 0 && W % 4 == 0) return WMH_BF16_CFG_WIDE;
+    return cfg;
+}
 
 extern "C" int wmh_conv3d_k3_bf16_supported(int cfg) { return bf16_nt(cfg) > 0; }
 // InstanceNorm partial records per (n, c) row the bf16 kernel writes (its wave split differs from the fp32 kernel's)
@@ -218,9 +237,8 @@ extern "C" int wmh_conv3d_k3_num_partials_bf16(int cfg, int N, int Do, int Ho, i
     if (!bf16_nt(cfg)) return wmh_fail(WMH_EINVAL, "num_partials_bf16: configuration has no bf16 kernel");
     (void)N;
     const bool w8 = bf16_variant() != 0;
-    const int TX = cfg == 0 ? BCfg0::TX : BCfg2::TX, TY = cfg == 0 ? BCfg0::TY : BCfg2::TY, TZ = cfg == 0 ? BCfg0::TZ : BCfg2::TZ;
-    const int WPS = cfg == 0 ? (w8 ? BCfg0w::WPS : BCfg0::WPS) : (w8 ? BCfg2w::WPS : BCfg2::WPS);
-    return cdiv(Wo, TX) * cdiv(Ho, TY) * cdiv(Do, TZ) * WPS;
+    const BGeo ge = bf16_geo(cfg, w8);
+    return cdiv(Wo, ge.TX) * cdiv(Ho, ge.TY) * cdiv(Do, ge.TZ) * ge.WPS;
 }
 extern "C" size_t wmh_conv3d_k3_packed_halfs_bf16(int cfg, int Cin, int Cout) {
     const int NT = bf16_nt(cfg);
@@ -304,11 +322,10 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     a.wf = reinterpret_cast<const float*>(wf); a.bias = bias; a.y = y; a.part = partials;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Do = D; a.Ho = H; a.Wo = W; a.Cout = Cout;
     a.nchunks = (C1 > 0) ? (C0 / 16 + cdiv(C1, 16)) : cdiv(C0, 16);
-    const int TX = cfg == 0 ? BCfg0::TX : BCfg2::TX, TY = cfg == 0 ? BCfg0::TY : BCfg2::TY, TZ = cfg == 0 ? BCfg0::TZ : BCfg2::TZ;
     const bool w8 = bf16_variant() != 0;
-    const int WPS = cfg == 0 ? (w8 ? BCfg0w::WPS : BCfg0::WPS) : (w8 ? BCfg2w::WPS : BCfg2::WPS);
-    a.ntx = cdiv(W, TX); a.nty = cdiv(H, TY); a.ntz = cdiv(D, TZ);
-    a.npart = a.ntx * a.nty * a.ntz * WPS;
+    const BGeo ge = bf16_geo(cfg, w8);
+    a.ntx = cdiv(W, ge.TX); a.nty = cdiv(H, ge.TY); a.ntz = cdiv(D, ge.TZ);
+    a.npart = a.ntx * a.nty * a.ntz * ge.WPS;
     a.slope = lrelu_slope;
     a.G = cdiv(Cout, 32 * NT);
     a.KS = 1;
@@ -325,6 +342,10 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     if (in16 || out16) {                          // bf16 tensors: only the wave-specialised kernel reads / writes them
         if (!quad_ok) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16_st: bf16 storage needs W % 4 == 0 and 16-byte aligned sources");
         return wmh_launch_conv_bf16_ws(cfg, a, st, in16, out16);
+    }
+    if (cfg == WMH_BF16_CFG_WIDE) {
+        if (!quad_ok) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: configuration 21 needs W % 4 == 0 and 16-byte aligned sources");
+        return wmh_launch_conv_bf16_ws(cfg, a, st, 0, 0);
     }
     if (use_ws && abl_env == 0 && !w8 && quad_ok) return wmh_launch_conv_bf16_ws(cfg, a, st, 0, 0);
     if (bf16_variant() == 2) {

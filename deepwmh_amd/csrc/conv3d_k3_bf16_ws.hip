@@ -356,6 +356,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 
 typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> WBCfg0;
 typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> WBCfg2;
+typedef ConvCfg<1, 32, 1, 4, 4, 1, 4, 2, 4, 6> WBCfgW;      // configuration 21: 4 x 4 x 32 voxels x 64 output channels
 
 template <class C, bool IN16 = false, bool OUT16 = false>
 static int launch_bf16_ws(const ConvArgs& a, hipStream_t st) {
@@ -385,5 +386,6 @@ int wmh_launch_conv_bf16_ws(int cfg, const ConvArgs& a, hipStream_t st, int in16
         return in16 ? (out16 ? launch_bf16_ws<WBCfg0, true, true>(a, st) : launch_bf16_ws<WBCfg0, true, false>(a, st))
                     : launch_bf16_ws<WBCfg0, false, true>(a, st);
     }
+    if (cfg == 21) return launch_bf16_ws<WBCfgW>(a, st);
     return cfg == 0 ? launch_bf16_ws<WBCfg0>(a, st) : launch_bf16_ws<WBCfg2>(a, st);
 }

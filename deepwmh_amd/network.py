@@ -159,6 +159,8 @@ class UNetEngine:
         cfg = _lib.check(self.lib.wmh_conv3d_config(layer.cin, layer.cout, D, H, W, layer.kz, layer.sz, s), 'wmh_conv3d_config')
         use_bf16 = (self.precision == 'bf16' and s == 1 and layer.sz == 1 and layer.kz == 3 and self.lib.wmh_conv3d_k3_bf16_supported(cfg)
                     and (C1 == 0 or C0 % 16 == 0))
+        if use_bf16 and not (in16 or out16):       # wide tile for >= 64 output channels (bf16 kernel only)
+            cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
         if use_bf16:
             npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials_bf16')
         else:

@@ -193,6 +193,7 @@ class UNetTrainer:
         cfg = _lib.check(self.lib.wmh_conv3d_k3_config(conv.cin, conv.cout, D, H, W, conv.stride), 'config')
         C1 = 0 if x1 is None else x1.shape[1]
         if self._use_bf16(cfg, conv.stride, x0.shape[1], C1):
+            cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, conv.cout, W)          # wide tile for >= 64 output channels
             wf = self._pack_bf16(conv, cfg, 0, 0, conv.cin)
             y, part, npart = self._run_conv_bf16(key, cfg, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout, True)
         else:
@@ -324,6 +325,7 @@ class UNetTrainer:
         for part, (off, cnt) in enumerate([(0, C0)] + ([(C0, C1)] if C1 else [])):
             cfg = _lib.check(lib.wmh_conv3d_k3_config(Cc, cnt, D, H, W, 1), 'config')
             if self._use_bf16(cfg, 1, Cc, 0, 'dgrad'):
+                cfg = lib.wmh_conv3d_k3_bf16_config(cfg, cnt, W)
                 wf = self._pack_bf16(conv, cfg, 1, off, cnt)
                 dx, _, _ = self._run_conv_bf16('b.dx%d.%s' % (part, rec['key']), cfg, src, None, None, None, wf, None, cnt, False)
             else:

@@ -94,6 +94,11 @@ int wmh_conv3d_k3_pack_weights_bf16(int cfg, const float* w, int Cin, int Cout, 
  * wmh_conv3d_k3_pack_weights_device (mixed-precision training: forward and data-gradient convolutions in bf16). */
 int wmh_conv3d_k3_pack_weights_bf16_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
                                            uint16_t* wf, void* stream);
+/* The configuration to call the bf16 entry points with, given the one wmh_conv3d_config chose for the layer: layers with
+ * 32-voxel rows and a multiple of 64 output channels are served by a tile of 4 x 4 x 32 voxels x 64 channels
+ * (configuration 21, this kernel only), which halves the staging work per output; everything else keeps its cfg.
+ * packed_halfs / pack_weights / num_partials / fwd must all be called with the returned value. */
+int wmh_conv3d_k3_bf16_config(int cfg, int Cout, int W);
 int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1,
                            int C1, const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D,
                            int H, int W, int Cout, float lrelu_slope, void* stream);

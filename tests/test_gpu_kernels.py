@@ -208,7 +208,9 @@ def test_convtranspose3d_anisotropic_1x2x2(lib, shape):
 
 
 BF16_CASES = [(1, 32, 0, 32, 8, 16, 64, True, False), (2, 16, 16, 8, 8, 8, 32, False, True), (1, 6, 0, 40, 5, 9, 33, True, False),
-              (2, 64, 0, 64, 8, 8, 16, True, False), (1, 16, 32, 24, 6, 20, 13, True, True)]
+              (2, 64, 0, 64, 8, 8, 16, True, False), (1, 16, 32, 24, 6, 20, 13, True, True),
+              # 64-channel tiles (configuration 21): whole and ragged tiles, two sources, two cout groups
+              (2, 64, 0, 64, 8, 8, 32, True, False), (1, 64, 64, 64, 6, 9, 36, False, True), (1, 24, 0, 128, 5, 7, 44, True, False)]
 
 
 @pytest.mark.parametrize('case', BF16_CASES, ids=[str(c) for c in BF16_CASES])
@@ -232,6 +234,8 @@ def test_conv3d_k3_bf16_operands(lib, case):
     full = F.conv3d(xin, w, b, padding=1)
     cfg = lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, 1)
     assert lib.wmh_conv3d_k3_bf16_supported(cfg)
+    cfg = lib.wmh_conv3d_k3_bf16_config(cfg, Cout, W)          # 64-channel tile (configuration 21) where it applies
+    assert cfg == (21 if (Cout % 64 == 0 and W % 4 == 0 and W >= 24) else cfg)
     wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_bf16(cfg, Cin, Cout), np.uint16)
     wn = w.numpy()
     assert lib.wmh_conv3d_k3_pack_weights_bf16(cfg, wn.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)) == 0

@@ -25,6 +25,8 @@ for name, C0, C1, Cout, D in LAYERS:
     Dz, Dy, Dx = (D, D, D) if isinstance(D, int) else D
     cfg = lib.wmh_conv3d_k3_config(Cin, Cout, Dz, Dy, Dx, 1)
     st_layer = ST and cfg == 0
+    if not st_layer:
+        cfg = lib.wmh_conv3d_k3_bf16_config(cfg, Cout, Dx)      # 64-channel tile where it applies (WMH_BF16_WIDE=0: off)
     dt_in = torch.bfloat16 if (st_layer and IN16) else torch.float32
     x0 = torch.randn(B, C0, Dz, Dy, Dx, device='cuda').to(dt_in); x1 = torch.randn(B, C1, Dz, Dy, Dx, device='cuda').to(dt_in) if C1 else None
     ss0 = torch.rand(B, C0, 2, device='cuda') + 0.5; ss1 = torch.rand(B, C1, 2, device='cuda') + 0.5 if C1 else None
