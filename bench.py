@@ -1,19 +1,24 @@
 #!/usr/bin/env python
 """bench.py -- FLAIR volumes/sec of sliding-window inference (160x192x160, 128^3 patches, step 0.5,
-Gaussian aggregation, fp32) on N MI355X.  One "step" = one whole volume through the hot path on
-every rank (extract patches -> Generic_UNet forward -> seg head + softmax + mirror average + Gaussian
-accumulate -> normalise + argmax), volume already resident in HBM.  Prints ONE JSON line (rank 0).
+Gaussian aggregation) on N MI355X.  One "step" = one whole volume through the hot path on every rank:
+volume H2D -> extract patches -> Generic_UNet forward -> seg head + softmax + mirror average + Gaussian
+accumulate -> normalise + argmax -> label-map D2H (SURVEY.md 8d's timing protocol).  Prints ONE JSON line.
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py                         # N=1, configs[1] (fp32, mirroring on): the headline
+  python bench.py --gpus N                # spawns the N ranks itself (fresh child processes, one per GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N    # or under torchrun
+  python bench.py --precision bf16 --storage bf16      # configs[2]: bf16 forward, a step = 8 volumes
 
-Multi-GPU: volumes are independent, so ranks shard the cohort (one volume per rank per step, no
-data-path collective): weak scaling.  `--tta 0` drops nnU-Net's 8-fold mirroring (the reference's
-`--disable_tta` stage-II predictions); the default keeps it, as `DeepWMH_predict` does.
+Multi-GPU: volumes are independent, so ranks shard the cohort (one volume per rank per step, no data-path
+collective): weak scaling.  `--shard patches` is the patch-sharded mode of configs[3] (one volume per
+step, RCCL all-gather of the weighted tiles).  `--tta 0` drops nnU-Net's 8-fold mirroring (the
+reference's `--disable_tta` stage-II predictions); the default keeps it, as `DeepWMH_predict` does.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,17 +27,81 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-FWD_GFLOP_PER_PATCH = 954.46
-FWD_GBYTES_PER_PATCH = 4.17      # every layer reads its input once and writes its output once (fp32) + weights
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (dense peaks)
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}
+HBM_PEAK_GBS = 8000.0
+FWD_GFLOP_PER_PATCH = 954.46     # BASELINE.md section 2 (the engine's own count of what it queued is reported next to it)
 AGG_GBYTES_PER_VOLUME = 0.46     # aggregation read-modify-write + volume in / label map out
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
+KERNEL_NAME = {
+    'fp32': 'conv3d_k3_ws_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM, wave-specialised)',
+    'bf16': 'conv3d_k3_bf16_ws_kernel<cfg0> (v_mfma_f32_32x32x16_bf16 implicit GEMM, wave-specialised)',
+}
 
 
-def cpu_baseline(plan, sd, vol, tta, gpu_patch_logits, budget_s=30.0):
-    """Times the CPU oracle (kind 'port': our torch-CPU restatement of nnU-Net; the reference's own
-    nnU-Net fork is not available) on a bounded sample and extrapolates to volumes/s."""
+def mode_key(precision, storage):
+    return 'fp32' if precision == 'fp32' else ('bf16_storage' if storage == 'bf16' else 'bf16')
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--tta', type=int, default=1, help='1: 8-fold mirroring as DeepWMH_predict; 0: --disable_tta')
+    ap.add_argument('--shape', type=int, nargs=3, default=[160, 192, 160])
+    ap.add_argument('--cpu-baseline', choices=['auto', 'full', 'sample', 'off'], default='auto',
+                    help='auto: time the oracle on the WHOLE volume without mirroring when a probe says that fits in '
+                         '~60 s (it does on the GPU box), else on one patch; full / sample force one of the two')
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='same as --cpu-baseline off')
+    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
+                    help='bf16 = BASELINE.json configs[2] (bf16 matrix-core operands, fp32 accumulate); not the headline')
+    ap.add_argument('--storage', choices=['fp32', 'bf16'], default='fp32',
+                    help='bf16 (with --precision bf16): activation tensors are kept as bf16; not the headline')
+    ap.add_argument('--volumes-per-step', type=int, default=0,
+                    help='volumes each rank predicts per step (default 1; 8 with --precision bf16 = configs[2])')
+    ap.add_argument('--shard', choices=['volumes', 'patches'], default='volumes',
+                    help='volumes: one volume per rank per step (weak scaling, no collective); patches: ONE volume per '
+                         'step, its patches split over the ranks with an RCCL all-gather of the weighted tiles (strong)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launch plumbing only (CPU test of --gpus N): gloo process group, no kernels, value null')
+    args = ap.parse_args(argv)
+    if args.no_cpu_baseline:
+        args.cpu_baseline = 'off'
+    if args.volumes_per_step <= 0:
+        args.volumes_per_step = 8 if args.precision == 'bf16' else 1
+    return args
+
+
+# ------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` from a bare shell
+# ------------------------------------------------------------------------------------------------------------
+def self_launch(argv):
+    """Parent of a multi-GPU run.  Nothing in this process touches the GPU (no torch import either): it starts
+    `torch.distributed.run` as a CHILD, which starts one fresh rank per GPU, relays their output and returns
+    the child's exit code.  (Replacing a GPU-initialised process with exec is what takes boxes down.)"""
+    n = parse_args(argv).gpus
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle as the checker and as the reported baseline; never in the timed GPU region)
+# ------------------------------------------------------------------------------------------------------------
+def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits):
+    """Times the CPU oracle (kind 'port': our torch-CPU restatement of nnU-Net; the reference's own nnU-Net
+    fork is not available).  'full': the whole volume without mirroring -- 8 patch forwards + Gaussian
+    aggregation + argmax, after one warm-up forward -- which is the complete path at 1/8 of the mirrored
+    forward count; the mirrored figure is that time with the forward part x8.  'sample': one patch forward.
+    gpu_notta: (seg, prob) numpy of the HIP path on the same volume without mirroring, or None."""
     import torch
+    from oracle import sliding_window as osw
     from oracle.generic_unet import unet_from_plan
     cores = torch.get_num_threads()                 # torch's default for this host (physical cores it may use)
     net = unet_from_plan(plan).eval()
@@ -40,67 +109,171 @@ def cpu_baseline(plan, sd, vol, tta, gpu_patch_logits, budget_s=30.0):
     net.do_ds = False
     P = plan.patch_size
     x = torch.from_numpy(np.ascontiguousarray(vol[None, :, :P[0], :P[1], :P[2]]))
+    sub = x[:, :, :P[0] // 2, :P[1] // 2, :P[2] // 2]
     with torch.no_grad():
+        net(sub)                                    # cold: oneDNN primitive creation
         t0 = time.time()
-        net(x[:, :, :P[0] // 2, :P[1] // 2, :P[2] // 2])            # 1/8 of a patch forward: probe + warm-up
-        t_probe = time.time() - t0
-        if 8 * t_probe <= 4.0 * budget_s:       # the probe is cold (oneDNN primitive creation): generous
-            frac, sample = 1.0, 'one %dx%dx%d patch forward (1/%d of the volume)' % (P[0], P[1], P[2], 64 if tta else 8)
-            t0 = time.time()
-            ref = net(x).numpy()
-            t = time.time() - t0
-        else:
-            frac, sample, ref = 0.125, 'one %dx%dx%d sub-patch forward (1/8 patch), scaled x8' % (P[0] // 2, P[1] // 2, P[2] // 2), None
-            t0 = time.time()
-            net(x[:, :, :P[0] // 2, :P[1] // 2, :P[2] // 2])
-            t = time.time() - t0
-    forwards = 8 * (8 if tta else 1)
-    est = forwards * t / frac
-    out = dict(value=1.0 / est, unit='volumes/s', cores=cores, kind='port',
-               sample='%s, %.1f s, torch-CPU fp32 oracle on %d threads; forward only (aggregation excluded)' % (sample, t, cores))
+        net(sub)
+        t_probe = time.time() - t0                  # 1/8 of a patch forward, warm
+    npatch = 8
+    est_full = 8 * t_probe * (npatch + 1)
+    if mode == 'auto':
+        mode = 'full' if est_full <= 60.0 else 'sample'
+    mirrors = 8 if tta else 1
     parity = None
-    if ref is not None and gpu_patch_logits is not None:
-        def sm(a):
-            e = np.exp(a - a.max(1, keepdims=True))
-            return e / e.sum(1, keepdims=True)
-        margin = np.abs(ref[:, 1] - ref[:, 0])
+
+    def sm(a):
+        e = np.exp(a - a.max(1, keepdims=True))
+        return e / e.sum(1, keepdims=True)
+
+    if mode == 'full':
+        with torch.no_grad():
+            t0 = time.time()
+            ref_patch = net(x).numpy()              # warm-up at the real size (also the single-patch parity reference)
+            t_patch = time.time() - t0
+        fwd_s = [0.0]
+        orig = osw.mirror_and_predict
+
+        def timed_mirror(*a, **k):
+            t = time.time()
+            r = orig(*a, **k)
+            fwd_s[0] += time.time() - t
+            return r
+        osw.mirror_and_predict = timed_mirror
+        try:
+            t0 = time.time()
+            seg_o, prob_o = osw.predict_3d_tiled(net, vol, P, 0.5, False, True)
+            t_full = time.time() - t0
+        finally:
+            osw.mirror_and_predict = orig
+        t_est = t_full + (mirrors - 1) * fwd_s[0]
+        out = dict(value=1.0 / t_est, unit='volumes/s', cores=cores, kind='port',
+                   sample='whole %dx%dx%d volume WITHOUT mirroring, timed end to end after one warm-up patch forward: %.1f s '
+                          '(%d patch forwards %.1f s + padding/aggregation/argmax %.1f s) = %.4f volumes/s timed; '
+                          'the mirrored workload is 8x the forwards -> %.1f s per volume (that factor is the only '
+                          'extrapolation); torch-CPU fp32 oracle on %d threads'
+                          % (vol.shape[1], vol.shape[2], vol.shape[3], t_full, npatch, fwd_s[0], t_full - fwd_s[0],
+                             1.0 / t_full, t_est, cores),
+                   timed_no_mirroring=dict(value=1.0 / t_full, seconds=round(t_full, 2), forward_seconds=round(fwd_s[0], 2)))
+        if gpu_notta is not None:
+            seg_g, prob_g = gpu_notta
+            margin = np.abs(prob_o[1] - prob_o[0])
+            parity = dict(sample='whole volume, 8 tiles, Gaussian aggregation, no mirroring: HIP path vs oracle',
+                          max_abs_softmax_err=float(np.abs(prob_g - prob_o).max()),
+                          argmax_mismatches=int(((seg_g != seg_o) & (margin > 2e-4)).sum()),
+                          argmax_mismatches_any_margin=int((seg_g != seg_o).sum()),
+                          dice_vs_oracle_mask=float(osw.hard_dice_binary(seg_o, seg_g)))
+    else:
+        with torch.no_grad():
+            if 8 * t_probe <= 120.0:
+                t0 = time.time()
+                ref_patch = net(x).numpy()
+                t = time.time() - t0
+                frac, what = 1.0, 'one %dx%dx%d patch forward (1/%d of the volume)' % (P[0], P[1], P[2], npatch * mirrors)
+            else:
+                ref_patch, t, frac = None, t_probe, 0.125
+                what = 'one %dx%dx%d sub-patch forward (1/8 patch), scaled x8' % (P[0] // 2, P[1] // 2, P[2] // 2)
+        est = npatch * mirrors * t / frac
+        out = dict(value=1.0 / est, unit='volumes/s', cores=cores, kind='port',
+                   sample='%s, %.1f s, torch-CPU fp32 oracle on %d threads; forward only (aggregation excluded), '
+                          'extrapolated to %d forwards' % (what, t, cores, npatch * mirrors))
+    if parity is None and ref_patch is not None and gpu_patch_logits is not None:
+        margin = np.abs(ref_patch[:, 1] - ref_patch[:, 0])
         parity = dict(sample='first patch, no mirroring',
-                      max_abs_softmax_err=float(np.abs(sm(gpu_patch_logits) - sm(ref)).max()),
-                      argmax_mismatches=int(((gpu_patch_logits.argmax(1) != ref.argmax(1)) & (margin > 4e-4)).sum()))
+                      max_abs_softmax_err=float(np.abs(sm(gpu_patch_logits) - sm(ref_patch)).max()),
+                      argmax_mismatches=int(((gpu_patch_logits.argmax(1) != ref_patch.argmax(1)) & (margin > 4e-4)).sum()))
     return out, parity
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--tta', type=int, default=1, help='1: 8-fold mirroring as DeepWMH_predict; 0: --disable_tta')
-    ap.add_argument('--shape', type=int, nargs=3, default=[160, 192, 160])
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
-                    help='bf16 = BASELINE.json config 3 (bf16 matrix-core operands, fp32 accumulate/storage); not the headline number')
-    ap.add_argument('--storage', choices=['fp32', 'bf16'], default='fp32',
-                    help='bf16 (with --precision bf16): the full-resolution activation tensors are kept as bf16; not the headline number')
-    ap.add_argument('--shard', choices=['volumes', 'patches'], default='volumes',
-                    help='volumes: one volume per rank per step (weak scaling, no collective); patches: ONE volume per '
-                         'step, its patches split over the ranks with an RCCL all-gather of the weighted tiles (strong)')
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------------------
+# roofline block of the dominant kernel, per precision mode
+# ------------------------------------------------------------------------------------------------------------
+def roofline_block(timings, precision, storage, dt):
+    """timings: (cfg, start_event, end_event, algorithmic_flop, algorithmic_bytes) per launch of the dominant
+    kernel, HIP events recorded on the launch stream inside the timed region."""
+    tot_ms = sum(e0.elapsed_time(e1) for (_, e0, e1, _, _) in timings)
+    tot_flop = sum(f for (_, _, _, f, _) in timings)
+    tot_bytes = sum(b for (_, _, _, _, b) in timings)
+    nl = max(1, len(timings))
+    secs = tot_ms * 1e-3
+    tflops = tot_flop / secs / 1e12 if secs > 0 else 0.0
+    gbs = tot_bytes / secs / 1e9 if secs > 0 else 0.0
+    peak_t = PEAK_TFLOPS[precision]
+    # the roof that bounds this kernel = the larger of its two floor times
+    bound = 'mfma' if tot_flop / (peak_t * 1e12) >= tot_bytes / (HBM_PEAK_GBS * 1e9) else 'hbm'
+    traffic, traffic_note = None, None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            t = json.load(f)
+        t = t.get(mode_key(precision, storage), t if precision == 'fp32' else {})
+        traffic = t.get('traffic_bytes_per_launch')     # PMC counters cannot be read live: separate rocprofv3 passes
+        traffic_note = t.get('measured')
+    except Exception:
+        pass
+    r = dict(bound=bound, kernel=KERNEL_NAME[precision])
+    if bound == 'mfma':
+        r.update(achieved=round(tflops, 3), peak=peak_t, unit='TFLOP/s', frac=round(tflops / peak_t, 4))
+    else:
+        r.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
+    r.update(traffic=traffic, traffic_measured=traffic_note, launches=len(timings), avg_launch_ms=round(tot_ms / nl, 4),
+             algorithmic_gflop_per_launch=round(tot_flop / nl / 1e9, 3),
+             algorithmic_gbytes_per_launch=round(tot_bytes / nl / 1e9, 4),
+             mfma_frac=round(tflops / peak_t, 4), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
+             share_of_step_time=round(secs / dt, 4) if dt > 0 else None)
+    assert r['frac'] <= 1.0, 'roofline fraction above 1: wrong peak for this mode'
+    return r
 
+
+def workload_string(args, tta, forwards, world):
+    shp = '%dx%dx%d' % tuple(args.shape)
+    mir = 'mirroring (TTA x8) %s' % ('on' if tta else 'off')
+    if args.precision == 'fp32':
+        return ('configs[1]: one %s FLAIR volume per GPU, 128^3 patches, step 0.5, fp32, Gaussian aggregation, %s; '
+                '%d patch forwards per volume' % (shp, mir, forwards))
+    return ('configs[2]: bf16 forward (bf16 matrix-core operands, fp32 accumulate, %s activation tensors, fused '
+            'InstanceNorm+LeakyReLU), batch of %d synthetic %s volumes per step per GPU, 128^3 patches, step 0.5, Gaussian '
+            'aggregation, %s; %d patch forwards per volume'
+            % ('bf16' if args.storage == 'bf16' else 'fp32', args.volumes_per_step, shp, mir, forwards))
+
+
+# ------------------------------------------------------------------------------------------------------------
+def run_rank(args):
     import torch
     import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        print('bench.py: WORLD_SIZE=%d overrides --gpus %d' % (world, args.gpus), file=sys.stderr)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+
+    if args.dry_run:                                   # plumbing test: no device, no kernels
+        if world > 1:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.01)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if rank == 0:
+            print(json.dumps(dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=None,
+                                  unit='volumes/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                                  ms_per_step=1e3 * dt / args.steps, dry_run=True)), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
     from deepwmh_amd.network import UNetEngine
     from deepwmh_amd.plan import baseline_plan
     from deepwmh_amd.sliding_window import SlidingWindowPredictor
     from deepwmh_amd.synthetic import he_init_state_dict, synthetic_flair
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local_rank)                  # before the process group: RCCL binds to the current device
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL
     device = 'cuda:%d' % local_rank
 
@@ -110,14 +283,23 @@ def main():
     tta = bool(args.tta)
     pred = SlidingWindowPredictor(eng, do_mirroring=tta, batch=8)
     by_patch = args.shard == 'patches'
-    vol_h = synthetic_flair(tuple(args.shape), seed=0 if by_patch else rank)
-    vol = torch.from_numpy(vol_h).to(device)          # resident in HBM before the timed region
+    V = 1 if by_patch else args.volumes_per_step
+    vols_h = [torch.from_numpy(synthetic_flair(tuple(args.shape), seed=(0 if by_patch else rank * V + v))).pin_memory()
+              for v in range(V)]
+    seg_h = torch.empty(tuple(args.shape), dtype=torch.uint8).pin_memory()
+    vol_d = torch.empty((1,) + tuple(args.shape), dtype=torch.float32, device=device)
     if by_patch:
         from deepwmh_amd.distributed import HipTileBackend, PatchShardedPredictor
         sharded = PatchShardedPredictor(HipTileBackend(pred))
-        run_step = lambda: sharded.predict(vol)
-    else:
-        run_step = lambda: pred.predict_device(vol, return_prob=True)
+
+    def run_step():
+        """The boundary hands over host volumes and takes host label maps: both copies are part of the step."""
+        out = None
+        for v in range(V):
+            vol_d.copy_(vols_h[v], non_blocking=True)                  # H2D, stream ordered
+            out = sharded.predict(vol_d) if by_patch else pred.predict_device(vol_d, return_prob=True)
+            seg_h.copy_(out[0], non_blocking=True)                     # D2H of the label map
+        return out
 
     def barrier():
         if world > 1:
@@ -126,8 +308,11 @@ def main():
 
     for _ in range(args.warmup):
         run_step()
-    eng.timed_cfgs = {0}                               # dominant kernel: conv3d_k3 config 0
+    eng.timed_cfgs = {0}                               # dominant kernel: conv configuration 0 of either precision
     eng.timings = []
+    # algorithmic work queued in the timed region, counted by the engine per launch with the tensor formats of this mode
+    # (a layer reads its input once, writes its output once, + weights; fp32 mode: 4.17 GB per patch forward)
+    eng.acct = dict(flop=0.0, bytes=0.0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -135,64 +320,76 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     eng.timed_cfgs = set()
+    acct, eng.acct = eng.acct, None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # dominant-kernel roofline from HIP events recorded on the launch stream during the timed region
-    tot_ms = sum(e0.elapsed_time(e1) for (_, e0, e1, _, _) in eng.timings)
-    tot_flop = sum(f for (_, _, _, f, _) in eng.timings)
-    tot_bytes = sum(b for (_, _, _, _, b) in eng.timings)
-    nl = max(1, len(eng.timings))
-    achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
-            traffic = json.load(f)['traffic_bytes_per_launch']     # PMC counters cannot be read live: separate rocprofv3 passes
-    except Exception:
-        pass
-    roofline = dict(bound='mfma', kernel='conv3d_k3_ws_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM, wave-specialised)',
-                    achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
-                    launches=len(eng.timings), avg_launch_ms=round(tot_ms / nl, 4),
-                    algorithmic_gflop_per_launch=round(tot_flop / nl / 1e9, 3),
-                    algorithmic_gbytes_per_launch=round(tot_bytes / nl / 1e9, 4),
-                    share_of_step_time=round(tot_ms * 1e-3 / dt, 4))
+    roofline = roofline_block(eng.timings, args.precision, args.storage, dt)
 
     if rank == 0:
         forwards = 8 * (8 if tta else 1)
-        nvol = args.steps if by_patch else args.gpus * args.steps
+        nvol = args.steps if by_patch else world * args.steps * V
+        vols_rank = args.steps * V                      # volumes this rank queued in the timed region
+        gb_vol = acct['bytes'] / vols_rank / 1e9 + AGG_GBYTES_PER_VOLUME
+        dtype = ('f32' if args.precision == 'fp32' else
+                 'bf16 operands / f32 accumulate+storage' if args.storage == 'fp32' else
+                 'bf16 operands and activation tensors / f32 accumulate')
         res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=nvol / dt,
-                   unit='volumes/s', n_gpus=args.gpus, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='strong' if by_patch else 'weak', vs_baseline=None,
-                   dtype='f32' if args.precision == 'fp32' else ('bf16 operands / f32 accumulate+storage' if args.storage == 'fp32' else
-                                                                 'bf16 operands, bf16 full-resolution tensors / f32 accumulate'), data='synthetic',
-                   config=dict(workload='configs[1]: one %dx%dx%d FLAIR volume per GPU, 128^3 patches, step 0.5, fp32, '
-                                        'Gaussian aggregation, mirroring (TTA x8) %s; %d patch forwards per volume'
-                                        % (args.shape[0], args.shape[1], args.shape[2], 'on' if tta else 'off', forwards),
-                               tta=tta, patch=[128, 128, 128], step=0.5, batch=8, weights='random He-init (seed 0)',
+                   unit='volumes/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='strong' if by_patch else 'weak',
+                   vs_baseline=None, dtype=dtype, data='synthetic',
+                   config=dict(workload=workload_string(args, tta, forwards, world),
+                               tta=tta, patch=[128, 128, 128], step=0.5, batch=8, volumes_per_step=V,
+                               weights='random He-init (seed 0)',
+                               timed_region='volume H2D (19.7 MB, pinned) + hot path + label-map D2H (4.9 MB) per volume',
                                parallelism='patches of one volume sharded over ranks, RCCL all-gather of weighted tiles' if by_patch
                                else 'volumes sharded over ranks, no collective'),
                    end_to_end_tflops=round(forwards * FWD_GFLOP_PER_PATCH / 1e3 * nvol / dt, 2),
-                   # north_star's "fraction of the HBM roofline" for the whole path (algorithmic fp32 bytes; the fp32 path is
-                   # bound by the matrix cores, see roofline below and DESIGN.md 3.1)
-                   hbm_whole_path=dict(algorithmic_gbytes_per_volume=round(forwards * FWD_GBYTES_PER_PATCH + AGG_GBYTES_PER_VOLUME, 2),
-                                       achieved_gbs=round((forwards * FWD_GBYTES_PER_PATCH + AGG_GBYTES_PER_VOLUME) * nvol / dt, 1),
-                                       peak_gbs=HBM_PEAK_GBS,
-                                       frac=round((forwards * FWD_GBYTES_PER_PATCH + AGG_GBYTES_PER_VOLUME) * nvol / dt / HBM_PEAK_GBS, 4)),
+                   counted_gflop_per_patch_forward=round(acct['flop'] / vols_rank / forwards / 1e9, 2),
+                   # north_star's "fraction of the HBM roofline" for the whole path (algorithmic bytes of this mode)
+                   hbm_whole_path=dict(algorithmic_gbytes_per_volume=round(gb_vol, 2),
+                                       achieved_gbs=round(gb_vol * nvol / dt, 1), peak_gbs=HBM_PEAK_GBS,
+                                       frac=round(gb_vol * nvol / dt / HBM_PEAK_GBS, 4)),
                    roofline=roofline)
-        if args.gpus == 1 and not args.no_cpu_baseline:
-            # first patch, no mirroring, for the parity figure reported next to the baseline
-            from deepwmh_amd import _lib
+        if args.precision != 'fp32':
+            # accuracy of the reduced-precision mode against the fp32 HIP path on the same volume (same weights)
+            eng32 = UNetEngine(plan, sd, device)
+            pred32 = SlidingWindowPredictor(eng32, do_mirroring=tta, batch=8)
+            vol_d.copy_(vols_h[0])
+            s16, p16 = pred.predict_device(vol_d, return_prob=True)
+            s16, p16 = s16.clone(), p16.clone()
+            s32, p32 = pred32.predict_device(vol_d, return_prob=True)
+            inter = float(((s16 > 0) & (s32 > 0)).sum())
+            res['parity_vs_fp32_path'] = dict(
+                max_abs_softmax_diff=float((p16 - p32).abs().max()),
+                voxels_changing_class=int((s16 != s32).sum()), voxels=int(s32.numel()),
+                dice_vs_fp32_mask=2 * inter / (float((s16 > 0).sum()) + float((s32 > 0).sum()) + 1e-6))
+            del eng32, pred32
+        if world == 1 and args.cpu_baseline != 'off':
             P = plan.patch_size
-            x = vol[None, :, :P[0], :P[1], :P[2]].contiguous()
-            lg = eng.forward_logits(x).cpu().numpy()
-            res['cpu_baseline'], res['parity'] = cpu_baseline(plan, sd, vol_h, tta, lg)
+            vol_d.copy_(vols_h[0])
+            eng32 = eng if args.precision == 'fp32' else UNetEngine(plan, sd, device)
+            x = vol_d[None, :, :P[0], :P[1], :P[2]].contiguous()
+            lg = eng32.forward_logits(x).cpu().numpy()
+            p_nt = SlidingWindowPredictor(eng32, do_mirroring=False, batch=8)
+            seg_nt, prob_nt = p_nt.predict_device(vol_d, return_prob=True)
+            gpu_nt = (seg_nt.cpu().numpy(), prob_nt.cpu().numpy())
+            res['cpu_baseline'], res['parity'] = cpu_baseline(plan, sd, vols_h[0].numpy(), tta, args.cpu_baseline, gpu_nt, lg)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(argv)
+    return run_rank(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

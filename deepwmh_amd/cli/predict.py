@@ -9,9 +9,16 @@ and the environment contract RESULTS_FOLDER / CUDA_VISIBLE_DEVICES (predict.py:1
 `--selected_cases` and `--save_softmax` follow the fork's semantics: only the listed cases are predicted;
 `--save_softmax` additionally writes channel 0 (background probability) as <case>_0.nii.gz
 (DCNN_multistage.py:340-344,359).  Errors exit non-zero (external_call.py:64-72 aborts the pipeline).
+
+Multi-GPU extension (the reference passes exactly one GPU id, predict.py:150): with
+`MI355WMH_GPUS=0-7` (or `0,2,5`, or `all`) in the environment this process does not touch a GPU at all.  It
+starts one child `nnUNet_predict` per GPU with `CUDA_VISIBLE_DEVICES=<id>` and nnU-Net's own `--part_id r
+--num_parts N`, so that the cases are sharded over the GPUs with no data-path collective, waits, and exits
+non-zero if any child did.
 """
 import argparse
 import os
+import subprocess
 import sys
 import time
 
@@ -45,7 +52,85 @@ def build_parser():
     return ap
 
 
+def parse_gpu_list(spec):
+    """'0-7' -> [0..7]; '0,2,5' -> [0,2,5]; '1' -> [1]; 'all' -> every visible device; ''/None -> [].  An id may repeat
+    ('0,0'): that many processes then share the GPU."""
+    if spec is None or not spec.strip():
+        return []
+    spec = spec.strip()
+    if spec == 'all':
+        import torch                                   # counting devices does not initialise the HIP runtime
+        return list(range(torch.cuda.device_count()))
+    ids = []
+    for part in spec.split(','):
+        part = part.strip()
+        if '-' in part:
+            lo, hi = part.split('-')
+            lo, hi = int(lo), int(hi)
+            if hi < lo:
+                raise ValueError('MI355WMH_GPUS: empty range %r' % part)
+            ids += list(range(lo, hi + 1))
+        elif part:
+            ids.append(int(part))
+    if any(i < 0 for i in ids):
+        raise ValueError('MI355WMH_GPUS: negative GPU id in %r' % spec)
+    return ids
+
+
+def list_cases(input_folder, selected):
+    """Case ids of the input folder (files <case>_0000.nii.gz), restricted to --selected_cases (fork-only flag; the
+    reference pads the list with extra spaces, DCNN_multistage.py:327-333, hence the empty-string filter)."""
+    files = sorted(f for f in os.listdir(input_folder) if f.endswith('_0000.nii.gz'))
+    cases = [f[:-len('_0000.nii.gz')] for f in files]
+    if selected:
+        wanted = [c for c in selected if c]
+        missing = [c for c in wanted if c not in cases]
+        if missing:
+            sys.exit('selected cases not found in %s: %s' % (input_folder, ' '.join(missing)))
+        cases = [c for c in cases if c in wanted]
+    return cases
+
+
+def fan_out(argv, gpus, ncases, child_cmd=None, poll_s=0.05):
+    """Parent of a multi-GPU prediction: one child per GPU, case sharding by --part_id/--num_parts.  The parent never
+    initialises a GPU.  Returns the exit code: 0 if every child returned 0, else the first failing child's code (the
+    other children are terminated -- the reference aborts its pipeline on the first failed command,
+    /root/reference/deepwmh/utilities/external_call.py:64-72)."""
+    n = max(1, min(len(gpus), ncases))
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    child_cmd = child_cmd or [sys.executable, '-m', 'deepwmh_amd.cli.predict']
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.pop('MI355WMH_GPUS', None)                          # the children are plain single-GPU runs
+        env['CUDA_VISIBLE_DEVICES'] = str(gpus[r])              # the reference's own convention (predict.py:150-152)
+        env.pop('HIP_VISIBLE_DEVICES', None)
+        env.pop('ROCR_VISIBLE_DEVICES', None)
+        env['PYTHONPATH'] = root + (os.pathsep + env['PYTHONPATH'] if env.get('PYTHONPATH') else '')
+        cmd = list(child_cmd) + list(argv) + ['--part_id', str(r), '--num_parts', str(n)]
+        procs.append((r, gpus[r], subprocess.Popen(cmd, env=env)))
+    print('deepwmh_amd nnUNet_predict: %d case(s) over %d GPU(s) %s' % (ncases, n, [g for _, g, _ in procs]), flush=True)
+    rc_final, live = 0, list(procs)
+    while live:
+        for item in list(live):
+            r, g, p = item
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(item)
+            if rc != 0 and rc_final == 0:
+                rc_final = rc if rc > 0 else 1
+                print('deepwmh_amd nnUNet_predict: part %d on GPU %d exited with code %d; stopping the other parts'
+                      % (r, g, rc), file=sys.stderr, flush=True)
+                for _, _, q in live:
+                    q.terminate()
+        if live:
+            time.sleep(poll_s)
+    return rc_final
+
+
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = build_parser().parse_args(argv)
     if args.model != '3d_fullres':
         sys.exit('nnUNet_predict (deepwmh_amd): only -m 3d_fullres is implemented (DeepWMH uses nothing else)')
@@ -54,6 +139,11 @@ def main(argv=None):
     results = os.environ.get('RESULTS_FOLDER')
     if not results:
         sys.exit('RESULTS_FOLDER is not set')
+    gpus = parse_gpu_list(os.environ.get('MI355WMH_GPUS'))
+    if len(gpus) > 1 and args.num_parts == 1:
+        return fan_out(argv, gpus, len(list_cases(args.input_folder, args.selected_cases)))
+    if len(gpus) == 1 and args.num_parts == 1:
+        os.environ['CUDA_VISIBLE_DEVICES'] = str(gpus[0])       # before torch initialises the runtime
 
     import numpy as np
     import torch
@@ -78,15 +168,7 @@ def main(argv=None):
     eng = UNetEngine(plan, sd, 'cuda:0', precision=precision, storage=storage)   # CUDA_VISIBLE_DEVICES already selected the GPU (predict.py:150)
     pred = SlidingWindowPredictor(eng, plan.patch_size, args.step_size, True, not args.disable_tta, batch=8)
 
-    files = sorted(f for f in os.listdir(args.input_folder) if f.endswith('_0000.nii.gz'))
-    cases = [f[:-len('_0000.nii.gz')] for f in files]
-    if args.selected_cases:
-        wanted = [c for c in args.selected_cases if c]
-        missing = [c for c in wanted if c not in cases]
-        if missing:
-            sys.exit('selected cases not found in %s: %s' % (args.input_folder, ' '.join(missing)))
-        cases = [c for c in cases if c in wanted]
-    cases = cases[args.part_id::args.num_parts]
+    cases = list_cases(args.input_folder, args.selected_cases)[args.part_id::args.num_parts]
     os.makedirs(args.output_folder, exist_ok=True)
     nmod = plan.num_input_channels
     print('deepwmh_amd nnUNet_predict: task %s, checkpoint %s (epoch %s), %d case(s), mirroring %s'

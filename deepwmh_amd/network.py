@@ -106,6 +106,9 @@ class UNetEngine:
         # optional live kernel timing (bench.py): conv configs to bracket with HIP events on the launch stream
         self.timed_cfgs = set()
         self.timings = []          # (cfg, start_event, end_event, algorithmic_flop, algorithmic_bytes)
+        # optional accounting of the algorithmic work queued (bench.py): {'flop': .., 'bytes': ..} or None.  Bytes follow
+        # every layer reads its input once and writes its output once, plus its weights.
+        self.acct = None
 
     def _check_storage_supported(self):
         """storage='bf16' is served by specific kernel configurations (include/deepwmh_amd.h, the *_st calls): say so
@@ -196,13 +199,17 @@ class UNetEngine:
                 cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
                 _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws),
                 N, D, H, W, layer.cout, s, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd')
-        if timed:
-            e1.record()
+        if timed or self.acct is not None:
             vox = N * Do * Ho * Wo
-            flop = 2.0 * layer.cin * layer.cout * 27 * vox
+            flop = 2.0 * layer.cin * layer.cout * 9 * layer.kz * vox
             nbytes = ((2.0 if in16 else 4.0) * N * layer.cin * D * H * W + (2.0 if out16 else 4.0) * layer.cout * vox
-                      + 4.0 * layer.cout * layer.cin * 27)
-            self.timings.append((cfg, e0, e1, flop, nbytes))
+                      + (2.0 if use_bf16 else 4.0) * layer.cout * layer.cin * 9 * layer.kz)
+            if timed:
+                e1.record()
+                self.timings.append((cfg, e0, e1, flop, nbytes))
+            if self.acct is not None:
+                self.acct['flop'] += flop
+                self.acct['bytes'] += nbytes
         _lib.check(self.lib.wmh_instnorm_finalize(
             _lib.ptr(part), npart, _lib.ptr(layer.gamma), _lib.ptr(layer.beta), IN_EPS, _lib.ptr(ss), None,
             N, layer.cout, st), 'wmh_instnorm_finalize')
@@ -210,6 +217,10 @@ class UNetEngine:
 
     def _convT(self, key, w, wf, x, ss, cout, kt=2, out16=False):
         N, Cin, D, H, W = x.shape
+        if self.acct is not None:
+            self.acct['flop'] += 2.0 * Cin * cout * N * D * H * W * 4 * kt
+            self.acct['bytes'] += ((2.0 if x.dtype == torch.bfloat16 else 4.0) * x.numel()
+                                   + (2.0 if out16 else 4.0) * N * cout * D * H * W * 4 * kt + 4.0 * Cin * cout * 4 * kt)
         if out16:
             if (D * H * W) % 4 != 0:
                 raise ValueError("storage='bf16' needs D*H*W % 4 == 0 below the full-resolution level")

@@ -54,3 +54,41 @@ def test_nnunet_predict_cli_end_to_end(tmp_path, tiny_net, tiny_io):
     # a missing checkpoint must fail loudly (non-zero exit aborts the reference pipeline)
     bad = subprocess.run(shlex.split(cmd.replace('model_best', 'model_ep_0046')), env=env, capture_output=True, text=True)
     assert bad.returncode != 0
+
+
+def test_nnunet_predict_fans_out_over_MI355WMH_GPUS(tmp_path, tiny_net, tiny_io):
+    """The multi-GPU extension through the executable: MI355WMH_GPUS=0,0 makes the parent start two children (both on
+    this box's one GPU) with --part_id 0/1 --num_parts 2; together they must write exactly what one process writes."""
+    from deepwmh_amd import checkpoint as ck
+    from deepwmh_amd import nifti
+    plan, net, sd = tiny_net
+    model_dir = str(tmp_path / 'model')
+    plans = ck.make_plans(plan, spacing=(1.0, 1.0, 1.0), use_mask_for_norm=True)
+    ck.save_checkpoint(ck.trainer_folder(model_dir, 'Task002_FinalModel'), sd, plans, 'all', 'model_best', epoch=100)
+    img_dir = str(tmp_path / 'in')
+    os.makedirs(img_dir)
+    rng = np.random.default_rng(11)
+    names = ['s%02d' % i for i in range(5)]
+    for name in names:
+        vol = tiny_io['volume'][0] * 40 + 200 + rng.standard_normal((40, 48, 40)).astype(np.float32)
+        nifti.write(os.path.join(img_dir, name + '_0000.nii.gz'), vol.astype(np.float32), spacing=(1.0, 1.0, 1.0))
+    base = dict(os.environ, RESULTS_FOLDER=model_dir, PATH=os.path.join(ROOT, 'bin') + os.pathsep + os.environ['PATH'])
+    outs = {}
+    for key, extra in (('one', dict(CUDA_VISIBLE_DEVICES='0')), ('fan', dict(MI355WMH_GPUS='0,0'))):
+        out_dir = str(tmp_path / key)
+        cmd = 'nnUNet_predict -i %s -o %s -tr nnUNetTrainerV2 -m 3d_fullres -p nnUNetPlansv2.1 -t Task002_FinalModel -f all ' \
+              '-chk model_best --disable_post_processing' % (img_dir, out_dir)
+        env = dict(base, **extra)
+        env.pop('MI355WMH_GPUS', None) if key == 'one' else None
+        p = subprocess.run(shlex.split(cmd), env=env, capture_output=True, text=True)
+        print(p.stdout[-1500:], p.stderr[-1500:])
+        assert p.returncode == 0
+        if key == 'fan':
+            assert 'over 2 GPU(s)' in p.stdout and p.stdout.count('deepwmh_amd nnUNet_predict: task') == 2
+        outs[key] = {n: nifti.read(os.path.join(out_dir, n + '.nii.gz'))[0] for n in names}
+    for n in names:
+        assert np.array_equal(outs['one'][n], outs['fan'][n])
+    # a failing part fails the whole command
+    bad = subprocess.run(shlex.split(cmd.replace('model_best', 'model_ep_0046')), env=dict(base, MI355WMH_GPUS='0,0'),
+                         capture_output=True, text=True)
+    assert bad.returncode != 0

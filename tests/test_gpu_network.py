@@ -168,6 +168,72 @@ def test_full_size_patch_forward_vs_oracle():
     assert perr <= TOL and mism == 0
 
 
+@pytest.fixture(scope='module')
+def baseline_pair():
+    """BASELINE.json architecture (31.2 M parameters): the oracle net with trained-like parameters and the HIP engine
+    holding the same state dict."""
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.plan import baseline_plan
+    from oracle.generic_unet import unet_from_plan, perturb_like_trained, state_dict_numpy
+    torch.manual_seed(0)
+    plan = baseline_plan()
+    net = perturb_like_trained(unet_from_plan(plan), seed=2).eval()
+    net.do_ds = False
+    return plan, net, UNetEngine(plan, state_dict_numpy(net), 'cuda:0')
+
+
+@pytest.mark.timeout(1500)
+def test_configs1_full_volume_no_mirroring_vs_oracle(baseline_pair):
+    """configs[1] end to end at full size, the workload /root/reference/deepwmh/main/predict.py:153-156 launches (here with
+    `--disable_tta`, DCNN_multistage.py:331-336, so that the CPU oracle finishes in about a minute on the GPU box's host):
+    160x192x160 volume, 8 tiles of 128^3 at step 0.5, Gaussian aggregation, argmax -- HIP path vs `predict_3d_tiled`."""
+    import time
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    from oracle import sliding_window as osw
+    plan, net, eng = baseline_pair
+    vol = osw.synthetic_flair((160, 192, 160), seed=3)
+    seg, prob = SlidingWindowPredictor(eng, do_mirroring=False, batch=8).predict(vol)
+    t0 = time.time()
+    tiles = []
+    seg_o, prob_o = osw.predict_3d_tiled(net, vol, plan.patch_size, 0.5, False, True, patch_hook=lambda o, p: tiles.append(o))
+    t_cpu = time.time() - t0
+    assert tiles == [(x, y, z) for x in (0, 32) for y in (0, 64) for z in (0, 32)]          # SURVEY 8a row a9
+    err = float(np.abs(prob - prob_o).max())
+    mism, unsure = _mask_check(seg, seg_o, prob_o)
+    dice = osw.hard_dice_binary(seg_o, seg)
+    print('configs[1] volume, no mirroring: max|softmax err| %.3g, argmax mismatches %d (+%d voxels inside the %.0e margin band, '
+          '%d of them differing), Dice vs oracle mask %.7f, foreground voxels %d; CPU oracle %.1f s on %d threads'
+          % (err, mism, unsure, 2 * TOL, int((seg != seg_o).sum()) - mism, dice, int(seg_o.sum()), t_cpu, torch.get_num_threads()))
+    assert seg.shape == seg_o.shape == (160, 192, 160)
+    assert err <= TOL and mism == 0
+    assert int((seg != seg_o).sum()) == 0 or dice > 0.99999
+
+
+@pytest.mark.timeout(1500)
+def test_configs1_full_patch_all_mirrors_vs_oracle(baseline_pair):
+    """One 128^3 patch through all 8 mirrored forwards of the 31 M-parameter net against `mirror_and_predict`
+    (nnU-Net `_internal_maybe_mirror_and_pred_3D`): the mirror order, the un-flip and the 1/8 averaging at full width."""
+    import time
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    from oracle import sliding_window as osw
+    plan, net, eng = baseline_pair
+    vol = osw.synthetic_flair((128, 128, 128), seed=4)
+    seg, prob = SlidingWindowPredictor(eng, do_mirroring=True, batch=8).predict(vol)       # one tile: no Gaussian weighting
+    t0 = time.time()
+    ref = osw.mirror_and_predict(net, torch.from_numpy(vol[None]), True, None)[0].numpy()
+    t_cpu = time.time() - t0
+    seg_o = ref.argmax(0).astype(np.uint8)
+    err = float(np.abs(prob - ref).max())
+    mism, unsure = _mask_check(seg, seg_o, ref)
+    dice = osw.hard_dice_binary(seg_o, seg)
+    print('full-width patch, 8 mirrors: max|softmax err| %.3g, argmax mismatches %d (%d voxels in the margin band), Dice %.7f; '
+          'CPU oracle %.1f s' % (err, mism, unsure, dice, t_cpu))
+    assert err <= TOL and mism == 0 and dice > 0.99999
+    # and the mirrored result differs from the un-mirrored one by far more than the tolerance (the test has teeth)
+    _, p0 = SlidingWindowPredictor(eng, do_mirroring=False).predict(vol)
+    assert float(np.abs(p0 - ref).max()) > 10 * TOL
+
+
 def test_full_size_volume_properties():
     """BASELINE.json configs[1] at full size (160x192x160, 128^3 patches, mirroring): size-independent properties, since the
     CPU oracle needs minutes for this volume.  (1) determinism: two runs give the same bits; (2) every voxel's class
