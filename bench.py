@@ -110,27 +110,27 @@ def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits):
     P = plan.patch_size
     x = torch.from_numpy(np.ascontiguousarray(vol[None, :, :P[0], :P[1], :P[2]]))
     sub = x[:, :, :P[0] // 2, :P[1] // 2, :P[2] // 2]
+    npatch, mirrors, parity = 8, (8 if tta else 1), None
     with torch.no_grad():
         net(sub)                                    # cold: oneDNN primitive creation
         t0 = time.time()
         net(sub)
-        t_probe = time.time() - t0                  # 1/8 of a patch forward, warm
-    npatch = 8
-    est_full = 8 * t_probe * (npatch + 1)
-    if mode == 'auto':
-        mode = 'full' if est_full <= 60.0 else 'sample'
-    mirrors = 8 if tta else 1
-    parity = None
+        t_probe = time.time() - t0                  # 1/8 of a patch forward, warm (scales badly on many-core hosts: a bound only)
 
     def sm(a):
         e = np.exp(a - a.max(1, keepdims=True))
         return e / e.sum(1, keepdims=True)
 
-    if mode == 'full':
+    ref_patch = t_patch = None
+    if mode != 'sample' or 8 * t_probe <= 120.0:
         with torch.no_grad():
             t0 = time.time()
-            ref_patch = net(x).numpy()              # warm-up at the real size (also the single-patch parity reference)
+            ref_patch = net(x).numpy()              # one whole patch forward: the sample, and the warm-up of the full run
             t_patch = time.time() - t0
+    if mode == 'auto':                              # whole volume when it fits in about two minutes of host time
+        mode = 'full' if npatch * t_patch <= 120.0 else 'sample'
+
+    if mode == 'full':
         fwd_s = [0.0]
         orig = osw.mirror_and_predict
 
@@ -164,15 +164,12 @@ def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits):
                           argmax_mismatches_any_margin=int((seg_g != seg_o).sum()),
                           dice_vs_oracle_mask=float(osw.hard_dice_binary(seg_o, seg_g)))
     else:
-        with torch.no_grad():
-            if 8 * t_probe <= 120.0:
-                t0 = time.time()
-                ref_patch = net(x).numpy()
-                t = time.time() - t0
-                frac, what = 1.0, 'one %dx%dx%d patch forward (1/%d of the volume)' % (P[0], P[1], P[2], npatch * mirrors)
-            else:
-                ref_patch, t, frac = None, t_probe, 0.125
-                what = 'one %dx%dx%d sub-patch forward (1/8 patch), scaled x8' % (P[0] // 2, P[1] // 2, P[2] // 2)
+        if t_patch is not None:
+            t, frac = t_patch, 1.0
+            what = 'one %dx%dx%d patch forward (1/%d of the volume)' % (P[0], P[1], P[2], npatch * mirrors)
+        else:
+            t, frac = t_probe, 0.125
+            what = 'one %dx%dx%d sub-patch forward (1/8 patch), scaled x8' % (P[0] // 2, P[1] // 2, P[2] // 2)
         est = npatch * mirrors * t / frac
         out = dict(value=1.0 / est, unit='volumes/s', cores=cores, kind='port',
                    sample='%s, %.1f s, torch-CPU fp32 oracle on %d threads; forward only (aggregation excluded), '
