@@ -99,6 +99,20 @@ SIGNATURES = {
     'wmh_nll': (_i, [_vp, _vp, _i, _sz, _d, _i, _vp, _vp, _vp, _vp, _vp]),
     'wmh_median_filter_f64': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'wmh_component_filtering': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'wmh_cl_from_ncdhw': (_i, [_vp, _vp, _i, _i, _sz, _vp]),
+    'wmh_cl_to_ncdhw': (_i, [_vp, _vp, _i, _i, _sz, _vp]),
+    'wmh_cl_conv3_first_packed_halfs': (_sz, [_i]),
+    'wmh_cl_conv3_first_pack_weights': (_i, [_vp, _i, _vp]),
+    'wmh_cl_conv3_first_num_partials': (_i, [_i, _i, _i]),
+    'wmh_cl_conv3_first_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'wmh_cl_conv3_num_partials': (_i, [_i, _i, _i]),
+    'wmh_cl_conv3_fwd': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_cl_conv3s2_num_partials': (_i, [_i, _i, _i]),
+    'wmh_cl_conv3s2_fwd': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_cl_convT_packed_halfs': (_sz, [_i, _i]),
+    'wmh_cl_convT_pack_weights': (_i, [_vp, _i, _i, _vp]),
+    'wmh_cl_convT_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_cl_seghead_softmax_accumulate': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ip, _i, _ip, _f, _vp]),
     'wmh_selftest_mfma_32x32x2': (_i, [_vp, _vp, _vp, _vp]),
 }
 

@@ -72,8 +72,8 @@ class UNetEngine:
         tensors of nnU-Net's autocast predict; everything below the first pooling stays fp32."""
         if precision not in ('fp32', 'bf16'):
             raise ValueError('precision must be fp32 or bf16')
-        if storage not in ('fp32', 'bf16') or (storage == 'bf16' and precision != 'bf16'):
-            raise ValueError("storage must be 'fp32', or 'bf16' together with precision='bf16'")
+        if storage not in ('fp32', 'bf16', 'bf16_ncdhw') or (storage != 'fp32' and precision != 'bf16'):
+            raise ValueError("storage must be 'fp32', or 'bf16' / 'bf16_ncdhw' together with precision='bf16'")
         self.precision = precision
         self.storage = storage
         plan.check_supported()
@@ -100,8 +100,11 @@ class UNetEngine:
             convs = [_ConvLayer(self.lib, sd, c.name, c.cin, c.cout, 1, dev, c.kz, c.sz) for c in st['convs']]
             seg_w = torch.from_numpy(_np(sd[st['seg'] + '.weight']).reshape(plan.num_classes, cskip)).contiguous().to(dev)
             self.dec.append(dict(tu_w=tu_w, tu_wf=tu_wf, kt=kt, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
-        if storage == 'bf16':
+        if storage == 'bf16_ncdhw':
             self._check_storage_supported()
+        self.ncl = 0                                   # resolution levels held as channels-last bf16 tensors
+        if storage == 'bf16':
+            self._setup_channels_last(sd)
         self._bufs = {}
         # optional live kernel timing (bench.py): conv configs to bracket with HIP events on the launch stream
         self.timed_cfgs = set()
@@ -242,6 +245,164 @@ class UNetEngine:
                 self._stream()), 'wmh_convtranspose3d_k2s2_fwd')
         return y
 
+    # ---- channels-last bf16 levels (storage='bf16') ---------------------------------------------
+    def _setup_channels_last(self, sd):
+        """Decide which resolution levels run channels-last (rows of the level that are multiples of 32 voxels, isotropic
+        3x3x3 / 2x2x2 plan there) and pack the weights of their layers.  Fails at construction when level 0 cannot."""
+        plan = self.plan
+        W = int(plan.patch_size[2])
+        nlev = plan.num_pool + 1
+        ncl = 0
+        for lv in range(nlev):
+            iso = list(plan.conv_kernel_sizes[lv]) == [3, 3, 3] and (lv == 0 or list(plan.pool_op_kernel_sizes[lv - 1]) == [2, 2, 2])
+            wl = W >> lv
+            if not iso or wl < 32 or wl % 32 or (W % (1 << lv)):
+                break
+            ncl = lv + 1
+        problems = []
+        if ncl == 0:
+            problems.append('the last patch axis must be a multiple of 32 voxels and the first stage isotropic (3x3x3)')
+        if plan.num_input_channels != 1:
+            problems.append('one input modality (has %d)' % plan.num_input_channels)
+        feats = plan.features()
+        if any(f % 32 for f in feats[:max(ncl, 1)]):
+            problems.append('feature counts of the channels-last levels must be multiples of 32 (%s)' % feats[:ncl])
+        if plan.num_classes != 2 or feats[0] != 32:
+            problems.append('segmentation head kernel: 32 feature maps at full resolution and 2 classes')
+        if problems:
+            raise ValueError("storage='bf16' is not available for this plan: " + '; '.join(problems))
+        self.ncl = ncl
+        lib, dev = self.lib, self.device
+        e0 = self.enc[0]
+        wf = np.empty(lib.wmh_cl_conv3_first_packed_halfs(e0.cout), dtype=np.uint16)
+        _lib.check(lib.wmh_cl_conv3_first_pack_weights(e0.w_host.ctypes.data_as(C.c_void_p), e0.cout, wf.ctypes.data_as(C.c_void_p)),
+                   'wmh_cl_conv3_first_pack_weights')
+        self._cl_first_wf = torch.from_numpy(wf.view(np.int16)).to(dev)
+        nd = len(self.dec)
+        for u, st in enumerate(self.dec):
+            level = nd - 1 - u                     # level this stage up-samples TO
+            if level < ncl and level + 1 < ncl:    # both sides channels-last: the cl transposed convolution
+                tu_host = _np(sd['tu.%d.weight' % u])
+                wt = np.empty(lib.wmh_cl_convT_packed_halfs(st['cdown'], st['cskip']), dtype=np.uint16)
+                _lib.check(lib.wmh_cl_convT_pack_weights(tu_host.ctypes.data_as(C.c_void_p), st['cdown'], st['cskip'],
+                                                         wt.ctypes.data_as(C.c_void_p)), 'wmh_cl_convT_pack_weights')
+                st['tu_wf_cl'] = torch.from_numpy(wt.view(np.int16)).to(dev)
+
+    def _account(self, flop, nbytes):
+        if self.acct is not None:
+            self.acct['flop'] += flop
+            self.acct['bytes'] += nbytes
+
+    def _finalize(self, layer, part, npart, ss, N):
+        _lib.check(self.lib.wmh_instnorm_finalize(_lib.ptr(part), npart, _lib.ptr(layer.gamma), _lib.ptr(layer.beta), IN_EPS,
+                                                  _lib.ptr(ss), None, N, layer.cout, self._stream()), 'wmh_instnorm_finalize')
+
+    def _cl_conv(self, key, layer, x0, ss0, x1=None, ss1=None):
+        """x0 (x1): CL16 tensors [N, D, H, W, C] (torch.bfloat16).  Stride 1 (one or two sources) or stride 2 (one source)."""
+        N, D, H, W, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[4]
+        assert C0 + C1 == layer.cin and layer.kz == 3
+        lib = self.lib
+        s = layer.stride
+        Do, Ho, Wo = (D - 1) // s + 1, (H - 1) // s + 1, (W - 1) // s + 1
+        if s == 1:
+            npart = _lib.check(lib.wmh_cl_conv3_num_partials(D, H, W), 'wmh_cl_conv3_num_partials')
+        else:
+            assert x1 is None and layer.sz == 2
+            npart = _lib.check(lib.wmh_cl_conv3s2_num_partials(Do, Ho, Wo), 'wmh_cl_conv3s2_num_partials')
+        y = self._buf(key + '.ycl', (N, Do, Ho, Wo, layer.cout), torch.bfloat16)
+        part = self._buf(key + '.part', (N, layer.cout, npart, 4))
+        ss = self._buf(key + '.ss', (N, layer.cout, 2))
+        wf = layer.packed_bf16(0)
+        timed = 0 in self.timed_cfgs and s == 1
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if s == 1:
+            _lib.check(lib.wmh_cl_conv3_fwd(_lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wf),
+                                            _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part), N, D, H, W, layer.cout, LRELU_SLOPE,
+                                            self._stream()), 'wmh_cl_conv3_fwd')
+        else:
+            _lib.check(lib.wmh_cl_conv3s2_fwd(_lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y),
+                                              _lib.ptr(part), N, D, H, W, layer.cout, LRELU_SLOPE, self._stream()), 'wmh_cl_conv3s2_fwd')
+        vox = N * Do * Ho * Wo
+        flop = 2.0 * layer.cin * layer.cout * 27 * vox
+        nbytes = 2.0 * N * layer.cin * D * H * W + 2.0 * layer.cout * vox + 2.0 * layer.cout * layer.cin * 27
+        if timed:
+            e1.record()
+            self.timings.append((0, e0, e1, flop, nbytes))
+        self._account(flop, nbytes)
+        self._finalize(layer, part, npart, ss, N)
+        return y, ss
+
+    def _to_cl(self, key, x):
+        """NCDHW fp32 -> CL16 (level boundary; raw values, the pending scale/shift stays valid)."""
+        N, Cc, D, H, W = x.shape
+        y = self._buf(key + '.cl', (N, D, H, W, Cc), torch.bfloat16)
+        _lib.check(self.lib.wmh_cl_from_ncdhw(_lib.ptr(x), _lib.ptr(y), N, Cc, D * H * W, self._stream()), 'wmh_cl_from_ncdhw')
+        self._account(0.0, 6.0 * x.numel())
+        return y
+
+    def _from_cl(self, key, x):
+        N, D, H, W, Cc = x.shape
+        y = self._buf(key + '.nc', (N, Cc, D, H, W))
+        _lib.check(self.lib.wmh_cl_to_ncdhw(_lib.ptr(x), _lib.ptr(y), N, Cc, D * H * W, self._stream()), 'wmh_cl_to_ncdhw')
+        self._account(0.0, 6.0 * x.numel())
+        return y
+
+    def _forward_features_cl(self, x, deep_supervision=False):
+        """The forward graph with the first `ncl` resolution levels channels-last (see _setup_channels_last)."""
+        if deep_supervision:
+            raise NotImplementedError("storage='bf16' serves inference (the last segmentation head only)")
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.device == self.device
+        lib, ncl = self.lib, self.ncl
+        N, _, D, H, W = x.shape
+        nenc = len(self.enc)
+        skips = []
+        cur = cur_ss = None
+        for i, layer in enumerate(self.enc):
+            level = i // 2
+            if i == 0:
+                npart = _lib.check(lib.wmh_cl_conv3_first_num_partials(D, H, W), 'wmh_cl_conv3_first_num_partials')
+                cur = self._buf('enc0.ycl', (N, D, H, W, layer.cout), torch.bfloat16)
+                part = self._buf('enc0.part', (N, layer.cout, npart, 4))
+                cur_ss = self._buf('enc0.ss', (N, layer.cout, 2))
+                _lib.check(lib.wmh_cl_conv3_first_fwd(_lib.ptr(x), _lib.ptr(self._cl_first_wf), _lib.ptr(layer.bias), _lib.ptr(cur),
+                                                      _lib.ptr(part), N, D, H, W, layer.cout, self._stream()), 'wmh_cl_conv3_first_fwd')
+                self._account(2.0 * 27 * layer.cout * x.numel(), 4.0 * x.numel() + 2.0 * layer.cout * x.numel())
+                self._finalize(layer, part, npart, cur_ss, N)
+            elif level < ncl:
+                cur, cur_ss = self._cl_conv('enc%d' % i, layer, cur, cur_ss)
+            else:
+                if cur.dtype == torch.bfloat16:            # first layer below the channels-last levels
+                    cur = self._from_cl('enc%d.in' % i, cur)
+                cur, cur_ss = self._conv('enc%d' % i, layer, cur, cur_ss)
+            if i % 2 == 1 and i < nenc - 2:
+                skips.append((cur, cur_ss))
+        nd = len(self.dec)
+        outs = []
+        for u, st in enumerate(self.dec):
+            level = nd - 1 - u
+            skip, skip_ss = skips[-(u + 1)]
+            if level < ncl:
+                if cur.dtype == torch.bfloat16:
+                    Nn, Dd, Hh, Ww, Cc = cur.shape
+                    up = self._buf('tu%d.ycl' % u, (Nn, 2 * Dd, 2 * Hh, 2 * Ww, st['cskip']), torch.bfloat16)
+                    _lib.check(lib.wmh_cl_convT_fwd(_lib.ptr(cur), _lib.ptr(cur_ss), _lib.ptr(st['tu_wf_cl']), _lib.ptr(up), Nn, Cc,
+                                                    st['cskip'], Dd, Hh, Ww, LRELU_SLOPE, self._stream()), 'wmh_cl_convT_fwd')
+                    self._account(2.0 * Cc * st['cskip'] * 8 * Nn * Dd * Hh * Ww, 2.0 * cur.numel() + 2.0 * up.numel() + 2.0 * Cc * st['cskip'] * 8)
+                else:                                       # up-sampling out of the NCDHW levels
+                    up = self._to_cl('tu%d' % u, self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt']))
+                cur, cur_ss = self._cl_conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss)
+                cur, cur_ss = self._cl_conv('dec%d.1' % u, st['convs'][1], cur, cur_ss)
+            else:
+                up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt'])
+                cur, cur_ss = self._conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss)
+                cur, cur_ss = self._conv('dec%d.1' % u, st['convs'][1], cur, cur_ss)
+            if u == nd - 1:
+                outs.append((cur, cur_ss, st['seg_w']))
+        return outs
+
     # ---- graph ---------------------------------------------------------------------------------
     def forward_features(self, x, deep_supervision=False):
         """x: [N, Cin, P0, P1, P2] fp32 on the device.  Returns a list of (y, ss, seg_w) per decoder
@@ -251,7 +412,9 @@ class UNetEngine:
         cur, cur_ss = x, None
         skips = []
         nenc = len(self.enc)
-        st16 = self.storage == 'bf16'              # the two encoder and two decoder convolutions + the up-sampling of level 0
+        if self.ncl:
+            return self._forward_features_cl(x, deep_supervision)
+        st16 = self.storage == 'bf16_ncdhw'        # the two encoder and two decoder convolutions + the up-sampling of level 0
         for i, layer in enumerate(self.enc):
             cur, cur_ss = self._conv('enc%d' % i, layer, cur, cur_ss, out16=st16 and i < 2)
             if i % 2 == 1 and i < nenc - 2:
@@ -273,6 +436,8 @@ class UNetEngine:
         K = self.plan.num_classes
         res = []
         for (y, ss, seg_w) in outs:
+            if self.ncl:                               # channels-last feature map: through the NCDHW head kernel
+                y = self._from_cl('head.in', y)
             N, Cc = y.shape[:2]
             sp = int(np.prod(y.shape[2:]))
             lg = torch.empty((N, K) + tuple(y.shape[2:]), dtype=torch.float32, device=self.device)

@@ -367,6 +367,46 @@ int wmh_component_filtering(const uint8_t* mask, uint8_t* out, uint8_t* scratch_
                             unsigned long long* best, int D, int H, int W, const int* do_filter3, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Channels-last bf16 tensors ("CL16": [n][z][y][x][c], c fastest, bf16 bit patterns, 16-byte aligned) -- the
+ * storage='bf16' form of the bf16 inference configuration (BASELINE.json configs[2]: "bf16 forward, fused
+ * InstanceNorm+LeakyReLU"; the reference reaches its reduced-precision forward through nnU-Net's autocast predict,
+ * [nnU-Net neural_network.py::predict_3D(mixed_precision=True), not in tree], called at
+ * /root/reference/deepwmh/main/predict.py:153-156).  Same contract as the NCDHW calls above: a tensor holds RAW
+ * convolution outputs, its InstanceNorm+LeakyReLU is a per-(n, c) {scale, shift} table applied by the consumer; the
+ * moment records come from the fp32 accumulators and go through wmh_instnorm_finalize unchanged.  Served shapes:
+ * rows (last axis) that are multiples of 32 voxels, input channels % 16 == 0, output channels % 32 == 0; anything else
+ * fails with WMH_EINVAL (the levels with shorter rows stay on the NCDHW kernels, converted at the boundary).
+ * ------------------------------------------------------------------------------------------- */
+int wmh_cl_from_ncdhw(const float* x_ncdhw, void* y_cl16, int N, int C, size_t spatial, void* stream);      /* C % 8 == 0 */
+int wmh_cl_to_ncdhw(const void* x_cl16, float* y_ncdhw, int N, int C, size_t spatial, void* stream);
+/* First convolution of the network: ONE input channel, fp32 NCDHW patches (nothing pending on them) -> CL16. */
+size_t wmh_cl_conv3_first_packed_halfs(int Cout);
+int wmh_cl_conv3_first_pack_weights(const float* w /* [Cout][1][3][3][3] */, int Cout, uint16_t* wf);
+int wmh_cl_conv3_first_num_partials(int D, int H, int W);
+int wmh_cl_conv3_first_fwd(const float* x, const uint16_t* wf, const float* bias, void* y, float* partials, int N, int D,
+                           int H, int W, int Cout, void* stream);
+/* Conv3d 3x3x3, stride 1 (x1 == NULL) or the decoder's two-source form (the torch.cat of Generic_UNet.forward is never
+ * materialised).  wf: the bf16 fragment image of wmh_conv3d_k3_pack_weights_bf16(cfg 0, ...). */
+int wmh_cl_conv3_num_partials(int D, int H, int W);
+int wmh_cl_conv3_fwd(const void* x0, const float* ss0, int C0, const void* x1, const float* ss1, int C1,
+                     const uint16_t* wf, const float* bias, void* y, float* partials, int N, int D, int H, int W,
+                     int Cout, float lrelu_slope, void* stream);
+/* Conv3d 3x3x3, stride 2, padding 1 (the first convolution of an encoder stage): x [N][D][H][W][Cin] ->
+ * y [N][(D+1)/2][(H+1)/2][W/2][Cout]; W % 64 == 0.  wf: image of wmh_conv3d_k3_pack_weights_bf16(cfg 0, ...). */
+int wmh_cl_conv3s2_num_partials(int Do, int Ho, int Wo);
+int wmh_cl_conv3s2_fwd(const void* x, const float* ss, int Cin, const uint16_t* wf, const float* bias, void* y,
+                       float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
+/* ConvTranspose3d kernel 2 stride 2 without bias: x [N][D][H][W][Cin] -> y [N][2D][2H][2W][Cout]; D*H*W % 32 == 0. */
+size_t wmh_cl_convT_packed_halfs(int Cin, int Cout);
+int wmh_cl_convT_pack_weights(const float* w /* [Cin][Cout][2][2][2] */, int Cin, int Cout, uint16_t* wf);
+int wmh_cl_convT_fwd(const void* x, const float* ss, const uint16_t* wf, void* y, int N, int Cin, int Cout, int D, int H,
+                     int W, float lrelu_slope, void* stream);
+/* wmh_seghead_softmax_accumulate on a CL16 feature map x [n][P0][P1][P2][C] (C = 32, K = 2). */
+int wmh_cl_seghead_softmax_accumulate(const void* x, const float* ss, const float* wseg, int K, const float* gauss,
+                                      float* agg, int C, int P0, int P1, int P2, int A0, int A1, int A2,
+                                      const int* origin, int n, const int* flips, float lrelu_slope, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Self-test helper: D = A(32x2) * B(2x32) through one v_mfma_f32_32x32x2_f32, used by the GPU
  * tests to pin the fragment layout this library assumes (a: [32][2], b: [2][32], d: [32][32]).
  * ------------------------------------------------------------------------------------------- */

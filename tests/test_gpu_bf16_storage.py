@@ -1,4 +1,5 @@
-"""bf16 TENSORS at the full-resolution level (storage='bf16' of the bf16 inference configuration), through the C ABI.
+"""NCDHW bf16 TENSORS at the full-resolution level (round 1's storage mode, now storage='bf16_ncdhw'; storage='bf16' is the
+channels-last form, tests/test_gpu_cl.py), through the C ABI.
 
 Every "_st" call is the plain call with a format flag per side, so the bar is bit-exactness against the plain call:
   y_bf16: the stored tensor equals the fp32 result rounded to bf16 (round to nearest even = torch's cast), the
@@ -233,25 +234,25 @@ def test_engine_with_bf16_storage_close_to_oracle():
         ref = torch.softmax(net(x), 1)
     seg_o, prob_o = osw.predict_3d_tiled(net, vol, plan.patch_size, 0.5, True, True)
     res = {}
-    for storage in ('fp32', 'bf16'):
+    for storage in ('fp32', 'bf16_ncdhw'):
         eng = UNetEngine(plan, sd, 'cuda:0', precision='bf16', storage=storage)
         feats = eng.forward_features(x.cuda())
-        assert feats[-1][0].dtype == (torch.bfloat16 if storage == 'bf16' else torch.float32)
+        assert feats[-1][0].dtype == (torch.bfloat16 if storage == 'bf16_ncdhw' else torch.float32)
         sm = torch.softmax(eng.forward_logits(x.cuda()), 1).cpu()
         seg, prob = SlidingWindowPredictor(eng, do_mirroring=True).predict(vol)
         res[storage] = (sm, seg, prob)
-    d_or = float((res['bf16'][0] - ref).abs().max())
-    d_st = float((res['bf16'][0] - res['fp32'][0]).abs().max())
-    p_or = float(np.abs(res['bf16'][2] - prob_o).max())
-    dice = osw.hard_dice_binary(seg_o, res['bf16'][1])
+    d_or = float((res['bf16_ncdhw'][0] - ref).abs().max())
+    d_st = float((res['bf16_ncdhw'][0] - res['fp32'][0]).abs().max())
+    p_or = float(np.abs(res['bf16_ncdhw'][2] - prob_o).max())
+    dice = osw.hard_dice_binary(seg_o, res['bf16_ncdhw'][1])
     print('bf16 storage: softmax max abs vs oracle %.3g, vs fp32 storage %.3g; tiled+mirrored vs oracle %.3g, Dice %.5f' % (d_or, d_st, p_or, dice))
     assert d_or < 5e-2 and d_st < 5e-2 and p_or < 5e-2 and dice > 0.98
     with pytest.raises(ValueError):
-        UNetEngine(plan, sd, 'cuda:0', precision='fp32', storage='bf16')
+        UNetEngine(plan, sd, 'cuda:0', precision='fp32', storage='bf16_ncdhw')
 
 
 def test_storage_mode_is_refused_up_front_for_plans_it_does_not_serve(tiny_net):
     from deepwmh_amd.network import UNetEngine
     plan, _, sd = tiny_net                          # 4 feature maps at full resolution, 32-voxel rows
     with pytest.raises(ValueError, match='not available for this plan'):
-        UNetEngine(plan, sd, 'cuda:0', precision='bf16', storage='bf16')
+        UNetEngine(plan, sd, 'cuda:0', precision='bf16', storage='bf16_ncdhw')
