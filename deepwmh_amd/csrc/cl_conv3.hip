@@ -54,12 +54,12 @@ struct ClGeo {
     static constexpr int TZ = TZ_, TY = TY_, TX = 32;
     static constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
     static constexpr int NV = IZ * IY * IX;                       // halo voxels of a tile
-    static constexpr int LTH = 512;                               // loader threads (8 waves)
+    static constexpr int LTH = 448;                               // staging threads: 7 waves (the 8th loader wave moves the weights)
     static constexpr int NSLOT = (NV + LTH - 1) / LTH;            // voxels per loader lane (the last slot: only the waves below NVP)
     static constexpr int NVP = (NV + 63) / 64 * 64;               // plane stride: whole wave-instructions
     static constexpr int BUF = 2 * NVP * 16;                      // bytes of one activation buffer: [2 halves][NVP] x 16
     static constexpr int WQ = 27 * 64;                            // 16-byte weight pieces per chunk (one 32-cout tile)
-    static constexpr int WIT = (WQ + LTH - 1) / LTH;
+    static constexpr int WIT = WQ / 64;                           // per lane of the weight wave
     static constexpr int SCR = 4 * 256;                           // per consumer wave: bias and moment shift of its 2 x 16 rows
     static constexpr int LDS = 3 * BUF + WQ * 16 + SCR;           // + 2 scale/shift tables of 8 bytes per input channel (launcher)
     static_assert((NSLOT - 1) * LTH < NVP && NVP <= NSLOT * LTH, "slot split");
@@ -103,8 +103,39 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
     for (int v = blockIdx.x; v < T; v += gridDim.x) ++ntiles_mine;
     const int total = ntiles_mine * nch;                    // chunk iterations of this workgroup
 
-    if (loader) {
-        // ================================ loader waves =====================================================
+    if (wave == 11) {
+        // ================================ weight wave ======================================================
+        // One wave moves the weight fragments: chunk it+1's 27 KB ride in its registers (27 x 16 bytes per lane) while chunk it
+        // is consumed, and drop into the single LDS weight buffer between the two barriers of the chunk.  It issues ordinary
+        // loads ONLY and the staging waves LDS-DMA ONLY: s_waitcnt vmcnt(N) counts the two kinds together but they do not
+        // complete in one order, so a counted wait over a mix does not say which operations are still out (as one stream,
+        // "all but the N youngest" let a chunk's DMA pass as landed while it was not -- rare garbage tiles at full size).
+        cl_u32x4 wst[WIT];
+        int kw_ = 0, cw = 0, g_w = 0;
+        auto locate_w = [&]() __attribute__((always_inline)) { int tx, ty, tz, n0; tile_of(kw_, g_w, tx, ty, tz, n0); };
+        auto issue_w = [&]() __attribute__((always_inline)) {
+            const cl_u32x4* wsrc = reinterpret_cast<const cl_u32x4*>(a.wf) + ((size_t)g_w * nch + cw) * WQ + lane;
+#pragma unroll
+            for (int i = 0; i < WIT; ++i) wst[i] = wsrc[i * 64];
+        };
+        auto write_w = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < WIT; ++i) reinterpret_cast<cl_u32x4*>(wlds)[i * 64 + lane] = wst[i];
+        };
+        locate_w();
+        CL_BARRIER();                                        // (the staging waves' table barrier)
+        issue_w();
+        write_w();
+        CL_BARRIER();
+        for (int it = 0; it < total; ++it) {
+            if (kw_ * nch + cw + 1 < total && ++cw == nch) { cw = 0; ++kw_; locate_w(); }
+            issue_w();                                       // chunk it+1 (the last iteration repeats the last chunk)
+            CL_BARRIER();                                    // consumers are done with chunk `it`: its weights may go
+            write_w();
+            CL_BARRIER();
+        }
+    } else if (loader) {
+        // ================================ staging waves ====================================================
         if (!CL_ABL(6)) __builtin_amdgcn_s_setprio(2);       // ahead of the MFMA-issuing consumer on the same SIMD
         const int lt = tid - 256;
         const int lw = wave - 4;
@@ -123,7 +154,7 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         // Three streams run over this workgroup's chunk sequence (tile-major, chunk-minor), each with its own (tile, chunk)
         // counter -- no division in the loop: DMA (chunk it+2), transform and weights (chunk it+1).
         int gv[NSLOT];                                       // DMA: voxel index inside the sample, clamped when outside the volume
-        int n_dma = 0, n_tr = 0, g_w = 0;
+        int n_dma = 0, n_tr = 0;
         unsigned keep_tr = 0;                                // transform: bit k = slot k's voxel is inside the volume
         int kd = 0, cd = 0, kt = 0, ct = 0;                  // (tile, chunk) of the DMA stream and of the transform / weight stream
         auto inside = [&](int k, int z0, int y0, int x0) __attribute__((always_inline)) {
@@ -163,8 +194,8 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
             for (int k = 0; k < NSLOT; ++k) gv[k] = vb + (inside(k, z0, y0, x0) ? rel[k] : rel_center);
         };
         auto setup_tr = [&]() __attribute__((always_inline)) {
-            int tx, ty, tz;
-            tile_of(kt, g_w, tx, ty, tz, n_tr);
+            int g, tx, ty, tz;
+            tile_of(kt, g, tx, ty, tz, n_tr);
             const int z0 = tz * G::TZ - 1, y0 = ty * G::TY - 1, x0 = tx * G::TX - 1;
             keep_tr = 0;
 #pragma unroll
@@ -250,26 +281,6 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
                     }
             }
         };
-        // The next chunk's weight fragments ride in registers.  Their loads are inline asm on purpose: beside LDS-DMA in flight
-        // hipcc waits vmcnt(0) before the first use of an ordinary load's result, i.e. it would drain the DMA issued behind
-        // the weights at every chunk; hidden from it, the wait is the exact count (the DMAs issued since stay in flight).
-        cl_u32x4 wst[WIT];
-        auto issue_w = [&]() __attribute__((always_inline)) {                           // chunk ct of the weight stream's tile
-            const cl_u32x4* wsrc = reinterpret_cast<const cl_u32x4*>(a.wf) + ((size_t)g_w * nch + ct) * WQ;
-#pragma unroll
-            for (int i = 0; i < WIT; ++i) {
-                const cl_u32x4* p = wsrc + min(lt + i * LTH, WQ - 1);
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wst[i]) : "v"(p) : "memory");
-            }
-        };
-        // all but the NEWER youngest vector-memory operations have completed; names the staging registers so that nothing
-        // reads them before
-        static_assert(WIT == 4, "operand list of CL_WAIT_W");
-#define CL_WAIT_W(NEWER) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wst[0]), "+v"(wst[1]), "+v"(wst[2]), "+v"(wst[3]) : "n"(NEWER) : "memory")
-        auto write_w = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < WIT; ++i) { const int k = lt + i * LTH; if (WIT * LTH == WQ || k < WQ) reinterpret_cast<cl_u32x4*>(wlds)[k] = wst[i]; }
-        };
         // advance a stream by one chunk; false when it already stands on the last chunk (the streams then repeat it into
         // buffers nobody reads any more: the loop body stays branch-free)
         auto advance = [&](int& k, int& c) __attribute__((always_inline)) -> bool {
@@ -283,14 +294,11 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         CL_BARRIER();                                        // the first sample's scale / shift table is complete
         setup_tr();
         load_ss();
-        issue_w();
         dma(0);
         if (advance(kd, cd)) setup_dma();
         dma(1);
-        CL_WAIT_W(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" : CL_TQ_OPS :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS :: "memory");
         transform(0);
-        write_w();
         CL_BARRIER();
         int b_tr = 1, b_dma = 2;                             // buffers of chunk it+1 / it+2
 #ifdef WMH_CL_DIAG
@@ -300,23 +308,23 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
             CL_STAMP(t0);
             if (advance(kt, ct)) setup_tr();
             load_ss();
-            if (!CL_ABL(2)) issue_w();
             if (advance(kd, cd)) setup_dma();
             if (!CL_ABL(1)) dma(b_dma);
             CL_STAMP(t1);
-            // everything older than this iteration's WIT weight loads and 2*NSLOT DMAs has landed, i.e. chunk it+1's DMA
-            // (issued one iteration ago); a lane transforms exactly the pieces it fetched itself
-            if (last_slot) asm volatile("s_waitcnt vmcnt(%8)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS : "n"(WIT + 2 * NSLOT) : "memory");
-            else           asm volatile("s_waitcnt vmcnt(%8)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS : "n"(WIT + 2 * NSLOT - 2) : "memory");
+            // everything older than this iteration's DMAs has landed, i.e. chunk it+1's DMA (issued one iteration ago; this wave
+            // has nothing but LDS-DMA in flight, which completes in issue order); a lane transforms exactly the pieces it fetched
+#ifdef WMH_CL_DRAIN
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS :: "memory");
+#else
+            if (last_slot) asm volatile("s_waitcnt vmcnt(%8)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS : "n"(2 * NSLOT) : "memory");
+            else           asm volatile("s_waitcnt vmcnt(%8)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS : "n"(2 * NSLOT - 2) : "memory");
+#endif
             CL_STAMP(t2);
             if (!CL_ABL(3)) transform(b_tr);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             CL_STAMP(t3);
             CL_BARRIER();                                    // consumers are done with chunk `it`: its weights may go
             CL_STAMP(t4);
-            if (last_slot) { CL_WAIT_W(2 * NSLOT); } else { CL_WAIT_W(2 * NSLOT - 2); }   // the weights have landed; chunk it+2's DMA stays in flight
-            write_w();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             CL_STAMP(t5);
             CL_BARRIER();
             CL_STAMP(t6);
@@ -415,9 +423,11 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
                                         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kr][kw], bv[kw], acc[m], 0, 0, 0);
                                 }
                                 const int nkd = iy + 1 < IY ? kd : kd + 1, niy = iy + 1 < IY ? iy + 1 : 0;      // next step
+                                if (!CL_ABL(7)) {
                                 if (nkd < 3) bv[kw] = *reinterpret_cast<const cl_bf16x8*>(cur + ((nkd * IY + niy) * IX + kw) * 16);
                                 if (iy + 1 <= 2) av[iy + 1][kw] = wl[(kd * 9 + (iy + 1) * 3 + kw) * 64];
                                 else if (iy == IY - 1 && kd < 2) av[0][kw] = wl[((kd + 1) * 9 + kw) * 64];
+                                } else if (iy + 1 <= 2) av[iy + 1][kw] = av[0][kw];
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                 }
@@ -565,16 +575,15 @@ struct ClConvS2Args {
 struct ClS2Geo {
     static constexpr int IZ = 5, IY = 5, IX = 65, NE = 33;        // NE: even positions of a row (0, 2, .., 64)
     static constexpr int NV = IZ * IY * IX, NVP = 1664, NSLOT = 7;  // NVP: multiple of 128 >= NV; slot 6 exists for waves 0-1
-    static constexpr int ACT = 2 * NVP * 16, WQ = 27 * 64, WIT = 7;  // weight slot 6 exists for waves 0-2
-    static constexpr int LDS = ACT + WQ * 16;
-    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+    static constexpr int ACT = 2 * NVP * 16, WQ = 27 * 64;
+    static constexpr int LDS = ACT;                               // the weights do not pass through LDS here (see the kernel)
+    static_assert(3 * LDS <= 160 * 1024, "three workgroups per CU");
 };
 
-__global__ __launch_bounds__(256, 2) void cl_conv3s2_kernel(const ClConvS2Args a) {
+__global__ __launch_bounds__(256, 3) void cl_conv3s2_kernel(const ClConvS2Args a) {
     using G = ClS2Geo;
     constexpr int IY = G::IY, IX = G::IX, NE = G::NE, NV = G::NV, NVP = G::NVP, NSLOT = G::NSLOT, WQ = G::WQ;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* wlds = lds + G::ACT;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int t = blockIdx.x;
@@ -606,7 +615,6 @@ __global__ __launch_bounds__(256, 2) void cl_conv3s2_kernel(const ClConvS2Args a
     const char* xbase = reinterpret_cast<const char*>(a.x) + (size_t)n * DHW * rowb;
     const int zz = wave >> 1, yy = wave & 1;                              // this wave's output row inside the tile
     const unsigned char* bbase = lds + (kh * NVP + ((2 * zz) * IY + 2 * yy) * IX + j) * 16;
-    const cl_bf16x8* wl = reinterpret_cast<const cl_bf16x8*>(wlds) + lane;
     static __device__ const float ident2s[2] = {1.f, 0.f};
     const bool has_ss = a.ss != nullptr;
     const float slope = has_ss ? a.slope : 1.f;
@@ -622,11 +630,13 @@ __global__ __launch_bounds__(256, 2) void cl_conv3s2_kernel(const ClConvS2Args a
                 for (int h = 0; h < 2; ++h)
                     __builtin_amdgcn_global_load_lds(CL_GLOBAL_PTR(src + off + 16 * h), CL_LDS_PTR(dst + (h * NVP + k * 256) * 16), 16, 0, 0);
             }
-        const char* wsrc = reinterpret_cast<const char*>(a.wf) + ((size_t)g * a.nchunks + ch) * WQ * 16 + tid * 16;
+        // A operands straight from global memory (the layer's whole weight image is a few hundred KB and every workgroup
+        // reads it: L2 hits): with 27 MFMAs per chunk their latency is cheap, and without a 27 KB weight buffer three
+        // workgroups fit a CU and hide each other's DMA latency.  kd = 0, 1 now (they land under the transform), kd = 2 later.
+        const cl_bf16x8* wg = reinterpret_cast<const cl_bf16x8*>(a.wf) + ((size_t)g * a.nchunks + ch) * WQ + lane;
+        cl_bf16x8 av[18];
 #pragma unroll
-        for (int i = 0; i < G::WIT; ++i)
-            if (i < G::WIT - 1 || wave < 3)
-                __builtin_amdgcn_global_load_lds(CL_GLOBAL_PTR(wsrc + i * 4096), CL_LDS_PTR(wlds + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        for (int t = 0; t < 18; ++t) av[t] = wg[t * 64];
         const float* tab = has_ss ? a.ss + ((size_t)n * a.Cin + 16 * ch) * 2 : ident2s;
         const int mul = has_ss ? 2 : 0;
         float sc[2][8], sh[2][8];
@@ -646,12 +656,15 @@ __global__ __launch_bounds__(256, 2) void cl_conv3s2_kernel(const ClConvS2Args a
                 }
             }
         CL_BARRIER();
+        cl_bf16x8 av2[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) av2[t] = wg[(18 + t) * 64];
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int kd = tap / 9, kr = (tap / 3) % 3, kw = tap % 3;
             const int posoff = kw == 0 ? 0 : (kw == 1 ? NE : 1);
             const cl_bf16x8 bv = *reinterpret_cast<const cl_bf16x8*>(bbase + ((kd * IY + kr) * IX + posoff) * 16);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[tap * 64], bv, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tap < 18 ? av[tap < 18 ? tap : 0] : av2[tap >= 18 ? tap - 18 : 0], bv, acc[0], 0, 0, 0);
         }
     }
     // ---- epilogue

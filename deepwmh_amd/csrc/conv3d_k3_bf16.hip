@@ -216,10 +216,21 @@ static inline unsigned short f2bf(float f) {
 // 512 x 64 outputs against 2400 per 1024 x 32).  Served by the wave-specialised kernel only.
 #define WMH_BF16_CFG_WIDE 21
 typedef ConvCfg<1, 32, 1, 4, 4, 1, 4, 2, 4, 6> BCfgW;
-static int bf16_nt(int cfg) { return cfg == 0 ? 1 : (cfg == 2 || cfg == WMH_BF16_CFG_WIDE) ? 2 : 0; }
+// The levels below 16-voxel rows and the strided convolutions into them (inference with bf16 operands: they hold ~2 ms of
+// fp32 matrix work per batch-8 forward of the BASELINE network, 1/8 of it on the bf16 instruction): the one-role kernel on
+// the fp32 kernel's tile geometries (configuration 3 with half the rows per tile: its stride-2 halo tile must fit LDS as
+// [voxel][16 channels]).  Configurations 6 / 7 (4-voxel rows, four samples per workgroup) stay on the fp32 instruction.
+typedef ConvCfg<2, 16, 2, 2, 8, 1, 2, 2, 2, 6> BCfg3;     // stride 2, 16-wide output, 2 x 8 x 16 outputs x 64 channels
+typedef ConvCfg<1, 8, 4, 4, 8, 1, 2, 1, 8, 6> BCfg4;      // stride 1, 8-wide
+typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 1, 2, 6> BCfg5;      // stride 2, 8-wide output
+static int bf16_nt(int cfg) { return (cfg == 0 || cfg == 4 || cfg == 5) ? 1 : (cfg == 2 || cfg == 3 || cfg == WMH_BF16_CFG_WIDE) ? 2 : 0; }
+static int bf16_stride(int cfg) { return (cfg == 3 || cfg == 5) ? 2 : 1; }
 struct BGeo { int TX, TY, TZ, WPS; };
 static BGeo bf16_geo(int cfg, bool w8) {
     if (cfg == WMH_BF16_CFG_WIDE) return BGeo{BCfgW::TX, BCfgW::TY, BCfgW::TZ, BCfgW::WPS};
+    if (cfg == 3) return BGeo{BCfg3::TX, BCfg3::TY, BCfg3::TZ, BCfg3::WPS};
+    if (cfg == 4) return BGeo{BCfg4::TX, BCfg4::TY, BCfg4::TZ, BCfg4::WPS};
+    if (cfg == 5) return BGeo{BCfg5::TX, BCfg5::TY, BCfg5::TZ, BCfg5::WPS};
     if (cfg == 0) return BGeo{BCfg0::TX, BCfg0::TY, BCfg0::TZ, w8 ? BCfg0w::WPS : BCfg0::WPS};
     return BGeo{BCfg2::TX, BCfg2::TY, BCfg2::TZ, w8 ? BCfg2w::WPS : BCfg2::WPS};
 }
@@ -236,7 +247,7 @@ extern "C" int wmh_conv3d_k3_bf16_supported(int cfg) { return bf16_nt(cfg) > 0; 
 extern "C" int wmh_conv3d_k3_num_partials_bf16(int cfg, int N, int Do, int Ho, int Wo) {
     if (!bf16_nt(cfg)) return wmh_fail(WMH_EINVAL, "num_partials_bf16: configuration has no bf16 kernel");
     (void)N;
-    const bool w8 = bf16_variant() != 0;
+    const bool w8 = bf16_variant() != 0 && (cfg == 0 || cfg == 2);
     const BGeo ge = bf16_geo(cfg, w8);
     return cdiv(Wo, ge.TX) * cdiv(Ho, ge.TY) * cdiv(Do, ge.TZ) * ge.WPS;
 }
@@ -320,11 +331,13 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     ConvArgs a;
     a.x0 = x0; a.ss0 = ss0; a.C0 = C0; a.x1 = x1; a.ss1 = ss1; a.C1 = C1;
     a.wf = reinterpret_cast<const float*>(wf); a.bias = bias; a.y = y; a.part = partials;
-    a.N = N; a.D = D; a.H = H; a.W = W; a.Do = D; a.Ho = H; a.Wo = W; a.Cout = Cout;
+    const int S = bf16_stride(cfg);                 // configurations 3 and 5 are the stride-2 ones: (D, H, W) is the INPUT extent
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Do = (D - 1) / S + 1; a.Ho = (H - 1) / S + 1; a.Wo = (W - 1) / S + 1; a.Cout = Cout;
     a.nchunks = (C1 > 0) ? (C0 / 16 + cdiv(C1, 16)) : cdiv(C0, 16);
-    const bool w8 = bf16_variant() != 0;
+    const bool small = cfg == 3 || cfg == 4 || cfg == 5;
+    const bool w8 = bf16_variant() != 0 && !small;
     const BGeo ge = bf16_geo(cfg, w8);
-    a.ntx = cdiv(W, ge.TX); a.nty = cdiv(H, ge.TY); a.ntz = cdiv(D, ge.TZ);
+    a.ntx = cdiv(a.Wo, ge.TX); a.nty = cdiv(a.Ho, ge.TY); a.ntz = cdiv(a.Do, ge.TZ);
     a.npart = a.ntx * a.nty * a.ntz * ge.WPS;
     a.slope = lrelu_slope;
     a.G = cdiv(Cout, 32 * NT);
@@ -339,6 +352,12 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     static const int use_ws = env_int("WMH_BF16_WS", 1);
     // the wave-specialised form loads aligned 16-byte quads: rows must start 16-byte aligned
     const bool quad_ok = (W % 4) == 0 && (size_t)16 * D * H * W * 4 < ((size_t)1 << 32) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && (!x1 || (reinterpret_cast<uintptr_t>(x1) & 15) == 0);
+    if (small) {
+        if (in16 || out16) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16_st: bf16 storage is served for configurations 0 and 21");
+        if (cfg == 3) return launch_bf16<BCfg3, 4>(a, (unsigned)nblk, st);
+        if (cfg == 4) return launch_bf16<BCfg4, 3>(a, (unsigned)nblk, st);
+        return launch_bf16<BCfg5, 4>(a, (unsigned)nblk, st);
+    }
     if (in16 || out16) {                          // bf16 tensors: only the wave-specialised kernel reads / writes them
         if (!quad_ok) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16_st: bf16 storage needs W % 4 == 0 and 16-byte aligned sources");
         return wmh_launch_conv_bf16_ws(cfg, a, st, in16, out16);

@@ -163,8 +163,11 @@ class UNetEngine:
         s = layer.stride
         Do, Ho, Wo = (D - 1) // layer.sz + 1, (H - 1) // s + 1, (W - 1) // s + 1
         cfg = _lib.check(self.lib.wmh_conv3d_config(layer.cin, layer.cout, D, H, W, layer.kz, layer.sz, s), 'wmh_conv3d_config')
-        use_bf16 = (self.precision == 'bf16' and s == 1 and layer.sz == 1 and layer.kz == 3 and self.lib.wmh_conv3d_k3_bf16_supported(cfg)
-                    and (C1 == 0 or C0 % 16 == 0))
+        # bf16 operands: every 3x3x3 configuration the library has a bf16 kernel for (stride 1: rows of >= 8 voxels; stride 2:
+        # output rows of 8 or 16 voxels; the stride-2 convolutions with longer rows are channels-last or stay fp32)
+        plain = not (in16 or out16)
+        use_bf16 = (self.precision == 'bf16' and layer.kz == 3 and layer.sz == s and (C1 == 0 or C0 % 16 == 0)
+                    and bool(self.lib.wmh_conv3d_k3_bf16_supported(cfg)) and (plain or (cfg == 0 and s == 1)))
         if use_bf16 and not (in16 or out16):       # wide tile for >= 64 output channels (bf16 kernel only)
             cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
         if use_bf16:

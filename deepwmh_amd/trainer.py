@@ -141,7 +141,7 @@ class UNetTrainer:
         return wf
 
     def _use_bf16(self, cfg, stride, C0, C1, which='fwd'):
-        return ((self.bf16_forward if which == 'fwd' else self.bf16_dgrad) and stride == 1 and bool(self.lib.wmh_conv3d_k3_bf16_supported(cfg))
+        return ((self.bf16_forward if which == 'fwd' else self.bf16_dgrad) and stride == 1 and cfg in (0, 2) and bool(self.lib.wmh_conv3d_k3_bf16_supported(cfg))
                 and (C1 == 0 or C0 % 16 == 0))
 
     def _pack_bf16(self, conv, cfg, mode, ci_off, ci_cnt):

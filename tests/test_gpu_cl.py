@@ -153,6 +153,36 @@ def test_conv3_stride1(lib, N, D, H, W, C0, C1, Cout, has0, has1):
     print('cl_conv3 %s: max err %.3g' % ((N, D, H, W, C0, C1, Cout), e))
 
 
+def test_conv3_many_tiles_per_workgroup(lib):
+    """More tiles than workgroups (the persistent loop: buffer ring, table slots, running moments across tiles and across a
+    sample change inside a workgroup's run), two sources, two cout groups."""
+    from deepwmh_amd import _lib
+    rng = np.random.default_rng(7)
+    N, D, H, W, C0, C1, Cout = 2, 40, 48, 64, 16, 16, 64          # 2 * 10 * 12 * 2 tiles * 2 groups = 960 tiles
+    Cin = C0 + C1
+    x = bf16_round(rng.standard_normal((N, Cin, D, H, W)).astype(np.float32) * 1.5 + 0.3)
+    ss = np.stack([1 + 0.3 * rng.standard_normal((N, Cin)), 0.4 * rng.standard_normal((N, Cin))], -1).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3, 3)) / np.sqrt(27 * Cin)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    x0, x1 = to_cl(x[:, :C0]), to_cl(x[:, C0:])
+    ss0 = torch.from_numpy(np.ascontiguousarray(ss[:, :C0])).cuda()
+    ss1 = torch.from_numpy(np.ascontiguousarray(ss[:, C0:])).cuda()
+    npart = lib.wmh_cl_conv3_num_partials(D, H, W)
+    y = torch.full((N, D, H, W, Cout), float('nan'), dtype=torch.bfloat16, device='cuda')
+    part = torch.full((N, Cout, npart, 4), float('nan'), device='cuda')
+    bd, wfd = torch.from_numpy(bias).cuda(), pack_w(lib, w)
+    _lib.check(lib.wmh_cl_conv3_fwd(_lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wfd), _lib.ptr(bd),
+                                    _lib.ptr(y), _lib.ptr(part), N, D, H, W, Cout, SLOPE, None), 'cl_conv3')
+    torch.cuda.synchronize()
+    xin = np.concatenate([pending(x[:, :C0], ss[:, :C0]), pending(x[:, C0:], ss[:, C0:])], 1)
+    ref = F.conv3d(torch.from_numpy(xin).double(), torch.from_numpy(bf16_round(w)).double(), torch.from_numpy(bias).double(), padding=1).numpy()
+    got = from_cl(y)
+    assert not np.isnan(got).any(), 'output voxels never written: %d' % int(np.isnan(got).sum())
+    close(got, ref, 'cl_conv3, many tiles')
+    assert not torch.isnan(part).any()
+    close(finalize(lib, part, npart, N, Cout), ref_scale_shift(ref), 'cl_conv3 scale/shift, many tiles', rel=3e-4, abs_=3e-4)
+
+
 def test_conv3_is_deterministic_and_batch_independent(lib):
     from deepwmh_amd import _lib
     rng = np.random.default_rng(3)

@@ -435,6 +435,51 @@ def test_wave_specialised_form_is_bit_identical(tmp_path):
     assert float(np.abs(outs[0][0]).max()) > 0.1
 
 
+BF16_SMALL_CASES = [(2, 32, 0, 64, 8, 8, 8, 1), (1, 48, 16, 32, 5, 9, 7, 1), (2, 32, 0, 64, 16, 16, 16, 2), (1, 16, 0, 32, 9, 13, 15, 2),
+                    (2, 32, 0, 128, 8, 32, 32, 2), (1, 16, 0, 64, 7, 20, 27, 2)]
+
+
+@pytest.mark.parametrize('case', BF16_SMALL_CASES, ids=[str(c) for c in BF16_SMALL_CASES])
+def test_conv3d_k3_bf16_small_rows_and_strided(lib, case):
+    """bf16 operands on the deep levels: rows of 8 voxels (configuration 4) and the stride-2 convolutions whose output rows
+    are 8 or 16 voxels (configurations 5 and 3; D, H, W = the INPUT extent), against the convolution of bf16-rounded operands."""
+    from deepwmh_amd import _lib
+    N, C0, C1, Cout, D, H, W, s = case
+    g = torch.Generator().manual_seed(98)
+    Cin = C0 + C1
+    x = torch.randn(N, Cin, D, H, W, generator=g) * 1.5 + 0.3
+    ss = torch.stack([0.5 + torch.rand(N, Cin, generator=g), 0.3 * torch.randn(N, Cin, generator=g)], -1)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (27 * Cin)) ** 0.5
+    b = 0.1 * torch.randn(Cout, generator=g)
+    r = lambda t: t.to(torch.bfloat16).float()
+    ref = F.conv3d(r(_lrelu_affine(x, ss)), r(w), b, padding=1, stride=s)
+    Do, Ho, Wo = ref.shape[2:]
+    cfg = lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, s)
+    assert cfg in (3, 4, 5) and lib.wmh_conv3d_k3_bf16_supported(cfg)
+    wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_bf16(cfg, Cin, Cout), np.uint16)
+    wn = w.numpy()
+    assert lib.wmh_conv3d_k3_pack_weights_bf16(cfg, wn.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)) == 0
+    npart = lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, Do, Ho, Wo)
+    y = torch.full((N, Cout, Do, Ho, Wo), float('nan'), device='cuda')
+    part = torch.full((N, Cout, npart, 4), float('nan'), device='cuda')
+    mr = torch.full((N, Cout, 2), float('nan'), device='cuda'); ss_out = torch.empty(N, Cout, 2, device='cuda')
+    x0 = x[:, :C0].contiguous().cuda()
+    x1 = x[:, C0:].contiguous().cuda() if C1 else None
+    s0 = ss[:, :C0].contiguous().cuda()
+    s1 = ss[:, C0:].contiguous().cuda() if C1 else None
+    wfd, bd = dev(wf.view(np.int16)), b.cuda()
+    _lib.check(lib.wmh_conv3d_k3_fwd_bf16(cfg, P(x0), P(s0), C0, P(x1), P(s1), C1, P(wfd), P(bd), P(y), P(part),
+                                          N, D, H, W, Cout, SLOPE, None), 'conv bf16')
+    _lib.check(lib.wmh_instnorm_finalize(P(part), npart, None, None, 1e-5, P(ss_out), P(mr), N, Cout, None), 'fin')
+    torch.cuda.synchronize()
+    yh = y.cpu()
+    assert not torch.isnan(yh).any()
+    scale = float(ref.abs().max())
+    assert float((yh - ref).abs().max()) <= 5e-4 * scale + 1e-5
+    mean = yh.mean((2, 3, 4)).double()
+    assert float((mr.cpu().double()[..., 0] - mean).abs().max()) <= 1e-5 * (1 + float(mean.abs().max()))
+
+
 def test_bf16_wave_specialised_form_is_bit_identical(tmp_path):
     """conv3d_k3_bf16_ws.hip (loader / consumer waves, persistent, default) against the one-role bf16 kernel (WMH_BF16_WS=0):
     same arithmetic and k order, so outputs and InstanceNorm partials must agree bit for bit.  Two sources, channel tails,
