@@ -602,7 +602,9 @@ __global__ __launch_bounds__(256, 3) void cl_conv3s2_kernel(const ClConvS2Args a
         const int e = k * 256 + tid;
         const int ec = min(e, NV - 1);
         const int iz = ec / (IY * IX), rem = ec - iz * (IY * IX), iy = rem / IX, pos = rem - iy * IX;
-        const int ix = pos < NE ? 2 * pos : 2 * (pos - NE) + 1;
+        const int ix = pos;      // rows in natural order: consecutive DMA lanes fetch consecutive voxels (half the cache lines per
+                                 // instruction of an even/odd split); the stride-2 operand reads then are 2-way bank conflicts, and
+                                 // there are only 27 of them per chunk
         const int gz = z0 + iz, gy = y0 + iy, gx = x0 + ix;
         const int ok = (int)(e < NV) & (int)((unsigned)gz < (unsigned)a.D) & (int)((unsigned)gy < (unsigned)a.H) & (int)((unsigned)gx < (unsigned)a.W);
         gv[k] = ok ? (gz * a.H + gy) * a.W + gx : center;
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(256, 3) void cl_conv3s2_kernel(const ClConvS2Args a
     const unsigned rowb = 2u * (unsigned)a.Cin;
     const char* xbase = reinterpret_cast<const char*>(a.x) + (size_t)n * DHW * rowb;
     const int zz = wave >> 1, yy = wave & 1;                              // this wave's output row inside the tile
-    const unsigned char* bbase = lds + (kh * NVP + ((2 * zz) * IY + 2 * yy) * IX + j) * 16;
+    const unsigned char* bbase = lds + (kh * NVP + ((2 * zz) * IY + 2 * yy) * IX + 2 * j) * 16;
     static __device__ const float ident2s[2] = {1.f, 0.f};
     const bool has_ss = a.ss != nullptr;
     const float slope = has_ss ? a.slope : 1.f;
@@ -662,8 +664,7 @@ __global__ __launch_bounds__(256, 3) void cl_conv3s2_kernel(const ClConvS2Args a
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int kd = tap / 9, kr = (tap / 3) % 3, kw = tap % 3;
-            const int posoff = kw == 0 ? 0 : (kw == 1 ? NE : 1);
-            const cl_bf16x8 bv = *reinterpret_cast<const cl_bf16x8*>(bbase + ((kd * IY + kr) * IX + posoff) * 16);
+            const cl_bf16x8 bv = *reinterpret_cast<const cl_bf16x8*>(bbase + ((kd * IY + kr) * IX + kw) * 16);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tap < 18 ? av[tap < 18 ? tap : 0] : av2[tap >= 18 ? tap - 18 : 0], bv, acc[0], 0, 0, 0);
         }
     }
