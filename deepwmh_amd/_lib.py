@@ -109,9 +109,9 @@ SIGNATURES = {
     'wmh_cl_conv3_fwd': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_cl_conv3s2_num_partials': (_i, [_i, _i, _i]),
     'wmh_cl_conv3s2_fwd': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    'wmh_cl_convT_packed_halfs': (_sz, [_i, _i]),
-    'wmh_cl_convT_pack_weights': (_i, [_vp, _i, _i, _vp]),
-    'wmh_cl_convT_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_cl_convt_packed_halfs': (_sz, [_i, _i]),
+    'wmh_cl_convt_pack_weights': (_i, [_vp, _i, _i, _vp]),
+    'wmh_cl_convt_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_cl_seghead_softmax_accumulate': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ip, _i, _ip, _f, _vp]),
     'wmh_selftest_mfma_32x32x2': (_i, [_vp, _vp, _vp, _vp]),
 }

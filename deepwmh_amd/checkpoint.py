@@ -98,17 +98,28 @@ def save_checkpoint(folder, state_dict, plans, fold='all', checkpoint_name='mode
     os.makedirs(fdir, exist_ok=True)
     sd = OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)
                      for k, v in state_dict.items())
+    # no 'amp_grad_scaler' key: nnU-Net's load_checkpoint_ram only restores the scaler when the key exists, and a None
+    # value would be passed to GradScaler.load_state_dict if real nnU-Net continued training from this file
     ck = dict(epoch=epoch, state_dict=sd, optimizer_state_dict=None, lr_scheduler_state_dict=None,
-              plot_stuff=([], [], [], []), best_stuff=(None, None, None), amp_grad_scaler=None)
+              plot_stuff=([], [], [], []), best_stuff=(None, None, None))
     if extra:
         ck.update(extra)
     model = os.path.join(fdir, checkpoint_name + '.model')
-    torch.save(ck, model)
     plans_file = os.path.join(folder, 'plans.pkl')
     init = (plans_file, fold, folder, '', True, 0, True, False, True)
-    with open(model + '.pkl', 'wb') as f:
-        pickle.dump(OrderedDict(init=init, name=TRAINER, **{'class': "<class 'nnunet.training.network_training.nnUNetTrainerV2.nnUNetTrainerV2'>"},
-                                plans=plans), f)
-    with open(plans_file, 'wb') as f:
-        pickle.dump(plans, f)
+
+    def atomically(path, writer):
+        # a kill in the middle of a write must not leave a truncated model_latest behind (the next `-c` would die on it)
+        tmp = '%s.tmp%d' % (path, os.getpid())
+        try:
+            with open(tmp, 'wb') as f:
+                writer(f)
+            os.replace(tmp, path)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    atomically(model, lambda f: torch.save(ck, f))
+    atomically(model + '.pkl', lambda f: pickle.dump(OrderedDict(
+        init=init, name=TRAINER, **{'class': "<class 'nnunet.training.network_training.nnUNetTrainerV2.nnUNetTrainerV2'>"}, plans=plans), f))
+    atomically(plans_file, lambda f: pickle.dump(plans, f))
     return model

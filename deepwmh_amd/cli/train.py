@@ -84,7 +84,7 @@ def main(argv=None):
 
     bs = int(plans['plans_per_stage'][max(plans['plans_per_stage'].keys())]['batch_size'])
     precision = 'bf16' if (args.bf16 or os.environ.get('WMH_TRAIN_PRECISION', '') == 'bf16') and not args.fp32 else 'fp32'
-    start_epoch, best = 0, None
+    start_epoch, best, ma_resume = 0, None, None
     latest = os.path.join(fdir, 'model_latest.model')
     if args.continue_training and os.path.isfile(latest):
         _, _, sd, info = ck.load_checkpoint(folder, args.fold, 'model_latest')
@@ -95,6 +95,7 @@ def main(argv=None):
             tr.mom.copy_(torch.as_tensor(np.asarray(mom)).to(tr.mom.device))
             tr.first_step = False
         best = info['checkpoint'].get('deepwmh_amd_best')
+        ma_resume = info['checkpoint'].get('deepwmh_amd_ma')
         if rank == 0:
             print('continuing from %s (epoch %d)' % (latest, start_epoch), flush=True)
     else:
@@ -104,12 +105,15 @@ def main(argv=None):
     loader = PrefetchLoader(PatchLoader(stage_dir, train_cases, plan.patch_size, bs, seed=args.seed + 1000 * rank + start_epoch))
     vloader = PatchLoader(stage_dir, val_cases, plan.patch_size, bs, seed=args.seed + 77, mirror=False)
     nval = args.val_batches if args.val_batches is not None else max(1, min(50, args.batches_per_epoch // 5))
-    ma = None
+    ma = ma_resume                                      # the smoothed criterion continues across `-c` (it decides model_best)
 
     def save(name, epoch):
         if rank != 0:
             return
-        extra = dict(deepwmh_amd_momentum=tr.momentum_state(), deepwmh_amd_best=best)
+        # the SGD momentum (as large as the weights) only where training can continue from: model_latest
+        extra = dict(deepwmh_amd_best=best, deepwmh_amd_ma=ma)
+        if name == 'model_latest':
+            extra['deepwmh_amd_momentum'] = tr.momentum_state()
         ck.save_checkpoint(folder, tr.state_dict(), plans, args.fold, name, epoch=epoch, extra=extra)
 
     for epoch in range(start_epoch, args.epochs):
@@ -118,14 +122,14 @@ def main(argv=None):
         for _ in range(args.batches_per_epoch):
             data, seg = loader.next_batch()
             x = torch.from_numpy(data).to(device)
-            tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool)
+            tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool, plan.pool_op_kernel_sizes)
             losses.append(tr.run_iteration(x, tg, lr).clone())           # stays on the device: no per-iteration sync
         losses = [float(v) for v in torch.stack(losses).cpu()]
         vl = []
         for _ in range(nval):
             data, seg = vloader.next_batch()
             x = torch.from_numpy(data).to(device)
-            tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool)
+            tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool, plan.pool_op_kernel_sizes)
             vl.append(float(tr.run_iteration(x, tg, lr, do_backprop=False).cpu()))
         v = float(np.mean(vl))
         ma = -v if ma is None else 0.9 * ma + 0.1 * (-v)           # moving-average criterion (higher is better)

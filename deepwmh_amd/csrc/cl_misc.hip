@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256, 2) void cl_convT_kernel(const ClConvTArgs a) {
     }
 }
 // weight image: [G][Cin/16][8 taps][64 lanes][8] bf16 from torch layout [Cin][Cout][2][2][2] fp32 (host)
-extern "C" size_t wmh_cl_convT_packed_halfs(int Cin, int Cout) { return (size_t)(Cout / 32) * (Cin / 16) * 8 * 64 * 8; }
-extern "C" int wmh_cl_convT_pack_weights(const float* w, int Cin, int Cout, uint16_t* wf) {
+extern "C" size_t wmh_cl_convt_packed_halfs(int Cin, int Cout) { return (size_t)(Cout / 32) * (Cin / 16) * 8 * 64 * 8; }
+extern "C" int wmh_cl_convt_pack_weights(const float* w, int Cin, int Cout, uint16_t* wf) {
     if (!w || !wf || Cin < 16 || Cin % 16 || Cout < 32 || Cout % 32) return wmh_fail(WMH_EINVAL, "cl_convT_pack_weights: Cin % 16, Cout % 32");
     const int nks = Cin / 16;
     for (int g = 0; g < Cout / 32; ++g)
@@ -244,7 +244,7 @@ extern "C" int wmh_cl_convT_pack_weights(const float* w, int Cin, int Cout, uint
                     }
     return WMH_OK;
 }
-extern "C" int wmh_cl_convT_fwd(const void* x, const float* ss, const uint16_t* wf, void* y, int N, int Cin, int Cout,
+extern "C" int wmh_cl_convt_fwd(const void* x, const float* ss, const uint16_t* wf, void* y, int N, int Cin, int Cout,
                                 int D, int H, int W, float lrelu_slope, void* stream) {
     if (!x || !wf || !y || N < 1 || D < 1 || H < 1 || W < 1 || Cin < 16 || Cin % 16 || Cout < 32 || Cout % 32)
         return wmh_fail(WMH_EINVAL, "cl_convT_fwd: bad args (Cin % 16, Cout % 32)");

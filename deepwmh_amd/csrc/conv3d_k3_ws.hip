@@ -18,7 +18,7 @@
 #include <stdlib.h>
 #include "conv3d_common.h"
 
-__device__ __forceinline__ bool getenv_dbg_perwave(int dbg) { return (dbg & 8) != 0; }
+__device__ __forceinline__ bool getenv_dbg_perwave(int dbg) { return (dbg & 8) != 0; }      // diagnostic build: per-wave stamps
 // Uniform read of a value no kernel in flight writes (InstanceNorm scale/shift come from the previous launch): through the
 // constant address space = the scalar cache, on its own counter.  As (conditional) vector loads these reads were several
 // serialised memory round trips per chunk: the loader needed a whole consumer period for ~300 instructions.
@@ -29,7 +29,17 @@ static __device__ const float ws_ident2[2] = {1.f, 0.f};
 
 // IN16: the sources are bf16 tensors (a quad is one 8-byte load per channel, widened by a shift in the loader)
 template <class C, bool IN16 = false>
-__global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, const int T /*tiles*/, const int dbg /*timing experiments; 0 in production*/) {
+__global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, const int T /*tiles*/, const int dbg /*timing experiments of the WMH_DIAG_ABLATIONS build; unused otherwise*/) {
+    // Stamps and ablation switches exist in the diagnostic build only (-DWMH_DIAG_ABLATIONS): in the library they are
+    // compile-time constants and every branch on them folds away.
+#ifdef WMH_DIAG_ABLATIONS
+    const int dbg_ = dbg;
+    unsigned long long* const stamps_ = a.stamps;
+#else
+    constexpr int dbg_ = 0;
+    constexpr unsigned long long* stamps_ = nullptr;
+    (void)dbg;
+#endif
     constexpr int S = C::S, MT = C::MT, NT = C::NT, CK = C::CK, V = CK / 2;
     constexpr int LTH = 256;                                   // loader threads
     // LDS halo rows are the 16-byte-aligned span [ox0-4, ox0+TX+4) of the row (QPR quads; the halo row [ox0-1, ox0+TX] sits
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
         // ================================ loader waves =====================================================
         // A loader shares its SIMD with a consumer that always has an MFMA ready; left at equal priority it got to issue about
         // one instruction per MFMA slot and needed a whole consumer period (29 k cycles) for ~300 instructions.
-        if (!(dbg & 32)) __builtin_amdgcn_s_setprio(3);
+        if (!(dbg_ & 32)) __builtin_amdgcn_s_setprio(3);
         const int lt = tid - 256;
         typedef float f32x4_t __attribute__((ext_vector_type(4)));
         unsigned q_off[NSL]; unsigned q_ok = 0;               // byte offsets of this thread's quads in a channel plane
@@ -186,19 +196,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
         unsigned long long lw = 0, lb = 0, l0 = 0;                 // diagnostics: loader work / barrier wait
         for (int it = 0; it < total; ++it) {
             const int nx = it + 1;
-            if (a.stamps) l0 = __builtin_amdgcn_s_memtime();
-            if (nx < total && !(dbg & 1)) {
+            if (stamps_) l0 = __builtin_amdgcn_s_memtime();
+            if (nx < total && !(dbg_ & 1)) {
                 const int ch = nx % nch;
                 if (ch == 0) { vnext += gridDim.x; setup(vnext); }
                 load_chunk(ch);
                 write_chunk(nx & 1);
             }
-            if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); lw += t - l0; l0 = t; }
+            if (stamps_) { const unsigned long long t = __builtin_amdgcn_s_memtime(); lw += t - l0; l0 = t; }
             __syncthreads();
-            if (a.stamps) lb += __builtin_amdgcn_s_memtime() - l0;
+            if (stamps_) lb += __builtin_amdgcn_s_memtime() - l0;
         }
-        if (a.stamps && (dbg & 16) && tid == 256) {
-            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 4;
+        if (stamps_ && (dbg_ & 16) && tid == 256) {
+            unsigned long long* o = stamps_ + (size_t)blockIdx.x * 4;
             o[0] = lw; o[1] = lb; o[2] = 0; o[3] = (unsigned long long)total;
         }
     } else {
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
         }
         __syncthreads();
         int it = 0;
-        unsigned long long tm = 0, tb = 0, te = 0, t0 = 0;         // diagnostics (a.stamps != NULL)
+        unsigned long long tm = 0, tb = 0, te = 0, t0 = 0;         // diagnostics (stamps_ != NULL)
         for (int v = blockIdx.x; v < T; v += gridDim.x) {
             int g, tx, ty, tz, n0;
             tile_of(v, g, tx, ty, tz, n0);
@@ -232,8 +242,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
             for (int ch = 0; ch < nch; ++ch, ++it) {
                 const float* cur = X + (it & 1) * TILE;
                 const AV* wcur = reinterpret_cast<const AV*>(Wl + (it & 1) * WT) + lane;
-                if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
-                if (!(dbg & 64))
+                if (stamps_) t0 = __builtin_amdgcn_s_memtime();
+                if (!(dbg_ & 64))
 #pragma unroll
                 for (int tap = 0; tap < 27; ++tap) {
                     const int toff = (tap / 9) * ZSL + ((tap / 3) % 3) * YSL + (tap % 3);
@@ -251,21 +261,21 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
                         }
                     }
                 }
-                if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
+                if (stamps_) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
                 __syncthreads();
-                if (a.stamps) tb += __builtin_amdgcn_s_memtime() - t0;
+                if (stamps_) tb += __builtin_amdgcn_s_memtime() - t0;
             }
-            if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
-            if (!(dbg & 2))
+            if (stamps_) t0 = __builtin_amdgcn_s_memtime();
+            if (!(dbg_ & 2))
                 conv_epilogue<C>(a, acc, g, 0, n0, wave, j, kh, dx, dy, dz, ts0, tz * C::TZ, ty * C::TY, tx * C::TX,
                                  (tz * a.nty + ty) * a.ntx + tx);
             else if (acc[0][0][0] == 12345.678f) a.y[0] = acc[NT - 1][1][3];     // keep the accumulators live
-            if (a.stamps) te += __builtin_amdgcn_s_memtime() - t0;
+            if (stamps_) te += __builtin_amdgcn_s_memtime() - t0;
         }
-        if (a.stamps && getenv_dbg_perwave(dbg)) {                  // per consumer wave: its own MFMA-phase total
-            if (lane == 0) a.stamps[(size_t)blockIdx.x * 4 + wave] = wave == 3 ? (unsigned long long)total : tm;
-        } else if (a.stamps && tid == 0 && !(dbg & 16)) {            // barrier wait, MFMA phases, epilogues, chunk iterations
-            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 4;
+        if (stamps_ && getenv_dbg_perwave(dbg_)) {                  // per consumer wave: its own MFMA-phase total
+            if (lane == 0) stamps_[(size_t)blockIdx.x * 4 + wave] = wave == 3 ? (unsigned long long)total : tm;
+        } else if (stamps_ && tid == 0 && !(dbg_ & 16)) {            // barrier wait, MFMA phases, epilogues, chunk iterations
+            unsigned long long* o = stamps_ + (size_t)blockIdx.x * 4;
             o[0] = tb; o[1] = tm; o[2] = te; o[3] = (unsigned long long)total;
         }
     }
@@ -297,7 +307,11 @@ static int launch_ws(const ConvArgs& a, hipStream_t st) {
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 (wave-specialised): too many tiles");
     const int ncu = ws_num_cus();
     const int grid = T < ncu ? (int)T : ncu;
+#ifdef WMH_DIAG_ABLATIONS
     static const int dbg = getenv("WMH_WS_DBG") ? atoi(getenv("WMH_WS_DBG")) : 0;
+#else
+    const int dbg = 0;
+#endif
     hipLaunchKernelGGL((conv3d_k3_ws_kernel<C, IN16>), dim3(grid), dim3(512), lds, st, a, (int)T, dbg);
     return wmh_check_launch("conv3d_k3_ws_kernel");
 }

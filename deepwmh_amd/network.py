@@ -286,9 +286,9 @@ class UNetEngine:
             level = nd - 1 - u                     # level this stage up-samples TO
             if level < ncl and level + 1 < ncl:    # both sides channels-last: the cl transposed convolution
                 tu_host = _np(sd['tu.%d.weight' % u])
-                wt = np.empty(lib.wmh_cl_convT_packed_halfs(st['cdown'], st['cskip']), dtype=np.uint16)
-                _lib.check(lib.wmh_cl_convT_pack_weights(tu_host.ctypes.data_as(C.c_void_p), st['cdown'], st['cskip'],
-                                                         wt.ctypes.data_as(C.c_void_p)), 'wmh_cl_convT_pack_weights')
+                wt = np.empty(lib.wmh_cl_convt_packed_halfs(st['cdown'], st['cskip']), dtype=np.uint16)
+                _lib.check(lib.wmh_cl_convt_pack_weights(tu_host.ctypes.data_as(C.c_void_p), st['cdown'], st['cskip'],
+                                                         wt.ctypes.data_as(C.c_void_p)), 'wmh_cl_convt_pack_weights')
                 st['tu_wf_cl'] = torch.from_numpy(wt.view(np.int16)).to(dev)
 
     def _account(self, flop, nbytes):
@@ -391,8 +391,8 @@ class UNetEngine:
                 if cur.dtype == torch.bfloat16:
                     Nn, Dd, Hh, Ww, Cc = cur.shape
                     up = self._buf('tu%d.ycl' % u, (Nn, 2 * Dd, 2 * Hh, 2 * Ww, st['cskip']), torch.bfloat16)
-                    _lib.check(lib.wmh_cl_convT_fwd(_lib.ptr(cur), _lib.ptr(cur_ss), _lib.ptr(st['tu_wf_cl']), _lib.ptr(up), Nn, Cc,
-                                                    st['cskip'], Dd, Hh, Ww, LRELU_SLOPE, self._stream()), 'wmh_cl_convT_fwd')
+                    _lib.check(lib.wmh_cl_convt_fwd(_lib.ptr(cur), _lib.ptr(cur_ss), _lib.ptr(st['tu_wf_cl']), _lib.ptr(up), Nn, Cc,
+                                                    st['cskip'], Dd, Hh, Ww, LRELU_SLOPE, self._stream()), 'wmh_cl_convt_fwd')
                     self._account(2.0 * Cc * st['cskip'] * 8 * Nn * Dd * Hh * Ww, 2.0 * cur.numel() + 2.0 * up.numel() + 2.0 * Cc * st['cskip'] * 8)
                 else:                                       # up-sampling out of the NCDHW levels
                     up = self._to_cl('tu%d' % u, self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt']))

@@ -49,12 +49,53 @@ def _resize(vol, new_shape, order):
     return zoom(vol, factors, order=order, mode='nearest', grid_mode=True, prefilter=order > 1)
 
 
+SEPARATE_Z_ANISO_THRESHOLD = 3.0     # nnU-Net RESAMPLING_SEPARATE_Z_ANISO_THRESHOLD [preprocessing.py, not in tree]
+
+
+def separate_z_axis(spacing_a, spacing_b):
+    """nnU-Net `resample_patient` with force_separate_z=None [preprocessing.get_do_separate_z / get_lowres_axis]: the axis that
+    is resampled on its own (nearest neighbour along it, spline only inside the slices) or None.  Anisotropy (max/min
+    spacing > 3) of `spacing_a` decides first (the case's own spacing), then of `spacing_b` (the plan's); the low-resolution
+    axis is the one with the largest spacing, and if that is not a single axis (e.g. (0.24, 1.25, 1.25)) everything is
+    resampled jointly.  Thick-slice FLAIR is the case the reference treats as normal
+    (/root/reference/deepwmh/analysis/image_ops.py:354-359)."""
+    for sp in (spacing_a, spacing_b):
+        sp = np.asarray(sp, float)
+        if sp.max() / sp.min() > SEPARATE_Z_ANISO_THRESHOLD:
+            axis = np.where(sp.max() / sp == 1)[0]
+            return int(axis[0]) if len(axis) == 1 else None
+    return None
+
+
+def _resize_separate_z(vol, new_shape, order, axis):
+    """`resample_data_or_seg(do_separate_z=True, order_z=0)`: every slice across `axis` resized in its plane (order), then
+    nearest neighbour along `axis` at the pixel-centre coordinates (o + 0.5) * in / out - 0.5 (map_coordinates order 0)."""
+    from scipy.ndimage import map_coordinates
+    new_shape = tuple(int(v) for v in new_shape)
+    plane = tuple(n for i, n in enumerate(new_shape) if i != axis)
+    slices = [_resize(np.take(vol, k, axis=axis), plane, order) for k in range(vol.shape[axis])]
+    out = np.stack(slices, axis)
+    if out.shape[axis] == new_shape[axis]:
+        return out
+    grids = np.mgrid[tuple(slice(0, n) for n in new_shape)].astype(np.float64)
+    grids[axis] = (grids[axis] + 0.5) * (out.shape[axis] / new_shape[axis]) - 0.5
+    return map_coordinates(out, grids, order=0, mode='nearest')
+
+
+def resample_volume(vol, new_shape, order, axis=None):
+    """One channel to new_shape: jointly (axis None) or with the low-resolution axis on its own."""
+    if tuple(vol.shape) == tuple(int(v) for v in new_shape):
+        return vol
+    return _resize(vol, new_shape, order) if axis is None else _resize_separate_z(vol, new_shape, order, axis)
+
+
 def resample_to_spacing(data, spacing, target_spacing, order=3):
     spacing, target_spacing = np.asarray(spacing, float), np.asarray(target_spacing, float)
     new_shape = np.round(spacing / target_spacing * np.array(data.shape[1:])).astype(int)
     if np.all(new_shape == np.array(data.shape[1:])):
         return data
-    return np.stack([_resize(data[c].astype(np.float64), new_shape, order).astype(np.float32) for c in range(data.shape[0])])
+    axis = separate_z_axis(spacing, target_spacing)
+    return np.stack([resample_volume(data[c].astype(np.float64), new_shape, order, axis).astype(np.float32) for c in range(data.shape[0])])
 
 
 def preprocess_case(volume_zyx, spacing, plans, stage=None):
@@ -78,7 +119,8 @@ def preprocess_case(volume_zyx, spacing, plans, stage=None):
     use_mask = bool(umn[0] if isinstance(umn, dict) else umn)
     out = normalize_noncT(res, nzmask, use_mask)
     props = dict(original_shape=orig_shape, bbox=bbox, shape_after_crop=tuple(shape_after_crop), transpose_forward=tf,
-                 transpose_backward=list(plans.get('transpose_backward', [0, 1, 2])))
+                 transpose_backward=list(plans.get('transpose_backward', [0, 1, 2])),
+                 original_spacing=tuple(float(v) for v in np.asarray(spacing, float)), spacing_after_resampling=tuple(float(v) for v in target))
     return np.ascontiguousarray(out), props
 
 
@@ -90,7 +132,10 @@ def export_prediction(prob, props):
     tgt = props['shape_after_crop']
     tgt = tuple(np.array(tgt)[[props['transpose_forward'].index(i) for i in range(3)]]) if tb != [0, 1, 2] else tuple(tgt)
     if prob.shape[1:] != tgt:
-        prob = np.stack([_resize(prob[k].astype(np.float64), tgt, 1).astype(np.float32) for k in range(prob.shape[0])])
+        # save_segmentation_nifti_from_softmax [nnU-Net, not in tree]: order 1, and the low-resolution axis on its own (order 0)
+        # when the case's spacing (original axis order) or the resampled spacing is anisotropic
+        axis = _export_axis(props)
+        prob = np.stack([resample_volume(prob[k].astype(np.float64), tgt, 1, axis).astype(np.float32) for k in range(prob.shape[0])])
     seg_c = prob.argmax(0).astype(np.uint8)
     full = np.zeros(props['original_shape'], dtype=np.uint8)
     bb = props['bbox']
@@ -100,6 +145,15 @@ def export_prediction(prob, props):
     pfull[0] = 1.0                                  # outside the crop everything is background
     pfull[(slice(None),) + sl] = prob
     return full, pfull
+
+
+def _export_axis(props):
+    """Low-resolution axis (in the input's axis order) for the export resampling, or None."""
+    if 'original_spacing' not in props:
+        return None
+    tb = props['transpose_backward']
+    after = np.asarray(props['spacing_after_resampling'], float)[tb]          # back to the input's axis order
+    return separate_z_axis(props['original_spacing'], after)
 
 
 # ---- device path: crop-to-nonzero + z-score on the GPU (no resampling: volumes already at the plan's spacing) ----------
@@ -113,13 +167,22 @@ def needs_resampling(shape_zyx, spacing, plans, stage=None):
     return bool(np.any(np.round(sp / target * shp).astype(int) != shp))
 
 
-def _resample_device(x, new_shape, order):
-    """x: device float32 [C,D,H,W] -> [C,*new_shape] through wmh_resample (double arithmetic, scipy's tap order)."""
+def _resample_device(x, new_shape, order, axis=None):
+    """x: device float32 [C,D,H,W] -> [C,*new_shape] through wmh_resample (double arithmetic, scipy's tap order).  axis: the
+    low-resolution axis resampled on its own (nnU-Net's separate-z): first the slices across it with `order` (the same
+    kernel with that axis left at its length: an interpolating spline reproduces the samples along an unchanged axis), then
+    nearest neighbour along the axis."""
     import torch
     from . import _lib
+    if axis is not None and int(new_shape[axis]) != int(x.shape[1 + axis]):
+        mid = list(int(v) for v in new_shape)
+        mid[axis] = int(x.shape[1 + axis])
+        return _resample_device(_resample_device(x, mid, order), new_shape, 0)
     lib = _lib.load()
     Cn, D, H, W = (int(v) for v in x.shape)
     Do, Ho, Wo = (int(v) for v in new_shape)
+    if (D, H, W) == (Do, Ho, Wo):
+        return x
     out = torch.empty((Cn, Do, Ho, Wo), dtype=torch.float32, device=x.device)
     nws = lib.wmh_resample_workspace_doubles(D, H, W, order)
     ws = torch.empty(max(1, nws), dtype=torch.float64, device=x.device)
@@ -164,7 +227,8 @@ def preprocess_case_device(volume_zyx, spacing, plans, stage=None, device='cuda:
     stats = torch.empty(Cn, 2, dtype=torch.float32, device=device)
     ws = torch.empty(max(1, lib.wmh_zscore_crop_workspace_doubles(Cn)), dtype=torch.float64, device=device)
     props = dict(original_shape=(D, H, W), bbox=bbox, shape_after_crop=shape_t, transpose_forward=tf,
-                 transpose_backward=list(plans.get('transpose_backward', [0, 1, 2])), bbox_device=bbox_d)
+                 transpose_backward=list(plans.get('transpose_backward', [0, 1, 2])), bbox_device=bbox_d,
+                 original_spacing=tuple(float(v) for v in np.asarray(spacing, float)), spacing_after_resampling=tuple(float(v) for v in target))
     if tf == [0, 1, 2] and new_shape == shape_t:
         out = torch.empty((Cn,) + crop_shape, dtype=torch.float32, device=device)
         _lib.check(lib.wmh_zscore_crop(_lib.ptr(x), _lib.ptr(mask), _lib.ptr(bbox_d), _lib.ptr(out), None, _lib.ptr(stats), _lib.ptr(ws),
@@ -174,7 +238,7 @@ def preprocess_case_device(volume_zyx, spacing, plans, stage=None, device='cuda:
     xc = x[(slice(None),) + sl].permute([0] + [i + 1 for i in tf]).contiguous()
     mc = mask[sl].permute(tf).contiguous()
     if new_shape != shape_t:
-        xc = _resample_device(xc, new_shape, 3)
+        xc = _resample_device(xc, new_shape, 3, separate_z_axis(sp, target))
         m2 = torch.empty(new_shape, dtype=torch.uint8, device=device)
         _lib.check(lib.wmh_resample_nearest_u8(_lib.ptr(mc), _lib.ptr(m2), shape_t[0], shape_t[1], shape_t[2], new_shape[0], new_shape[1],
                                                new_shape[2], st), 'wmh_resample_nearest_u8')
@@ -201,7 +265,7 @@ def export_prediction_device(seg_d, prob_d, props, want_prob0=False):
         assert prob_d is not None, 'export_prediction_device: probabilities needed (resampled case or --save_softmax)'
         prob = prob_d.permute([0] + [i + 1 for i in tb]).contiguous()
         if tuple(prob.shape[1:]) != tgt:
-            prob = _resample_device(prob, tgt, 1)
+            prob = _resample_device(prob, tgt, 1, _export_axis(props))
             seg_c = prob.argmax(0).to(torch.uint8)
         else:
             seg_c = seg_d.permute(tb).contiguous()

@@ -440,11 +440,26 @@ class UNetTrainer:
         return self.loss_acc
 
 
-def downsample_targets(seg, num_scales):
-    """Deep-supervision targets: nearest-neighbour picks at strides 1, 2, 4, ...  seg: uint8 tensor [N, X, Y, Z]."""
-    out = []
-    for s in range(num_scales):
-        k = 2 ** s
-        t = seg[:, ::k, ::k, ::k] if k > 1 else seg
+def ds_pick_indices(in_size, factor):
+    """Voxels nnU-Net's order-0 `resize_segmentation` [batchgenerators, via DownsampleSegForDSTransform2; not in tree] keeps
+    along one axis when it shrinks it by `factor`: out = round(in / factor) (half to even), output voxel o reads input
+    coordinate (o + 0.5) * in / out - 0.5 rounded to nearest (skimage resize / scipy zoom with grid_mode) = floor((o + 0.5) *
+    in / out), clipped.  Factor 2 keeps voxels 1, 3, 5, ...; factor 4 keeps 2, 6, 10, ..."""
+    out = int(np.round(in_size / float(factor)))
+    o = np.arange(out, dtype=np.float64)
+    return np.clip(np.floor((o + 0.5) * in_size / out).astype(np.int64), 0, in_size - 1)
+
+
+def downsample_targets(seg, num_scales, pool_op_kernel_sizes=None):
+    """Deep-supervision targets (nnUNetTrainerV2: scales 1 / cumprod(pooling kernels), order 0).  seg: uint8 tensor
+    [N, X, Y, Z] on any device; returns one [N, voxels] tensor per scale."""
+    pools = pool_op_kernel_sizes or [[2, 2, 2]] * max(0, num_scales - 1)
+    out, cum = [seg.contiguous().view(seg.shape[0], -1)], [1, 1, 1]
+    for s in range(1, num_scales):
+        cum = [c * int(p) for c, p in zip(cum, pools[s - 1])]
+        t = seg
+        for ax in range(3):
+            idx = torch.from_numpy(ds_pick_indices(seg.shape[1 + ax], cum[ax])).to(seg.device)
+            t = t.index_select(1 + ax, idx)
         out.append(t.contiguous().view(seg.shape[0], -1))
     return out

@@ -397,9 +397,9 @@ int wmh_cl_conv3s2_num_partials(int Do, int Ho, int Wo);
 int wmh_cl_conv3s2_fwd(const void* x, const float* ss, int Cin, const uint16_t* wf, const float* bias, void* y,
                        float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
 /* ConvTranspose3d kernel 2 stride 2 without bias: x [N][D][H][W][Cin] -> y [N][2D][2H][2W][Cout]; D*H*W % 32 == 0. */
-size_t wmh_cl_convT_packed_halfs(int Cin, int Cout);
-int wmh_cl_convT_pack_weights(const float* w /* [Cin][Cout][2][2][2] */, int Cin, int Cout, uint16_t* wf);
-int wmh_cl_convT_fwd(const void* x, const float* ss, const uint16_t* wf, void* y, int N, int Cin, int Cout, int D, int H,
+size_t wmh_cl_convt_packed_halfs(int Cin, int Cout);
+int wmh_cl_convt_pack_weights(const float* w /* [Cin][Cout][2][2][2] */, int Cin, int Cout, uint16_t* wf);
+int wmh_cl_convt_fwd(const void* x, const float* ss, const uint16_t* wf, void* y, int N, int Cin, int Cout, int D, int H,
                      int W, float lrelu_slope, void* stream);
 /* wmh_seghead_softmax_accumulate on a CL16 feature map x [n][P0][P1][P2][C] (C = 32, K = 2). */
 int wmh_cl_seghead_softmax_accumulate(const void* x, const float* ss, const float* wseg, int K, const float* gauss,

@@ -15,6 +15,17 @@ torch.nn / scipy.ndimage calls nnU-Net itself makes, so each layer is exact, but
 the glue (tiling, Gaussian map, mirroring order, aggregation) is pinned only by
 our own golden fixtures (tests/golden), not by reference outputs.
 
+What is a GUESS about the fork (its source is not available; each is inferred from how the reference uses the result):
+* `--save_softmax` writes ONLY channel 0 as `<case>_0.nii.gz`, i.e. P(background): DCNN_multistage.py:340-344 reads exactly
+  that file name and :106-108 treats it as an inverted lesion probability.  Dtype float32 (:359 loads it as such).
+* `--selected_cases` restricts the prediction to the listed case ids (padding spaces in the list: :327-333).
+* `nnUNet_train -b N` = batches per epoch (num_batches_per_epoch), `-e` = epochs, `--save_every_epoch` writes
+  `model_ep_%04d` (:196-216, 292-304, 331-336), `--custom_val_cases` replaces the validation split, `--noval` skips the final
+  validation.  None of these exist in upstream MIC-DKFZ/nnUNet v1.
+* Deep-supervision targets follow upstream's `DownsampleSegForDSTransform2` / `resize_segmentation(order=0)` pixel-centre
+  coordinate map (oracle/training.py; round 1 used `seg[::k]`, which upstream does not).
+Everything else (module order and names, He init, poly LR, Dice+CE, Gaussian map, mirror order, step rule) is upstream v1.
+
 Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py`
 may import this package.  The product (`deepwmh_amd`) never does.
 """

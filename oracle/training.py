@@ -62,12 +62,30 @@ def multiple_output_loss(outputs, targets, weights):
     return l
 
 
-def downsample_targets(seg, num_scales):
-    """DownsampleSegForDSTransform2 with order 0: nearest-neighbour pick at strides 1, 2, 4, ... seg [N,1,X,Y,Z]."""
-    out = []
-    for s in range(num_scales):
-        k = 2 ** s
-        out.append(seg[:, :, ::k, ::k, ::k].contiguous() if k > 1 else seg)
+def resize_segmentation_order0(seg, new_shape):
+    """batchgenerators `resize_segmentation(segmentation, new_shape, order=0)` = skimage `resize(seg.astype(float), new_shape,
+    0, mode='edge', clip=True, anti_aliasing=False)`, which for order 0 is scipy's `ndimage.zoom(..., order=0, mode='nearest',
+    grid_mode=True)`: output voxel o reads input coordinate (o + 0.5) * in / out - 0.5, rounded to the nearest voxel.  For
+    a factor 2 that is voxel 2o + 1 (NOT 2o), for 4 it is 4o + 2."""
+    from scipy.ndimage import zoom
+    seg = np.asarray(seg)
+    factors = [n / o for n, o in zip(new_shape, seg.shape)]
+    return zoom(seg.astype(float), factors, order=0, mode='nearest', grid_mode=True).astype(seg.dtype)
+
+
+def downsample_targets(seg, num_scales, pool_op_kernel_sizes=None):
+    """nnU-Net `DownsampleSegForDSTransform2(deep_supervision_scales, 0, 0)` [nnUNetTrainerV2.setup_DA_params: scales =
+    1 / cumprod(net_num_pool_op_kernel_sizes)]: per scale, `resize_segmentation(seg[b, c], round(shape * scale), order=0)`.
+    seg: torch tensor [N, 1, X, Y, Z].  pool_op_kernel_sizes: per pooling [kz, ky, kx] (default 2, 2, 2)."""
+    import torch
+    pools = pool_op_kernel_sizes or [[2, 2, 2]] * max(0, num_scales - 1)
+    out, cum = [seg], np.ones(3)
+    a = seg.numpy()
+    for s in range(1, num_scales):
+        cum = cum * np.asarray(pools[s - 1], dtype=float)
+        new_shape = np.round(np.asarray(a.shape[2:]) * (1.0 / cum)).astype(int)
+        t = np.stack([np.stack([resize_segmentation_order0(a[b, c], new_shape) for c in range(a.shape[1])]) for b in range(a.shape[0])])
+        out.append(torch.from_numpy(t))
     return out
 
 

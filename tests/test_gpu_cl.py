@@ -243,12 +243,12 @@ def test_transposed_convolution(lib, N, D, H, W, Cin, Cout, has_ss):
     x = bf16_round(rng.standard_normal((N, Cin, D, H, W)).astype(np.float32))
     ss = np.stack([1 + 0.3 * rng.standard_normal((N, Cin)), 0.4 * rng.standard_normal((N, Cin))], -1).astype(np.float32)
     w = (rng.standard_normal((Cin, Cout, 2, 2, 2)) / np.sqrt(Cin)).astype(np.float32)
-    wf = np.empty(lib.wmh_cl_convT_packed_halfs(Cin, Cout), dtype=np.uint16)
-    _lib.check(lib.wmh_cl_convT_pack_weights(w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
+    wf = np.empty(lib.wmh_cl_convt_packed_halfs(Cin, Cout), dtype=np.uint16)
+    _lib.check(lib.wmh_cl_convt_pack_weights(w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
     y = torch.full((N, 2 * D, 2 * H, 2 * W, Cout), float('nan'), dtype=torch.bfloat16, device='cuda')
     ssd = torch.from_numpy(ss).cuda() if has_ss else None
     xc, wfd = to_cl(x), torch.from_numpy(wf.view(np.int16)).cuda()
-    _lib.check(lib.wmh_cl_convT_fwd(_lib.ptr(xc), _lib.ptr(ssd), _lib.ptr(wfd), _lib.ptr(y),
+    _lib.check(lib.wmh_cl_convt_fwd(_lib.ptr(xc), _lib.ptr(ssd), _lib.ptr(wfd), _lib.ptr(y),
                                     N, Cin, Cout, D, H, W, SLOPE, None), 'cl_convT')
     torch.cuda.synchronize()
     ref = F.conv_transpose3d(torch.from_numpy(pending(x, ss if has_ss else None)).double(), torch.from_numpy(bf16_round(w)).double(), stride=2).numpy()
@@ -291,7 +291,7 @@ def test_argument_checks(lib):
     assert lib.wmh_cl_conv3_fwd(_lib.ptr(t), None, 24, None, None, 0, _lib.ptr(t), None, _lib.ptr(t), None, 1, 4, 4, 32, 32, SLOPE, None) < 0   # C0 % 16
     assert lib.wmh_cl_conv3_fwd(_lib.ptr(t), None, 32, None, None, 0, _lib.ptr(t), None, _lib.ptr(t), None, 1, 4, 4, 48, 32, SLOPE, None) < 0   # W % 32
     assert lib.wmh_cl_conv3s2_fwd(_lib.ptr(t), None, 32, _lib.ptr(t), None, _lib.ptr(t), None, 1, 4, 4, 32, 32, SLOPE, None) < 0              # W % 64
-    assert lib.wmh_cl_convT_fwd(_lib.ptr(t), None, _lib.ptr(t), _lib.ptr(t), 1, 32, 32, 1, 3, 5, SLOPE, None) < 0                             # voxels % 32
+    assert lib.wmh_cl_convt_fwd(_lib.ptr(t), None, _lib.ptr(t), _lib.ptr(t), 1, 32, 32, 1, 3, 5, SLOPE, None) < 0                             # voxels % 32
     assert lib.wmh_cl_conv3_num_partials(8, 8, 40) < 0
 
 

@@ -153,7 +153,9 @@ def test_resample_matches_scipy_zoom(lib, order):
 
 
 @pytest.mark.parametrize('spacing,tf', [((0.9, 0.9, 1.2), [0, 1, 2]), ((1.3, 0.8, 1.0), [0, 1, 2]), ((3.0, 0.9, 0.9), [0, 1, 2]),
-                                        ((1.0, 1.0, 1.0), [1, 2, 0])])
+                                        ((1.0, 1.0, 1.0), [1, 2, 0]),
+                                        # thick slices (anisotropy > 3): nnU-Net resamples the low-resolution axis on its own
+                                        ((5.0, 1.1, 1.1), [0, 1, 2]), ((0.9, 0.9, 4.0), [0, 1, 2]), ((1.0, 0.8, 3.6), [2, 0, 1])])
 def test_preprocess_and_export_device_with_resampling(lib, spacing, tf):
     from deepwmh_amd import checkpoint as ck, preprocess
     from deepwmh_amd.plan import tiny_plan

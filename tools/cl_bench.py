@@ -79,11 +79,11 @@ def convT(name, S, Cin, Cout):
     x = rnd_cl(N, S, S, S, Cin)
     ss = torch.randn(N, Cin, 2, device='cuda') * 0.2 + torch.tensor([1.0, 0.0], device='cuda')
     w = np.random.default_rng(0).standard_normal((Cin, Cout, 8)).astype(np.float32)
-    wf = np.empty(lib.wmh_cl_convT_packed_halfs(Cin, Cout), dtype=np.uint16)
-    lib.wmh_cl_convT_pack_weights(w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p))
+    wf = np.empty(lib.wmh_cl_convt_packed_halfs(Cin, Cout), dtype=np.uint16)
+    lib.wmh_cl_convt_pack_weights(w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p))
     wfd = torch.from_numpy(wf.view(np.int16)).cuda()
     y = torch.empty(N, 2 * S, 2 * S, 2 * S, Cout, dtype=torch.bfloat16, device='cuda')
-    ms = timeit(lambda: _lib.check(lib.wmh_cl_convT_fwd(_lib.ptr(x), _lib.ptr(ss), _lib.ptr(wfd), _lib.ptr(y), N, Cin, Cout, S, S, S, 0.01, None), name))
+    ms = timeit(lambda: _lib.check(lib.wmh_cl_convt_fwd(_lib.ptr(x), _lib.ptr(ss), _lib.ptr(wfd), _lib.ptr(y), N, Cin, Cout, S, S, S, 0.01, None), name))
     nbytes = 2.0 * x.numel() + 2.0 * y.numel()
     print('%-28s %7.3f ms  %6.2f TB/s algorithmic (%.3f of 8)' % (name, ms, nbytes / ms / 1e9, nbytes / ms / 1e9 / 8), flush=True)
     return ms
