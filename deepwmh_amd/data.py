@@ -13,6 +13,7 @@ import numpy as np
 from . import nifti, preprocess
 from .checkpoint import PLANS_ID, make_plans
 from .plan import UNetPlan
+from .planner import plan_3d_fullres
 
 DATA_ID = 'nnUNetData_plans_v2.1'
 
@@ -27,19 +28,6 @@ def find_task(raw_base, task):
     if len(hits) != 1:
         raise FileNotFoundError('task %s: %d matching folders under %s' % (task, len(hits), base))
     return hits[0]
-
-
-def plan_patch(median_shape):
-    """Fixed-architecture planner: isotropic 2x pooling, 3x3x3 kernels (what the HIP path implements).  Patch =
-    median shape rounded down to a multiple of 2^num_pool, at most 128 per axis; up to 5 poolings while the
-    bottleneck keeps >= 4 voxels per axis (ExperimentPlanner3D_v21's stopping rule)."""
-    shp = [int(s) for s in median_shape]
-    num_pool = 5
-    while num_pool > 1 and min(shp) < 4 * 2 ** num_pool:
-        num_pool -= 1
-    div = 2 ** num_pool
-    patch = [max(div, min(128, s // div * div)) for s in shp]
-    return patch, num_pool
 
 
 def plan_and_preprocess(raw_base, preprocessed_base, task, verify=True, log=print):
@@ -81,25 +69,36 @@ def plan_and_preprocess(raw_base, preprocessed_base, task, verify=True, log=prin
         loaded.append((c, cropped, seg, nz, bbox, meta, data.shape[1:]))
         spacings.append(meta['spacing'])
         shapes.append(cropped.shape[1:])
-    target_spacing = np.median(np.array(spacings), 0)
-    new_shapes = [np.round(np.array(sp) / target_spacing * np.array(sh)).astype(int) for sp, sh in zip(spacings, shapes)]
-    median_shape = np.median(np.array(new_shapes), 0).astype(int)
-    patch, num_pool = plan_patch(median_shape)
+    # ExperimentPlanner3D_v21 (deepwmh_amd/planner.py): target spacing, axis order, pooling / kernel sizes per stage, patch, batch
+    target_spacing, tf, tb, stage = plan_3d_fullres(spacings, shapes, nmod, nclass)
+    patch, num_pool = [int(v) for v in stage['patch_size']], len(stage['pool_op_kernel_sizes'])
+    median_shape = stage['median_patient_size_in_voxels']
     crop_frac = np.median([np.prod(sh) / np.prod(full) for (_, _, _, _, _, _, full), sh in zip(loaded, shapes)])
-    plan = UNetPlan(nmod, 32, nclass, [[2, 2, 2]] * num_pool, [[3, 3, 3]] * (num_pool + 1), 2, 320, patch)
-    plans = make_plans(plan, tuple(float(v) for v in target_spacing), use_mask_for_norm=bool(crop_frac < 0.75), batch_size=2)
+    plan = UNetPlan(nmod, 32, nclass, stage['pool_op_kernel_sizes'], stage['conv_kernel_sizes'], 2, 320, patch)
+    plans = make_plans(plan, tuple(float(v) for v in stage['current_spacing']), use_mask_for_norm=bool(crop_frac < 0.75),
+                       batch_size=int(stage['batch_size']))
+    plans['transpose_forward'], plans['transpose_backward'] = list(tf), list(tb)
     plans['original_spacings'] = [np.array(s) for s in spacings]
     plans['original_sizes'] = [np.array(s) for s in shapes]
     plans['preprocessed_data_folder'] = out
-    plans['plans_per_stage'][0]['median_patient_size_in_voxels'] = median_shape
+    st0 = plans['plans_per_stage'][0]
+    st0['median_patient_size_in_voxels'] = median_shape
+    st0['num_pool_per_axis'] = list(stage['num_pool_per_axis'])
+    st0['do_dummy_2D_data_aug'] = stage['do_dummy_2D_data_aug']
     use_mask = plans['use_mask_for_norm'][0]
-    for (c, cropped, seg, nz, bbox, meta, full), nshape in zip(loaded, new_shapes):
-        res = preprocess.resample_to_spacing(cropped, meta['spacing'], target_spacing, 3)
-        if res.shape[1:] != seg.shape:
-            seg_r = preprocess._resize(seg.astype(np.float64), res.shape[1:], 0).astype(np.int8)
+    target_t = np.asarray(stage['current_spacing'], float)
+    for (c, cropped, seg, nz, bbox, meta, full) in loaded:
+        # network axis order (transpose_forward), then resampling (the low-resolution axis on its own when anisotropic) as in
+        # GenericPreprocessor.resample_and_normalize; segmentation label-wise linear
+        cropped_t = cropped.transpose([0] + [i + 1 for i in tf])
+        seg_t, nz_t = seg.transpose(tf), nz.transpose(tf)
+        sp_t = np.asarray(meta['spacing'], float)[tf]
+        res = preprocess.resample_to_spacing(cropped_t, sp_t, target_t, 3)
+        if res.shape[1:] != seg_t.shape:
+            seg_r = preprocess.resample_segmentation(seg_t, res.shape[1:], preprocess.separate_z_axis(sp_t, target_t))
             nz_r = seg_r >= 0
         else:
-            seg_r, nz_r = seg, nz
+            seg_r, nz_r = seg_t, nz_t
         norm = preprocess.normalize_noncT(res, nz_r, use_mask)
         allc = np.concatenate([norm, seg_r[None].astype(np.float32)], 0)
         np.savez_compressed(os.path.join(stage_dir, c + '.npz'), data=allc)
@@ -109,7 +108,7 @@ def plan_and_preprocess(raw_base, preprocessed_base, task, verify=True, log=prin
         with open(os.path.join(stage_dir, c + '.pkl'), 'wb') as f:
             pickle.dump(OrderedDict(original_size_of_raw_data=np.array(full), original_spacing=np.array(meta['spacing']),
                                     crop_bbox=bbox, size_after_cropping=cropped.shape[1:], size_after_resampling=res.shape[1:],
-                                    spacing_after_resampling=target_spacing, class_locations={1: fg}), f)
+                                    spacing_after_resampling=target_t, class_locations={1: fg}), f)
     for name in ('%s_plans_3D.pkl' % PLANS_ID, '%s_plans_2D.pkl' % PLANS_ID):
         with open(os.path.join(out, name), 'wb') as f:
             pickle.dump(plans, f)
@@ -118,8 +117,13 @@ def plan_and_preprocess(raw_base, preprocessed_base, task, verify=True, log=prin
                                 modalities=ds['modality'], size_reductions=OrderedDict()), f)
     with open(os.path.join(out, 'dataset.json'), 'w') as f:
         json.dump(ds, f, indent=4)
-    log('planned %s: %d cases, median shape %s, target spacing %s, patch %s, %d poolings, use_mask_for_norm %s'
-        % (task, len(cases), median_shape.tolist(), np.round(target_spacing, 3).tolist(), patch, num_pool, use_mask))
+    log('planned %s: %d cases, axis order %s, median shape %s, target spacing %s, patch %s, batch %d, poolings %s, kernels %s, '
+        'use_mask_for_norm %s' % (task, len(cases), tf, np.asarray(median_shape).tolist(), np.round(target_t, 3).tolist(), patch,
+                                  int(stage['batch_size']), stage['pool_op_kernel_sizes'], stage['conv_kernel_sizes'], use_mask))
+    try:
+        plan.check_supported()
+    except (NotImplementedError, ValueError) as e:
+        log('WARNING: this plan is outside what the HIP kernels implement (%s); nnUNet_predict / nnUNet_train will refuse it' % e)
     return task, plans
 
 

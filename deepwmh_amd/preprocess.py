@@ -89,6 +89,35 @@ def resample_volume(vol, new_shape, order, axis=None):
     return _resize(vol, new_shape, order) if axis is None else _resize_separate_z(vol, new_shape, order, axis)
 
 
+def _resize_labels(seg, new_shape):
+    """batchgenerators `resize_segmentation(order=1)` [not in tree]: every label's indicator resized linearly, the label set
+    where that is >= 0.5 (labels in ascending order, so the larger label wins a tie)."""
+    if tuple(seg.shape) == tuple(int(v) for v in new_shape):
+        return seg
+    out = np.zeros(tuple(int(v) for v in new_shape), seg.dtype)
+    for c in np.unique(seg):
+        out[_resize((seg == c).astype(np.float64), new_shape, 1) >= 0.5] = c
+    return out
+
+
+def resample_segmentation(seg, new_shape, axis=None):
+    """`resample_patient`'s segmentation branch (order_seg=1, order_z_seg=0): label-wise linear jointly, or in the plane of every
+    slice across `axis` followed by nearest neighbour along it."""
+    from scipy.ndimage import map_coordinates
+    new_shape = tuple(int(v) for v in new_shape)
+    if tuple(seg.shape) == new_shape:
+        return seg
+    if axis is None:
+        return _resize_labels(seg, new_shape)
+    plane = tuple(n for i, n in enumerate(new_shape) if i != axis)
+    out = np.stack([_resize_labels(np.take(seg, k, axis=axis), plane) for k in range(seg.shape[axis])], axis)
+    if out.shape[axis] == new_shape[axis]:
+        return out
+    grids = np.mgrid[tuple(slice(0, n) for n in new_shape)].astype(np.float64)
+    grids[axis] = (grids[axis] + 0.5) * (out.shape[axis] / new_shape[axis]) - 0.5
+    return map_coordinates(out, grids, order=0, mode='nearest').astype(seg.dtype)
+
+
 def resample_to_spacing(data, spacing, target_spacing, order=3):
     spacing, target_spacing = np.asarray(spacing, float), np.asarray(target_spacing, float)
     new_shape = np.round(spacing / target_spacing * np.array(data.shape[1:])).astype(int)

@@ -47,7 +47,8 @@ class UNetTrainer:
         self.bf16_forward = self.bf16_dgrad = self.bf16_wgrad = precision == 'bf16'      # diagnostic switches (tools/diag_bf16_train.py)
         plan.check_supported()
         if not plan.isotropic:
-            raise NotImplementedError('training implements the isotropic [3,3,3] / [2,2,2] architecture only (the planner emits nothing else)')
+            raise NotImplementedError('nnUNet_train (deepwmh_amd): the backward kernels cover the isotropic [3,3,3] / [2,2,2] architecture only; this plan '
+                                      '(thick-slice data: [1,3,3] kernels / [1,2,2] pooling) can be predicted with but not trained here yet')
         self.plan, self.device = plan, torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('UNetTrainer needs a HIP device; there is no CPU path')

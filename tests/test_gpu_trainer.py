@@ -126,3 +126,65 @@ def test_mixed_precision_step_close_to_fp32_and_reproducible(tiny_net, tiny_io):
         assert np.isfinite(la) and abs(la - lb) <= 3e-2 * (1 + abs(lb))
     with pytest.raises(ValueError):
         UNetTrainer(plan, tiny_net[2], 'cuda:0', precision='fp16')
+
+
+@pytest.mark.timeout(1500)
+def test_full_width_backward_matches_autograd():
+    """The BASELINE architecture at full WIDTH (32 ... 320 feature maps, 31 M parameters, every kernel configuration of the
+    backward pass incl. the 320-channel bottleneck) on a batch of 2 x 64^3: loss and all parameter gradients of one
+    iteration against torch autograd on the CPU (training parity had only been shown on the 4-feature net)."""
+    import copy
+    from deepwmh_amd.plan import UNetPlan
+    from deepwmh_amd.trainer import UNetTrainer, downsample_targets
+    from oracle import training as ot
+    from oracle.generic_unet import unet_from_plan, perturb_like_trained, state_dict_numpy
+    from oracle.sliding_window import synthetic_flair
+    torch.manual_seed(3)
+    plan = UNetPlan(patch_size=[64, 64, 64])
+    net = perturb_like_trained(unet_from_plan(plan), seed=4).train()
+    sd = state_dict_numpy(net)
+    vol = synthetic_flair((72, 80, 72), seed=6)[0]
+    data = np.stack([vol[4:68, 8:72, 4:68], vol[8:72, 16:80, 0:64][::-1].copy()])[:, None].astype(np.float32)
+    rng = np.random.default_rng(8)
+    labels = np.stack([(data[0, 0] > 1.0), rng.random((64, 64, 64)) < 0.1]).astype(np.uint8)
+    weights = ot.deep_supervision_weights(plan.num_pool)
+    x = torch.from_numpy(data)
+    tgt = ot.downsample_targets(torch.from_numpy(labels[:, None].astype(np.float32)), plan.num_pool)
+    net.do_ds = True
+    out = net(x)
+    loss = ot.multiple_output_loss(out, tgt, weights)
+    loss.backward()
+    tr = UNetTrainer(plan, sd, 'cuda:0')
+    td = downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
+    lg = tr.forward(x.cuda())
+    for i, (a, b) in enumerate(zip(lg, out)):
+        assert float((a.cpu() - b.detach()).abs().max()) <= 2e-4, 'logits scale %d' % i
+    l = tr.backward(td)
+    torch.cuda.synchronize()
+    assert abs(float(l.cpu()) - float(loss.detach())) <= 1e-5 * (1 + abs(float(loss.detach())))
+    # The judge of both: float64 autograd.  The gradients of this net are small differences of long sums (every conv sits in
+    # front of an InstanceNorm), so fp32 on EITHER side is good to a few 1e-3 per tensor; what is asserted is that the HIP
+    # step is as close to float64 as torch's own fp32 autograd is.
+    net64 = copy.deepcopy(net).double()
+    net64.zero_grad()
+    ot.multiple_output_loss(net64(x.double()), [t.double() for t in tgt], weights).backward()
+    g64 = dict((n, p.grad) for n, p in net64.named_parameters() if p.grad is not None)
+    gmax = max(float(g.abs().max()) for g in g64.values())
+    rows = []
+    for name, p in net.named_parameters():
+        r = g64.get(name)
+        if r is None or float(r.abs().max()) < 1e-4 * gmax:        # conv biases in front of an InstanceNorm: gradient 0 (1e-10 here)
+            continue
+        e_hip = float((tr.g[name].cpu().double() - r).norm() / r.norm())
+        e_cpu = float((p.grad.double() - r).norm() / r.norm())
+        rows.append((e_hip, e_cpu, name))
+    rows.sort(reverse=True)
+    med_hip, med_cpu = float(np.median([r[0] for r in rows])), float(np.median([r[1] for r in rows]))
+    print('full width: loss %.6f; relative L2 error of the gradients against float64 autograd, HIP | torch CPU fp32: median %.3g | %.3g, worst:'
+          % (float(loss.detach()), med_hip, med_cpu))
+    for r in rows[:5]:
+        print('   %-55s %.3g | %.3g' % (r[2], r[0], r[1]))
+    assert len(rows) >= 60
+    assert rows[0][0] <= 1e-2 and med_hip <= max(1.5 * med_cpu, 1e-3)
+    for e_hip, e_cpu, name in rows:
+        assert e_hip <= max(3.0 * e_cpu, 2e-3), 'grad %s: %.3g against float64 (torch fp32: %.3g)' % (name, e_hip, e_cpu)

@@ -13,7 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def make_raw_dataset(raw_base, task='Task001_LabelDenoising', n=4, shape=(40, 48, 44), seed=0):
+def make_raw_dataset(raw_base, task='Task001_LabelDenoising', n=4, shape=(40, 48, 44), seed=0, spacing=(1.0, 1.0, 1.0)):
     """What reference _prepare_nnunet_training_data writes (DCNN_multistage.py:39-93)."""
     from deepwmh_amd import nifti
     from deepwmh_amd.synthetic import synthetic_flair
@@ -25,14 +25,41 @@ def make_raw_dataset(raw_base, task='Task001_LabelDenoising', n=4, shape=(40, 48
         vol = synthetic_flair(shape, seed=seed + i)[0]
         img = vol * 40 + 200 * (vol != 0)
         lab = (vol > 1.6).astype(np.float32)
-        nifti.write(os.path.join(root, 'imagesTr', name + '_0000.nii.gz'), img, spacing=(1.0, 1.0, 1.0))
-        nifti.write(os.path.join(root, 'labelsTr', name + '.nii.gz'), lab, spacing=(1.0, 1.0, 1.0))
+        nifti.write(os.path.join(root, 'imagesTr', name + '_0000.nii.gz'), img, spacing=spacing)
+        nifti.write(os.path.join(root, 'labelsTr', name + '.nii.gz'), lab, spacing=spacing)
         training.append({'image': os.path.join(root, 'imagesTr', name + '.nii.gz'), 'label': os.path.join(root, 'labelsTr', name + '.nii.gz')})
     js = {'name': '', 'description': '', 'reference': '', 'license': '', 'release': 'v1.0', 'tensorImageSize': '3D',
           'modality': {'0': 'Modality_01'}, 'labels': {'0': 'background', '1': 'lesion'}, 'numTraining': n, 'numTest': 0,
           'training': training, 'test': []}
     json.dump(js, open(os.path.join(root, 'dataset.json'), 'w'), indent=4)
     return task
+
+
+def test_plan_and_preprocess_thick_slices(tmp_path):
+    """Thick-slice FLAIR (reference image_ops.py:354-359 accepts anisotropy > 3): the slice axis goes first, the stage is stored in
+    that order with [1,3,3] / [1,2,2] first levels, and inference preprocessing lands on the same grid as the training data."""
+    from deepwmh_amd import nifti, preprocess
+    from deepwmh_amd.data import DATA_ID, plan_and_preprocess
+    from deepwmh_amd.plan import UNetPlan
+    raw, pre = str(tmp_path / 'raw'), str(tmp_path / 'pre')
+    # nifti.write takes [z,y,x] arrays and (z,y,x) spacing: 12 slices of 4 mm, 1 mm in plane; slice axis in the MIDDLE here
+    task = make_raw_dataset(raw, n=3, shape=(48, 12, 56), spacing=(1.0, 4.0, 1.0))
+    t, plans = plan_and_preprocess(raw, pre, '1', True, log=lambda *a: None)
+    assert plans['transpose_forward'] == [1, 0, 2] and plans['transpose_backward'] == [1, 0, 2]
+    st = plans['plans_per_stage'][0]
+    assert np.allclose(st['current_spacing'], [4.0, 1.0, 1.0])
+    assert st['pool_op_kernel_sizes'][:2] == [[1, 2, 2], [1, 2, 2]] and st['conv_kernel_sizes'][:2] == [[1, 3, 3], [1, 3, 3]]
+    d = np.load(os.path.join(pre, task, DATA_ID + '_stage0', 'case_00.npz'))['data']
+    assert d.shape[1] <= 12 and d.shape[2] > 30 and d.shape[3] > 30          # slices first
+    plan = UNetPlan.from_nnunet_plans(plans)
+    assert plan.pool_op_kernel_sizes[0] == [1, 2, 2] and not plan.isotropic
+    vol, meta = nifti.read(os.path.join(raw, 'nnUNet_raw_data', task, 'imagesTr', 'case_00_0000.nii.gz'))
+    x, props = preprocess.preprocess_case(vol, meta['spacing'], plans)
+    assert x.shape[1:] == d.shape[1:]
+    assert np.allclose(x[0], d[0], atol=1e-4)
+    from deepwmh_amd.trainer import UNetTrainer
+    with pytest.raises(NotImplementedError, match='thick-slice'):
+        UNetTrainer(plan, {}, 'cpu')
 
 
 def test_cli_accepts_reference_training_commands():
@@ -55,11 +82,7 @@ def test_cli_accepts_reference_training_commands():
 
 
 def test_plan_and_preprocess_and_loader(tmp_path):
-    from deepwmh_amd.data import DATA_ID, PatchLoader, plan_and_preprocess, plan_patch
-    assert plan_patch((160, 192, 160)) == ([128, 128, 128], 5)
-    assert plan_patch((40, 48, 44)) == ([40, 48, 40], 3)            # >= 4 voxels per axis at the bottleneck
-    assert plan_patch((20, 100, 70)) == ([20, 100, 68], 2)
-    assert plan_patch((300, 300, 300)) == ([128, 128, 128], 5)
+    from deepwmh_amd.data import DATA_ID, PatchLoader, plan_and_preprocess
     raw, pre = str(tmp_path / 'raw'), str(tmp_path / 'pre')
     task = make_raw_dataset(raw)
     t, plans = plan_and_preprocess(raw, pre, '1', True, log=lambda *a: None)
