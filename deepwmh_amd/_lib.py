@@ -52,6 +52,11 @@ SIGNATURES = {
     'wmh_conv3d_k3_wgrad_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_wgrad': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_upsample_zero2': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'wmh_upsample_zero_plane': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'wmh_conv3d_wgrad_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_wgrad': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_convtranspose3d_wgrad_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    'wmh_convtranspose3d_wgrad': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_dice_ce_loss_workspace_doubles': (_sz, []),
     'wmh_dice_ce_loss_fwd_bwd': (_i, [_vp, _vp, _i, _i, _sz, _f, _f, _vp, _vp, _vp, _vp]),
     'wmh_in_lrelu_bwd_scratch_doubles': (_sz, [_i, _i, _sz]),

@@ -436,7 +436,8 @@ extern "C" int wmh_conv3d_k3_pack_weights(int cfg, const float* w, int Cin, int 
 // mode 1: the image of the DATA-GRADIENT conv Cout -> ci_cnt, i.e. W'[ci][co][tap] = W[co][ci][26 - tap].
 // mode 2: w is a ConvTranspose3d(k2,s2) weight [Cout][ci_cnt][2][2][2] (Cout = the transposed conv's INPUT channels);
 // the image is its data gradient as a stride-2 3x3x3 convolution ci_cnt -> Cout over dY: taps (1|2) of the padded
-// 3-window are the 2-window, tap 0 is zero  (out[m] = sum_t in[2m + t - 1] W3[t]).
+// 3-window are the 2-window, tap 0 is zero  (out[m] = sum_t in[2m + t - 1] W3[t]).  With a kernel-[1,3,3] configuration:
+// the same for a ConvTranspose3d((1,2,2)) weight [Cout][ci_cnt][1][2][2].
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float* wf, int Cin_total, int Cout, int ci_off,
                                                            int ci_cnt, int mode, int CK, int NT, int NCH, int NTAPS, size_t total) {
     const int V = CK / 2;
@@ -454,7 +455,10 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float
             if (eco < Cout && eci < ci_cnt) v = w[((size_t)eco * Cin_total + ci_off + eci) * NTAPS + tap];
         } else if (mode == 2) {
             const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-            if (eco < Cout && eci < ci_cnt && tz && ty && tx)
+            if (NTAPS == 9) {                      // (1,2,2) transposed convolution [Cout][ci_cnt][1][2][2] in a (1,3,3) window
+                if (eco < Cout && eci < ci_cnt && ty && tx)
+                    v = w[((size_t)eco * Cin_total + ci_off + eci) * 4 + (ty - 1) * 2 + (tx - 1)];
+            } else if (eco < Cout && eci < ci_cnt && tz && ty && tx)
                 v = w[((size_t)eco * Cin_total + ci_off + eci) * 8 + (tz - 1) * 4 + (ty - 1) * 2 + (tx - 1)];
         } else {
             if (eco < ci_cnt && eci < Cout) v = w[((size_t)eci * Cin_total + ci_off + eco) * NTAPS + (NTAPS - 1 - tap)];
@@ -467,7 +471,7 @@ extern "C" int wmh_conv3d_k3_pack_weights_device(int cfg, const float* w, int Ci
     if (cfg < 0 || cfg >= WMH_NUM_CONV_CFG || !w || !wf || ci_off < 0 || ci_cnt < 1 || ci_off + ci_cnt > Cin_total)
         return wmh_fail(WMH_EINVAL, "pack_weights_device: bad args");
     const CfgInfo& c = cfg_info(cfg);
-    if (mode < 0 || mode > 2 || (mode == 2 && c.KZ != 3)) return wmh_fail(WMH_EINVAL, "pack_weights_device: bad mode");
+    if (mode < 0 || mode > 2) return wmh_fail(WMH_EINVAL, "pack_weights_device: bad mode");
     const int eCin = mode == 1 ? Cout : ci_cnt, eCout = mode == 1 ? ci_cnt : Cout;
     const int NCH = cdiv(eCin, c.CK);
     const size_t total = (size_t)cdiv(eCout, 32 * c.NT) * NCH * (c.KZ * 9) * c.NT * 64 * (c.CK / 2);

@@ -135,9 +135,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_kernel(const WgradArgs
 //    to LDS afterwards;
 //  * the next tile's dy is fetched the same way under the last chunk; two barriers per tile swap it in.
 // ------------------------------------------------------------------------------------------------
-template <int S, int TX, int TY, int TZ>
+// KZ / SZ: kernel extent and stride along the first spatial axis (nnU-Net's anisotropic stages: kernel [1,3,3], pooling
+// [1,2,2]); the tap index on the lanes is (kz, ky, kx) with KZ * 9 taps used.
+template <int S, int TX, int TY, int TZ, int KZ = 3, int SZ = S>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_pipe_kernel(const WgradArgs a) {
-    constexpr int IX = S * (TX - 1) + 3, IY = S * (TY - 1) + 3, IZ = S * (TZ - 1) + 3;
+    constexpr int IX = S * (TX - 1) + 3, IY = S * (TY - 1) + 3, IZ = SZ * (TZ - 1) + KZ, NTAP = 9 * KZ;
     constexpr int TV = TZ * TY * TX, ZS = IY * IX, SPX = IZ * ZS, DYS = TV + 1;
     constexpr int NK = (SPX + 63) / 64, XB = NK * 64;          // x' elements per lane / floats per wave buffer
     constexpr int NDY = TV / 8, CPK = 256 / TV;                // dy elements per thread / co rows per pass
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_pipe_kernel(const Wgra
     const int g = bid % a.NG, cg = bid / a.NG;
     const int nchunks = min(8, (a.Cin - cg * 32 + 3) / 4);     // uniform: chunks that hold any input channel
 
-    const int tapj = min(i, 26);
+    const int tapj = min(i, NTAP - 1);
     const int LB = kh * S + (tapj / 9) * ZS + ((tapj / 3) % 3) * IX + (tapj % 3);
     const int LA = i * DYS + kh;
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_pipe_kernel(const Wgra
         tn = __builtin_amdgcn_readfirstlane(b);                 // (scalar division runs on the VALU)
         const int ox0 = __builtin_amdgcn_readfirstlane(tx * TX), oy0 = __builtin_amdgcn_readfirstlane(ty * TY),
                   oz0 = __builtin_amdgcn_readfirstlane(tz * TZ);
-        const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
+        const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * SZ - KZ / 2;
         okm = 0;
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_pipe_kernel(const Wgra
 #pragma unroll
                     for (int y = 0; y < TY; ++y) {
                         const float* ap = a0 + (z * TY + y) * TX;
-                        const float* bp = b0 + S * (z * ZS + y * IX);
+                        const float* bp = b0 + SZ * z * ZS + S * y * IX;
 #pragma unroll
                         for (int xp = 0; xp < TX / 2; ++xp)
                             acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * xp], bp[S * 2 * xp], acc[c], 0, 0, 0);
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_pipe_kernel(const Wgra
             }
         }
     }
-    if (i < 27) {
+    if (i < NTAP) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int ci = cg * 32 + 4 * c + wave;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_pipe_kernel(const Wgra
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (co < a.Cout) a.part[(((size_t)p * a.Cout + co) * a.Cin + ci) * 27 + i] = acc[c][r];
+                if (co < a.Cout) a.part[(((size_t)p * a.Cout + co) * a.Cin + ci) * NTAP + i] = acc[c][r];
             }
         }
     }
@@ -305,11 +307,12 @@ static bool wgrad_old_form() {
     static const bool v = getenv("WMH_WGRAD_OLD") != nullptr;      // diagnostic: the unpipelined kernel
     return v;
 }
-static WgradPlan plan_wgrad(int Cin, int Cout, int N, int D, int H, int W, int S) {
+static WgradPlan plan_wgrad(int Cin, int Cout, int N, int D, int H, int W, int S, int KZ = 3, int SZ = 0) {
     WgradPlan q;
-    const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+    if (SZ == 0) SZ = S;
+    const int Do = (D - 1) / SZ + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
     q.TX = Wo >= 24 ? 32 : Wo >= 12 ? 16 : Wo >= 6 ? 8 : 4;
-    if (S == 2 && !wgrad_old_form()) {                           // pipelined stride 2: halo tiles small enough to prefetch
+    if (S == 2 && (!wgrad_old_form() || KZ != 3 || SZ != S)) {   // pipelined stride 2: halo tiles small enough to prefetch
         if (q.TX == 32) q.TX = 16;
         if (q.TX == 16) { q.TY = 2; q.TZ = 2; } else if (q.TX == 8) { q.TY = 4; q.TZ = 2; } else { q.TY = 4; q.TZ = 4; }
     }
@@ -317,7 +320,7 @@ static WgradPlan plan_wgrad(int Cin, int Cout, int N, int D, int H, int W, int S
     else if (q.TX == 16) { q.TY = S == 1 ? 8 : 4; q.TZ = 2; }
     else if (q.TX == 8) { q.TY = 8; q.TZ = S == 1 ? 4 : 2; }
     else { q.TY = 4; q.TZ = 4; }
-    q.IX = S * (q.TX - 1) + 3; q.IY = S * (q.TY - 1) + 3; q.IZ = S * (q.TZ - 1) + 3;
+    q.IX = S * (q.TX - 1) + 3; q.IY = S * (q.TY - 1) + 3; q.IZ = SZ * (q.TZ - 1) + KZ;
     q.ntx = cdiv(Wo, q.TX); q.nty = cdiv(Ho, q.TY); q.ntz = cdiv(Do, q.TZ);
     q.ntiles = N * q.ntx * q.nty * q.ntz;
     q.NG = cdiv(Cout, 32); q.NCG = cdiv(Cin, 32);
@@ -329,19 +332,27 @@ static WgradPlan plan_wgrad(int Cin, int Cout, int N, int D, int H, int W, int S
     return q;
 }
 
+static bool wgrad_shape_ok(int kz, int sz, int stride) {
+    return (stride == 1 || stride == 2) && (sz == 1 || sz == 2) && (kz == 1 || kz == 3) && sz <= stride && !(kz == 1 && sz == 2);
+}
+// General form: kernel (kz,3,3), stride (sz, stride, stride) -- the combinations wmh_conv3d_config has forward kernels for
+extern "C" size_t wmh_conv3d_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W, int kz, int sz, int stride) {
+    if (!wgrad_shape_ok(kz, sz, stride)) return 0;
+    const WgradPlan q = plan_wgrad(Cin, Cout, N, D, H, W, stride, kz, sz);
+    return (size_t)q.P * Cout * Cin * 9 * kz;
+}
 extern "C" size_t wmh_conv3d_k3_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W, int stride) {
-    const WgradPlan q = plan_wgrad(Cin, Cout, N, D, H, W, stride);
-    return (size_t)q.P * Cout * Cin * 27;
+    return wmh_conv3d_wgrad_workspace_floats(Cin, Cout, N, D, H, W, 3, stride, stride);
 }
 
-template <int S, int TX, int TY, int TZ>
+template <int S, int TX, int TY, int TZ, int KZ = 3, int SZ = S>
 static int launch_wgrad_pipe(const WgradArgs& a, unsigned nblk, hipStream_t st) {
-    constexpr int IX = S * (TX - 1) + 3, IY = S * (TY - 1) + 3, IZ = S * (TZ - 1) + 3;
+    constexpr int IX = S * (TX - 1) + 3, IY = S * (TY - 1) + 3, IZ = SZ * (TZ - 1) + KZ;
     constexpr int XB = ((IX * IY * IZ + 63) / 64) * 64;
     constexpr int lds = (32 * (TX * TY * TZ + 1) + 8 * XB) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_pipe_kernel<S, TX, TY, TZ>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_pipe_kernel<S, TX, TY, TZ, KZ, SZ>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((conv3d_k3_wgrad_pipe_kernel<S, TX, TY, TZ>), dim3(nblk), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_pipe_kernel<S, TX, TY, TZ, KZ, SZ>), dim3(nblk), dim3(256), lds, st, a);
     return wmh_check_launch("conv3d_k3_wgrad_pipe_kernel");
 }
 
@@ -353,21 +364,22 @@ static int launch_wgrad(const WgradArgs& a, unsigned nblk, int lds, hipStream_t 
     return wmh_check_launch("conv3d_k3_wgrad_kernel");
 }
 
-extern "C" int wmh_conv3d_k3_wgrad(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
-                                   const float* dy, float* dW, float* workspace, int N, int D, int H, int W, int Cout,
-                                   int stride, float lrelu_slope, void* stream) {
-    if (!x0 || !dy || !dW || !workspace || C0 < 1 || N < 1 || Cout < 1 || (stride != 1 && stride != 2))
-        return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad: bad args");
+extern "C" int wmh_conv3d_wgrad(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
+                                const float* dy, float* dW, float* workspace, int N, int D, int H, int W, int Cout,
+                                int kz, int sz, int stride, float lrelu_slope, void* stream) {
+    if (!x0 || !dy || !dW || !workspace || C0 < 1 || N < 1 || Cout < 1 || !wgrad_shape_ok(kz, sz, stride))
+        return wmh_fail(WMH_EINVAL, "conv3d_wgrad: bad args");
     if (!x1) C1 = 0;
     const int Cin = C0 + C1;
-    const WgradPlan q = plan_wgrad(Cin, Cout, N, D, H, W, stride);
-    if (q.lds_bytes > 160 * 1024) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad: tile does not fit LDS");
+    const bool iso = kz == 3 && sz == stride;
+    const WgradPlan q = plan_wgrad(Cin, Cout, N, D, H, W, stride, kz, sz);
+    if (q.lds_bytes > 160 * 1024) return wmh_fail(WMH_EINVAL, "conv3d_wgrad: tile does not fit LDS");
     if ((size_t)D * H * W * 4 >= ((size_t)1 << 32) || (size_t)Cout * D * H * W * 4 >= ((size_t)1 << 32))
-        return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad: volume too large for 32-bit lane offsets");
+        return wmh_fail(WMH_EINVAL, "conv3d_wgrad: volume too large for 32-bit lane offsets");
     WgradArgs a;
     a.x0 = x0; a.ss0 = ss0; a.C0 = C0; a.x1 = x1; a.ss1 = ss1; a.C1 = C1; a.dy = dy; a.part = workspace;
     a.N = N; a.D = D; a.H = H; a.W = W;
-    a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+    a.Do = (D - 1) / sz + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
     a.Cout = Cout; a.Cin = Cin;
     a.TZ = q.TZ; a.TY = q.TY; a.IZ = q.IZ; a.IY = q.IY; a.IX = q.IX;
     a.ntx = q.ntx; a.nty = q.nty; a.ntz = q.ntz; a.ntiles = q.ntiles;
@@ -377,16 +389,30 @@ extern "C" int wmh_conv3d_k3_wgrad(const float* x0, const float* ss0, int C0, co
     int rc;
 #define WG(SS, TT, YY, ZZ) rc = launch_wgrad<SS, TT, YY, ZZ>(a, nblk, q.lds_bytes, st)
 #define WP(SS, TT, YY, ZZ) rc = launch_wgrad_pipe<SS, TT, YY, ZZ>(a, nblk, st)
+#define WA(SS, TT, YY, ZZ, KK, SZZ) rc = launch_wgrad_pipe<SS, TT, YY, ZZ, KK, SZZ>(a, nblk, st)
     const bool old_form = wgrad_old_form();
-    if (stride == 2 && !old_form) { if (q.TX == 16) WP(2, 16, 2, 2); else if (q.TX == 8) WP(2, 8, 4, 2); else WP(2, 4, 4, 4); }
+    if (!iso && stride == 1) {                       // kernel [1,3,3], stride 1
+        if (q.TX == 32) WA(1, 32, 4, 2, 1, 1); else if (q.TX == 16) WA(1, 16, 8, 2, 1, 1); else if (q.TX == 8) WA(1, 8, 8, 4, 1, 1); else WA(1, 4, 4, 4, 1, 1);
+    } else if (!iso && kz == 1) {                    // kernel [1,3,3], stride (1,2,2)
+        if (q.TX == 16) WA(2, 16, 2, 2, 1, 1); else if (q.TX == 8) WA(2, 8, 4, 2, 1, 1); else WA(2, 4, 4, 4, 1, 1);
+    } else if (!iso) {                               // kernel [3,3,3], stride (1,2,2)
+        if (q.TX == 16) WA(2, 16, 2, 2, 3, 1); else if (q.TX == 8) WA(2, 8, 4, 2, 3, 1); else WA(2, 4, 4, 4, 3, 1);
+    }
+    else if (stride == 2 && !old_form) { if (q.TX == 16) WP(2, 16, 2, 2); else if (q.TX == 8) WP(2, 8, 4, 2); else WP(2, 4, 4, 4); }
     else if (stride == 1 && !old_form) { if (q.TX == 32) WP(1, 32, 4, 2); else if (q.TX == 16) WP(1, 16, 8, 2); else if (q.TX == 8) WP(1, 8, 8, 4); else WP(1, 4, 4, 4); }
     else if (stride == 1) { if (q.TX == 32) WG(1, 32, 4, 2); else if (q.TX == 16) WG(1, 16, 8, 2); else if (q.TX == 8) WG(1, 8, 8, 4); else WG(1, 4, 4, 4); }
     else             { if (q.TX == 32) WG(2, 32, 4, 2); else if (q.TX == 16) WG(2, 16, 4, 2); else if (q.TX == 8) WG(2, 8, 8, 2); else WG(2, 4, 4, 4); }
 #undef WG
 #undef WP
+#undef WA
     if (rc != WMH_OK) return rc;
-    const size_t n = (size_t)Cout * Cin * 27;
+    const size_t n = (size_t)Cout * Cin * 9 * kz;
     unsigned rb = (unsigned)((n + 255) / 256); if (rb > 2048) rb = 2048;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, workspace, dW, n, q.P);
     return wmh_check_launch("wgrad_reduce_kernel");
+}
+extern "C" int wmh_conv3d_k3_wgrad(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
+                                   const float* dy, float* dW, float* workspace, int N, int D, int H, int W, int Cout,
+                                   int stride, float lrelu_slope, void* stream) {
+    return wmh_conv3d_wgrad(x0, ss0, C0, x1, ss1, C1, dy, dW, workspace, N, D, H, W, Cout, 3, stride, stride, lrelu_slope, stream);
 }

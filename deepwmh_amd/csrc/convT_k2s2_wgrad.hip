@@ -24,9 +24,11 @@ struct CTWArgs {
     float slope;
 };
 
-template <int TX, int TY, int TZ>
+// KT: kernel = stride along the first spatial axis (2, or 1 for nnU-Net's [1,2,2] pooling stages: 4 taps, one accumulator)
+template <int TX, int TY, int TZ, int KT = 2>
 __global__ __launch_bounds__(256, 2) void convT_k2s2_wgrad_kernel(const CTWArgs a) {
-    constexpr int TVL = TX * TY * TZ, XS = TVL + 1, YS = 8 * TVL + 1;
+    constexpr int TVL = TX * TY * TZ, XS = TVL + 1, NTAP = 4 * KT, YS = NTAP * TVL + 1;
+    constexpr int RT = 128 * KT, CP = 256 / RT, NKY = 32 / CP;     // threads per dY channel, channels per pass, passes
     static_assert(TVL == 64, "64 low-resolution voxels per tile");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                   // [32 ci][XS]
@@ -41,13 +43,15 @@ __global__ __launch_bounds__(256, 2) void convT_k2s2_wgrad_kernel(const CTWArgs 
     const size_t DHW = (size_t)a.D * a.H * a.W;
 
     // staging geometry: dY -- thread = (x, hi-res row) of one output channel per pass; x' -- thread = voxel, wave = channel
-    const int sx = tid % TX, sr = tid / TX, sy2 = sr % (2 * TY), sz2 = sr / (2 * TY);
-    const int stap = (sz2 & 1) * 4 + (sy2 & 1) * 2, sm = ((sz2 >> 1) * TY + (sy2 >> 1)) * TX + sx;
+    const int t2 = tid % RT, cpi = tid / RT;
+    const int sx = t2 % TX, sr = t2 / TX, sy2 = sr % (2 * TY), sz2 = sr / (2 * TY);      // sz2: high-resolution plane of the tile
+    const int szl = KT == 2 ? (sz2 >> 1) : sz2;                                           // its low-resolution plane
+    const int stap = (KT == 2 ? (sz2 & 1) * 4 : 0) + (sy2 & 1) * 2, sm = (szl * TY + (sy2 >> 1)) * TX + sx;
     const int mx = lane % TX, my = (lane / TX) % TY, mz = lane / (TX * TY);
 
-    f32x16 acc[2];
+    f32x16 acc[KT];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < KT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
@@ -60,19 +64,19 @@ __global__ __launch_bounds__(256, 2) void convT_k2s2_wgrad_kernel(const CTWArgs 
         tn = __builtin_amdgcn_readfirstlane(b);
         const int x0 = __builtin_amdgcn_readfirstlane(tx * TX), y0 = __builtin_amdgcn_readfirstlane(ty * TY),
                   z0 = __builtin_amdgcn_readfirstlane(tz * TZ);
-        yok = x0 + sx < a.W && y0 + (sy2 >> 1) < a.H && z0 + (sz2 >> 1) < a.D;
-        yoff = yok ? 4u * (unsigned)(((2 * z0 + sz2) * H2 + 2 * y0 + sy2) * W2 + 2 * (x0 + sx)) : 0u;
+        yok = x0 + sx < a.W && y0 + (sy2 >> 1) < a.H && z0 + szl < a.D;
+        yoff = yok ? 4u * (unsigned)(((KT * z0 + sz2) * H2 + 2 * y0 + sy2) * W2 + 2 * (x0 + sx)) : 0u;
         xok = x0 + mx < a.W && y0 + my < a.H && z0 + mz < a.D;
         xoff = xok ? 4u * (unsigned)(((z0 + mz) * a.H + y0 + my) * a.W + x0 + mx) : 0u;
     };
-    float2 yr[32]; float xr[8]; int wn = 0; bool wyok = false, wxok = false;
-    const unsigned ycs = 4u * 8u * (unsigned)DHW;               // bytes between channels of dY (host checks the range)
+    float2 yr[NKY]; float xr[8]; int wn = 0; bool wyok = false, wxok = false;
+    const unsigned ycs = 4u * (unsigned)NTAP * (unsigned)DHW;               // bytes between channels of dY (host checks the range)
     const unsigned xcs = 4u * (unsigned)DHW;
     auto issue = [&]() {
-        const char* ysrc = (const char*)(a.dy + (size_t)tn * a.Cout * 8 * DHW);
+        const char* ysrc = (const char*)(a.dy + (size_t)tn * a.Cout * NTAP * DHW);
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const unsigned co = (unsigned)min(g * 32 + k, a.Cout - 1);
+        for (int k = 0; k < NKY; ++k) {
+            const unsigned co = (unsigned)min(g * 32 + k * CP + cpi, a.Cout - 1);
             yr[k] = *(const float2*)(ysrc + (co * ycs + yoff));
         }
         const char* xsrc = (const char*)(a.x + (size_t)tn * a.Cin * DHW);
@@ -85,10 +89,11 @@ __global__ __launch_bounds__(256, 2) void convT_k2s2_wgrad_kernel(const CTWArgs 
     };
     auto write = [&]() {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const bool ok = wyok && g * 32 + k < a.Cout;
-            ys[k * YS + stap * TVL + sm] = ok ? yr[k].x : 0.f;
-            ys[k * YS + (stap + 1) * TVL + sm] = ok ? yr[k].y : 0.f;
+        for (int k = 0; k < NKY; ++k) {
+            const int col = k * CP + cpi;
+            const bool ok = wyok && g * 32 + col < a.Cout;
+            ys[col * YS + stap * TVL + sm] = ok ? yr[k].x : 0.f;
+            ys[col * YS + (stap + 1) * TVL + sm] = ok ? yr[k].y : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -116,17 +121,17 @@ __global__ __launch_bounds__(256, 2) void convT_k2s2_wgrad_kernel(const CTWArgs 
         for (int pp = 0; pp < TVL / 2; ++pp) {
             const float av = ap[2 * pp];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[2 * pp], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[4 * TVL + 2 * pp], acc[1], 0, 0, 0);
+            if constexpr (KT == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[4 * TVL + 2 * pp], acc[1], 0, 0, 0);
         }
     }
     const int co = g * 32 + i;
     if (co < a.Cout) {
 #pragma unroll
-        for (int kz = 0; kz < 2; ++kz)
+        for (int kz = 0; kz < KT; ++kz)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (ci < a.Cin) a.part[(((size_t)p * a.Cin + ci) * a.Cout + co) * 8 + kz * 4 + wave] = acc[kz][r];
+                if (ci < a.Cin) a.part[(((size_t)p * a.Cin + ci) * a.Cout + co) * NTAP + kz * 4 + wave] = acc[kz][r];
             }
     }
 }
@@ -151,26 +156,31 @@ static CTWPlan plan_ctw(int Cin, int Cout, int N, int D, int H, int W) {
     return q;
 }
 
-extern "C" size_t wmh_convtranspose3d_k2s2_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W) {
+// kt: kernel = stride along the first spatial axis (2, or 1 for the [1,2,2] stages); D, H, W: the INPUT (low-resolution) size
+extern "C" size_t wmh_convtranspose3d_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W, int kt) {
+    if (kt != 1 && kt != 2) return 0;
     const CTWPlan q = plan_ctw(Cin, Cout, N, D, H, W);
-    return (size_t)q.P * Cin * Cout * 8;
+    return (size_t)q.P * Cin * Cout * 4 * kt;
+}
+extern "C" size_t wmh_convtranspose3d_k2s2_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W) {
+    return wmh_convtranspose3d_wgrad_workspace_floats(Cin, Cout, N, D, H, W, 2);
 }
 
-template <int TX, int TY, int TZ>
+template <int TX, int TY, int TZ, int KT>
 static int launch_ctw(const CTWArgs& a, unsigned nblk, hipStream_t st) {
-    constexpr int lds = (32 * (TX * TY * TZ + 1) + 32 * (8 * TX * TY * TZ + 1)) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT_k2s2_wgrad_kernel<TX, TY, TZ>),
+    constexpr int lds = (32 * (TX * TY * TZ + 1) + 32 * (4 * KT * TX * TY * TZ + 1)) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT_k2s2_wgrad_kernel<TX, TY, TZ, KT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((convT_k2s2_wgrad_kernel<TX, TY, TZ>), dim3(nblk), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((convT_k2s2_wgrad_kernel<TX, TY, TZ, KT>), dim3(nblk), dim3(256), lds, st, a);
     return wmh_check_launch("convT_k2s2_wgrad_kernel");
 }
 
-extern "C" int wmh_convtranspose3d_k2s2_wgrad(const float* x, const float* ss, const float* dY, float* dW, float* workspace,
-                                              int N, int Cin, int Cout, int D, int H, int W, float slope, void* stream) {
-    if (!x || !dY || !dW || !workspace || N < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1)
-        return wmh_fail(WMH_EINVAL, "convtranspose3d_k2s2_wgrad: bad args");
-    if ((size_t)Cout * 8 * D * H * W * 4 >= ((size_t)1 << 32) || (size_t)Cin * D * H * W * 4 >= ((size_t)1 << 32))
-        return wmh_fail(WMH_EINVAL, "convtranspose3d_k2s2_wgrad: volume too large for 32-bit lane offsets");
+extern "C" int wmh_convtranspose3d_wgrad(const float* x, const float* ss, const float* dY, float* dW, float* workspace,
+                                         int N, int Cin, int Cout, int D, int H, int W, int kt, float slope, void* stream) {
+    if (!x || !dY || !dW || !workspace || N < 1 || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (kt != 1 && kt != 2))
+        return wmh_fail(WMH_EINVAL, "convtranspose3d_wgrad: bad args");
+    if ((size_t)Cout * 4 * kt * D * H * W * 4 >= ((size_t)1 << 32) || (size_t)Cin * D * H * W * 4 >= ((size_t)1 << 32))
+        return wmh_fail(WMH_EINVAL, "convtranspose3d_wgrad: volume too large for 32-bit lane offsets");
     const CTWPlan q = plan_ctw(Cin, Cout, N, D, H, W);
     CTWArgs a;
     a.x = x; a.ss = ss; a.dy = dY; a.part = workspace;
@@ -179,12 +189,22 @@ extern "C" int wmh_convtranspose3d_k2s2_wgrad(const float* x, const float* ss, c
     const unsigned nblk = (unsigned)(q.NG * q.NCG * q.P);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (q.TX == 16) rc = launch_ctw<16, 2, 2>(a, nblk, st);
-    else if (q.TX == 8) rc = launch_ctw<8, 4, 2>(a, nblk, st);
-    else rc = launch_ctw<4, 4, 4>(a, nblk, st);
+    if (kt == 2) {
+        if (q.TX == 16) rc = launch_ctw<16, 2, 2, 2>(a, nblk, st);
+        else if (q.TX == 8) rc = launch_ctw<8, 4, 2, 2>(a, nblk, st);
+        else rc = launch_ctw<4, 4, 4, 2>(a, nblk, st);
+    } else {
+        if (q.TX == 16) rc = launch_ctw<16, 2, 2, 1>(a, nblk, st);
+        else if (q.TX == 8) rc = launch_ctw<8, 4, 2, 1>(a, nblk, st);
+        else rc = launch_ctw<4, 4, 4, 1>(a, nblk, st);
+    }
     if (rc != WMH_OK) return rc;
-    const size_t n = (size_t)Cin * Cout * 8;
+    const size_t n = (size_t)Cin * Cout * 4 * kt;
     unsigned rb = (unsigned)((n + 255) / 256); if (rb > 2048) rb = 2048;
     hipLaunchKernelGGL(convT_wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, workspace, dW, n, q.P);
     return wmh_check_launch("convT_wgrad_reduce_kernel");
+}
+extern "C" int wmh_convtranspose3d_k2s2_wgrad(const float* x, const float* ss, const float* dY, float* dW, float* workspace,
+                                              int N, int Cin, int Cout, int D, int H, int W, float slope, void* stream) {
+    return wmh_convtranspose3d_wgrad(x, ss, dY, dW, workspace, N, Cin, Cout, D, H, W, 2, slope, stream);
 }

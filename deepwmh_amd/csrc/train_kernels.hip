@@ -321,6 +321,26 @@ __global__ __launch_bounds__(256) void upsample_zero2_kernel(const float* dy, fl
         op[v] = on ? ip[((size_t)(z >> 1) * Ho + (yy >> 1)) * Wo + (x >> 1)] : 0.f;
     }
 }
+// the same for a stride (1,2,2) convolution: zeros inserted in the plane only (Do == D)
+__global__ __launch_bounds__(256) void upsample_zero_plane_kernel(const float* dy, float* up, int Ho, int Wo, int D, int H, int W) {
+    const size_t nc = blockIdx.y, S = (size_t)D * H * W;
+    const float* ip = dy + nc * D * Ho * Wo;
+    float* op = up + nc * S;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < S; v += (size_t)gridDim.x * 256) {
+        const int x = (int)(v % W), yy = (int)((v / W) % H), z = (int)(v / ((size_t)W * H));
+        const bool on = !((x | yy) & 1);
+        op[v] = on ? ip[((size_t)z * Ho + (yy >> 1)) * Wo + (x >> 1)] : 0.f;
+    }
+}
+extern "C" int wmh_upsample_zero_plane(const float* dy, float* up, int N, int C, int Ho, int Wo, int D, int H, int W, void* stream) {
+    if (!dy || !up || (H - 1) / 2 + 1 != Ho || (W - 1) / 2 + 1 != Wo || D < 1)
+        return wmh_fail(WMH_EINVAL, "upsample_zero_plane: bad args");
+    const size_t S = (size_t)D * H * W;
+    unsigned gx = cdivu(S, 256 * 4); if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(upsample_zero_plane_kernel, dim3(gx, (unsigned)((size_t)N * C)), dim3(256), 0, (hipStream_t)stream, dy, up,
+                       Ho, Wo, D, H, W);
+    return wmh_check_launch("upsample_zero_plane_kernel");
+}
 extern "C" int wmh_upsample_zero2(const float* dy, float* up, int N, int C, int Do, int Ho, int Wo, int D, int H, int W,
                                   void* stream) {
     if (!dy || !up || (D - 1) / 2 + 1 != Do || (H - 1) / 2 + 1 != Ho || (W - 1) / 2 + 1 != Wo)

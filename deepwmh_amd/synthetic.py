@@ -36,21 +36,22 @@ def he_init_state_dict(plan, seed=0, trained_like=True):
     gain = np.sqrt(2.0 / (1 + 1e-2 ** 2))
     sd = OrderedDict()
 
-    def conv_block(prefix, cin, cout):
-        sd[prefix + '.conv.weight'] = (rng.standard_normal((cout, cin, 3, 3, 3)) * gain / np.sqrt(cin * 27)).astype(np.float32)
+    def conv_block(prefix, cin, cout, kz=3):
+        sd[prefix + '.conv.weight'] = (rng.standard_normal((cout, cin, kz, 3, 3)) * gain / np.sqrt(cin * 9 * kz)).astype(np.float32)
         sd[prefix + '.conv.bias'] = (0.1 * rng.standard_normal(cout) if trained_like else np.zeros(cout)).astype(np.float32)
         sd[prefix + '.instnorm.weight'] = (1 + 0.2 * rng.standard_normal(cout) if trained_like else np.ones(cout)).astype(np.float32)
         sd[prefix + '.instnorm.bias'] = (0.1 * rng.standard_normal(cout) if trained_like else np.zeros(cout)).astype(np.float32)
 
     for s in plan.encoder_convs():
-        conv_block(s.name, s.cin, s.cout)
+        conv_block(s.name, s.cin, s.cout, s.kz)
     dec = plan.decoder_stages()
     for st in dec:
         for c in st['convs']:
-            conv_block(c.name, c.cin, c.cout)
+            conv_block(c.name, c.cin, c.cout, c.kz)
     for st in dec:
         name, cdown, cskip = st['tu']
-        sd[name + '.weight'] = (rng.standard_normal((cdown, cskip, 2, 2, 2)) * gain / np.sqrt(cskip * 8)).astype(np.float32)
+        kt = int(st['tu_kt'])
+        sd[name + '.weight'] = (rng.standard_normal((cdown, cskip, kt, 2, 2)) * gain / np.sqrt(cskip * 4 * kt)).astype(np.float32)
     for st in dec:
         cskip = st['tu'][2]
         sd[st['seg'] + '.weight'] = (rng.standard_normal((plan.num_classes, cskip, 1, 1, 1)) * gain / np.sqrt(cskip)).astype(np.float32)

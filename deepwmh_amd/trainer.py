@@ -31,8 +31,12 @@ def poly_lr(epoch, max_epochs, initial_lr=1e-2, exponent=0.9):
 
 
 class _Conv:
-    def __init__(self, name, cin, cout, stride):
+    """kernel (kz,3,3), stride (sz, stride, stride): kz = 1 / sz = 1 on nnU-Net's anisotropic stages (thick-slice data)."""
+
+    def __init__(self, name, cin, cout, stride, kz=3, sz=0):
         self.name, self.cin, self.cout, self.stride = name, cin, cout, stride
+        self.kz, self.sz = kz, (sz or stride)
+        self.iso = kz == 3 and self.sz == stride
 
 
 class UNetTrainer:
@@ -46,9 +50,6 @@ class UNetTrainer:
         self.precision = precision
         self.bf16_forward = self.bf16_dgrad = self.bf16_wgrad = precision == 'bf16'      # diagnostic switches (tools/diag_bf16_train.py)
         plan.check_supported()
-        if not plan.isotropic:
-            raise NotImplementedError('nnUNet_train (deepwmh_amd): the backward kernels cover the isotropic [3,3,3] / [2,2,2] architecture only; this plan '
-                                      '(thick-slice data: [1,3,3] kernels / [1,2,2] pooling) can be predicted with but not trained here yet')
         self.plan, self.device = plan, torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('UNetTrainer needs a HIP device; there is no CPU path')
@@ -57,23 +58,26 @@ class UNetTrainer:
         self.momentum, self.weight_decay, self.clip = momentum, weight_decay, clip
         self.K = plan.num_classes
         self.ds_weights = deep_supervision_weights(plan.num_pool)
-        self.enc = [_Conv(s.name, s.cin, s.cout, s.stride) for s in plan.encoder_convs()]
+        self.enc = [_Conv(s.name, s.cin, s.cout, s.stride, s.kz, s.sz) for s in plan.encoder_convs()]
+        for c in self.enc:
+            if c.kz == 1 and c.sz == 2:
+                raise NotImplementedError('%s: kernel 1 with stride 2 along the same axis has no kernel' % c.name)
         self.dec = []
         for st in plan.decoder_stages():
             name, cdown, cskip = st['tu']
-            self.dec.append(dict(tu=name, cdown=cdown, cskip=cskip, seg=st['seg'],
-                                 convs=[_Conv(c.name, c.cin, c.cout, 1) for c in st['convs']]))
+            self.dec.append(dict(tu=name, cdown=cdown, cskip=cskip, seg=st['seg'], kt=int(st['tu_kt']),
+                                 convs=[_Conv(c.name, c.cin, c.cout, 1, c.kz, 1) for c in st['convs']]))
         # ---- flat arenas: upstream parameter order (localization, context, tu, seg_outputs) ------------------
         order = []
         for st in self.dec:
             for c in st['convs']:
-                order += [(c.name + '.conv.weight', (c.cout, c.cin, 3, 3, 3)), (c.name + '.conv.bias', (c.cout,)),
+                order += [(c.name + '.conv.weight', (c.cout, c.cin, c.kz, 3, 3)), (c.name + '.conv.bias', (c.cout,)),
                           (c.name + '.instnorm.weight', (c.cout,)), (c.name + '.instnorm.bias', (c.cout,))]
         for c in self.enc:
-            order += [(c.name + '.conv.weight', (c.cout, c.cin, 3, 3, 3)), (c.name + '.conv.bias', (c.cout,)),
+            order += [(c.name + '.conv.weight', (c.cout, c.cin, c.kz, 3, 3)), (c.name + '.conv.bias', (c.cout,)),
                       (c.name + '.instnorm.weight', (c.cout,)), (c.name + '.instnorm.bias', (c.cout,))]
         for st in self.dec:
-            order.append((st['tu'] + '.weight', (st['cdown'], st['cskip'], 2, 2, 2)))
+            order.append((st['tu'] + '.weight', (st['cdown'], st['cskip'], st['kt'], 2, 2)))
         for st in self.dec:
             order.append((st['seg'] + '.weight', (self.K, st['cskip'], 1, 1, 1)))
         self.param_order = order
@@ -172,10 +176,10 @@ class UNetTrainer:
                    'wmh_conv3d_k3_fwd_bf16')
         return y, part, npart
 
-    def _run_conv(self, key, cfg, x0, ss0, x1, ss1, wf, bias, cout, stride, want_stats):
+    def _run_conv(self, key, cfg, x0, ss0, x1, ss1, wf, bias, cout, stride, want_stats, sz=0):
         N, C0, D, H, W = x0.shape
         C1 = 0 if x1 is None else x1.shape[1]
-        Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+        Do, Ho, Wo = (D - 1) // (sz or stride) + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
         y = self._buf(key + '.y', (N, cout, Do, Ho, Wo))
         part, npart = None, 0
         if want_stats:
@@ -191,16 +195,16 @@ class UNetTrainer:
     # ---- forward -------------------------------------------------------------------------------------------------
     def _conv_fwd(self, key, conv, x0, ss0, x1=None, ss1=None):
         N, _, D, H, W = x0.shape
-        cfg = _lib.check(self.lib.wmh_conv3d_k3_config(conv.cin, conv.cout, D, H, W, conv.stride), 'config')
+        cfg = _lib.check(self.lib.wmh_conv3d_config(conv.cin, conv.cout, D, H, W, conv.kz, conv.sz, conv.stride), 'config')
         C1 = 0 if x1 is None else x1.shape[1]
-        if self._use_bf16(cfg, conv.stride, x0.shape[1], C1):
+        if conv.iso and self._use_bf16(cfg, conv.stride, x0.shape[1], C1):
             cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, conv.cout, W)          # wide tile for >= 64 output channels
             wf = self._pack_bf16(conv, cfg, 0, 0, conv.cin)
             y, part, npart = self._run_conv_bf16(key, cfg, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout, True)
         else:
             wf = self._pack(conv, cfg, 0, 0, conv.cin)
             y, part, npart = self._run_conv(key, cfg, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout,
-                                            conv.stride, True)
+                                            conv.stride, True, conv.sz)
         ss = self._buf(key + '.ss', (N, conv.cout, 2))
         mr = self._buf(key + '.mr', (N, conv.cout, 2))
         _lib.check(self.lib.wmh_instnorm_finalize(_lib.ptr(part), npart, _lib.ptr(self.p[conv.name + '.instnorm.weight']),
@@ -224,12 +228,15 @@ class UNetTrainer:
         logits = []
         for u, st in enumerate(self.dec):
             N, Cin, D, H, W = cur.shape
-            up = self._buf('t.tu%d.y' % u, (N, st['cskip'], 2 * D, 2 * H, 2 * W))
+            kt = st['kt']
+            up = self._buf('t.tu%d.y' % u, (N, st['cskip'], kt * D, 2 * H, 2 * W))
             wtu = self.p[st['tu'] + '.weight']
             if (D * H * W) % 4 == 0:
                 wf = self._pack_tu(u, wtu, st)
-                _lib.check(self.lib.wmh_convtranspose3d_k2s2_mfma_fwd(_lib.ptr(cur), _lib.ptr(cur_ss), _lib.ptr(wf), _lib.ptr(up), N,
-                                                                      Cin, st['cskip'], D, H, W, LRELU_SLOPE, self._st()), 'convT fwd')
+                _lib.check(self.lib.wmh_convtranspose3d_mfma_fwd(_lib.ptr(cur), _lib.ptr(cur_ss), _lib.ptr(wf), _lib.ptr(up), N,
+                                                                 Cin, st['cskip'], D, H, W, kt, LRELU_SLOPE, self._st()), 'convT fwd')
+            elif kt != 2:
+                raise NotImplementedError('(1,2,2) transposed convolution needs D*H*W % 4 == 0')
             else:
                 _lib.check(self.lib.wmh_convtranspose3d_k2s2_fwd(_lib.ptr(cur), _lib.ptr(cur_ss), _lib.ptr(wtu), _lib.ptr(up), N, Cin,
                                                                  st['cskip'], D, H, W, LRELU_SLOPE, self._st()), 'convT fwd')
@@ -251,9 +258,9 @@ class UNetTrainer:
         hit = self._packed.get(key)
         if hit is not None and hit[0] == self._version:
             return hit[1]
-        n = self.lib.wmh_convtranspose3d_k2s2_packed_floats(st['cdown'], st['cskip'])
+        n = self.lib.wmh_convtranspose3d_packed_floats(st['cdown'], st['cskip'], st['kt'])
         wf = hit[1] if hit is not None else torch.empty(n, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.wmh_convtranspose3d_pack_weights_device(_lib.ptr(wtu), st['cdown'], st['cskip'], 2, _lib.ptr(wf), self._st()),
+        _lib.check(self.lib.wmh_convtranspose3d_pack_weights_device(_lib.ptr(wtu), st['cdown'], st['cskip'], st['kt'], _lib.ptr(wf), self._st()),
                    'wmh_convtranspose3d_pack_weights_device')
         self._packed[key] = (self._version, wf)
         return wf
@@ -291,7 +298,13 @@ class UNetTrainer:
         x0, x1 = rec['x0'], rec['x1']
         _, C0, D, H, W = x0.shape
         C1 = 0 if x1 is None else x1.shape[1]
-        if self.bf16_wgrad and lib.wmh_conv3d_k3_wgrad_bf16_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
+        if not conv.iso:                                     # anisotropic stage: the general fp32 kernel
+            nws = lib.wmh_conv3d_wgrad_workspace_floats(C0 + C1, Cc, N, D, H, W, conv.kz, conv.sz, conv.stride)
+            ws = self._buf('b.wgrad.ws', (nws,))
+            _lib.check(lib.wmh_conv3d_wgrad(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
+                                            _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, conv.kz, conv.sz,
+                                            conv.stride, LRELU_SLOPE, st), 'wmh_conv3d_wgrad')
+        elif self.bf16_wgrad and lib.wmh_conv3d_k3_wgrad_bf16_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
             nws = lib.wmh_conv3d_k3_wgrad_bf16_workspace_floats(C0 + C1, Cc, N, D, H, W)
             ws = self._buf('b.wgrad.ws', (nws,))
             _lib.check(lib.wmh_conv3d_k3_wgrad_bf16(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
@@ -307,7 +320,7 @@ class UNetTrainer:
                     + ([wseg_name] if (wseg_name and dl is not None) else []))
         if not need_dx:
             return None
-        if conv.stride == 2:                                 # gather form: 27 MFMAs per channel pair for the 8 output parities
+        if conv.stride == 2 and conv.iso:                    # gather form: 27 MFMAs per channel pair for the 8 output parities
             assert C1 == 0
             key = ('dgrad.s2', conv.name)
             hit = self._packed.get(key)
@@ -322,10 +335,15 @@ class UNetTrainer:
             _lib.check(lib.wmh_conv3d_k3s2_dgrad(_lib.ptr(dy), _lib.ptr(wp), _lib.ptr(dx), N, C0, Cc, D, H, W, st), 'wmh_conv3d_k3s2_dgrad')
             return [dx]
         src = dy
+        if conv.stride == 2:                                 # stride (1,2,2): zeros inserted in the plane, then the stride-1 form below
+            assert C1 == 0 and conv.sz == 1
+            src = self._buf('b.up.%s' % rec['key'], (N, Cc, D, H, W))
+            _lib.check(lib.wmh_upsample_zero_plane(_lib.ptr(dy), _lib.ptr(src), N, Cc, y.shape[3], y.shape[4], D, H, W, st),
+                       'wmh_upsample_zero_plane')
         outs = []
         for part, (off, cnt) in enumerate([(0, C0)] + ([(C0, C1)] if C1 else [])):
-            cfg = _lib.check(lib.wmh_conv3d_k3_config(Cc, cnt, D, H, W, 1), 'config')
-            if self._use_bf16(cfg, 1, Cc, 0, 'dgrad'):
+            cfg = _lib.check(lib.wmh_conv3d_config(Cc, cnt, D, H, W, conv.kz, 1, 1), 'config')
+            if conv.kz == 3 and self._use_bf16(cfg, 1, Cc, 0, 'dgrad'):
                 cfg = lib.wmh_conv3d_k3_bf16_config(cfg, cnt, W)
                 wf = self._pack_bf16(conv, cfg, 1, off, cnt)
                 dx, _, _ = self._run_conv_bf16('b.dx%d.%s' % (part, rec['key']), cfg, src, None, None, None, wf, None, cnt, False)
@@ -381,14 +399,16 @@ class UNetTrainer:
             tu = self.dec[u]['tu'] + '.weight'
             cskip = self.dec[u]['cskip']
             # dW on the matrix cores; dX as a stride-2 convolution of dY with the 2-window embedded in the 3-window
-            nws = lib.wmh_convtranspose3d_k2s2_wgrad_workspace_floats(Cin, cskip, N, D, H, W)
+            kt = self.dec[u]['kt']
+            nws = lib.wmh_convtranspose3d_wgrad_workspace_floats(Cin, cskip, N, D, H, W, kt)
             ws = self._buf('b.wgrad.ws', (max(nws, 1),))
-            _lib.check(lib.wmh_convtranspose3d_k2s2_wgrad(_lib.ptr(x_in), _lib.ptr(ss_in), _lib.ptr(d_up), _lib.ptr(self.g[tu]), _lib.ptr(ws),
-                                                          N, Cin, cskip, D, H, W, LRELU_SLOPE, st), 'wmh_convtranspose3d_k2s2_wgrad')
+            _lib.check(lib.wmh_convtranspose3d_wgrad(_lib.ptr(x_in), _lib.ptr(ss_in), _lib.ptr(d_up), _lib.ptr(self.g[tu]), _lib.ptr(ws),
+                                                     N, Cin, cskip, D, H, W, kt, LRELU_SLOPE, st), 'wmh_convtranspose3d_wgrad')
             self._ready([tu])
-            cfg = _lib.check(lib.wmh_conv3d_k3_config(cskip, Cin, 2 * D, 2 * H, 2 * W, 2), 'config')
+            # (1,2,2): the window embedded in a (1,3,3) one, stride (1,2,2)
+            cfg = _lib.check(lib.wmh_conv3d_config(cskip, Cin, kt * D, 2 * H, 2 * W, 3 if kt == 2 else 1, kt, 2), 'config')
             wf = self._pack_tu_dgrad(u, self.p[tu], cfg, Cin, cskip)
-            g_in, _, _ = self._run_conv('b.tu%d.dx' % u, cfg, d_up, None, None, None, wf, None, Cin, 2, False)
+            g_in, _, _ = self._run_conv('b.tu%d.dx' % u, cfg, d_up, None, None, None, wf, None, Cin, 2, False, kt)
             g_next = g_in
         # encoder: bottleneck back to the first layer; stage outputs also receive the decoder's skip gradient
         nenc = len(self.enc)

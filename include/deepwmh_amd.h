@@ -219,7 +219,14 @@ int wmh_finalize_argmax(const float* agg, const float* cnt, float* prob, uint8_t
  * ci_cnt -> Cout over dY (cfg from wmh_conv3d_k3_config(ci_cnt, Cout, 2D, 2H, 2W, 2)). */
 int wmh_conv3d_k3_pack_weights_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt,
                                       int mode, float* wf, void* stream);
-/* dW[Cout][C0+C1][27] = sum over (n, voxel) of dy * lrelu(instnorm(x)) (transform on load as in the forward). */
+/* dW[Cout][C0+C1][27] = sum over (n, voxel) of dy * lrelu(instnorm(x)) (transform on load as in the forward).
+ * General form (nnU-Net's anisotropic stages, [not in tree] generic_UNet.py with conv_kernel_sizes [1,3,3] /
+ * pool_op_kernel_sizes [1,2,2]): kernel (kz,3,3), stride (sz, stride, stride), the combinations wmh_conv3d_config serves;
+ * dW = [Cout][C0+C1][kz*9]. */
+size_t wmh_conv3d_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W, int kz, int sz, int stride);
+int wmh_conv3d_wgrad(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
+                     const float* dy, float* dW, float* workspace, int N, int D, int H, int W, int Cout,
+                     int kz, int sz, int stride, float lrelu_slope, void* stream);
 size_t wmh_conv3d_k3_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W, int stride);
 int wmh_conv3d_k3_wgrad(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
                         const float* dy, float* dW, float* workspace, int N, int D, int H, int W, int Cout,
@@ -238,6 +245,9 @@ int wmh_conv3d_k3_wgrad_bf16(const float* x0, const float* ss0, int C0, const fl
 size_t wmh_conv3d_k3s2_dgrad_packed_floats(int Cin, int Cout);
 int wmh_conv3d_k3s2_dgrad_pack_weights_device(const float* w, int Cin, int Cout, float* wp, void* stream);
 int wmh_conv3d_k3s2_dgrad(const float* dy, const float* wp, float* dx, int N, int Cin, int Cout, int D, int H, int W, void* stream);
+/* up[n,c,z,2y,2x] = dy[n,c,z,y,x], zero elsewhere: the data gradient of a stride (1,2,2) convolution is the stride-1
+ * convolution of `up` with the mode-1 weight image. */
+int wmh_upsample_zero_plane(const float* dy, float* up, int N, int C, int Ho, int Wo, int D, int H, int W, void* stream);
 /* up[n,c,2z,2y,2x] = dy[n,c,z,y,x], zero elsewhere (up has the stride-2 conv's input size D,H,W). */
 int wmh_upsample_zero2(const float* dy, float* up, int N, int C, int Do, int Ho, int Wo, int D, int H, int W,
                        void* stream);
@@ -262,6 +272,10 @@ int wmh_convtranspose3d_k2s2_bwd(const float* x, const float* ss, const float* w
 /* The same dW on the matrix cores (voxels as the MFMA K dimension, fixed-order slab reduction).
  * workspace >= wmh_convtranspose3d_k2s2_wgrad_workspace_floats(...) floats. */
 size_t wmh_convtranspose3d_k2s2_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
+/* kt = kernel and stride along the first spatial axis: 2, or 1 for ConvTranspose3d((1,2,2)) (dW = [Cin][Cout][kt*4]). */
+size_t wmh_convtranspose3d_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int H, int W, int kt);
+int wmh_convtranspose3d_wgrad(const float* x, const float* ss, const float* dY, float* dW, float* workspace,
+                              int N, int Cin, int Cout, int D, int H, int W, int kt, float slope, void* stream);
 int wmh_convtranspose3d_k2s2_wgrad(const float* x, const float* ss, const float* dY, float* dW, float* workspace,
                                    int N, int Cin, int Cout, int D, int H, int W, float slope, void* stream);
 /* out2[0] = ||grads||_2, out2[1] = min(1, max_norm/(norm+1e-6)); workspace = 1024 doubles. */

@@ -188,3 +188,122 @@ def test_full_width_backward_matches_autograd():
     assert rows[0][0] <= 1e-2 and med_hip <= max(1.5 * med_cpu, 1e-3)
     for e_hip, e_cpu, name in rows:
         assert e_hip <= max(3.0 * e_cpu, 2e-3), 'grad %s: %.3g against float64 (torch fp32: %.3g)' % (name, e_hip, e_cpu)
+
+
+def _aniso_plan():
+    from deepwmh_amd.plan import UNetPlan
+    # what planner.py gives thick-slice data: in-plane pooling / [1,3,3] kernels first; covers kernel (1,3,3) stride 1 and (1,2,2),
+    # kernel (3,3,3) stride (1,2,2), transposed convolutions (1,2,2) and (2,2,2)
+    return UNetPlan(1, 8, 2, [[1, 2, 2], [1, 2, 2], [2, 2, 2]], [[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3]], 2, 64, [8, 32, 32])
+
+
+def test_anisotropic_training_step_matches_autograd_oracle():
+    """Thick-slice plans (reference image_ops.py:354-359 takes anisotropy > 3 as normal input): the whole step against autograd."""
+    import copy
+    from oracle import training as ot
+    from oracle.generic_unet import unet_from_plan
+    from deepwmh_amd.synthetic import he_init_state_dict
+    from deepwmh_amd.trainer import UNetTrainer, downsample_targets
+    plan = _aniso_plan()
+    sd = he_init_state_dict(plan, seed=11)
+    net = unet_from_plan(plan).train()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    rng = np.random.default_rng(3)
+    data = rng.standard_normal((2, 1, 8, 32, 32)).astype(np.float32)
+    data[:, :, :, :4] = 0
+    labels = (rng.random((2, 8, 32, 32)) < 0.25).astype(np.uint8)
+    weights = ot.deep_supervision_weights(plan.num_pool)
+    x = torch.from_numpy(data)
+    tgt = ot.downsample_targets(torch.from_numpy(labels[:, None].astype(np.float32)), plan.num_pool, plan.pool_op_kernel_sizes)
+    xd = x.cuda()
+    td = downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool, plan.pool_op_kernel_sizes)
+    for a, b in zip(td, tgt):
+        assert np.array_equal(a.cpu().numpy().reshape(-1), b.numpy().reshape(-1).astype(np.uint8))
+    tr = UNetTrainer(plan, sd, 'cuda:0')
+    net.do_ds = True
+    out = net(x)
+    loss = ot.multiple_output_loss(out, tgt, weights)
+    loss.backward()
+    lg = tr.forward(xd)
+    for i, (a, b) in enumerate(zip(lg, out)):
+        assert tuple(a.shape) == tuple(b.shape)
+        assert float((a.cpu() - b.detach()).abs().max()) <= 1e-4, 'logits scale %d' % i
+    l = tr.backward(td)
+    torch.cuda.synchronize()
+    assert abs(float(l.cpu()) - float(loss.detach())) <= 1e-5 * (1 + abs(float(loss.detach())))
+    for name, p in net.named_parameters():
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        got = tr.g[name].cpu()
+        assert tuple(got.shape) == tuple(ref.shape), name
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        assert err <= 3e-3 * scale + 2e-6, 'grad %s: err %.3g scale %.3g' % (name, err, scale)
+    # two optimizer steps
+    net2 = unet_from_plan(plan).train()
+    net2.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net2.do_ds = True
+    opt2 = ot.make_optimizer(net2, 1e-2)
+    tr2 = UNetTrainer(plan, sd, 'cuda:0')
+    for it in range(2):
+        lo = ot.run_iteration(net2, opt2, x, tgt, weights)
+        lh = tr2.run_iteration(xd, td, 1e-2)
+        torch.cuda.synchronize()
+        assert abs(float(lh.cpu()) - lo) <= 1e-4 * (1 + abs(lo)), (it, float(lh.cpu()), lo)
+    sd2 = tr2.state_dict()
+    for name, p in net2.named_parameters():
+        assert float(np.abs(sd2[name] - p.detach().numpy()).max()) <= 2e-5, name
+
+
+@pytest.mark.parametrize('kz,sz,s,shape', [(1, 1, 1, (6, 40, 36)), (1, 1, 2, (5, 33, 30)), (3, 1, 2, (7, 26, 50)), (1, 1, 1, (3, 9, 7))])
+def test_conv3d_wgrad_anisotropic_vs_autograd(kz, sz, s, shape):
+    import ctypes as C
+    from deepwmh_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(kz * 100 + s * 10 + shape[0])
+    N, C0, C1, Co = 2, 5, (3 if s == 1 else 0), 37
+    D, H, W = shape
+    x0 = torch.randn(N, C0, D, H, W, generator=g)
+    x1 = torch.randn(N, C1, D, H, W, generator=g) if C1 else None
+    ss0 = torch.stack([1 + 0.3 * torch.randn(N, C0, generator=g), 0.2 * torch.randn(N, C0, generator=g)], -1).contiguous()
+    act0 = torch.nn.functional.leaky_relu(x0 * ss0[..., 0, None, None, None] + ss0[..., 1, None, None, None], 0.01)
+    xin = act0 if x1 is None else torch.cat([act0, x1], 1)            # second source without pending normalisation
+    w = torch.zeros(Co, C0 + C1, kz, 3, 3, requires_grad=True)
+    y = torch.nn.functional.conv3d(xin.double(), w.double(), None, (sz, s, s), (kz // 2, 1, 1))
+    dy = torch.randn(y.shape, generator=g)
+    (y * dy.double()).sum().backward()
+    ref = w.grad.float()
+    dw = torch.empty(Co, C0 + C1, kz, 3, 3, device='cuda')
+    nws = lib.wmh_conv3d_wgrad_workspace_floats(C0 + C1, Co, N, D, H, W, kz, sz, s)
+    ws = torch.empty(nws, device='cuda')
+    x0d, ss0d, dyd = x0.cuda(), ss0.cuda(), dy.cuda().contiguous()
+    x1d = x1.cuda() if C1 else None
+    _lib.check(lib.wmh_conv3d_wgrad(_lib.ptr(x0d), _lib.ptr(ss0d), C0, _lib.ptr(x1d), None, C1, _lib.ptr(dyd), _lib.ptr(dw), _lib.ptr(ws),
+                                    N, D, H, W, Co, kz, sz, s, 0.01, None), 'wmh_conv3d_wgrad')
+    torch.cuda.synchronize()
+    err = float((dw.cpu() - ref).abs().max())
+    assert err <= 2e-4 * float(ref.abs().max()) + 1e-5, err
+
+
+@pytest.mark.parametrize('shape', [(4, 6, 20), (3, 5, 7), (2, 4, 4)])
+def test_convtranspose_122_wgrad_vs_autograd(shape):
+    from deepwmh_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(shape[2])
+    N, Ci, Co = 2, 37, 21
+    D, H, W = shape
+    x = torch.randn(N, Ci, D, H, W, generator=g)
+    ss = torch.stack([1 + 0.3 * torch.randn(N, Ci, generator=g), 0.2 * torch.randn(N, Ci, generator=g)], -1).contiguous()
+    act = torch.nn.functional.leaky_relu(x * ss[..., 0, None, None, None] + ss[..., 1, None, None, None], 0.01)
+    w = torch.zeros(Ci, Co, 1, 2, 2, requires_grad=True)
+    y = torch.nn.functional.conv_transpose3d(act.double(), w.double(), None, (1, 2, 2))
+    dy = torch.randn(y.shape, generator=g)
+    (y * dy.double()).sum().backward()
+    ref = w.grad.float()
+    dw = torch.empty(Ci, Co, 1, 2, 2, device='cuda')
+    ws = torch.empty(lib.wmh_convtranspose3d_wgrad_workspace_floats(Ci, Co, N, D, H, W, 1), device='cuda')
+    xd, ssd, dyd = x.cuda(), ss.cuda(), dy.cuda().contiguous()
+    _lib.check(lib.wmh_convtranspose3d_wgrad(_lib.ptr(xd), _lib.ptr(ssd), _lib.ptr(dyd), _lib.ptr(dw), _lib.ptr(ws), N, Ci, Co, D, H, W, 1,
+                                             0.01, None), 'wmh_convtranspose3d_wgrad')
+    torch.cuda.synchronize()
+    err = float((dw.cpu() - ref).abs().max())
+    assert err <= 2e-4 * float(ref.abs().max()) + 1e-5, err

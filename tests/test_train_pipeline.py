@@ -57,9 +57,6 @@ def test_plan_and_preprocess_thick_slices(tmp_path):
     x, props = preprocess.preprocess_case(vol, meta['spacing'], plans)
     assert x.shape[1:] == d.shape[1:]
     assert np.allclose(x[0], d[0], atol=1e-4)
-    from deepwmh_amd.trainer import UNetTrainer
-    with pytest.raises(NotImplementedError, match='thick-slice'):
-        UNetTrainer(plan, {}, 'cpu')
 
 
 def test_cli_accepts_reference_training_commands():
@@ -146,3 +143,33 @@ def test_plan_train_continue_predict_through_the_executables(tmp_path):
     from deepwmh_amd import nifti
     p0, _ = nifti.read(os.path.join(out, 'case_00_0.nii.gz'))
     assert p0.shape == (40, 48, 44) and 0.0 <= float(p0.min()) and float(p0.max()) <= 1.0 + 1e-6
+
+
+@pytest.mark.gpu
+def test_thick_slice_dataset_through_the_executables(tmp_path):
+    """Thick-slice FLAIR (12 slices of 4 mm, slice axis in the middle of the file's order): planned with [1,3,3] / [1,2,2] first
+    stages, trained and predicted; the output comes back on the image's own grid."""
+    raw, pre, res = str(tmp_path / 'raw'), str(tmp_path / 'pre'), str(tmp_path / 'results')
+    task = make_raw_dataset(raw, n=3, shape=(48, 12, 56), spacing=(1.0, 4.0, 1.0))
+    env = dict(os.environ, nnUNet_raw_data_base=raw, nnUNet_preprocessed=pre, RESULTS_FOLDER=res, CUDA_VISIBLE_DEVICES='0',
+               PATH=os.path.join(ROOT, 'bin') + os.pathsep + os.environ['PATH'])
+
+    def run(cmd):
+        p = subprocess.run(shlex.split(cmd), env=env, capture_output=True, text=True)
+        print(p.stdout[-1500:], p.stderr[-1500:])
+        return p
+    assert run('nnUNet_plan_and_preprocess -t 1 --verify_dataset_integrity').returncode == 0
+    plans = pickle.load(open(os.path.join(pre, task, 'nnUNetPlansv2.1_plans_3D.pkl'), 'rb'))
+    assert plans['transpose_forward'] == [1, 0, 2] and plans['plans_per_stage'][0]['pool_op_kernel_sizes'][0] == [1, 2, 2]
+    p = run('nnUNet_train 3d_fullres nnUNetTrainerV2 1 all -e 2 -b 3 --noval --disable_postprocessing_on_folds')
+    assert p.returncode == 0 and 'epoch 2/2' in p.stdout
+    losses = [float(l.split('train loss')[1].split()[0]) for l in p.stdout.splitlines() if 'train loss' in l]
+    assert len(losses) == 2 and all(np.isfinite(losses))
+    out = str(tmp_path / 'seg')
+    pr = run('nnUNet_predict -i %s -o %s -tr nnUNetTrainerV2 -m 3d_fullres -p nnUNetPlansv2.1 -t %s -f all -chk model_latest '
+             '--selected_cases case_00 --disable_post_processing' % (os.path.join(raw, 'nnUNet_raw_data', task, 'imagesTr'), out, task))
+    assert pr.returncode == 0
+    from deepwmh_amd import nifti
+    seg, meta = nifti.read(os.path.join(out, 'case_00.nii.gz'))
+    assert seg.shape == (48, 12, 56) and np.allclose(meta['spacing'], (1.0, 4.0, 1.0), atol=1e-4)
+    assert set(np.unique(seg).astype(int).tolist()) <= {0, 1}
