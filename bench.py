@@ -35,6 +35,7 @@ AGG_GBYTES_PER_VOLUME = 0.46     # aggregation read-modify-write + volume in / l
 KERNEL_NAME = {
     'fp32': 'conv3d_k3_ws_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM, wave-specialised)',
     'bf16': 'conv3d_k3_bf16_ws_kernel<cfg0> (v_mfma_f32_32x32x16_bf16 implicit GEMM, wave-specialised)',
+    'bf16_storage': 'cl_conv3_kernel<ClGeo<4,4>> (channels-last bf16 tensors, v_mfma_f32_32x32x16_bf16, LDS-DMA staging, every stride-1 launch)',
 }
 
 
@@ -207,7 +208,7 @@ def roofline_block(timings, precision, storage, dt):
         traffic_note = t.get('measured')
     except Exception:
         pass
-    r = dict(bound=bound, kernel=KERNEL_NAME[precision])
+    r = dict(bound=bound, kernel=KERNEL_NAME[mode_key(precision, storage)])
     if bound == 'mfma':
         r.update(achieved=round(tflops, 3), peak=peak_t, unit='TFLOP/s', frac=round(tflops / peak_t, 4))
     else:

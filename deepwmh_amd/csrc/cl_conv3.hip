@@ -580,14 +580,21 @@ struct ClS2Geo {
     static_assert(3 * LDS <= 160 * 1024, "three workgroups per CU");
 };
 
-__global__ __launch_bounds__(256, 3) void cl_conv3s2_kernel(const ClConvS2Args a) {
+// GW: groups of 32 output channels a workgroup computes from ONE staged box (1, 2 or 4).  Wave w owns output-channel group
+// w % GW for the MT = GW output rows [w / GW * MT, +MT) of the 2 x 2 x 32 tile: the box is staged and transformed once for all
+// GW groups (not once per group), and a weight fragment is loaded by 4 / GW waves instead of by all four -- the kernel is bound
+// by the L2 -> CU traffic of exactly these two streams.
+template <int GW>
+__global__ __launch_bounds__(256, GW == 4 ? 2 : 3) void cl_conv3s2_kernel(const ClConvS2Args a) {
     using G = ClS2Geo;
+    constexpr int MT = GW;
     constexpr int IY = G::IY, IX = G::IX, NE = G::NE, NV = G::NV, NVP = G::NVP, NSLOT = G::NSLOT, WQ = G::WQ;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int t = blockIdx.x;
-    const int g = t % a.G; t /= a.G;
+    const int g = (t % a.G) * GW + wave % GW; t /= a.G;              // a.G: workgroups per tile = Cout / (32 GW)
+    const int m0 = wave / GW * MT;                                   // first of this wave's output rows (row m: z = m >> 1, y = m & 1)
     const int tx = t % a.ntx; t /= a.ntx;
     const int ty = t % a.nty; t /= a.nty;
     const int tz = t % a.ntz; t /= a.ntz;
@@ -610,13 +617,16 @@ __global__ __launch_bounds__(256, 3) void cl_conv3s2_kernel(const ClConvS2Args a
         gv[k] = ok ? (gz * a.H + gy) * a.W + gx : center;
         keep |= ok ? (1u << k) : 0u;
     }
-    f32x16 acc[1];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = a.bias != nullptr ? a.bias[g * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] : 0.f;
+    for (int r = 0; r < 16; ++r) {
+        const float b = a.bias != nullptr ? a.bias[g * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][r] = b;
+    }
     const unsigned rowb = 2u * (unsigned)a.Cin;
     const char* xbase = reinterpret_cast<const char*>(a.x) + (size_t)n * DHW * rowb;
-    const int zz = wave >> 1, yy = wave & 1;                              // this wave's output row inside the tile
-    const unsigned char* bbase = lds + (kh * NVP + ((2 * zz) * IY + 2 * yy) * IX + 2 * j) * 16;
+    const unsigned char* bbase = lds + (kh * NVP + 2 * j) * 16;
     static __device__ const float ident2s[2] = {1.f, 0.f};
     const bool has_ss = a.ss != nullptr;
     const float slope = has_ss ? a.slope : 1.f;
@@ -664,29 +674,40 @@ __global__ __launch_bounds__(256, 3) void cl_conv3s2_kernel(const ClConvS2Args a
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int kd = tap / 9, kr = (tap / 3) % 3, kw = tap % 3;
-            const cl_bf16x8 bv = *reinterpret_cast<const cl_bf16x8*>(bbase + ((kd * IY + kr) * IX + kw) * 16);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tap < 18 ? av[tap < 18 ? tap : 0] : av2[tap >= 18 ? tap - 18 : 0], bv, acc[0], 0, 0, 0);
+            const cl_bf16x8 aw = tap < 18 ? av[tap < 18 ? tap : 0] : av2[tap >= 18 ? tap - 18 : 0];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int zz = (m0 + i) >> 1, yy = (m0 + i) & 1;
+                const cl_bf16x8 bv = *reinterpret_cast<const cl_bf16x8*>(bbase + (((2 * zz + kd) * IY + 2 * yy + kr) * IX + kw) * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw, bv, acc[i], 0, 0, 0);
+            }
         }
     }
     // ---- epilogue
-    const int oz = 2 * tz + zz, oy = 2 * ty + yy, ox = 32 * tx + j, cob = g * 32;
-    const bool valid = oz < a.Do && oy < a.Ho;
+    const int ox = 32 * tx + j, cob = g * 32;
+    unsigned vmask = 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) vmask |= (2 * tz + ((m0 + i) >> 1) < a.Do && 2 * ty + ((m0 + i) & 1) < a.Ho) ? (1u << i) : 0u;
     if (a.part != nullptr) {
-        const float4 rec = cl_wave_moments<1>(acc, valid ? 1u : 0u, valid ? 32 : 0, j, kh);
+        const float4 rec = cl_wave_moments<MT>(acc, vmask, 32 * __builtin_popcount(vmask), j, kh);
         CL_BARRIER();                                                    // operand reads done: the activation area is free
         float4* scr = reinterpret_cast<float4*>(lds);
         if ((j & 1) == 0) scr[wave * 32 + cl_moment_channel(j, kh)] = rec;
         CL_BARRIER();
-        if (wave == 0 && (j & 1) == 0) {
+        if (wave < GW && (j & 1) == 0) {                                 // the waves of one channel group, in fixed order
             const int c = cl_moment_channel(j, kh);
-            float4 m = scr[c];
+            float4 m = scr[wave * 32 + c];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) m = cl_merge_moments(m, scr[w * 32 + c]);
+            for (int w = wave + GW; w < 4; w += GW) m = cl_merge_moments(m, scr[w * 32 + c]);
             reinterpret_cast<float4*>(a.part)[((size_t)n * a.Cout + cob + c) * a.npart + (tz * a.nty + ty) * a.ntx + tx] = m;
         }
     }
-    if (valid)
-        cl_store_mtile(acc[0], a.y + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + cob, kh);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+        if ((vmask >> i) & 1u) {
+            const int oz = 2 * tz + ((m0 + i) >> 1), oy = 2 * ty + ((m0 + i) & 1);
+            cl_store_mtile(acc[i], a.y + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + cob, kh);
+        }
 }
 
 extern "C" int wmh_cl_conv3s2_num_partials(int Do, int Ho, int Wo) {
@@ -709,11 +730,15 @@ extern "C" int wmh_cl_conv3s2_fwd(const void* x, const float* ss, int Cin, const
     a.nchunks = Cin / 16;
     a.ntx = a.Wo / 32; a.nty = cl_cdiv(a.Ho, 2); a.ntz = cl_cdiv(a.Do, 2);
     a.npart = a.ntx * a.nty * a.ntz;
-    a.G = Cout / 32;
+    const int G = Cout / 32, GW = G % 4 == 0 ? 4 : G % 2 == 0 ? 2 : 1;   // channel groups per workgroup
+    a.G = G / GW;
     a.slope = lrelu_slope;
     const long long T = (long long)a.ntx * a.nty * a.ntz * N * a.G;
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "cl_conv3s2_fwd: too many tiles");
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cl_conv3s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ClS2Geo::LDS);
-    hipLaunchKernelGGL(cl_conv3s2_kernel, dim3((unsigned)T), dim3(256), ClS2Geo::LDS, (hipStream_t)stream, a);
+    auto launch = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ClS2Geo::LDS);
+        hipLaunchKernelGGL(kern, dim3((unsigned)T), dim3(256), ClS2Geo::LDS, (hipStream_t)stream, a);
+    };
+    if (GW == 4) launch(&cl_conv3s2_kernel<4>); else if (GW == 2) launch(&cl_conv3s2_kernel<2>); else launch(&cl_conv3s2_kernel<1>);
     return wmh_check_launch("cl_conv3s2_kernel");
 }
