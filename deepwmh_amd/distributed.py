@@ -115,26 +115,54 @@ class PatchShardedPredictor:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
+    def _exchange_buffers(self, W, K, P):
+        """Two send tiles and two gather buffers (W x 16.8 MB each at the BASELINE plan), allocated once per geometry."""
+        key = (W, K, tuple(P))
+        if getattr(self, '_xkey', None) != key:
+            self._xkey = key
+            self._send = [self.b.zeros((K,) + tuple(P)) for _ in range(2)]
+            self._recv = [self.b.zeros((W, K) + tuple(P)) for _ in range(2)]
+        return self._send, self._recv
+
     def predict(self, vol):
         V = tuple(int(v) for v in vol.shape[1:])
         A, pad_lo, origins, K, P = self.b.geometry(V)
         W, r = self.world, self.rank
         rounds = (len(origins) + W - 1) // W
         agg = self.b.zeros((K,) + A)
-        for rd in range(rounds):
-            idx = rd * W + r
-            # ranks without a patch in the last round contribute a zero tile that nobody accumulates
-            mine = self.b.tile(vol, origins[idx]) if idx < len(origins) else self.b.zeros((K,) + P)
-            if W > 1:
-                gathered = self.b.zeros((W, K) + P)
-                # the one exchange step (output viewed as the concatenation along dim 0: accepted by RCCL and gloo)
-                dist.all_gather_into_tensor(gathered.view((W * K,) + tuple(P)), mine.contiguous(), group=self.group)
-            else:
-                gathered = mine[None]
-            for w in range(W):                               # fixed global patch order
+        send, recv = self._exchange_buffers(W, K, P) if W > 1 else (None, None)
+
+        def drain(item):                                     # round rd's tiles, in the fixed global patch order
+            work, gathered, rd = item
+            if work is not None:
+                work.wait()
+            for w in range(W):
                 j = rd * W + w
                 if j < len(origins):
                     self.b.accumulate(agg, gathered[w], origins[j])
+
+        pending = None
+        for rd in range(rounds):
+            idx = rd * W + r
+            if W > 1:
+                # this round's forwards run while the previous round's all-gather is still on the wire; the exchange buffers
+                # alternate (round rd-2, the last user of this pair, was drained one iteration ago)
+                mine = send[rd & 1]
+                if idx < len(origins):
+                    mine.copy_(self.b.tile(vol, origins[idx]))
+                else:
+                    mine.zero_()                             # ragged last round: a zero tile that nobody accumulates
+                gathered = recv[rd & 1]
+                # the one exchange step (output viewed as the concatenation along dim 0: accepted by RCCL and gloo)
+                work = dist.all_gather_into_tensor(gathered.view((W * K,) + tuple(P)), mine, group=self.group, async_op=True)
+            else:                                            # one rank: nothing to overlap, and the backend may reuse its tile buffer
+                drain((None, self.b.tile(vol, origins[idx])[None], rd))
+                continue
+            if pending is not None:
+                drain(pending)
+            pending = (work, gathered, rd)
+        if pending is not None:
+            drain(pending)
         cnt = self.b.count_map(A, origins)
         return self.b.finalize(agg, cnt, pad_lo, V)
 

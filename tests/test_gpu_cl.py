@@ -346,3 +346,29 @@ def test_storage_mode_is_refused_up_front_for_plans_it_does_not_serve(tiny_net):
         UNetEngine(plan, sd, 'cuda:0', precision='bf16', storage='bf16')
     with pytest.raises(ValueError):
         UNetEngine(_cl_plan(), {}, 'cuda:0', precision='fp32', storage='bf16')
+
+
+def test_configs2_full_width_patch_against_the_fp32_path():
+    """BASELINE.json configs[2] at its own size: the 31 M-parameter plan, a batch of 128^3 patches, channels-last bf16 tensors on
+    the three wide levels against the exact-fp32 path (itself within 1.5e-5 of the oracle at this size, test_gpu_network.py).
+    Random He-init weights keep the probabilities near 0.5 -- the worst case for mask agreement."""
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.plan import baseline_plan
+    from deepwmh_amd.synthetic import he_init_state_dict, synthetic_flair
+    plan = baseline_plan()
+    sd = he_init_state_dict(plan, seed=0)
+    vol = synthetic_flair((128, 128, 160), seed=3)
+    x = torch.from_numpy(np.ascontiguousarray(np.stack([vol[:, :, :, :128], vol[:, :, :, 32:]]))).cuda()
+    ref = torch.softmax(UNetEngine(plan, sd, 'cuda:0').forward_logits(x), 1)
+    eng = UNetEngine(plan, sd, 'cuda:0', precision='bf16', storage='bf16')
+    assert eng.ncl == 3
+    a = torch.softmax(eng.forward_logits(x), 1)
+    b = torch.softmax(eng.forward_logits(x), 1)
+    assert torch.equal(a, b)                                     # no atomics, no race: bit-reproducible
+    assert bool(torch.isfinite(a).all())
+    d = float((a - ref).abs().max())
+    ma, mr = a[:, 1] > 0.5, ref[:, 1] > 0.5
+    dice = 2.0 * float((ma & mr).sum()) / max(1.0, float(ma.sum() + mr.sum()))
+    flips = float((ma != mr).float().mean())
+    print('configs[2] full width: max |softmax - fp32| %.3g, Dice vs fp32 mask %.5f, %.3f %% of voxels change class' % (d, dice, 100 * flips))
+    assert d < 5e-2 and dice > 0.99 and flips < 5e-3
