@@ -102,6 +102,7 @@ SIGNATURES = {
     'wmh_mul_mask_f64': (_i, [_vp, _vp, _sz, _vp]),
     'wmh_select_f64': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'wmh_nll': (_i, [_vp, _vp, _i, _sz, _d, _i, _vp, _vp, _vp, _vp, _vp]),
+    'wmh_nll_masked': (_i, [_vp, _vp, _vp, _i, _sz, _d, _i, _vp, _vp, _vp, _vp]),
     'wmh_median_filter_f64': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'wmh_component_filtering': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'wmh_cl_from_ncdhw': (_i, [_vp, _vp, _i, _i, _sz, _vp]),

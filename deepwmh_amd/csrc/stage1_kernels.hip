@@ -290,15 +290,27 @@ __device__ __forceinline__ double nll_one(double x, double mu, double sigma, int
     else if (side < 0) a = a * (x < mu ? 1.0 : 0.0);
     return a;
 }
-__global__ __launch_bounds__(256) void nll_kernel(const double* xp, const double* refs, int R, size_t n, double min_std, int side, double* anomaly,
-                                                   double* mu_out, double* sigma_out, double* anomaly_refs) {
+// thr != NULL (use_mask=True, lesion_analysis.py:87-92): reference r counts at a voxel only where refs[r] > thr[r] (its Otsu
+// threshold); nanmean / nanstd over the counted ones, NaN where none counts (the anomaly there becomes 0 by nan_to_num).
+__global__ __launch_bounds__(256) void nll_kernel(const double* xp, const double* refs, const double* thr, int R, size_t n, double min_std, int side,
+                                                   double* anomaly, double* mu_out, double* sigma_out, double* anomaly_refs) {
     for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
         double s = 0.0;
-        for (int r = 0; r < R; ++r) s += refs[(size_t)r * n + v];
-        const double mu = s / (double)R;
+        int cnt = 0;
+        for (int r = 0; r < R; ++r) {
+            const double x = refs[(size_t)r * n + v];
+            const bool on = thr == nullptr || x > thr[r];
+            s += on ? x : 0.0; cnt += on ? 1 : 0;
+        }
+        const double nan = __builtin_nan("");
+        const double mu = cnt ? s / (double)cnt : nan;
         double q = 0.0;
-        for (int r = 0; r < R; ++r) { const double d = refs[(size_t)r * n + v] - mu; q += d * d; }
-        double sigma = sqrt(q / (double)R);
+        for (int r = 0; r < R; ++r) {
+            const double x = refs[(size_t)r * n + v];
+            const double d = x - mu;
+            q += (thr == nullptr || x > thr[r]) ? d * d : 0.0;
+        }
+        double sigma = cnt ? sqrt(q / (double)cnt) : nan;
         if (min_std < 0) sigma += 1e-6; else sigma = sigma < min_std ? min_std : sigma;
         if (anomaly) anomaly[v] = nll_one(xp[v], mu, sigma, side);
         if (mu_out) mu_out[v] = mu;
@@ -310,8 +322,16 @@ __global__ __launch_bounds__(256) void nll_kernel(const double* xp, const double
 extern "C" int wmh_nll(const double* x_prime, const double* refs, int R, size_t n, double min_std, int side, double* anomaly, double* mu,
                        double* sigma, double* anomaly_refs, void* stream) {
     if (!refs || R < 1 || (anomaly && !x_prime) || side < -1 || side > 1) return wmh_fail(WMH_EINVAL, "nll: bad args");
-    if (n) hipLaunchKernelGGL(nll_kernel, dim3(s1::grid(n, 8192)), dim3(256), 0, (hipStream_t)stream, x_prime, refs, R, n, min_std, side, anomaly, mu, sigma,
-                              anomaly_refs);
+    if (n) hipLaunchKernelGGL(nll_kernel, dim3(s1::grid(n, 8192)), dim3(256), 0, (hipStream_t)stream, x_prime, refs, (const double*)nullptr, R, n, min_std,
+                              side, anomaly, mu, sigma, anomaly_refs);
+    return wmh_check_launch("nll_kernel");
+}
+// thresholds: R doubles on the device (each reference's Otsu threshold)
+extern "C" int wmh_nll_masked(const double* x_prime, const double* refs, const double* thresholds, int R, size_t n, double min_std, int side,
+                              double* anomaly, double* mu, double* sigma, void* stream) {
+    if (!refs || !thresholds || R < 1 || (anomaly && !x_prime) || side < -1 || side > 1) return wmh_fail(WMH_EINVAL, "nll_masked: bad args");
+    if (n) hipLaunchKernelGGL(nll_kernel, dim3(s1::grid(n, 8192)), dim3(256), 0, (hipStream_t)stream, x_prime, refs, thresholds, R, n, min_std, side,
+                              anomaly, mu, sigma, (double*)nullptr);
     return wmh_check_launch("nll_kernel");
 }
 
@@ -346,11 +366,52 @@ __global__ __launch_bounds__(256) void median_kernel(const double* in, double* o
         out[v] = res;
     }
 }
+// Windows of more than 27 voxels (voxels finer than 0.75 mm: 4 x 4 x 4 .. 8 x 8 x 8): the window in per-thread scratch memory,
+// rank N/2 by quickselect (median-of-three pivot, three-way partition).  The rank-N/2 VALUE does not depend on the selection
+// algorithm, so the result is the same as the counting form's.
+constexpr int MEDIAN_BIG_MAX = 512;
+__global__ __launch_bounds__(256) void median_big_kernel(const double* in, double* out, int D, int H, int W, int kz, int ky, int kx) {
+    const size_t n = (size_t)D * H * W;
+    const int N = kz * ky * kx, rank = N / 2;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
+        const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((size_t)W * H));
+        double w[MEDIAN_BIG_MAX];
+        int e = 0;
+        for (int dz = -(kz / 2); dz < kz - kz / 2; ++dz)
+            for (int dy = -(ky / 2); dy < ky - ky / 2; ++dy)
+                for (int dx = -(kx / 2); dx < kx - kx / 2; ++dx) {
+                    const int xx = x + dx, yy = y + dy, zz = z + dz;
+                    w[e++] = (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D) ? in[((size_t)zz * H + yy) * W + xx] : 0.0;
+                }
+        int lo = 0, hi = N - 1;
+        double res = w[rank];
+        while (lo < hi) {
+            const double a = w[lo], b = w[(lo + hi) >> 1], c = w[hi];
+            const double piv = a < b ? (b < c ? b : (a < c ? c : a)) : (a < c ? a : (b < c ? c : b));
+            int lt = lo, i = lo, gt = hi;                          // [lo, lt) < piv, [lt, i) == piv, (gt, hi] > piv
+            while (i <= gt) {
+                const double t = w[i];
+                if (t < piv) { w[i] = w[lt]; w[lt] = t; ++lt; ++i; }
+                else if (t > piv) { w[i] = w[gt]; w[gt] = t; --gt; }
+                else ++i;
+            }
+            if (rank < lt) hi = lt - 1;
+            else if (rank > gt) lo = gt + 1;
+            else { lo = hi = rank; w[rank] = piv; }
+        }
+        res = w[rank];
+        out[v] = res;
+    }
+}
 extern "C" int wmh_median_filter_f64(const double* in, double* out, int D, int H, int W, int kz, int ky, int kx, void* stream) {
     if (!in || !out || D < 1 || H < 1 || W < 1 || kz < 1 || ky < 1 || kx < 1) return wmh_fail(WMH_EINVAL, "median_filter_f64: bad args");
     const int N = kz * ky * kx;
-    if (N > 27) return wmh_fail(WMH_EINVAL, "median_filter_f64: windows of more than 27 voxels are not implemented");
+    if (N > MEDIAN_BIG_MAX) return wmh_fail(WMH_EINVAL, "median_filter_f64: windows of more than 512 voxels are not implemented");
     const unsigned g = s1::grid((size_t)D * H * W, 1u << 16);
+    if (N > 27) {
+        hipLaunchKernelGGL(median_big_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, in, out, D, H, W, kz, ky, kx);
+        return wmh_check_launch("median_big_kernel");
+    }
     if (N <= 9) hipLaunchKernelGGL((median_kernel<9>), dim3(g), dim3(256), 0, (hipStream_t)stream, in, out, D, H, W, kz, ky, kx);
     else hipLaunchKernelGGL((median_kernel<27>), dim3(g), dim3(256), 0, (hipStream_t)stream, in, out, D, H, W, kz, ky, kx);
     return wmh_check_launch("median_kernel");

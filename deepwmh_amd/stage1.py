@@ -172,15 +172,21 @@ def _side(side):
 
 
 def nll(x_prime, x_refs, min_std=None, side=None, return_all=False, use_mask=False):
-    """Anomaly score = NLL under the per-voxel Gaussian fitted to the references (lesion_analysis.py:84-113)."""
-    if use_mask:
-        raise NotImplementedError('nll: use_mask=True (Otsu-masked group statistics) is not used by the pipeline and not implemented')
+    """Anomaly score = NLL under the per-voxel Gaussian fitted to the references (lesion_analysis.py:84-113).  use_mask: every
+    reference counts only above its own Otsu threshold (:87-92; not used by the reference's pipeline)."""
     torch = _torch()
     c = _Ctx()
     xp = _f64(x_prime)
     refs = torch.stack([_f64(r) for r in x_refs])
-    anomaly, mu, sigma, _ = _nll_dev(c, xp, refs, min_std, side, with_refs=False)
     shape = np.asarray(x_prime).shape
+    if use_mask:
+        thr = torch.tensor([float(threshold_otsu(r)) for r in x_refs], dtype=torch.float64, device='cuda')
+        anomaly, mu, sigma = torch.empty_like(xp), torch.empty_like(xp), torch.empty_like(xp)
+        _lib.check(c.lib.wmh_nll_masked(_lib.ptr(xp), _lib.ptr(refs), _lib.ptr(thr), int(refs.shape[0]), xp.numel(),
+                                        -1.0 if min_std is None else float(min_std), _side(side), _lib.ptr(anomaly), _lib.ptr(mu), _lib.ptr(sigma),
+                                        c.st), 'wmh_nll_masked')
+    else:
+        anomaly, mu, sigma, _ = _nll_dev(c, xp, refs, min_std, side, with_refs=False)
     if not return_all:
         return anomaly.cpu().numpy().reshape(shape)
     return anomaly.cpu().numpy().reshape(shape), mu.cpu().numpy().reshape(shape), sigma.cpu().numpy().reshape(shape)
@@ -215,9 +221,8 @@ def _component_filtering_dev(c, mask_u8, voxel_size):
 
 
 def component_filtering(mask, voxel_size, return_type='float32', erosion=True):
-    """Per slice and orientation: cross erosion, then the largest component (image_ops.py:256-308)."""
-    if not erosion:
-        raise NotImplementedError('component_filtering: erosion=False is not used by the pipeline and not implemented')
+    """Per slice and orientation: cross erosion, then the largest component (image_ops.py:256-308).  `erosion` is accepted and,
+    as in the reference, has no effect: the reference's body erodes unconditionally (image_ops.py:286,293,300 never read it)."""
     return _component_filtering_dev(_Ctx(), _u8(mask), voxel_size).cpu().numpy().astype(return_type)
 
 

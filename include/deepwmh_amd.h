@@ -372,6 +372,10 @@ int wmh_select_f64(double* x, const double* y, const uint8_t* mask, size_t n, vo
  * min_std, or + 1e-6 when min_std < 0), anomaly of x_prime and (optionally) of every reference; side = +1 / -1 / 0. */
 int wmh_nll(const double* x_prime, const double* refs, int R, size_t n, double min_std, int side, double* anomaly, double* mu, double* sigma,
             double* anomaly_refs, void* stream);
+/* nll(use_mask=True) (/root/reference/deepwmh/analysis/lesion_analysis.py:87-92): a reference counts at a voxel only where it
+ * exceeds its own Otsu threshold (thresholds: R doubles on the device); NaN statistics where none counts (anomaly 0 there). */
+int wmh_nll_masked(const double* x_prime, const double* refs, const double* thresholds, int R, size_t n, double min_std, int side,
+                   double* anomaly, double* mu, double* sigma, void* stream);
 /* scipy.ndimage.median_filter(size=(kz,ky,kx), mode='constant', cval=0) (image_ops.py:181-183 via median_3mm :379-421);
  * windows up to 27 voxels. */
 int wmh_median_filter_f64(const double* in, double* out, int D, int H, int W, int kz, int ky, int kx, void* stream);

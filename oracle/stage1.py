@@ -176,8 +176,12 @@ def average_contiguous_labels(labels):
     return np.argmax(channels, axis=0)
 
 
-def nll(x_prime, x_refs, min_std=None, side=None, return_all=False):
-    mu, sigma = group_mean(x_refs), group_std(x_refs)
+def nll(x_prime, x_refs, min_std=None, side=None, return_all=False, use_mask=False):
+    if use_mask:                                  # lesion_analysis.py:87-92
+        masks = [np.where(x_i > threshold_otsu(x_i), 1, 0) for x_i in x_refs]
+        mu, sigma = group_mean(x_refs, masks=masks), group_std(x_refs, masks=masks)
+    else:
+        mu, sigma = group_mean(x_refs), group_std(x_refs)
     if min_std is None:
         sigma += 1e-6
     else:

@@ -50,8 +50,13 @@ def test_nll(side):
         ra, rm, rs = o.nll(xz, rz, min_std=min_std, side=side, return_all=True)
         assert float(np.abs(gm - rm).max()) <= 1e-12 and float(np.abs(gs - rs).max()) <= 1e-12
         assert float(np.abs(ga - ra).max()) <= 1e-9 * (1 + float(np.abs(ra).max()))
-    with pytest.raises(NotImplementedError):
-        stage1.nll(xz, rz, use_mask=True)
+    # use_mask=True (lesion_analysis.py:87-92): every reference counts only above its own Otsu threshold; NaN statistics where
+    # none does (the anomaly there is 0 by nan_to_num)
+    ga, gm, gs = stage1.nll(xz, rz, min_std=0.03, side=side, return_all=True, use_mask=True)
+    ra, rm, rs = o.nll(xz, rz, min_std=0.03, side=side, return_all=True, use_mask=True)
+    assert np.array_equal(np.isnan(gm), np.isnan(rm)) and np.array_equal(np.isnan(gs), np.isnan(rs)) and np.isnan(rm).any()
+    assert float(np.nanmax(np.abs(gm - rm))) <= 1e-12 and float(np.nanmax(np.abs(gs - rs))) <= 1e-12
+    assert float(np.abs(ga - ra).max()) <= 1e-9 * (1 + float(np.abs(ra).max()))
 
 
 def test_component_filtering_exact():
@@ -66,6 +71,8 @@ def test_component_filtering_exact():
         for vs in ([1.0, 1.0, 1.0], [0.9, 0.9, 4.0], [3.5, 1.0, 1.0]):
             got, ref = stage1.component_filtering(m, vs), o.component_filtering(m, vs)
             assert got.dtype == ref.dtype and np.array_equal(got, ref), (m.shape, vs)
+    # the reference's `erosion` argument is never read by its body (image_ops.py:256-308): same result either way
+    assert np.array_equal(stage1.component_filtering(masks[1], [1.0, 1.0, 1.0], erosion=False), o.component_filtering(masks[1], [1.0, 1.0, 1.0]))
 
 
 def test_median_3mm_and_label_vote_exact():
@@ -75,8 +82,11 @@ def test_median_3mm_and_label_vote_exact():
     a = rng.standard_normal((17, 19, 21)) * (rng.random((17, 19, 21)) < 0.6)
     for vs in ([1.0, 1.0, 1.0], [0.8, 0.8, 0.9], [0.9, 0.9, 4.5], [5.0, 0.7, 1.0]):
         assert np.array_equal(stage1.median_3mm(a, vs), o.median_3mm(a, vs)), vs
+    # voxels finer than 0.75 mm: windows of 4^3 .. 6^3 voxels, even extents (scipy centres them at k // 2), per-slice 2-D form too
+    for vs in ([0.7, 0.7, 0.7], [0.5, 0.5, 0.5], [0.6, 0.45, 0.9], [0.4, 0.5, 2.5]):
+        assert np.array_equal(stage1.median_3mm(a, vs), o.median_3mm(a, vs)), vs
     with pytest.raises(Exception):
-        stage1.median_3mm(a, [0.5, 0.5, 0.5])                      # 6x6x6 window: not implemented, must fail loudly
+        stage1.median_3mm(a, [0.3, 0.3, 0.3])                      # 10x10x10 window: beyond the 512-voxel limit, must fail loudly
     labs = [rng.integers(0, 4, (9, 10, 11)).astype(np.float32) for _ in range(5)]
     assert np.array_equal(stage1.average_contiguous_labels(labs), o.average_contiguous_labels(labs))
 
