@@ -71,6 +71,7 @@ __device__ __forceinline__ cl_u32x4 cl_transform8_plain(const cl_u32x4 u, const 
 // One M-tile (32 voxels on the lanes, 32 output channels in the 16 registers of both lane halves) -> CL16 rows:
 // registers pairwise to bf16, the two lane halves exchange 8-byte groups (v_permlane32_swap) so that every lane holds
 // 16 contiguous bytes, two 16-byte stores per lane.  yv: address of channel `cob` of this lane's voxel.
+template <bool NTS = false>     // NTS: streaming stores (conv3d_common.h): the first layer only
 __device__ __forceinline__ void cl_store_mtile(const f32x16& acc, unsigned short* yv, int kh) {
     unsigned d[8];
 #pragma unroll
@@ -82,7 +83,8 @@ __device__ __forceinline__ void cl_store_mtile(const f32x16& acc, unsigned short
         const auto r1 = __builtin_amdgcn_permlane32_swap(d[4 * gp + 1], d[4 * gp + 3], false, false);
         // lower half: channels 16gp .. 16gp+7, upper half: 16gp+8 .. 16gp+15
         const cl_u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
-        *reinterpret_cast<cl_u32x4*>(yv + 16 * gp + 8 * kh) = v;
+        if constexpr (NTS) __builtin_nontemporal_store(v, reinterpret_cast<cl_u32x4*>(yv + 16 * gp + 8 * kh));
+        else *reinterpret_cast<cl_u32x4*>(yv + 16 * gp + 8 * kh) = v;
     }
 }
 

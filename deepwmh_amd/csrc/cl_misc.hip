@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void cl_conv3_first_kernel(const ClFirstArgs a
 #pragma unroll
     for (int m = 0; m < TY; ++m)
         if ((vmask >> m) & 1u)
-            cl_store_mtile(acc[m], a.y + (((size_t)n * a.D + oz) * HW + (size_t)(oy0 + m) * a.W + ox) * a.Cout + cob, kh);
+            cl_store_mtile<true>(acc[m], a.y + (((size_t)n * a.D + oz) * HW + (size_t)(oy0 + m) * a.W + ox) * a.Cout + cob, kh);
 }
 // weight image of the first convolution: [G][2 k-steps][64 lanes][8] bf16; w = torch layout [Cout][1][27] fp32 (host)
 extern "C" size_t wmh_cl_conv3_first_packed_halfs(int Cout) { return (size_t)((Cout + 31) / 32) * 2 * 64 * 8; }

@@ -86,7 +86,10 @@ __device__ __forceinline__ void halve_step(float (&vals)[32], int j) {
 // Epilogue of one workgroup tile.  acc[nt][m][r]: row (r&3)+8*(r>>2)+4*kh of cout tile nt, voxel j of M-tile m.
 // ------------------------------------------------------------------------------------------------
 // OUT16: y is a bf16 tensor (uint16 bits, round to nearest even); the moments still come from the fp32 accumulators.
-template <class C, bool OUT16 = false>
+// NTS: nontemporal (streaming) stores.  Measured both ways: they help the layer that does nothing but write a tensor far
+// larger than the 256 MB Infinity Cache (first layer: 0.85 -> 0.66 ms) and HURT where the consumer finds its input still
+// cached (64^3 / 32^3 levels: the transposed convolutions got 1.2-1.6x slower with them), so only the first layer asks for them.
+template <class C, bool OUT16 = false, bool NTS = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C::NT][C::MT], int g, int ks, int n,
                                               int wave, int j, int kh, int dx, int dy, int dz, int ts0, int oz0,
                                               int oy0, int ox0, int tile_sp) {
@@ -174,8 +177,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
                         const ef2 f = {acc[nt][m][r], acc[nt][m][r + 1]};
                         const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(f, eb2));      // v_cvt_pk_bf16_f32
                         const int row0 = (r & 3) + 8 * (r >> 2), row1 = ((r + 1) & 3) + 8 * ((r + 1) >> 2);
-                        if (4 * kh + row0 < nrows) yp[(size_t)row0 * DoHoWo] = (unsigned short)(u & 0xFFFFu);
-                        if (4 * kh + row1 < nrows) yp[(size_t)row1 * DoHoWo] = (unsigned short)(u >> 16);
+                        if (4 * kh + row0 < nrows) {
+                            if constexpr (NTS) __builtin_nontemporal_store((unsigned short)(u & 0xFFFFu), yp + (size_t)row0 * DoHoWo);
+                            else yp[(size_t)row0 * DoHoWo] = (unsigned short)(u & 0xFFFFu);
+                        }
+                        if (4 * kh + row1 < nrows) {
+                            if constexpr (NTS) __builtin_nontemporal_store((unsigned short)(u >> 16), yp + (size_t)row1 * DoHoWo);
+                            else yp[(size_t)row1 * DoHoWo] = (unsigned short)(u >> 16);
+                        }
                     }
                 }
             }
@@ -190,12 +199,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
                 float* yp = ych + (size_t)(4 * kh) * DoHoWo + (size_t)oz * HoWo + oy * a.Wo + ox;
                 if (nrows == 32) {                  // uniform: all 32 output channels of this tile exist
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * DoHoWo] = acc[nt][m][r];
+                    for (int r = 0; r < 16; ++r) {
+                        if constexpr (NTS) __builtin_nontemporal_store(acc[nt][m][r], yp + (size_t)((r & 3) + 8 * (r >> 2)) * DoHoWo);
+                        else yp[(size_t)((r & 3) + 8 * (r >> 2)) * DoHoWo] = acc[nt][m][r];
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2);
-                        if (4 * kh + row < nrows) yp[(size_t)row * DoHoWo] = acc[nt][m][r];
+                        if (4 * kh + row < nrows) {
+                            if constexpr (NTS) __builtin_nontemporal_store(acc[nt][m][r], yp + (size_t)row * DoHoWo);
+                            else yp[(size_t)row * DoHoWo] = acc[nt][m][r];
+                        }
                     }
                 }
             }

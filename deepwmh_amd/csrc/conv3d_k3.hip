@@ -249,6 +249,78 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
 }
 
 // ------------------------------------------------------------------------------------------------
+// First layer (ONE input channel, stride 1): the 27 taps are the K dimension.
+//   D[cout 32][voxel 32] += A[cout 32][tap pair] * B[tap pair][voxel 32]      14 MFMAs per M-tile (27 taps + 1 zero column)
+// The general kernel spends 27 MFMAs per M-tile here with half of every k pair a zero channel, and stages its halo through
+// the two-buffer pipeline built for many chunks; with one channel the whole layer is a single chunk: halo tile
+// (6 x 10 x 34 voxels) into LDS once, a lane's B operand is ONE float of it at (its voxel) + (its tap's offset), the 14 A
+// operands (this lane's output channel, its tap of the pair) stay in registers.  What is left is the store of 32 output
+// channels per voxel: the layer is HBM-bound.  Tile geometry, moments records and stores are configuration 8's
+// (conv_epilogue<Cfg8>), so the two kernels are interchangeable record for record.
+// ------------------------------------------------------------------------------------------------
+template <class C, bool OUT16>
+__global__ __launch_bounds__(256, 2) void conv3d_first_kernel(const ConvArgs a) {
+    static_assert(C::TX == 32 && C::LY == 1 && C::MT == C::TY && C::WM == C::TZ && C::NT == 1 && C::S == 1, "one z-slice of TY rows per wave");
+    constexpr int TY = C::TY, IY = C::IY, IX = C::IX, NH = C::IZ * C::IY * C::IX;
+    __shared__ float halo[NH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kh = lane >> 5;
+    int bid = blockIdx.x;
+    if (a.xcd_swizzle) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int g = bid % a.G;
+    int b = bid / a.G;
+    const int tx = b % a.ntx; b /= a.ntx;
+    const int ty = b % a.nty; b /= a.nty;
+    const int tz = b % a.ntz; b /= a.ntz;
+    const int n = b;
+    const int ox0 = tx * C::TX, oy0 = ty * C::TY, oz0 = tz * C::TZ;
+    const int HW = a.H * a.W;
+    const float* xn = a.x0 + (size_t)n * a.D * HW;
+    const bool has_ss = a.ss0 != nullptr;
+    const float sc = has_ss ? a.ss0[(size_t)n * 2] : 1.f, sh = has_ss ? a.ss0[(size_t)n * 2 + 1] : 0.f, slope = has_ss ? a.slope : 1.f;
+    for (int e = tid; e < NH; e += 256) {
+        const int iz = e / (IY * IX), rem = e - iz * (IY * IX), iy = rem / IX, ix = rem - iy * IX;
+        const int gz = oz0 - 1 + iz, gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+        const bool ok = (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        float v = 0.f;
+        if (ok) {
+            v = fmaf(xn[(size_t)gz * HW + gy * a.W + gx], sc, sh);
+            v = v > 0.f ? v : v * slope;
+        }
+        halo[e] = v;                                   // zero padding AFTER the producer's activation, as everywhere
+    }
+    // configuration 8's weight image: element (g, tap, lane) = w[g*32 + (lane & 31)][lane >> 5][tap]; channel 0 is lanes 0..31
+    float aw[14]; int toff[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int tap = 2 * s + kh, tc = tap < 27 ? tap : 0;
+        const float w = a.wf[((size_t)g * 27 + tc) * 64 + j];
+        aw[s] = tap < 27 ? w : 0.f;
+        toff[s] = ((tc / 9) * IY + (tc / 3) % 3) * IX + tc % 3;
+    }
+    f32x16 acc[1][TY];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int m = 0; m < TY; ++m) acc[0][m][r] = bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < TY; ++m) {
+        const float* hp = halo + (wave * IY + m) * IX + j;
+#pragma unroll
+        for (int s = 0; s < 14; ++s) acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s], hp[toff[s]], acc[0][m], 0, 0, 0);
+    }
+    conv_epilogue<C, OUT16, true>(a, acc, g, 0, n, wave, j, kh, j, 0, 0, wave * TY, oz0, oy0, ox0, (tz * a.nty + ty) * a.ntx + tx);
+}
+
+// ------------------------------------------------------------------------------------------------
 // split-K reduce: y[n,c,:] = bias[c] + sum_ks slab[ks][n,c,:] (fixed order), and InstanceNorm moments.
 // One workgroup per (n,c); the layers that use split-K are the low-resolution ones (<= 16^3 voxels).
 // ------------------------------------------------------------------------------------------------
@@ -554,10 +626,17 @@ static int conv_fwd(int cfg, const float* x0, const float* ss0, int C0, const fl
         if (cfg != 1 || out16 || !ws_ok) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_st: bf16 sources are implemented for config 1 (W % 4 == 0, aligned) only");
         return wmh_launch_conv_ws_in16(cfg, a, st);
     }
+    static const int first_env = env_int("WMH_FIRST_TAPS", 1);      // 0: the general kernel for the one-channel first layer too (diagnostics)
+    const bool first = cfg == 8 && C0 == 1 && C1 == 0 && first_env;
     if (out16) {
         if (cfg != 8) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_st: a bf16 output is implemented for config 8 only");
-        hipLaunchKernelGGL((conv3d_k3_kernel<Cfg8, 0, true>), dim3((unsigned)nblk), dim3(Cfg8::THREADS), Cfg8::LDS_FLOATS * 4, st, a);
+        if (first) hipLaunchKernelGGL((conv3d_first_kernel<Cfg8, true>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv3d_k3_kernel<Cfg8, 0, true>), dim3((unsigned)nblk), dim3(Cfg8::THREADS), Cfg8::LDS_FLOATS * 4, st, a);
         return wmh_check_launch("conv3d_k3_kernel (bf16 out)");
+    }
+    if (first) {
+        hipLaunchKernelGGL((conv3d_first_kernel<Cfg8, false>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+        return wmh_check_launch("conv3d_first_kernel");
     }
     if (use_ws && ws_ok && ((cfg == 0 && a.KS == 1) || (cfg >= 1 && cfg <= 3 && tiles >= wmh_conv_ws_min_tiles()))) {
         a.KS = 1; a.y = y;
