@@ -68,6 +68,9 @@ __device__ __forceinline__ float sum32(float v) {   // sum over the 32 lanes of 
 int wmh_launch_conv_ws_in16(int cfg, const ConvArgs& a, hipStream_t st);   // config 1 with bf16 sources
 int wmh_launch_conv_ws(int cfg, const ConvArgs& a, hipStream_t st);     // cfg 0..3: 32- and 16-wide rows, stride 1 and 2
 int wmh_conv_ws_min_tiles();
+// split-K reduce (conv3d_k3.hip): y = bias + sum of KS slabs in fixed order, one moments record per (n, c), rest of the row zeroed
+int wmh_launch_splitk_reduce(const float* slabs, const float* bias, float* y, float* partials, int npart, int KS, int N, int Cout,
+                             size_t spatial, hipStream_t st);
 
 // one step of the recursive-halving reduction (static indices only: a runtime index into a register array
 // would be lowered to a compare/select chain per element)

@@ -678,9 +678,12 @@ static int conv_fwd(int cfg, const float* x0, const float* ss0, int C0, const fl
     if (rc != WMH_OK || a.KS == 1) return rc;
     // split-K: fixed-order slab sum + bias + statistics.  The reduce writes ONE moments record per (n,c);
     // fill the rest of the caller's [npart] records with zeros so wmh_instnorm_finalize can be used unchanged.
-    const size_t NC = (size_t)N * Cout, spatial = (size_t)a.Do * a.Ho * a.Wo;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)NC), dim3(256), 0, st, workspace, bias, y, partials, a.npart,
-                       a.KS, Cout, NC, spatial);
+    return wmh_launch_splitk_reduce(workspace, bias, y, partials, a.npart, a.KS, N, Cout, (size_t)a.Do * a.Ho * a.Wo, st);
+}
+int wmh_launch_splitk_reduce(const float* slabs, const float* bias, float* y, float* partials, int npart, int KS, int N, int Cout,
+                             size_t spatial, hipStream_t st) {
+    const size_t NC = (size_t)N * Cout;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)NC), dim3(256), 0, st, slabs, bias, y, partials, npart, KS, Cout, NC, spatial);
     return wmh_check_launch("splitk_reduce_kernel");
 }
 

@@ -318,10 +318,35 @@ static int launch_bf16(const ConvArgs& a, unsigned nblk, hipStream_t st) {
     return wmh_check_launch("conv3d_k3_bf16_kernel");
 }
 
+// split-K factor of the small-row configurations (3, 4, 5: rows of 16 / 8 voxels, the 16^3 and 8^3 levels at batch 8): their
+// grids are one workgroup per CU or less and every chunk iteration ends in a barrier, so nothing hides the staging latency;
+// with the channel reduction cut into slabs several workgroups share a CU.  Same rule as the fp32 path's pick_ksplit.
+static int bf16_ksplit(long long nblk, int nchunks) {
+    static const int force = env_int("WMH_KSPLIT", 0);
+    if (force > 0) return force < nchunks ? force : nchunks;
+    if (nblk >= 512) return 1;
+    int ks = (int)((1024 + nblk - 1) / nblk);
+    if (ks > 16) ks = 16;
+    if (ks > nchunks / 2) ks = nchunks / 2;
+    return ks < 1 ? 1 : ks;
+}
+static long long bf16_small_blocks(int cfg, int N, int D, int H, int W, int Cout) {
+    const int S = bf16_stride(cfg), NT = bf16_nt(cfg);
+    const BGeo ge = bf16_geo(cfg, false);
+    const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+    return (long long)cdiv(Wo, ge.TX) * cdiv(Ho, ge.TY) * cdiv(Do, ge.TZ) * N * cdiv(Cout, 32 * NT);
+}
+extern "C" size_t wmh_conv3d_k3_bf16_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout) {
+    if (!(cfg == 3 || cfg == 4 || cfg == 5) || !bf16_nt(cfg)) return 0;
+    const int S = bf16_stride(cfg);
+    const int ks = bf16_ksplit(bf16_small_blocks(cfg, N, D, H, W, Cout), cdiv(Cin, 16));
+    return ks > 1 ? (size_t)ks * N * Cout * ((D - 1) / S + 1) * ((H - 1) / S + 1) * ((W - 1) / S + 1) : 0;
+}
+
 static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1,
                          const float* ss1, int C1, const uint16_t* wf, const float* bias, float* y,
                          float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope,
-                         int in16, int out16, void* stream) {
+                         int in16, int out16, void* stream, float* workspace = nullptr) {
     const int NT = bf16_nt(cfg);
     if (!NT) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: configuration has no bf16 kernel");
     if (!x0 || !wf || !y || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: null/empty argument");
@@ -354,9 +379,15 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     const bool quad_ok = (W % 4) == 0 && (size_t)16 * D * H * W * 4 < ((size_t)1 << 32) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && (!x1 || (reinterpret_cast<uintptr_t>(x1) & 15) == 0);
     if (small) {
         if (in16 || out16) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16_st: bf16 storage is served for configurations 0 and 21");
-        if (cfg == 3) return launch_bf16<BCfg3, 4>(a, (unsigned)nblk, st);
-        if (cfg == 4) return launch_bf16<BCfg4, 3>(a, (unsigned)nblk, st);
-        return launch_bf16<BCfg5, 4>(a, (unsigned)nblk, st);
+        a.KS = workspace != nullptr ? bf16_ksplit(nblk, a.nchunks) : 1;
+        if (a.KS > 1) a.y = workspace;                       // slabs [KS][N][Cout][Do][Ho][Wo]; bias and moments come with the reduce
+        const unsigned nb = (unsigned)(nblk * a.KS);
+        int rc;
+        if (cfg == 3) rc = launch_bf16<BCfg3, 4>(a, nb, st);
+        else if (cfg == 4) rc = launch_bf16<BCfg4, 3>(a, nb, st);
+        else rc = launch_bf16<BCfg5, 4>(a, nb, st);
+        if (rc != WMH_OK || a.KS == 1) return rc;
+        return wmh_launch_splitk_reduce(workspace, bias, y, partials, a.npart, a.KS, N, Cout, (size_t)a.Do * a.Ho * a.Wo, st);
     }
     if (in16 || out16) {                          // bf16 tensors: only the wave-specialised kernel reads / writes them
         if (!quad_ok) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16_st: bf16 storage needs W % 4 == 0 and 16-byte aligned sources");
@@ -384,6 +415,13 @@ extern "C" int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0
                                       float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope,
                                       void* stream) {
     return conv_fwd_bf16(cfg, x0, ss0, C0, x1, ss1, C1, wf, bias, y, partials, N, D, H, W, Cout, lrelu_slope, 0, 0, stream);
+}
+// The same with split-K slab memory for the small-row configurations (>= wmh_conv3d_k3_bf16_workspace_floats floats, or NULL)
+extern "C" int wmh_conv3d_k3_fwd_bf16_splitk(int cfg, const float* x0, const float* ss0, int C0, const float* x1,
+                                             const float* ss1, int C1, const uint16_t* wf, const float* bias, float* y,
+                                             float* partials, float* workspace, int N, int D, int H, int W, int Cout,
+                                             float lrelu_slope, void* stream) {
+    return conv_fwd_bf16(cfg, x0, ss0, C0, x1, ss1, C1, wf, bias, y, partials, N, D, H, W, Cout, lrelu_slope, 0, 0, stream, workspace);
 }
 // Same convolution with bf16 TENSORS either side (x_bf16: both sources, y_bf16: the output; uint16 bit patterns, NCDHW);
 // the InstanceNorm moments are still taken from the fp32 accumulators.

@@ -177,7 +177,10 @@ class UNetEngine:
         y = self._buf(key + ('.y16' if out16 else '.y'), (N, layer.cout, Do, Ho, Wo), torch.bfloat16 if out16 else torch.float32)
         part = self._buf(key + '.part', (N, layer.cout, npart, 4))
         ss = self._buf(key + '.ss', (N, layer.cout, 2))
-        nws = self.lib.wmh_conv3d_k3_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout, s)
+        if use_bf16:
+            nws = self.lib.wmh_conv3d_k3_bf16_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout)
+        else:
+            nws = self.lib.wmh_conv3d_k3_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout, s)
         ws = self._buf('splitk.ws', (nws,)) if nws else None      # shared: layers run one after another
         st = self._stream()
         wf = layer.packed_bf16(cfg) if use_bf16 else layer.packed(cfg)
@@ -196,10 +199,10 @@ class UNetEngine:
                 _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part),
                 N, D, H, W, layer.cout, s, LRELU_SLOPE, int(in16), int(out16), st), 'wmh_conv3d_k3_fwd_st')
         elif use_bf16:
-            _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16(
+            _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16_splitk(
                 cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
-                _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part),
-                N, D, H, W, layer.cout, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd_bf16')
+                _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws),
+                N, D, H, W, layer.cout, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd_bf16_splitk')
         else:
             _lib.check(self.lib.wmh_conv3d_k3_fwd(
                 cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,

@@ -102,6 +102,13 @@ int wmh_conv3d_k3_bf16_config(int cfg, int Cout, int W);
 int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1,
                            int C1, const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D,
                            int H, int W, int Cout, float lrelu_slope, void* stream);
+/* The same with split-K for the small-row configurations (rows of 16 / 8 voxels: the 16^3 / 8^3 levels): the channel reduction
+ * is cut into slabs in `workspace` (>= wmh_conv3d_k3_bf16_workspace_floats floats; 0 = this launch does not split) and summed in
+ * fixed order with the bias; the moments then come as one record per (n, c).  workspace NULL = wmh_conv3d_k3_fwd_bf16. */
+size_t wmh_conv3d_k3_bf16_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout);
+int wmh_conv3d_k3_fwd_bf16_splitk(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1,
+                                  int C1, const uint16_t* wf, const float* bias, float* y, float* partials, float* workspace,
+                                  int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * bf16 TENSORS for the full-resolution level (opt-in storage mode of the bf16 inference configuration; what
