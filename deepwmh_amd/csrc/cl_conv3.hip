@@ -110,8 +110,25 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         // loads ONLY and the staging waves LDS-DMA ONLY: s_waitcnt vmcnt(N) counts the two kinds together but they do not
         // complete in one order, so a counted wait over a mix does not say which operations are still out (as one stream,
         // "all but the N youngest" let a chunk's DMA pass as landed while it was not -- rare garbage tiles at full size).
+        // The buffer is handed over in three kd-slices: the consumers count themselves out of slices 0 and 1 on an LDS counter as
+        // soon as their last fragment of the slice has arrived (half way through the slice's MFMAs), and this wave refills
+        // those two under the remaining MFMAs; only the last 9 KB are written between the barriers, where everybody waits.
         cl_u32x4 wst[WIT];
         int kw_ = 0, cw = 0, g_w = 0;
+        const unsigned cnt_addr = (unsigned)(G::LDS + 2 * (a.C0 + a.C1) * 8);
+        if (lane < 4) reinterpret_cast<unsigned*>(lds + G::LDS + 2 * (a.C0 + a.C1) * 8)[lane] = 0u;
+        auto wait_slice = [&](int sl, unsigned target) __attribute__((always_inline)) {
+            for (;;) {
+                unsigned v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cnt_addr + 4u * sl) : "memory");
+                if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
+        auto write_slice = [&](int sl) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) reinterpret_cast<cl_u32x4*>(wlds)[(sl * 9 + i) * 64 + lane] = wst[sl * 9 + i];
+        };
         auto locate_w = [&]() __attribute__((always_inline)) { int tx, ty, tz, n0; tile_of(kw_, g_w, tx, ty, tz, n0); };
         auto issue_w = [&]() __attribute__((always_inline)) {
             const cl_u32x4* wsrc = reinterpret_cast<const cl_u32x4*>(a.wf) + ((size_t)g_w * nch + cw) * WQ + lane;
@@ -130,8 +147,15 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         for (int it = 0; it < total; ++it) {
             if (kw_ * nch + cw + 1 < total && ++cw == nch) { cw = 0; ++kw_; locate_w(); }
             issue_w();                                       // chunk it+1 (the last iteration repeats the last chunk)
-            CL_BARRIER();                                    // consumers are done with chunk `it`: its weights may go
-            write_w();
+            if (!CL_ABL(8)) {
+                wait_slice(0, 4u * (unsigned)(it + 1)); write_slice(0);
+                wait_slice(1, 4u * (unsigned)(it + 1)); write_slice(1);
+                CL_BARRIER();                                // consumers are done with chunk `it`: the last slice may go
+                write_slice(2);
+            } else {
+                CL_BARRIER();
+                write_w();
+            }
             CL_BARRIER();
         }
     } else if (loader) {
@@ -351,6 +375,14 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         // the host zero-fills the record buffer, so samples a workgroup never touches read as empty records.
         // (bias and the shift live in a wave-private LDS scratch, [bias | shift][lane half][16 registers]: registers are short)
         float* scr = reinterpret_cast<float*>(lds + 3 * BUF + WQ * 16) + wave * 64;
+        const unsigned cnt_addr = (unsigned)(G::LDS + 2 * (a.C0 + a.C1) * 8);
+        // "this wave has every fragment of weight slice sl": one lane adds 1 to the slice's counter (LDS operations of a wave
+        // complete in order, so the add lands after the wave's reads of the slice)
+        auto release_slice = [&](int sl) __attribute__((always_inline)) {
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
+                         : "=&s"(saved) : "v"(cnt_addr + 4u * sl), "v"(1u) : "memory");
+        };
         float m_sd[16], m_sq[16];
         int m_cnt = 0, m_n = -1, m_cob = 0;
         auto flush = [&]() __attribute__((always_inline)) {
@@ -428,6 +460,8 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
                                 if (iy + 1 <= 2) av[iy + 1][kw] = wl[(kd * 9 + (iy + 1) * 3 + kw) * 64];
                                 else if (iy == IY - 1 && kd < 2) av[0][kw] = wl[((kd + 1) * 9 + kw) * 64];
                                 } else if (iy + 1 <= 2) av[iy + 1][kw] = av[0][kw];
+                                // all nine fragments of this kd were issued by row step 1 and have been consumed by now
+                                if (iy == 2 && kw == 2 && kd < 2 && !CL_ABL(8)) release_slice(kd);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                 }
@@ -550,7 +584,7 @@ extern "C" int wmh_cl_conv3_fwd(const void* x0, const float* ss0, int C0, const 
     hipStream_t st = (hipStream_t)stream;
     if (partials != nullptr && hipMemsetAsync(partials, 0, (size_t)N * Cout * a.npart * 16, st) != hipSuccess)
         return wmh_fail(WMH_ELAUNCH, "cl_conv3_fwd: clearing the moment records failed");
-    const int lds_bytes = ClGeo44::LDS + 2 * (C0 + C1) * 8;
+    const int lds_bytes = ClGeo44::LDS + 2 * (C0 + C1) * 8 + 16;           // + the weight-slice counters
     if (lds_bytes > 160 * 1024) return wmh_fail(WMH_EINVAL, "cl_conv3_fwd: too many input channels for the LDS scale/shift tables");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cl_conv3_kernel<ClGeo44>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL((cl_conv3_kernel<ClGeo44>), dim3(grid), dim3(768), lds_bytes, st, a, (int)T);
