@@ -71,26 +71,35 @@ __device__ __forceinline__ void write_scale_shift(Moments t, const float* gamma,
     if (mean_rstd) { mean_rstd[2 * nc] = (float)t.mean; mean_rstd[2 * nc + 1] = (float)rstd; }
 }
 
-__global__ __launch_bounds__(64) void instnorm_finalize_kernel(const float4* part, int np, const float* gamma,
-                                                               const float* beta, float eps, float* ss,
-                                                               float* mean_rstd, int C) {
+// One workgroup of four waves per (n, c) row: the records are dealt round-robin to the 256 threads, merged per thread, per wave
+// (fixed butterfly) and across the four waves in wave order -- a fixed association whatever the record count (bit-reproducible).
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float4* part, int np, const float* gamma,
+                                                                const float* beta, float eps, float* ss,
+                                                                float* mean_rstd, int C) {
+    __shared__ double sh[4][3];
     const int nc = blockIdx.x, c = nc % C;
     const float4* p = part + (size_t)nc * np;
     Moments acc{0.0, 0.0, 0.0};
-    for (int i = threadIdx.x; i < np; i += 64) {
+    for (int i = threadIdx.x; i < np; i += 256) {
         const float4 r = p[i];
         Moments b;
         b.n = r.x; b.mean = r.x > 0.f ? (double)r.y / (double)r.x : 0.0; b.m2 = r.z;
         acc = chan_merge(acc, b);
     }
     acc = wave_merge(acc);
-    if (threadIdx.x == 0) write_scale_shift(acc, gamma, beta, eps, ss, mean_rstd, nc, c);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = acc.n; sh[threadIdx.x >> 6][1] = acc.mean; sh[threadIdx.x >> 6][2] = acc.m2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Moments t{sh[0][0], sh[0][1], sh[0][2]};
+        for (int w = 1; w < 4; ++w) t = chan_merge(t, Moments{sh[w][0], sh[w][1], sh[w][2]});
+        write_scale_shift(t, gamma, beta, eps, ss, mean_rstd, nc, c);
+    }
 }
 
 extern "C" int wmh_instnorm_finalize(const float* partials, int num_partials, const float* gamma, const float* beta,
                                      float eps, float* ss, float* mean_rstd, int N, int C, void* stream) {
     if (!partials || !ss || num_partials < 1 || N < 1 || C < 1) return wmh_fail(WMH_EINVAL, "instnorm_finalize: bad args");
-    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(N * C), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(partials), num_partials, gamma, beta, eps, ss, mean_rstd, C);
     return wmh_check_launch("instnorm_finalize_kernel");
 }
