@@ -28,19 +28,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (dense peaks)
-PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0}
+# bf16x3: a product is four bf16 matrix instructions (both operands split into two bf16 numbers), so the mode's ceiling in
+# ALGORITHMIC flops is a quarter of the bf16 peak
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 625.0}
 HBM_PEAK_GBS = 8000.0
 FWD_GFLOP_PER_PATCH = 954.46     # BASELINE.md section 2 (the engine's own count of what it queued is reported next to it)
 AGG_GBYTES_PER_VOLUME = 0.46     # aggregation read-modify-write + volume in / label map out
 KERNEL_NAME = {
     'fp32': 'conv3d_k3_ws_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM, wave-specialised)',
     'bf16': 'conv3d_k3_bf16_ws_kernel<cfg0> (v_mfma_f32_32x32x16_bf16 implicit GEMM, wave-specialised)',
+    'bf16x3': 'conv3d_k3_bf16_ws_kernel<cfg0, X3> (fp32 tensors; operands split into bf16 pairs, 4 x v_mfma_f32_32x32x16_bf16 per '
+              '16 channels and tap, fp32 accumulate; peak = bf16 peak / 4)',
     'bf16_storage': 'cl_conv3_kernel<ClGeo<4,4>> (channels-last bf16 tensors, v_mfma_f32_32x32x16_bf16, LDS-DMA staging, every stride-1 launch)',
 }
 
 
 def mode_key(precision, storage):
-    return 'fp32' if precision == 'fp32' else ('bf16_storage' if storage == 'bf16' else 'bf16')
+    return precision if precision in ('fp32', 'bf16x3') else ('bf16_storage' if storage == 'bf16' else 'bf16')
 
 
 def parse_args(argv=None):
@@ -54,8 +58,9 @@ def parse_args(argv=None):
                     help='auto: time the oracle on the WHOLE volume without mirroring when a probe says that fits in '
                          '~60 s (it does on the GPU box), else on one patch; full / sample force one of the two')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='same as --cpu-baseline off')
-    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
-                    help='bf16 = BASELINE.json configs[2] (bf16 matrix-core operands, fp32 accumulate); not the headline')
+    ap.add_argument('--precision', choices=['fp32', 'bf16', 'bf16x3'], default='fp32',
+                    help='bf16 = BASELINE.json configs[2] (bf16 matrix-core operands, fp32 accumulate); bf16x3 = fp32 tensors, '
+                         'products from bf16 pairs (fp32-grade results on the bf16 instruction); neither is the headline')
     ap.add_argument('--storage', choices=['fp32', 'bf16'], default='fp32',
                     help='bf16 (with --precision bf16): activation tensors are kept as bf16; not the headline')
     ap.add_argument('--volumes-per-step', type=int, default=0,
@@ -228,6 +233,10 @@ def workload_string(args, tta, forwards, world):
     if args.precision == 'fp32':
         return ('configs[1]: one %s FLAIR volume per GPU, 128^3 patches, step 0.5, fp32, Gaussian aggregation, %s; '
                 '%d patch forwards per volume' % (shp, mir, forwards))
+    if args.precision == 'bf16x3':
+        return ('configs[1] workload in the opt-in bf16x3 mode: one %s FLAIR volume per GPU, 128^3 patches, step 0.5, fp32 tensors, '
+                'stride-1 3x3x3 products from bf16 pairs (16 mantissa bits per operand, fp32 accumulate), Gaussian aggregation, %s; '
+                '%d patch forwards per volume' % (shp, mir, forwards))
     return ('configs[2]: bf16 forward (bf16 matrix-core operands, fp32 accumulate, %s activation tensors, fused '
             'InstanceNorm+LeakyReLU), batch of %d synthetic %s volumes per step per GPU, 128^3 patches, step 0.5, Gaussian '
             'aggregation, %s; %d patch forwards per volume'
@@ -332,6 +341,7 @@ def run_rank(args):
         vols_rank = args.steps * V                      # volumes this rank queued in the timed region
         gb_vol = acct['bytes'] / vols_rank / 1e9 + AGG_GBYTES_PER_VOLUME
         dtype = ('f32' if args.precision == 'fp32' else
+                 'f32 tensors and accumulate / bf16x3 products (two bf16 per operand)' if args.precision == 'bf16x3' else
                  'bf16 operands / f32 accumulate+storage' if args.storage == 'fp32' else
                  'bf16 operands and activation tensors / f32 accumulate')
         res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=nvol / dt,

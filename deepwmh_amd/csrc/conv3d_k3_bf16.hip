@@ -275,6 +275,35 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16(int cfg, const float* w, int Cin,
     return WMH_OK;
 }
 
+// ---- bf16x3 (conv3d_k3_bf16_ws.hip, X3): chunks of 8 input channels, a lane's 16 bytes are the HIGH bf16 parts of its output
+// channel's 8 weights (lanes 0-31) or the LOW parts (lanes 32-63): w = hi + lo + O(2^-17 w)
+extern "C" int wmh_conv3d_k3_bf16x3_supported(int cfg) { return cfg == 0 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE; }
+extern "C" size_t wmh_conv3d_k3_packed_halfs_bf16x3(int cfg, int Cin, int Cout) {
+    const int NT = bf16_nt(cfg);
+    if (!NT || !wmh_conv3d_k3_bf16x3_supported(cfg)) return 0;
+    return (size_t)cdiv(Cout, 32 * NT) * cdiv(Cin, 8) * 27 * NT * 64 * 8;
+}
+static inline float bf2f(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+// w: host fp32 torch layout [Cout][Cin][27]; wf: host uint16 out, [G][cin/8][tap][NT][lane][8]
+extern "C" int wmh_conv3d_k3_pack_weights_bf16x3(int cfg, const float* w, int Cin, int Cout, uint16_t* wf) {
+    const int NT = bf16_nt(cfg);
+    if (!NT || !wmh_conv3d_k3_bf16x3_supported(cfg) || !w || !wf) return wmh_fail(WMH_EINVAL, "pack_weights_bf16x3: unsupported cfg or null");
+    const int G = cdiv(Cout, 32 * NT), NCH = cdiv(Cin, 8);
+    for (int g = 0; g < G; ++g)
+        for (int ch = 0; ch < NCH; ++ch)
+            for (int tap = 0; tap < 27; ++tap)
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = (g * NT + nt) * 32 + (lane & 31), ci = ch * 8 + e;
+                            float v = 0.f;
+                            if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 27 + tap];
+                            const uint16_t hi = f2bf(v);
+                            wf[(((((size_t)g * NCH + ch) * 27 + tap) * NT + nt) * 64 + lane) * 8 + e] = (lane >> 5) ? f2bf(v - bf2f(hi)) : hi;
+                        }
+    return WMH_OK;
+}
+
 // Device-side repack (training: the weights change every step).  Same argument meaning as
 // wmh_conv3d_k3_pack_weights_device: w = torch layout [Cout][Cin_total][27] fp32 in HBM, channels [ci_off, ci_off+ci_cnt);
 // mode 0 = forward image (ci_cnt -> Cout), mode 1 = data-gradient image (Cout -> ci_cnt, transposed, taps flipped).
@@ -408,6 +437,39 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     }
     if (cfg == 0) return launch_bf16<BCfg0, 4>(a, (unsigned)nblk, st);
     return launch_bf16<BCfg2, 3>(a, (unsigned)nblk, st);
+}
+
+int wmh_launch_conv_bf16x3_ws(int cfg, const ConvArgs& a, hipStream_t st);
+// y = conv3x3x3 with both operands split into two bf16 numbers each and all four partial products accumulated in fp32
+// (16 mantissa bits per operand): fp32 tensors in and out, stride 1, wf from wmh_conv3d_k3_pack_weights_bf16x3.  Same
+// geometry, moments records (wmh_conv3d_k3_num_partials_bf16) and epilogue as wmh_conv3d_k3_fwd_bf16.
+extern "C" int wmh_conv3d_k3_fwd_bf16x3(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
+                                        const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D, int H, int W,
+                                        int Cout, float lrelu_slope, void* stream) {
+    const int NT = bf16_nt(cfg);
+    if (!NT || !wmh_conv3d_k3_bf16x3_supported(cfg)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: configuration has no bf16x3 kernel");
+    if (!x0 || !wf || !y || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: null/empty argument");
+    if (x1 == nullptr) C1 = 0;
+    if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: LeakyReLU slope must be in [0, 1]");
+    if (C1 > 0 && (C0 % 8) != 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: C0 must be a multiple of 8 with two sources");
+    if ((W % 4) != 0 || (size_t)16 * D * H * W * 4 >= ((size_t)1 << 32) || (reinterpret_cast<uintptr_t>(x0) & 15) != 0 ||
+        (x1 && (reinterpret_cast<uintptr_t>(x1) & 15) != 0))
+        return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: needs W % 4 == 0 and 16-byte aligned sources");
+    ConvArgs a;
+    a.x0 = x0; a.ss0 = ss0; a.C0 = C0; a.x1 = x1; a.ss1 = ss1; a.C1 = C1;
+    a.wf = reinterpret_cast<const float*>(wf); a.bias = bias; a.y = y; a.part = partials;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Do = D; a.Ho = H; a.Wo = W; a.Cout = Cout;
+    a.nchunks = (C1 > 0) ? (C0 / 8 + cdiv(C1, 8)) : cdiv(C0, 8);
+    const BGeo ge = bf16_geo(cfg, false);
+    a.ntx = cdiv(a.Wo, ge.TX); a.nty = cdiv(a.Ho, ge.TY); a.ntz = cdiv(a.Do, ge.TZ);
+    a.npart = a.ntx * a.nty * a.ntz * ge.WPS;
+    a.slope = lrelu_slope;
+    a.G = cdiv(Cout, 32 * NT);
+    a.KS = 1;
+    static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
+    a.xcd_swizzle = swz_env & 1;
+    a.stamps = nullptr;
+    return wmh_launch_conv_bf16x3_ws(cfg, a, (hipStream_t)stream);
 }
 
 extern "C" int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1,

@@ -54,9 +54,19 @@ __device__ __forceinline__ float ld_uniform(const float* p) {
 #endif
 
 // IN16: both sources are bf16 tensors (a quad is one 8-byte load per channel, widened by a shift); OUT16: y is stored as bf16.
-template <class C, bool IN16 = false, bool OUT16 = false>
+// X3 ("bf16x3", fp32 tensors): every operand is split into two bf16 numbers, x = x_hi + x_lo with x_hi = bf16(x), x_lo = bf16(x -
+// x_hi) (16 mantissa bits together), and the product is formed from all four partial products on the bf16 instruction.  A
+// chunk is 8 input channels; the 16 k slots of an MFMA carry B = [x_hi | x_lo] of those channels (the bf16 kernel's LDS image:
+// 32 bytes per voxel, the hi piece where channels 0-7 were, the lo piece where channels 8-15 were -- ONE operand read per
+// voxel tile and tap, as before), and the tap is issued twice, with A = [w_hi | w_hi] and A = [w_lo | w_lo]:
+// sum_k A B = w_hi (x_hi + x_lo), then w_lo (x_hi + x_lo).  (The other way round -- one A, two B -- costs an LDS read per
+// MFMA, and with one 32-channel output tile per wave that is exactly the LDS bandwidth: 4.3 instead of 3.x ms per layer.)
+// 4 MFMAs per 16 channels and tap instead of 1 -- still 4x fewer cycles than the fp32 instruction -- with fp32 accumulation,
+// fp32 tensors and the fp32 epilogue.
+template <class C, bool IN16 = false, bool OUT16 = false, bool X3 = false>
 __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArgs a, const int T /*tiles*/) {
-    constexpr int S = C::S, MT = C::MT, NT = C::NT, CKB = 16;
+    constexpr int S = C::S, MT = C::MT, NT = C::NT, CKB = X3 ? 8 : 16;
+    static_assert(!(X3 && (IN16 || OUT16)), "bf16x3 works on fp32 tensors");
     constexpr int LTH = 256;                                   // loader threads
     constexpr int NIT = (C::SP + LTH - 1) / LTH;
     constexpr int CS = NIT * LTH;                              // padded voxel count: every loader store in range
@@ -138,7 +148,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         // chunk go through a ring of RS register sets: while one set is normalised, packed and written, RS-1 are in flight.
         // bf16 sources: a set is half the registers, and with half the bytes per load the same ring would keep half the bytes
         // in flight -- the whole chunk rides in the ring instead
-        constexpr int NHS = 2 * NSL, RS = IN16 ? WMH_BF16_WS_RING16(NHS) : WMH_BF16_WS_RING(NHS);   // RS must divide NHS (static ring indices)
+        constexpr int HPS = X3 ? 1 : 2;                           // half-slots per quad slot (X3: the 8 channels of a chunk are one)
+        constexpr int NHS = HPS * NSL, RS = IN16 ? WMH_BF16_WS_RING16(NHS) : WMH_BF16_WS_RING(NHS);   // RS must divide NHS (static ring indices)
         f32x4_t v[IN16 ? 1 : RS][8];
         uint2 v16[IN16 ? RS : 1][8];
         unsigned okh[RS];
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         // checks the range): the loads are `global_load_dwordx4 v, v_off, s[base]`, no 64-bit arithmetic per channel.
         const unsigned pstride = 4u * (unsigned)DHW;
         auto issue = [&](auto hc, int ch) __attribute__((always_inline)) {                   // half-slot h of chunk ch of the tile set up last
-            constexpr int h = decltype(hc)::value, i = h / 2, half = h % 2, r = h % RS;
+            constexpr int h = decltype(hc)::value, i = h / HPS, half = h % HPS, r = h % RS;
             ch = __builtin_amdgcn_readfirstlane(ch);          // q % nch ran on the VALU
             const float* xs; const float* ss; int Cs, c0;
             src_of(ch, xs, ss, Cs, c0);
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             }
         };
         auto convert = [&](auto hc, int buf) __attribute__((always_inline)) {
-            constexpr int h = decltype(hc)::value, i = h / 2, half = h % 2, r = h % RS;
+            constexpr int h = decltype(hc)::value, i = h / HPS, half = h % HPS, r = h % RS;
             uint4* dst = ldsq + (size_t)buf * CS * 2;
             const int sidx = lt + i * LTH;
             const int row = sidx / QPR, q = sidx - row * QPR;
@@ -202,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             // be pushed out to scratch (their reload sits between the two barriers, where every wave of the workgroup waits,
             // and a scratch reload waits for ALL loads in flight -- the whole prefetch ring)
             unsigned w[4][4];                                      // [voxel of the quad][channel pair]
+            unsigned wlo[X3 ? 4 : 1][4];                           // X3: the low parts
 #pragma unroll
             for (int c = 0; c < 8; c += 2) {
                 f32x4_t t[2];
@@ -224,7 +236,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                     t[e] = f32x4_t{ws_vmax(lo[0], lo_s[0]), ws_vmax(lo[1], lo_s[1]), ws_vmax(hi[0], hi_s[0]), ws_vmax(hi[1], hi_s[1])};
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) w[k][c >> 1] = ws_pack_bf16x2(t[0][k], t[1][k]) & keep;
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned u = ws_pack_bf16x2(t[0][k], t[1][k]);
+                    w[k][c >> 1] = u & keep;
+                    if constexpr (X3) {                            // remainder after the high part, rounded to bf16 again
+                        const f32x2_t hi2 = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xFFFF0000u)};
+                        const f32x2_t lo2 = f32x2_t{t[0][k], t[1][k]} - hi2;
+                        wlo[k][c >> 1] = ws_pack_bf16x2(lo2[0], lo2[1]) & keep;
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -232,6 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 if (sidx < NQ && x >= 0 && x < C::IX) {
                     const int e = row * C::IX + x;
                     dst[e * 2 + (half ^ ((x >> 3) & 1))] = make_uint4(w[k][0], w[k][1], w[k][2], w[k][3]);
+                    if constexpr (X3) dst[e * 2 + (1 ^ ((x >> 3) & 1))] = make_uint4(wlo[k][0], wlo[k][1], wlo[k][2], wlo[k][3]);
                 }
             }
         };
@@ -257,7 +278,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             load_ss(q);                                       // before any enter(q + 1): n0_cur is still this chunk's
             issue_w(q);
             step(std::integral_constant<int, 0>{}, q, buf); step(std::integral_constant<int, 1>{}, q, buf);
-            step(std::integral_constant<int, 2>{}, q, buf); step(std::integral_constant<int, 3>{}, q, buf);
+            if constexpr (NHS > 2) step(std::integral_constant<int, 2>{}, q, buf);
+            if constexpr (NHS > 3) step(std::integral_constant<int, 3>{}, q, buf);
             if constexpr (NHS > 4) { step(std::integral_constant<int, 4>{}, q, buf); step(std::integral_constant<int, 5>{}, q, buf); }
         };
         if (total > 0) {
@@ -299,10 +321,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             const int tyi = ts % C::MY, tzi = ts / C::MY;
             const int e0 = (tzi * C::LZ + dz) * C::ZS + (tyi * C::LY + dy) * C::YS + dx;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) badr[kw][m] = (e0 + kw) * 32 + 16 * (kh ^ (((dx + kw) >> 3) & 1));
+            for (int kw = 0; kw < 3; ++kw) badr[kw][m] = (e0 + kw) * 32 + 16 * (kh ^ (((dx + kw) >> 3) & 1));   // X3: hi piece (kh 0) / lo piece (kh 1)
         }
         const char* ldsb = reinterpret_cast<const char*>(ldsq);
-        const bf16x8* wl = reinterpret_cast<const bf16x8*>(wlds) + lane;
+        // X3: a fragment's 64 pieces are [hi of cout 0..31 | lo of cout 0..31]; both lane halves read the same piece
+        const bf16x8* wl = reinterpret_cast<const bf16x8*>(wlds) + (X3 ? j : lane);
         int g, tx, ty, tz, n0;
         __syncthreads();
         int it = 0;
@@ -326,15 +349,23 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 for (int tap = 0; tap < 27; ++tap) {
                     const int kw = tap % 3;
                     const int rowoff = ((tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS) * 32;
-                    bf16x8 av[NT];
+                    bf16x8 av[NT], al[X3 ? NT : 1];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) av[nt] = wl[(tap * NT + nt) * 64];
+                    for (int nt = 0; nt < NT; ++nt) {
+                        av[nt] = wl[(tap * NT + nt) * 64];
+                        if constexpr (X3) al[nt] = wl[(tap * NT + nt) * 64 + 32];
+                    }
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const bf16x8 bv = *reinterpret_cast<const bf16x8*>(cur + badr[kw][m] + rowoff);
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[nt], bv, acc[nt][m], 0, 0, 0);
+                        if constexpr (X3) {                        // the low parts of the weights against the same operand
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[nt], bv, acc[nt][m], 0, 0, 0);
+                        }
                     }
                 }
                 if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
@@ -358,7 +389,7 @@ typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> WBCfg0;
 typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> WBCfg2;
 typedef ConvCfg<1, 32, 1, 4, 4, 1, 4, 2, 4, 6> WBCfgW;      // configuration 21: 4 x 4 x 32 voxels x 64 output channels
 
-template <class C, bool IN16 = false, bool OUT16 = false>
+template <class C, bool IN16 = false, bool OUT16 = false, bool X3 = false>
 static int launch_bf16_ws(const ConvArgs& a, hipStream_t st) {
     static int ncu = 0;
     if (!ncu) {
@@ -371,11 +402,11 @@ static int launch_bf16_ws(const ConvArgs& a, hipStream_t st) {
     constexpr int NITL = (C::SP + 255) / 256;
     constexpr int lds = 2 * NITL * 256 * 32 + 27 * C::NT * 64 * 16;
     static_assert(lds <= 160 * 1024, "LDS");
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_ws_kernel<C, IN16, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_ws_kernel<C, IN16, OUT16, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const long long T = (long long)a.ntx * a.nty * a.ntz * a.N * a.G;
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 bf16 (wave-specialised): too many tiles");
     const int grid = T < ncu ? (int)T : ncu;
-    hipLaunchKernelGGL((conv3d_k3_bf16_ws_kernel<C, IN16, OUT16>), dim3(grid), dim3(512), lds, st, a, (int)T);
+    hipLaunchKernelGGL((conv3d_k3_bf16_ws_kernel<C, IN16, OUT16, X3>), dim3(grid), dim3(512), lds, st, a, (int)T);
     return wmh_check_launch("conv3d_k3_bf16_ws_kernel");
 }
 // a: fully prepared by wmh_conv3d_k3_fwd_bf16 (one-role geometry: npart, nchunks, G ... are the same)
@@ -388,4 +419,12 @@ int wmh_launch_conv_bf16_ws(int cfg, const ConvArgs& a, hipStream_t st, int in16
     }
     if (cfg == 21) return launch_bf16_ws<WBCfgW>(a, st);
     return cfg == 0 ? launch_bf16_ws<WBCfg0>(a, st) : launch_bf16_ws<WBCfg2>(a, st);
+}
+
+// bf16x3: the same geometry, chunks of 8 input channels (a: prepared by wmh_conv3d_k3_fwd_bf16x3)
+int wmh_launch_conv_bf16x3_ws(int cfg, const ConvArgs& a, hipStream_t st) {
+    if (cfg == 21) return launch_bf16_ws<WBCfgW, false, false, true>(a, st);
+    if (cfg == 0) return launch_bf16_ws<WBCfg0, false, false, true>(a, st);
+    if (cfg == 2) return launch_bf16_ws<WBCfg2, false, false, true>(a, st);
+    return wmh_fail(WMH_EINVAL, "conv3d_k3 bf16x3: configurations 0, 2 and 21");
 }

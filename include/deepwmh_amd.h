@@ -102,6 +102,18 @@ int wmh_conv3d_k3_bf16_config(int cfg, int Cout, int W);
 int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1,
                            int C1, const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D,
                            int H, int W, int Cout, float lrelu_slope, void* stream);
+/* "bf16x3": fp32-grade products on the bf16 matrix instruction.  Every operand is split into two bf16
+ * numbers (x = x_hi + x_lo, 16 mantissa bits together) and all four partial products are accumulated in fp32: 4 bf16 MFMAs
+ * per 16 input channels and tap instead of 1, still a quarter of the fp32 instruction's cycles.  fp32 NCDHW tensors in and
+ * out, stride 1, configurations 0 / 2 / 21 (rows of >= 16 voxels); geometry, epilogue and moments records of
+ * wmh_conv3d_k3_fwd_bf16 (wmh_conv3d_k3_num_partials_bf16).  wf: wmh_conv3d_k3_pack_weights_bf16x3 ([G][cin/8][27][NT][64][8]
+ * bf16: lanes 0-31 the high parts, lanes 32-63 the low parts of an output channel's 8 weights). */
+int wmh_conv3d_k3_bf16x3_supported(int cfg);
+size_t wmh_conv3d_k3_packed_halfs_bf16x3(int cfg, int Cin, int Cout);
+int wmh_conv3d_k3_pack_weights_bf16x3(int cfg, const float* w, int Cin, int Cout, uint16_t* wf);
+int wmh_conv3d_k3_fwd_bf16x3(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
+                             const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D, int H, int W,
+                             int Cout, float lrelu_slope, void* stream);
 /* The same with split-K for the small-row configurations (rows of 16 / 8 voxels: the 16^3 / 8^3 levels): the channel reduction
  * is cut into slabs in `workspace` (>= wmh_conv3d_k3_bf16_workspace_floats floats; 0 = this launch does not split) and summed in
  * fixed order with the bias; the moments then come as one record per (n, c).  workspace NULL = wmh_conv3d_k3_fwd_bf16. */

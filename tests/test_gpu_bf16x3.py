@@ -1,0 +1,109 @@
+"""`precision='bf16x3'`: the stride-1 3x3x3 convolutions form their products from bf16 pairs (x = hi + lo, 16 mantissa bits per
+operand, all four partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- VERDICT r1 item 9.  The gate is the fp32
+path's own: softmax within 1e-4 of the oracle, identical argmax outside the margin band."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from deepwmh_amd import _lib
+    return _lib.load()
+
+
+CASES = [  # N, D, H, W, C0, C1, Cout, pending norm on source 0 / 1
+    (2, 8, 8, 32, 32, 0, 32, True, False),
+    (1, 5, 9, 36, 12, 0, 40, True, False),        # channel counts that are not multiples of the chunk / the tile; ragged tiles
+    (1, 6, 10, 32, 16, 24, 32, False, True),      # two sources (the decoder's concatenation), the second one normalised
+    (2, 4, 12, 64, 64, 64, 64, True, True),       # the 64-channel tile (configuration 21)
+    (2, 18, 6, 16, 48, 0, 64, True, False),       # rows of 16 voxels (configuration 2)
+]
+
+
+@pytest.mark.parametrize('N,D,H,W,C0,C1,Cout,has0,has1', CASES)
+def test_conv_bf16x3_against_float64(lib, N, D, H, W, C0, C1, Cout, has0, has1):
+    from deepwmh_amd import _lib
+    P = _lib.ptr
+    g = torch.Generator().manual_seed(N * 1000 + W + C0)
+    Cin = C0 + C1
+    x0 = torch.randn(N, C0, D, H, W, generator=g)
+    x1 = torch.randn(N, C1, D, H, W, generator=g) if C1 else None
+    mk = lambda c: torch.stack([1 + 0.3 * torch.randn(N, c, generator=g), 0.2 * torch.randn(N, c, generator=g)], -1).contiguous()
+    ss0, ss1 = (mk(C0) if has0 else None), (mk(C1) if (C1 and has1) else None)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / np.sqrt(27 * Cin)
+    bias = 0.1 * torch.randn(Cout, generator=g)
+
+    def act(x, ss):
+        x = x.double()
+        return x if ss is None else torch.nn.functional.leaky_relu(x * ss[..., 0, None, None, None].double() + ss[..., 1, None, None, None].double(), 0.01)
+    xin = act(x0, ss0) if x1 is None else torch.cat([act(x0, ss0), act(x1, ss1)], 1)
+    ref = torch.nn.functional.conv3d(xin, w.double(), bias.double(), padding=1)
+    cfg0 = _lib.check(lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, 1), 'config')
+    cfg = lib.wmh_conv3d_k3_bf16_config(cfg0, Cout, W)
+    assert lib.wmh_conv3d_k3_bf16x3_supported(cfg)
+    wh = np.ascontiguousarray(w.numpy().reshape(Cout, Cin, 27))
+    wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_bf16x3(cfg, Cin, Cout), np.uint16)
+    _lib.check(lib.wmh_conv3d_k3_pack_weights_bf16x3(cfg, wh.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
+    wfd = torch.from_numpy(wf.view(np.int16)).cuda()
+    y = torch.full((N, Cout, D, H, W), float('nan'), device='cuda')
+    npart = _lib.check(lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, D, H, W), 'npart')
+    part = torch.full((N, Cout, npart, 4), float('nan'), device='cuda')
+    x0d, x1d = x0.cuda(), (x1.cuda() if C1 else None)
+    ss0d, ss1d, bd = (ss0.cuda() if ss0 is not None else None), (ss1.cuda() if ss1 is not None else None), bias.cuda()
+    _lib.check(lib.wmh_conv3d_k3_fwd_bf16x3(cfg, P(x0d), P(ss0d), C0, P(x1d), P(ss1d), C1, P(wfd), P(bd), P(y), P(part), N, D, H, W, Cout,
+                                            0.01, None), 'wmh_conv3d_k3_fwd_bf16x3')
+    torch.cuda.synchronize()
+    got = y.cpu().double()
+    assert bool(torch.isfinite(got).all())
+    rel = float((got - ref).norm() / ref.norm())
+    mx = float((got - ref).abs().max()) / float(ref.abs().max())
+    # 16 mantissa bits per operand: ~2^-17 per product, random signs over the 27 Cin terms; fp32's own figure here is ~1e-6
+    assert rel <= 1e-5 and mx <= 2e-5, (rel, mx)
+    # InstanceNorm statistics from the fp32 accumulators, through the usual finalisation
+    ss = torch.empty(N, Cout, 2, device='cuda')
+    _lib.check(lib.wmh_instnorm_finalize(P(part), npart, None, None, 1e-5, P(ss), None, N, Cout, None), 'finalize')
+    mean, var = ref.mean((2, 3, 4)), ref.var((2, 3, 4), unbiased=False)
+    ss_ref = torch.stack([1 / torch.sqrt(var + 1e-5), -mean / torch.sqrt(var + 1e-5)], -1)
+    assert float((ss.cpu().double() - ss_ref).abs().max()) <= 2e-4 * (1 + float(ss_ref.abs().max()))
+
+
+def test_engine_bf16x3_meets_the_fp32_gate(tiny_net, tiny_io):
+    """Tiny net, tiled + mirrored prediction: the same bounds tests/test_gpu_network.py puts on the fp32 path."""
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    plan, net, sd = tiny_net
+    eng = UNetEngine(plan, sd, 'cuda:0', precision='bf16x3')
+    seg, prob = SlidingWindowPredictor(eng, do_mirroring=True).predict(tiny_io['volume'])
+    ref = tiny_io['prob_tta']
+    d = float(np.abs(prob - ref).max())
+    margin = np.abs(ref[1] - ref[0])
+    mism = int(((seg != tiny_io['seg_tta']) & (margin > 2e-4)).sum())
+    print('bf16x3 tiny net: max |softmax - golden| %.3g, argmax mismatches outside the margin band %d' % (d, mism))
+    assert d <= 1e-4 and mism == 0
+    with pytest.raises(ValueError):
+        UNetEngine(plan, sd, 'cuda:0', precision='bf16x3', storage='bf16')
+
+
+def test_engine_bf16x3_full_width_patch_vs_fp32_path():
+    """BASELINE plan (31 M parameters), a batch of 128^3 patches: against the exact-fp32 HIP path (itself within 1.5e-5 of the oracle)."""
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.plan import baseline_plan
+    from deepwmh_amd.synthetic import he_init_state_dict, synthetic_flair
+    plan = baseline_plan()
+    sd = he_init_state_dict(plan, seed=0)
+    vol = synthetic_flair((128, 128, 160), seed=3)
+    x = torch.from_numpy(np.ascontiguousarray(np.stack([vol[:, :, :, :128], vol[:, :, :, 32:]]))).cuda()
+    ref = torch.softmax(UNetEngine(plan, sd, 'cuda:0').forward_logits(x), 1)
+    eng = UNetEngine(plan, sd, 'cuda:0', precision='bf16x3')
+    a = torch.softmax(eng.forward_logits(x), 1)
+    assert torch.equal(a, torch.softmax(eng.forward_logits(x), 1))          # bit-reproducible
+    d = float((a - ref).abs().max())
+    margin = (ref[:, 1] - ref[:, 0]).abs()
+    mism = int((((a[:, 1] > 0.5) != (ref[:, 1] > 0.5)) & (margin > 2e-4)).sum())
+    print('bf16x3 full width: max |softmax - fp32 path| %.3g, class changes outside the margin band %d' % (d, mism))
+    assert d <= 1e-4 and mism == 0

@@ -1,0 +1,75 @@
+"""bf16x3 convolution (wmh_conv3d_k3_fwd_bf16x3): error against a float64 reference next to the exact-fp32 kernel's, and timing at the
+BASELINE shapes.  python tools/x3_check.py"""
+import ctypes as C
+import os
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepwmh_amd import _lib  # noqa: E402
+lib = _lib.load()
+P = _lib.ptr
+
+
+def run(N, S, C0, C1, Cout, check=True, reps=5):
+    Cin = C0 + C1
+    g = torch.Generator(device='cuda').manual_seed(1)
+    x0 = torch.randn(N, C0, S, S, S, device='cuda', generator=g)
+    x1 = torch.randn(N, C1, S, S, S, device='cuda', generator=g) if C1 else None
+    ss0 = torch.stack([1 + 0.3 * torch.randn(N, C0, device='cuda', generator=g), 0.2 * torch.randn(N, C0, device='cuda', generator=g)], -1).contiguous()
+    ss1 = torch.stack([1 + 0.3 * torch.randn(N, C1, device='cuda', generator=g), 0.2 * torch.randn(N, C1, device='cuda', generator=g)], -1).contiguous() if C1 else None
+    w = (np.random.default_rng(0).standard_normal((Cout, Cin, 27)) / np.sqrt(27 * Cin)).astype(np.float32)
+    bias = torch.randn(Cout, device='cuda', generator=g) * 0.1
+    cfg0 = lib.wmh_conv3d_k3_config(Cin, Cout, S, S, S, 1)
+    cfg = lib.wmh_conv3d_k3_bf16_config(cfg0, Cout, S)
+    assert lib.wmh_conv3d_k3_bf16x3_supported(cfg), cfg
+    wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_bf16x3(cfg, Cin, Cout), np.uint16)
+    _lib.check(lib.wmh_conv3d_k3_pack_weights_bf16x3(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
+    wfd = torch.from_numpy(wf.view(np.int16)).cuda()
+    y = torch.empty(N, Cout, S, S, S, device='cuda')
+    npart = lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, S, S, S)
+    part = torch.empty(N, Cout, npart, 4, device='cuda')
+
+    def x3():
+        _lib.check(lib.wmh_conv3d_k3_fwd_bf16x3(cfg, P(x0), P(ss0), C0, P(x1), P(ss1), C1, P(wfd), P(bias), P(y), P(part), N, S, S, S, Cout, 0.01, None), 'x3')
+    # the exact-fp32 kernel
+    wf32 = np.empty(lib.wmh_conv3d_k3_packed_floats(cfg0, Cin, Cout), np.float32)
+    lib.wmh_conv3d_k3_pack_weights(cfg0, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf32.ctypes.data_as(C.c_void_p))
+    wf32d = torch.from_numpy(wf32).cuda()
+    y32 = torch.empty_like(y)
+    np32 = lib.wmh_conv3d_k3_num_partials(cfg0, N, S, S, S)
+    part32 = torch.empty(N, Cout, np32, 4, device='cuda')
+
+    def f32():
+        _lib.check(lib.wmh_conv3d_k3_fwd(cfg0, P(x0), P(ss0), C0, P(x1), P(ss1), C1, P(wf32d), P(bias), P(y32), P(part32), None, N, S, S, S, Cout, 1, 0.01, None), 'f32')
+    x3(); f32(); torch.cuda.synchronize()
+    msg = '%dx%d^3 %d+%d->%d cfg %d:' % (N, S, C0, C1, Cout, cfg)
+    if check:
+        act = torch.nn.functional.leaky_relu(x0.double() * ss0[..., 0, None, None, None].double() + ss0[..., 1, None, None, None].double(), 0.01)
+        if C1:
+            act = torch.cat([act, torch.nn.functional.leaky_relu(x1.double() * ss1[..., 0, None, None, None].double() + ss1[..., 1, None, None, None].double(), 0.01)], 1)
+        ref = torch.nn.functional.conv3d(act, torch.from_numpy(w).cuda().double().view(Cout, Cin, 3, 3, 3), bias.double(), padding=1)
+        sc = float(ref.abs().max())
+        e3, e32 = float((y.double() - ref).abs().max()) / sc, float((y32.double() - ref).abs().max()) / sc
+        r3, r32 = float((y.double() - ref).norm() / ref.norm()), float((y32.double() - ref).norm() / ref.norm())
+        msg += '  max err / max|ref|: x3 %.3g fp32 %.3g;  rel L2: x3 %.3g fp32 %.3g' % (e3, e32, r3, r32)
+    for name, fn in (('x3', x3), ('fp32', f32)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        msg += '  %s %.3f ms' % (name, e0.elapsed_time(e1) / reps)
+    print(msg, flush=True)
+
+
+run(2, 64, 32, 0, 32)
+run(1, 64, 32, 32, 32)
+run(2, 32, 128, 0, 128)
+run(8, 16, 256, 0, 256)
+run(8, 128, 32, 0, 32, check=False)
+run(8, 128, 32, 32, 32, check=False)
+run(8, 64, 64, 0, 64, check=False)
+run(8, 64, 64, 64, 64, check=False)
+run(8, 32, 128, 0, 128, check=False)
+run(8, 32, 128, 128, 128, check=False)
