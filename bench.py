@@ -378,7 +378,8 @@ def run_rank(args):
         if world == 1 and args.cpu_baseline != 'off':
             P = plan.patch_size
             vol_d.copy_(vols_h[0])
-            eng32 = eng if args.precision == 'fp32' else UNetEngine(plan, sd, device)
+            # the oracle check runs on the engine of the mode when the mode claims fp32-grade results (fp32, bf16x3)
+            eng32 = eng if args.precision in ('fp32', 'bf16x3') else UNetEngine(plan, sd, device)
             x = vol_d[None, :, :P[0], :P[1], :P[2]].contiguous()
             lg = eng32.forward_logits(x).cpu().numpy()
             p_nt = SlidingWindowPredictor(eng32, do_mirroring=False, batch=8)

@@ -160,7 +160,8 @@ def main(argv=None):
                  % os.environ.get('CUDA_VISIBLE_DEVICES'))
     # nnU-Net predicts under fp16 autocast unless --disable_mixed_precision is given; here exact fp32 is the default (the
     # 1e-4 parity bar) and reduced precision is opt-in: WMH_PREDICT_PRECISION=bf16 (bf16 matrix-core operands) and
-    # WMH_PREDICT_STORAGE=bf16 (additionally bf16 full-resolution tensors).  --disable_mixed_precision always means fp32.
+    # WMH_PREDICT_STORAGE=bf16 (additionally channels-last bf16 tensors on the wide levels), or WMH_PREDICT_PRECISION=bf16x3 (fp32
+    # tensors, products from bf16 pairs: inside the same 1e-4 bar at ~1.8x the speed).  --disable_mixed_precision always means fp32.
     precision = os.environ.get('WMH_PREDICT_PRECISION', 'fp32')
     storage = os.environ.get('WMH_PREDICT_STORAGE', 'fp32')
     if args.disable_mixed_precision:

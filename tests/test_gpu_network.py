@@ -207,6 +207,15 @@ def test_configs1_full_volume_no_mirroring_vs_oracle(baseline_pair):
     assert seg.shape == seg_o.shape == (160, 192, 160)
     assert err <= TOL and mism == 0
     assert int((seg != seg_o).sum()) == 0 or dice > 0.99999
+    # the opt-in bf16x3 mode (products from bf16 pairs, tests/test_gpu_bf16x3.py) claims fp32-grade results: same gate, same oracle
+    from deepwmh_amd.network import UNetEngine
+    from oracle.generic_unet import state_dict_numpy
+    eng3 = UNetEngine(plan, state_dict_numpy(net), 'cuda:0', precision='bf16x3')
+    seg3, prob3 = SlidingWindowPredictor(eng3, do_mirroring=False, batch=8).predict(vol)
+    err3 = float(np.abs(prob3 - prob_o).max())
+    mism3, _ = _mask_check(seg3, seg_o, prob_o)
+    print('  bf16x3: max|softmax err| %.3g, argmax mismatches %d, Dice vs oracle mask %.7f' % (err3, mism3, osw.hard_dice_binary(seg_o, seg3)))
+    assert err3 <= TOL and mism3 == 0
 
 
 @pytest.mark.timeout(1500)
