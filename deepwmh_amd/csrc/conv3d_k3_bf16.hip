@@ -468,7 +468,7 @@ extern "C" int wmh_conv3d_k3_fwd_bf16x3(int cfg, const float* x0, const float* s
     a.KS = 1;
     static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
     a.xcd_swizzle = swz_env & 1;
-    a.stamps = nullptr;
+    a.stamps = g_conv_stamps;
     return wmh_launch_conv_bf16x3_ws(cfg, a, (hipStream_t)stream);
 }
 

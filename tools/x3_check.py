@@ -61,6 +61,16 @@ def run(N, S, C0, C1, Cout, check=True, reps=5):
         e1.record(); torch.cuda.synchronize()
         msg += '  %s %.3f ms' % (name, e0.elapsed_time(e1) / reps)
     print(msg, flush=True)
+    if os.environ.get('WMH_STAMPS'):
+        stamps = torch.zeros((1 << 20) * 4, dtype=torch.int64, device='cuda')
+        lib.wmh_debug_set_conv_stamps(C.c_void_p(stamps.data_ptr()))
+        x3(); torch.cuda.synchronize()
+        lib.wmh_debug_set_conv_stamps(None)
+        st = stamps.view(-1, 8).cpu().numpy(); st = st[st[:, 3] > 0]
+        n = st[:, 3].mean()
+        print('   x3 per chunk iteration of 8 channels (ticks): consumer mfma %.0f + barrier wait %.0f, epilogue %.0f per iteration; loader work %.0f + '
+              'barrier wait %.0f; %d workgroups x %.0f iterations' % (st[:, 0].mean() / n, st[:, 1].mean() / n, st[:, 2].mean() / n, st[:, 4].mean() / n,
+                                                                     st[:, 5].mean() / n, len(st), n))
 
 
 run(2, 64, 32, 0, 32)
