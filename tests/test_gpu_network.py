@@ -241,6 +241,15 @@ def test_configs1_full_patch_all_mirrors_vs_oracle(baseline_pair):
     # and the mirrored result differs from the un-mirrored one by far more than the tolerance (the test has teeth)
     _, p0 = SlidingWindowPredictor(eng, do_mirroring=False).predict(vol)
     assert float(np.abs(p0 - ref).max()) > 10 * TOL
+    # the bf16x3 mode against the same oracle output, same gate
+    from deepwmh_amd.network import UNetEngine
+    from oracle.generic_unet import state_dict_numpy
+    eng3 = UNetEngine(plan, state_dict_numpy(net), 'cuda:0', precision='bf16x3')
+    seg3, prob3 = SlidingWindowPredictor(eng3, do_mirroring=True, batch=8).predict(vol)
+    err3 = float(np.abs(prob3 - ref).max())
+    mism3, _ = _mask_check(seg3, seg_o, ref)
+    print('  bf16x3: max|softmax err| %.3g, argmax mismatches %d, Dice %.7f' % (err3, mism3, osw.hard_dice_binary(seg_o, seg3)))
+    assert err3 <= TOL and mism3 == 0
 
 
 def test_full_size_volume_properties():
