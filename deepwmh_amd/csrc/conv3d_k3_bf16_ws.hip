@@ -132,11 +132,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         // vmcnt(0) for the whole prefetch ring while every wave of the workgroup stood at the barrier (~5 k ticks per chunk)
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         u32x4_t wst[WIT];
-        auto issue_w = [&](int q) __attribute__((always_inline)) {                           // chunk q of this workgroup
+        // The chunk being produced: linear index pq of this workgroup's sequence = (tile counter pk, channel chunk pc), and the
+        // cout group pg of that tile.  Kept as counters: `q / nch`, `q % nch` and tile_of() per chunk were ~400 scalar
+        // instructions of the ~1700 a loader wave issues per chunk -- and the loader's instruction count is what bounds it.
+        int pq = 0, pk = 0, pc = 0, pg = 0;
+        auto group_of = [&](int k) __attribute__((always_inline)) {
             int g, tx, ty, tz, n0;
-            tile_of(blockIdx.x + (q / nch) * gridDim.x, g, tx, ty, tz, n0);
-            g = __builtin_amdgcn_readfirstlane(g);
-            const u32x4_t* wsrc = reinterpret_cast<const u32x4_t*>(a.wf) + ((size_t)g * nch + __builtin_amdgcn_readfirstlane(q % nch)) * WQ;
+            tile_of(blockIdx.x + k * gridDim.x, g, tx, ty, tz, n0);
+            return __builtin_amdgcn_readfirstlane(g);
+        };
+        auto issue_w = [&]() __attribute__((always_inline)) {                               // the weights of chunk (pk, pc)
+            const u32x4_t* wsrc = reinterpret_cast<const u32x4_t*>(a.wf) + ((size_t)pg * nch + pc) * WQ;
 #pragma unroll
             for (int i = 0; i < WIT; ++i) wst[i] = wsrc[min(lt + i * LTH, WQ - 1)];
         };
@@ -186,8 +192,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         // pending normalisation the reads go to {1, 0} (index multiplier 0); channels past the end get scale = shift = 0.
         float scv[CKB], shv[CKB], slope_eff = 1.f;
         static __device__ const float ident2[2] = {1.f, 0.f};
-        auto load_ss = [&](int q) __attribute__((always_inline)) {
-            const int ch = __builtin_amdgcn_readfirstlane(q % nch);
+        auto load_ss = [&]() __attribute__((always_inline)) {
+            const int ch = pc;
             const float* xs; const float* ss; int Cs, c0;
             src_of(ch, xs, ss, Cs, c0);
             const bool has_ss = ss != nullptr;
@@ -256,50 +262,63 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 }
             }
         };
-        // chunk q of this workgroup: tile blockIdx.x + (q / nch) * gridDim.x, channel chunk q % nch
-        auto enter = [&](int q) __attribute__((always_inline)) { if (q % nch == 0) setup(blockIdx.x + (q / nch) * gridDim.x); };
+        // (tile, chunk) after (pk, pc) in the sequence; the last chunk is followed by itself
+        auto next_of = [&](int& nk, int& nc) __attribute__((always_inline)) {
+            const bool last = pq + 1 >= total, wrap = pc + 1 == nch;
+            nc = last ? pc : (wrap ? 0 : pc + 1);
+            nk = last ? pk : (wrap ? pk + 1 : pk);
+        };
         // one step: put half-slot (h + RS - 1) of the running sequence in flight, then convert half-slot h of chunk q.
         // Branch-free on purpose (past the last chunk the ring re-reads the last chunk): the weight fragments issued at the
         // top of produce() are waited for between the two barriers, and the compiler's vmcnt for them is the minimum over all
         // paths of the loads issued since -- with a conditional issue that minimum was 0, i.e. the whole ring had to land
         // while every wave of the workgroup stood at the barrier (~5 k ticks per chunk).
-        auto step = [&](auto hc, int q, int buf) __attribute__((always_inline)) {
+        auto step = [&](auto hc, int buf) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value, hn = h + RS - 1;
             if constexpr (hn < NHS) {
-                issue(std::integral_constant<int, hn>{}, q % nch);
+                issue(std::integral_constant<int, hn>{}, pc);
             } else {
-                const int qn = min(q + 1, total - 1);
-                if constexpr (hn == NHS) enter(qn);               // first half-slot of the next chunk: maybe a new tile
-                issue(std::integral_constant<int, hn - NHS>{}, qn % nch);
+                int nk, nc;
+                next_of(nk, nc);
+                if constexpr (hn == NHS) { if (nc == 0) setup(blockIdx.x + nk * gridDim.x); }   // first half-slot of the next chunk: maybe a new tile
+                issue(std::integral_constant<int, hn - NHS>{}, nc);
             }
             convert(hc, buf);
         };
-        auto produce = [&](int q, int buf) __attribute__((always_inline)) {
-            load_ss(q);                                       // before any enter(q + 1): n0_cur is still this chunk's
-            issue_w(q);
-            step(std::integral_constant<int, 0>{}, q, buf); step(std::integral_constant<int, 1>{}, q, buf);
-            if constexpr (NHS > 2) step(std::integral_constant<int, 2>{}, q, buf);
-            if constexpr (NHS > 3) step(std::integral_constant<int, 3>{}, q, buf);
-            if constexpr (NHS > 4) { step(std::integral_constant<int, 4>{}, q, buf); step(std::integral_constant<int, 5>{}, q, buf); }
+        auto produce = [&](int buf) __attribute__((always_inline)) {                          // chunk (pk, pc)
+            load_ss();                                        // before the next tile's setup(): n0_cur is still this chunk's
+            issue_w();
+            step(std::integral_constant<int, 0>{}, buf); step(std::integral_constant<int, 1>{}, buf);
+            if constexpr (NHS > 2) step(std::integral_constant<int, 2>{}, buf);
+            if constexpr (NHS > 3) step(std::integral_constant<int, 3>{}, buf);
+            if constexpr (NHS > 4) { step(std::integral_constant<int, 4>{}, buf); step(std::integral_constant<int, 5>{}, buf); }
+        };
+        auto advance = [&]() __attribute__((always_inline)) {                                  // to the next chunk of the sequence (clamped)
+            int nk, nc;
+            next_of(nk, nc);
+            if (pq + 1 < total) ++pq;
+            if (nk != pk) pg = group_of(nk);
+            pk = nk; pc = nc;
         };
         if (total > 0) {
-            enter(0);
+            pg = group_of(0);
+            setup(blockIdx.x);
             issue(std::integral_constant<int, 0>{}, 0);
             if constexpr (RS > 2) issue(std::integral_constant<int, 1>{}, 0);
             if constexpr (RS > 3) issue(std::integral_constant<int, 2>{}, 0);
             if constexpr (RS > 4) issue(std::integral_constant<int, 3>{}, 0);
             if constexpr (RS > 5) issue(std::integral_constant<int, 4>{}, 0);
-            produce(0, 0);
+            produce(0);
             write_w();
         }
         __syncthreads();
         unsigned long long tw = 0, tb = 0, t0 = 0, twl = 0;  // diagnostics (a.stamps != NULL): work / barrier wait / work next to an epilogue
         for (int it = 0; it < total; ++it) {
-            const int nx = min(it + 1, total - 1);           // the chunk written during this iteration (the last iteration repeats
-                                                             // the last chunk into the buffer nobody reads any more)
+            advance();                                       // the chunk written during this iteration: it + 1 (the last iteration
+                                                             // repeats the last chunk into the buffer nobody reads any more)
             if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
-            produce(nx, (it + 1) & 1);
-            if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; if (it % nch == 0) twl += t - t0; t0 = t; }
+            produce((it + 1) & 1);
+            if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; if (pc == (nch > 1 ? 1 : 0)) twl += t - t0; t0 = t; }
             __syncthreads();                                 // consumers are done with chunk `it`: its weights may go
             write_w();
             __syncthreads();
