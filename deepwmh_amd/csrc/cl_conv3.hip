@@ -3,20 +3,22 @@
 //
 //   D[cout 32][voxel 32] += A[cout 32][16 cin of one tap] * B[16 cin][voxel 32]       (v_mfma_f32_32x32x16_bf16)
 //
-// One persistent 512-thread workgroup per CU, wave-specialised like conv3d_k3_bf16_ws.hip, but with the staging rebuilt
-// around the layout:
-//   waves 4-7  loaders.  A chunk (16 input channels of the tile's halo, 6 x 6 x 34 voxels) comes in by LDS-DMA
+// One persistent 768-thread workgroup per CU, twelve waves in three roles:
+//   waves 4-10 staging.  A chunk (16 input channels of the tile's halo, 6 x 6 x 34 voxels) comes in by LDS-DMA
 //              (global_load_lds_dwordx4: a lane's 16 bytes are 8 channels of one voxel, already the B operand) -- no
 //              staging registers, so three chunks ride in LDS: one being consumed, one being normalised, one landing.
-//              The producer's InstanceNorm + LeakyReLU is applied IN PLACE in LDS (read 16 B, 4 packed FMAs, write 16 B);
-//              voxels outside the volume become zeros there.  The next chunk's weight fragments ride in registers and
-//              are dropped into the single LDS weight buffer between two barriers (as in the NCDHW kernel).
+//              The producer's InstanceNorm + LeakyReLU is applied IN PLACE in LDS (read 16 B, FMAs + max + pack, write
+//              16 B); voxels outside the volume become zeros there.  These waves issue LDS-DMA ONLY (see the weight wave).
+//   wave 11    weights.  The next chunk's 27 KB ride in its registers (ordinary loads ONLY: a counted s_waitcnt vmcnt over a mix
+//              of ordinary loads and LDS-DMA does not say which are still out) and go into the single LDS weight buffer in
+//              three kd-slices, two of them under the consumers' MFMAs (LDS counter), the last between the two barriers.
 //   waves 0-3  consumers: one z-slice of the tile each (TY rows of 32 voxels).  LDS image is planar, [half][voxel] x 16 B
 //              (half = channels 0-7 / 8-15 of the chunk): consecutive lanes read consecutive 16-byte slots, conflict-free
-//              for every tap shift without a swizzle, and a DMA wave-instruction fills 64 consecutive voxels of one half
-//              (its channel half is uniform: scale / shift stay scalar).  An input row is read once per kd and feeds the up
-//              to three output rows that use it (54 + 27 LDS reads for 108 MFMAs per chunk).
-//              Epilogue: 16-byte stores (cl_store_mtile), fp32 InstanceNorm moments from the accumulators.
+//              for every tap shift without a swizzle, and a DMA wave-instruction fills 64 consecutive voxels of one half.
+//              An input row is read once per kd and feeds the up to three output rows that use it (54 + 27 LDS reads for 108
+//              MFMAs per chunk).  Epilogue: 16-byte stores (cl_store_mtile), fp32 InstanceNorm moments kept as running sums
+//              per (workgroup, sample) and flushed once per sample.
+// DESIGN.md 3.3c has the measurements (what bounds it, the ablations, the vmcnt finding).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
