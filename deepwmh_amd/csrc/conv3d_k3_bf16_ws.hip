@@ -136,6 +136,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         // cout group pg of that tile.  Kept as counters: `q / nch`, `q % nch` and tile_of() per chunk were ~400 scalar
         // instructions of the ~1700 a loader wave issues per chunk -- and the loader's instruction count is what bounds it.
         int pq = 0, pk = 0, pc = 0, pg = 0;
+        unsigned long long t_issue = 0, t_conv = 0;      // diagnostics (a.stamps): loads issued / conversion + LDS writes
         auto group_of = [&](int k) __attribute__((always_inline)) {
             int g, tx, ty, tz, n0;
             tile_of(blockIdx.x + k * gridDim.x, g, tx, ty, tz, n0);
@@ -275,6 +276,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         // while every wave of the workgroup stood at the barrier (~5 k ticks per chunk).
         auto step = [&](auto hc, int buf) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value, hn = h + RS - 1;
+            unsigned long long ts0 = 0;
+            if (a.stamps) ts0 = __builtin_amdgcn_s_memtime();
             if constexpr (hn < NHS) {
                 issue(std::integral_constant<int, hn>{}, pc);
             } else {
@@ -283,7 +286,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 if constexpr (hn == NHS) { if (nc == 0) setup(blockIdx.x + nk * gridDim.x); }   // first half-slot of the next chunk: maybe a new tile
                 issue(std::integral_constant<int, hn - NHS>{}, nc);
             }
+            if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_issue += t - ts0; ts0 = t; }
             convert(hc, buf);
+            if (a.stamps) t_conv += __builtin_amdgcn_s_memtime() - ts0;
         };
         auto produce = [&](int buf) __attribute__((always_inline)) {                          // chunk (pk, pc)
             load_ss();                                        // before the next tile's setup(): n0_cur is still this chunk's
@@ -326,7 +331,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         }
         if (a.stamps && tid == 256) {
             unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
-            o[4] = tw; o[5] = tb; o[6] = twl;               // twl: iterations whose consumers start with the previous tile's epilogue
+            o[4] = tw; o[5] = tb; o[6] = twl;
+            unsigned long long* o2 = a.stamps + (size_t)(gridDim.x + blockIdx.x) * 8;     // second record block
+            o2[0] = t_issue; o2[1] = t_conv;               // twl: iterations whose consumers start with the previous tile's epilogue
         }
     } else {
         // ================================ consumer waves ===================================================

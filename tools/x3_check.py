@@ -66,8 +66,11 @@ def run(N, S, C0, C1, Cout, check=True, reps=5):
         lib.wmh_debug_set_conv_stamps(C.c_void_p(stamps.data_ptr()))
         x3(); torch.cuda.synchronize()
         lib.wmh_debug_set_conv_stamps(None)
-        st = stamps.view(-1, 8).cpu().numpy(); st = st[st[:, 3] > 0]
+        raw = stamps.view(-1, 8).cpu().numpy()
+        st = raw[raw[:, 3] > 0]
         n = st[:, 3].mean()
+        nb = len(st)
+        print('   loader: issue of loads %.0f, conversion + LDS writes %.0f ticks per iteration' % (raw[nb:2 * nb, 0].mean() / n, raw[nb:2 * nb, 1].mean() / n))
         print('   x3 per chunk iteration of 8 channels (ticks): consumer mfma %.0f + barrier wait %.0f, epilogue %.0f per iteration; loader work %.0f + '
               'barrier wait %.0f; %d workgroups x %.0f iterations' % (st[:, 0].mean() / n, st[:, 1].mean() / n, st[:, 2].mean() / n, st[:, 4].mean() / n,
                                                                      st[:, 5].mean() / n, len(st), n))
