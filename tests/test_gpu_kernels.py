@@ -478,6 +478,24 @@ def test_conv3d_k3_bf16_small_rows_and_strided(lib, case):
     assert float((yh - ref).abs().max()) <= 5e-4 * scale + 1e-5
     mean = yh.mean((2, 3, 4)).double()
     assert float((mr.cpu().double()[..., 0] - mean).abs().max()) <= 1e-5 * (1 + float(mean.abs().max()))
+    # the split-K form of these configurations (wmh_conv3d_k3_fwd_bf16_splitk): the channel reduction in slabs, summed in fixed order with the
+    # bias, moments as one record per (n, c) -- same result up to the summation order, same statistics, deterministic
+    nws = lib.wmh_conv3d_k3_bf16_workspace_floats(cfg, Cin, N, D, H, W, Cout)
+    ws = torch.empty(max(nws, 1), device='cuda')
+    outs = []
+    for _ in range(2):
+        y2 = torch.full_like(y, float('nan')); part2 = torch.full_like(part, float('nan'))
+        mr2 = torch.empty_like(mr); ss2 = torch.empty_like(ss_out)
+        _lib.check(lib.wmh_conv3d_k3_fwd_bf16_splitk(cfg, P(x0), P(s0), C0, P(x1), P(s1), C1, P(wfd), P(bd), P(y2), P(part2), P(ws) if nws else None,
+                                                     N, D, H, W, Cout, SLOPE, None), 'conv bf16 split-K')
+        _lib.check(lib.wmh_instnorm_finalize(P(part2), npart, None, None, 1e-5, P(ss2), P(mr2), N, Cout, None), 'fin')
+        torch.cuda.synchronize()
+        outs.append((y2.cpu(), ss2.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][0] - yh).abs().max()) <= 2e-5 * scale + 1e-6
+    assert float((outs[0][1] - ss_out.cpu()).abs().max()) <= 1e-4 * (1 + float(ss_out.abs().max()))
+    if nws:
+        assert Cin >= 32          # the cases that split are the ones with enough channel chunks
 
 
 def test_bf16_wave_specialised_form_is_bit_identical(tmp_path):
