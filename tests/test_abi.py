@@ -90,3 +90,30 @@ def test_engine_refuses_cpu(tiny_net):
     plan, _, sd = tiny_net
     with pytest.raises(RuntimeError):
         UNetEngine(plan, sd, device='cpu')
+
+
+def test_bf16x3_weight_image_is_a_two_term_split():
+    """Host-side packing of the bf16x3 mode (no GPU needed): every fragment holds the high bf16 parts of an output channel's 8 weights
+    on lanes 0-31 and the low parts on lanes 32-63, and hi + lo reproduces the weight to 16 mantissa bits."""
+    import ctypes as C
+    import numpy as np
+    from deepwmh_amd import _lib
+    lib = _lib.load()
+    Cin, Cout, cfg = 20, 40, 0                       # ragged: 3 chunks of 8 channels, 2 groups of 32 output channels
+    assert lib.wmh_conv3d_k3_bf16x3_supported(cfg) and not lib.wmh_conv3d_k3_bf16x3_supported(8)
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((Cout, Cin, 27)) * np.exp(rng.uniform(-6, 6, (Cout, Cin, 27)))).astype(np.float32)
+    n = lib.wmh_conv3d_k3_packed_halfs_bf16x3(cfg, Cin, Cout)
+    assert n == 2 * 3 * 27 * 1 * 64 * 8
+    wf = np.zeros(n, np.uint16)
+    _lib.check(lib.wmh_conv3d_k3_pack_weights_bf16x3(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
+    img = (wf.astype(np.uint32) << 16).view(np.float32).reshape(2, 3, 27, 1, 64, 8)       # [g][chunk][tap][nt][lane][e]
+    hi, lo = img[:, :, :, 0, :32, :], img[:, :, :, 0, 32:, :]
+    full = np.zeros((2 * 32, 3 * 8, 27), np.float32)
+    full[:Cout, :Cin] = w
+    ref = full.reshape(2, 32, 3, 8, 27).transpose(0, 2, 4, 1, 3)                        # [g][chunk][tap][cout lane][e]
+    rec = hi.astype(np.float64) + lo.astype(np.float64)
+    err = np.abs(rec - ref) / np.maximum(np.abs(ref), 1e-30)
+    assert float(err[ref != 0].max()) <= 2.0 ** -16                                      # two bf16 terms: <= 2^-17 typical, 2^-16 worst
+    assert np.all(rec[ref == 0] == 0)                                                    # padding channels / rows are zero
+    assert np.array_equal(hi, (hi.view(np.uint32) & 0xFFFF0000).view(np.float32))        # both parts are bf16 values
