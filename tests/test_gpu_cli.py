@@ -92,3 +92,36 @@ def test_nnunet_predict_fans_out_over_MI355WMH_GPUS(tmp_path, tiny_net, tiny_io)
     bad = subprocess.run(shlex.split(cmd.replace('model_best', 'model_ep_0046')), env=dict(base, MI355WMH_GPUS='0,0'),
                          capture_output=True, text=True)
     assert bad.returncode != 0
+
+
+def test_nnunet_predict_precision_switches(tmp_path, tiny_net, tiny_io):
+    """WMH_PREDICT_PRECISION through the executable: bf16x3 (fp32-grade: the label map of the fp32 run up to voxels on the decision
+    boundary, probabilities within 1e-4) and --disable_mixed_precision forcing fp32 whatever the environment says."""
+    from deepwmh_amd import checkpoint as ck
+    from deepwmh_amd import nifti
+    plan, net, sd = tiny_net
+    model_dir = str(tmp_path / 'model')
+    plans = ck.make_plans(plan, spacing=(1.0, 1.0, 1.0), use_mask_for_norm=True)
+    ck.save_checkpoint(ck.trainer_folder(model_dir, 'Task002_FinalModel'), sd, plans, 'all', 'model_best', epoch=100)
+    img_dir = str(tmp_path / 'in')
+    os.makedirs(img_dir)
+    nifti.write(os.path.join(img_dir, 'c0_0000.nii.gz'), (tiny_io['volume'][0] * 40 + 200).astype(np.float32), spacing=(1.0, 1.0, 1.0))
+    base = dict(os.environ, RESULTS_FOLDER=model_dir, CUDA_VISIBLE_DEVICES='0', PATH=os.path.join(ROOT, 'bin') + os.pathsep + os.environ['PATH'])
+    base.pop('MI355WMH_GPUS', None)
+    res = {}
+    for key, env_extra, flag in (('fp32', {}, ''), ('x3', dict(WMH_PREDICT_PRECISION='bf16x3'), ''),
+                                 ('forced', dict(WMH_PREDICT_PRECISION='bf16', WMH_PREDICT_STORAGE='bf16_ncdhw'), ' --disable_mixed_precision')):
+        out_dir = str(tmp_path / key)
+        cmd = ('nnUNet_predict -i %s -o %s -tr nnUNetTrainerV2 -m 3d_fullres -p nnUNetPlansv2.1 -t Task002_FinalModel -f all -chk model_best '
+               '--save_softmax --disable_post_processing%s' % (img_dir, out_dir, flag))
+        p = subprocess.run(shlex.split(cmd), env=dict(base, **env_extra), capture_output=True, text=True)
+        print(p.stdout[-800:], p.stderr[-800:])
+        assert p.returncode == 0
+        res[key] = (nifti.read(os.path.join(out_dir, 'c0.nii.gz'))[0], nifti.read(os.path.join(out_dir, 'c0_0.nii.gz'))[0])
+    assert np.array_equal(res['fp32'][0], res['forced'][0]) and np.array_equal(res['fp32'][1], res['forced'][1])
+    d = float(np.abs(res['fp32'][1] - res['x3'][1]).max())
+    diff = res['fp32'][0] != res['x3'][0]
+    assert d <= 1e-4 and (not diff.any() or float(np.abs(res['fp32'][1] - 0.5)[diff].max()) <= 2e-4)
+    bad = subprocess.run(shlex.split(cmd.replace(' --disable_mixed_precision', '')), env=dict(base, WMH_PREDICT_PRECISION='fp8'),
+                         capture_output=True, text=True)
+    assert bad.returncode != 0                                        # unknown precision: fails loudly
