@@ -31,7 +31,8 @@ SIGNATURES = {
     'wmh_conv3d_k3_packed_halfs_bf16x3': (_sz, [_i, _i, _i]),
     'wmh_conv3d_k3_pack_weights_bf16x3': (_i, [_i, _vp, _i, _i, _vp]),
     'wmh_conv3d_k3_pack_weights_bf16x3_device': (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    'wmh_conv3d_k3_fwd_bf16x3': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_conv3d_k3_bf16x3_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_fwd_bf16x3': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_bf16_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_fwd_bf16_splitk': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_fwd_bf16': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),

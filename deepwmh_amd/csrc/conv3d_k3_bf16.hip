@@ -29,9 +29,11 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {     // v_c
     return __builtin_bit_cast(unsigned, b);
 }
 
-template <class C, int RIT>
+// X3: the bf16x3 form (conv3d_k3_bf16_ws.hip): chunks of 8 channels staged as [hi | lo] bf16 pairs, every tap issued with the
+// high and with the low parts of the weights (a fragment's lanes 0-31 / 32-63)
+template <class C, int RIT, bool X3 = false>
 __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d_k3_bf16_kernel(const ConvArgs a) {
-    constexpr int S = C::S, MT = C::MT, NT = C::NT, NIT = C::NIT, THREADS = C::THREADS, APF = 4, CKB = 16;
+    constexpr int S = C::S, MT = C::MT, NT = C::NT, NIT = C::NIT, THREADS = C::THREADS, APF = 4, CKB = X3 ? 8 : 16, NA = X3 ? 2 : 1;
     static_assert(C::TN == 1, "one sample per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];      // [CS voxels][2]
 
@@ -94,13 +96,16 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
             for (int m = 0; m < MT; ++m) acc[nt][m][r] = bv;
         }
 
-    const bf16x8* wl = reinterpret_cast<const bf16x8*>(a.wf) + (size_t)g * a.nchunks * 27 * NT * 64 + lane;
+    const bf16x8* wl = reinterpret_cast<const bf16x8*>(a.wf) + (size_t)g * a.nchunks * 27 * NT * 64 + (X3 ? j : lane);
     const int Tlast = ch_hi * 27 - 1;
-    bf16x8 aring[APF][NT];
-    auto loadA = [&](int T, bf16x8 (&dst)[NT]) {
+    bf16x8 aring[APF][NT * NA];                                   // X3: [nt] = high parts, [NT + nt] = low parts, both lane halves alike
+    auto loadA = [&](int T, bf16x8 (&dst)[NT * NA]) {
         T = min(T, Tlast);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) dst[nt] = wl[((size_t)T * NT + nt) * 64];
+        for (int nt = 0; nt < NT; ++nt) {
+            dst[nt] = wl[((size_t)T * NT + nt) * 64];
+            if constexpr (X3) dst[NT + nt] = wl[((size_t)T * NT + nt) * 64 + 32];
+        }
     };
 #pragma unroll
     for (int d = 0; d < APF; ++d) loadA(ch_lo * 27 + d, aring[d]);
@@ -150,7 +155,10 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
                     float t1 = fmaf(v[ii][c + 1], scv[c + 1], shv[c + 1]);
                     t0 = fmaxf(t0, t0 * slope_eff);
                     t1 = fmaxf(t1, t1 * slope_eff);
-                    w[c >> 1] = pack_bf16x2(t0, t1) & keep;
+                    const unsigned u = pack_bf16x2(t0, t1);
+                    w[c >> 1] = u & keep;
+                    if constexpr (X3)                      // words 4-7: what is left after the high parts, rounded to bf16 again
+                        w[4 + (c >> 1)] = pack_bf16x2(t0 - __uint_as_float(u << 16), t1 - __uint_as_float(u & 0xFFFF0000u)) & keep;
                 }
                 const int e = tid + it * THREADS;
                 const int key = (keymask >> it) & 1u;
@@ -166,22 +174,24 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
         for (int tap = 0; tap < 27; ++tap) {
             const int kw = tap % 3;
             const int rowoff = ((tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS) * 32;
-            bf16x8 anew[NT];
+            bf16x8 anew[NT * NA];
             loadA(ch * 27 + tap + APF, anew);
             __builtin_amdgcn_sched_barrier(0x38F);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const bf16x8 bv = *reinterpret_cast<const bf16x8*>(ldsb + badr[kw][m] + rowoff);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt) {
                     acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[0][nt], bv, acc[nt][m], 0, 0, 0);
+                    if constexpr (X3) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[0][NT + nt], bv, acc[nt][m], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int d = 0; d + 1 < APF; ++d)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) aring[d][nt] = aring[d + 1][nt];
+                for (int nt = 0; nt < NT * NA; ++nt) aring[d][nt] = aring[d + 1][nt];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) aring[APF - 1][nt] = anew[nt];
+            for (int nt = 0; nt < NT * NA; ++nt) aring[APF - 1][nt] = anew[nt];
         }
         if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mfma += t - t_mark; }
     }
@@ -277,7 +287,7 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16(int cfg, const float* w, int Cin,
 
 // ---- bf16x3 (conv3d_k3_bf16_ws.hip, X3): chunks of 8 input channels, a lane's 16 bytes are the HIGH bf16 parts of its output
 // channel's 8 weights (lanes 0-31) or the LOW parts (lanes 32-63): w = hi + lo + O(2^-17 w)
-extern "C" int wmh_conv3d_k3_bf16x3_supported(int cfg) { return cfg == 0 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE; }
+extern "C" int wmh_conv3d_k3_bf16x3_supported(int cfg) { return cfg == 0 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE || cfg == 3 || cfg == 4 || cfg == 5; }
 extern "C" size_t wmh_conv3d_k3_packed_halfs_bf16x3(int cfg, int Cin, int Cout) {
     const int NT = bf16_nt(cfg);
     if (!NT || !wmh_conv3d_k3_bf16x3_supported(cfg)) return 0;
@@ -373,12 +383,12 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16x3_device(int cfg, const float* w,
     return wmh_check_launch("pack_bf16x3_kernel");
 }
 
-template <class C, int RIT>
+template <class C, int RIT, bool X3 = false>
 static int launch_bf16(const ConvArgs& a, unsigned nblk, hipStream_t st) {
     const int lds = C::CS * 32;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_kernel<C, RIT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_kernel<C, RIT, X3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((conv3d_k3_bf16_kernel<C, RIT>), dim3(nblk), dim3(C::THREADS), lds, st, a);
+    hipLaunchKernelGGL((conv3d_k3_bf16_kernel<C, RIT, X3>), dim3(nblk), dim3(C::THREADS), lds, st, a);
     return wmh_check_launch("conv3d_k3_bf16_kernel");
 }
 
@@ -478,22 +488,30 @@ int wmh_launch_conv_bf16x3_ws(int cfg, const ConvArgs& a, hipStream_t st);
 // y = conv3x3x3 with both operands split into two bf16 numbers each and all four partial products accumulated in fp32
 // (16 mantissa bits per operand): fp32 tensors in and out, stride 1, wf from wmh_conv3d_k3_pack_weights_bf16x3.  Same
 // geometry, moments records (wmh_conv3d_k3_num_partials_bf16) and epilogue as wmh_conv3d_k3_fwd_bf16.
+extern "C" size_t wmh_conv3d_k3_bf16x3_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout) {
+    if (!(cfg == 3 || cfg == 4 || cfg == 5)) return 0;
+    const int S = bf16_stride(cfg);
+    const int ks = bf16_ksplit(bf16_small_blocks(cfg, N, D, H, W, Cout), cdiv(Cin, 8));
+    return ks > 1 ? (size_t)ks * N * Cout * ((D - 1) / S + 1) * ((H - 1) / S + 1) * ((W - 1) / S + 1) : 0;
+}
 extern "C" int wmh_conv3d_k3_fwd_bf16x3(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
-                                        const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D, int H, int W,
-                                        int Cout, float lrelu_slope, void* stream) {
+                                        const uint16_t* wf, const float* bias, float* y, float* partials, float* workspace,
+                                        int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream) {
     const int NT = bf16_nt(cfg);
     if (!NT || !wmh_conv3d_k3_bf16x3_supported(cfg)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: configuration has no bf16x3 kernel");
     if (!x0 || !wf || !y || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: null/empty argument");
     if (x1 == nullptr) C1 = 0;
     if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: LeakyReLU slope must be in [0, 1]");
     if (C1 > 0 && (C0 % 8) != 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: C0 must be a multiple of 8 with two sources");
-    if ((W % 4) != 0 || (size_t)16 * D * H * W * 4 >= ((size_t)1 << 32) || (reinterpret_cast<uintptr_t>(x0) & 15) != 0 ||
-        (x1 && (reinterpret_cast<uintptr_t>(x1) & 15) != 0))
+    const bool small = cfg == 3 || cfg == 4 || cfg == 5;
+    if (!small && ((W % 4) != 0 || (size_t)16 * D * H * W * 4 >= ((size_t)1 << 32) || (reinterpret_cast<uintptr_t>(x0) & 15) != 0 ||
+                   (x1 && (reinterpret_cast<uintptr_t>(x1) & 15) != 0)))
         return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: needs W % 4 == 0 and 16-byte aligned sources");
     ConvArgs a;
     a.x0 = x0; a.ss0 = ss0; a.C0 = C0; a.x1 = x1; a.ss1 = ss1; a.C1 = C1;
     a.wf = reinterpret_cast<const float*>(wf); a.bias = bias; a.y = y; a.part = partials;
-    a.N = N; a.D = D; a.H = H; a.W = W; a.Do = D; a.Ho = H; a.Wo = W; a.Cout = Cout;
+    const int S = bf16_stride(cfg);                 // configurations 3 and 5: stride 2, (D, H, W) is the INPUT extent
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Do = (D - 1) / S + 1; a.Ho = (H - 1) / S + 1; a.Wo = (W - 1) / S + 1; a.Cout = Cout;
     a.nchunks = (C1 > 0) ? (C0 / 8 + cdiv(C1, 8)) : cdiv(C0, 8);
     const BGeo ge = bf16_geo(cfg, false);
     a.ntx = cdiv(a.Wo, ge.TX); a.nty = cdiv(a.Ho, ge.TY); a.ntz = cdiv(a.Do, ge.TZ);
@@ -504,7 +522,20 @@ extern "C" int wmh_conv3d_k3_fwd_bf16x3(int cfg, const float* x0, const float* s
     static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
     a.xcd_swizzle = swz_env & 1;
     a.stamps = g_conv_stamps;
-    return wmh_launch_conv_bf16x3_ws(cfg, a, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (!small) return wmh_launch_conv_bf16x3_ws(cfg, a, st);
+    // rows of 16 / 8 voxels (stride 1 and 2): the one-role kernel, split-K when slab memory is given (wmh_conv3d_k3_fwd_bf16_splitk)
+    const long long nblk = (long long)a.ntx * a.nty * a.ntz * N * a.G;
+    if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: grid too large");
+    a.KS = workspace != nullptr ? bf16_ksplit(nblk, a.nchunks) : 1;
+    if (a.KS > 1) a.y = workspace;
+    const unsigned nb = (unsigned)(nblk * a.KS);
+    int rc;
+    if (cfg == 3) rc = launch_bf16<BCfg3, 4, true>(a, nb, st);
+    else if (cfg == 4) rc = launch_bf16<BCfg4, 3, true>(a, nb, st);
+    else rc = launch_bf16<BCfg5, 4, true>(a, nb, st);
+    if (rc != WMH_OK || a.KS == 1) return rc;
+    return wmh_launch_splitk_reduce(workspace, bias, y, partials, a.npart, a.KS, N, Cout, (size_t)a.Do * a.Ho * a.Wo, st);
 }
 
 extern "C" int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1,

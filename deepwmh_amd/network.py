@@ -179,11 +179,12 @@ class UNetEngine:
         plain = not (in16 or out16)
         use_bf16 = (self.precision == 'bf16' and layer.kz == 3 and layer.sz == s and (C1 == 0 or C0 % 16 == 0)
                     and bool(self.lib.wmh_conv3d_k3_bf16_supported(cfg)) and (plain or (cfg == 0 and s == 1)))
-        # 'bf16x3': the stride-1 3x3x3 convolutions with rows of >= 16 voxels (97 % of the FLOPs) form their products from bf16
+        # 'bf16x3': the 3x3x3 convolutions that have a bf16 kernel (stride 1: rows of >= 8 voxels; stride 2: output rows of 8 or 16) form their products from bf16
         # pairs (x = hi + lo, 16 mantissa bits per operand, all four partial products, fp32 accumulation): fp32-grade results at
         # 2-2.7x the fp32 instruction's speed.  Everything else is the exact-fp32 path.
-        use_x3 = (self.precision == 'bf16x3' and layer.kz == 3 and layer.sz == s == 1 and (C1 == 0 or C0 % 8 == 0) and W % 4 == 0
-                  and bool(self.lib.wmh_conv3d_k3_bf16x3_supported(self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W))))
+        cfg_x = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
+        use_x3 = (self.precision == 'bf16x3' and layer.kz == 3 and layer.sz == s and (C1 == 0 or C0 % 8 == 0)
+                  and bool(self.lib.wmh_conv3d_k3_bf16x3_supported(cfg_x)) and (cfg_x in (3, 4, 5) or W % 4 == 0))
         if use_x3:
             cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
         if use_bf16 and not (in16 or out16):       # wide tile for >= 64 output channels (bf16 kernel only)
@@ -196,7 +197,7 @@ class UNetEngine:
         part = self._buf(key + '.part', (N, layer.cout, npart, 4))
         ss = self._buf(key + '.ss', (N, layer.cout, 2))
         if use_x3:
-            nws = 0
+            nws = self.lib.wmh_conv3d_k3_bf16x3_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout)
         elif use_bf16:
             nws = self.lib.wmh_conv3d_k3_bf16_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout)
         else:
@@ -211,7 +212,7 @@ class UNetEngine:
         if use_x3:
             _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16x3(
                 cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
-                _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part),
+                _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws),
                 N, D, H, W, layer.cout, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd_bf16x3')
         elif (in16 or out16) and use_bf16:
             _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16_st(

@@ -153,7 +153,7 @@ class UNetTrainer:
                 and (C1 == 0 or C0 % 16 == 0))
 
     def _use_x3(self, cfg_b, stride, C0, C1, W):
-        return (self.x3 and stride == 1 and (C1 == 0 or C0 % 8 == 0) and W % 4 == 0 and bool(self.lib.wmh_conv3d_k3_bf16x3_supported(cfg_b)))
+        return (self.x3 and stride == 1 and (C1 == 0 or C0 % 8 == 0) and (W % 4 == 0 or cfg_b == 4) and bool(self.lib.wmh_conv3d_k3_bf16x3_supported(cfg_b)))
 
     def _pack_x3(self, conv, cfg, mode, ci_off, ci_cnt):
         key = (conv.name, cfg, mode, ci_off, ci_cnt, 'x3')
@@ -177,8 +177,11 @@ class UNetTrainer:
         if want_stats:
             npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, D, H, W), 'num_partials_bf16')
             part = self._buf(key + '.part', (N, cout, npart, 4))
+        nws = self.lib.wmh_conv3d_k3_bf16x3_workspace_floats(cfg, C0 + C1, N, D, H, W, cout)
+        ws = self._buf('splitk.ws', (nws,)) if nws else None
         _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16x3(cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wf),
-                                                     _lib.ptr(bias), _lib.ptr(y), _lib.ptr(part), N, D, H, W, cout, LRELU_SLOPE, self._st()),
+                                                     _lib.ptr(bias), _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws), N, D, H, W, cout, LRELU_SLOPE,
+                                                     self._st()),
                    'wmh_conv3d_k3_fwd_bf16x3')
         return y, part, npart
 

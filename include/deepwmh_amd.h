@@ -105,7 +105,7 @@ int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, c
 /* "bf16x3": fp32-grade products on the bf16 matrix instruction.  Every operand is split into two bf16
  * numbers (x = x_hi + x_lo, 16 mantissa bits together) and all four partial products are accumulated in fp32: 4 bf16 MFMAs
  * per 16 input channels and tap instead of 1, still a quarter of the fp32 instruction's cycles.  fp32 NCDHW tensors in and
- * out, stride 1, configurations 0 / 2 / 21 (rows of >= 16 voxels); geometry, epilogue and moments records of
+ * out, configurations 0 / 2 / 21 (stride 1, rows of >= 16 voxels) and 3 / 4 / 5; geometry, epilogue and moments records of
  * wmh_conv3d_k3_fwd_bf16 (wmh_conv3d_k3_num_partials_bf16).  wf: wmh_conv3d_k3_pack_weights_bf16x3 ([G][cin/8][27][NT][64][8]
  * bf16: lanes 0-31 the high parts, lanes 32-63 the low parts of an output channel's 8 weights). */
 int wmh_conv3d_k3_bf16x3_supported(int cfg);
@@ -114,9 +114,12 @@ int wmh_conv3d_k3_pack_weights_bf16x3(int cfg, const float* w, int Cin, int Cout
 /* the same image from weights in HBM (training); modes as wmh_conv3d_k3_pack_weights_bf16_device */
 int wmh_conv3d_k3_pack_weights_bf16x3_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
                                              uint16_t* wf, void* stream);
+/* Configurations 3 / 4 / 5 (rows of 16 / 8 voxels, stride 2 / 1 / 2; D, H, W = the INPUT extent) run the one-role kernel and
+ * take split-K slab memory like wmh_conv3d_k3_fwd_bf16_splitk (workspace >= wmh_conv3d_k3_bf16x3_workspace_floats floats, or NULL). */
+size_t wmh_conv3d_k3_bf16x3_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout);
 int wmh_conv3d_k3_fwd_bf16x3(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
-                             const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D, int H, int W,
-                             int Cout, float lrelu_slope, void* stream);
+                             const uint16_t* wf, const float* bias, float* y, float* partials, float* workspace,
+                             int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
 /* The same with split-K for the small-row configurations (rows of 16 / 8 voxels: the 16^3 / 8^3 levels): the channel reduction
  * is cut into slabs in `workspace` (>= wmh_conv3d_k3_bf16_workspace_floats floats; 0 = this launch does not split) and summed in
  * fixed order with the bias; the moments then come as one record per (n, c).  workspace NULL = wmh_conv3d_k3_fwd_bf16. */

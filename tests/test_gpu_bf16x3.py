@@ -16,8 +16,13 @@ def lib():
     return _lib.load()
 
 
-CASES = [  # N, D, H, W, C0, C1, Cout, pending norm on source 0 / 1
+CASES = [  # N, D, H, W, C0, C1, Cout, pending norm on source 0 / 1 [, stride]
     (2, 8, 8, 32, 32, 0, 32, True, False),
+    (2, 8, 8, 8, 48, 16, 64, True, True, 1),      # rows of 8 voxels (configuration 4, one-role kernel, split-K slabs)
+    (1, 5, 9, 7, 24, 0, 40, True, False, 1),      # ... ragged
+    (2, 16, 16, 16, 32, 0, 64, True, False, 2),   # stride 2, output rows of 8 (configuration 5)
+    (2, 8, 32, 32, 32, 0, 128, True, False, 2),   # stride 2, output rows of 16 (configuration 3)
+    (1, 7, 20, 27, 16, 0, 64, False, False, 2),   # ... odd extents
     (1, 5, 9, 36, 12, 0, 40, True, False),        # channel counts that are not multiples of the chunk / the tile; ragged tiles
     (1, 6, 10, 32, 16, 24, 32, False, True),      # two sources (the decoder's concatenation), the second one normalised
     (2, 4, 12, 64, 64, 64, 64, True, True),       # the 64-channel tile (configuration 21)
@@ -25,10 +30,12 @@ CASES = [  # N, D, H, W, C0, C1, Cout, pending norm on source 0 / 1
 ]
 
 
-@pytest.mark.parametrize('N,D,H,W,C0,C1,Cout,has0,has1', CASES)
-def test_conv_bf16x3_against_float64(lib, N, D, H, W, C0, C1, Cout, has0, has1):
+@pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
+def test_conv_bf16x3_against_float64(lib, case):
     from deepwmh_amd import _lib
     P = _lib.ptr
+    N, D, H, W, C0, C1, Cout, has0, has1 = case[:9]
+    stride = case[9] if len(case) > 9 else 1
     g = torch.Generator().manual_seed(N * 1000 + W + C0)
     Cin = C0 + C1
     x0 = torch.randn(N, C0, D, H, W, generator=g)
@@ -42,20 +49,23 @@ def test_conv_bf16x3_against_float64(lib, N, D, H, W, C0, C1, Cout, has0, has1):
         x = x.double()
         return x if ss is None else torch.nn.functional.leaky_relu(x * ss[..., 0, None, None, None].double() + ss[..., 1, None, None, None].double(), 0.01)
     xin = act(x0, ss0) if x1 is None else torch.cat([act(x0, ss0), act(x1, ss1)], 1)
-    ref = torch.nn.functional.conv3d(xin, w.double(), bias.double(), padding=1)
-    cfg0 = _lib.check(lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, 1), 'config')
+    ref = torch.nn.functional.conv3d(xin, w.double(), bias.double(), padding=1, stride=stride)
+    Do, Ho, Wo = ref.shape[2:]
+    cfg0 = _lib.check(lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, stride), 'config')
     cfg = lib.wmh_conv3d_k3_bf16_config(cfg0, Cout, W)
     assert lib.wmh_conv3d_k3_bf16x3_supported(cfg)
     wh = np.ascontiguousarray(w.numpy().reshape(Cout, Cin, 27))
     wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_bf16x3(cfg, Cin, Cout), np.uint16)
     _lib.check(lib.wmh_conv3d_k3_pack_weights_bf16x3(cfg, wh.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
     wfd = torch.from_numpy(wf.view(np.int16)).cuda()
-    y = torch.full((N, Cout, D, H, W), float('nan'), device='cuda')
-    npart = _lib.check(lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, D, H, W), 'npart')
+    y = torch.full((N, Cout, Do, Ho, Wo), float('nan'), device='cuda')
+    npart = _lib.check(lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, Do, Ho, Wo), 'npart')
+    nws = lib.wmh_conv3d_k3_bf16x3_workspace_floats(cfg, Cin, N, D, H, W, Cout)
+    ws = torch.empty(nws, device='cuda') if nws else None
     part = torch.full((N, Cout, npart, 4), float('nan'), device='cuda')
     x0d, x1d = x0.cuda(), (x1.cuda() if C1 else None)
     ss0d, ss1d, bd = (ss0.cuda() if ss0 is not None else None), (ss1.cuda() if ss1 is not None else None), bias.cuda()
-    _lib.check(lib.wmh_conv3d_k3_fwd_bf16x3(cfg, P(x0d), P(ss0d), C0, P(x1d), P(ss1d), C1, P(wfd), P(bd), P(y), P(part), N, D, H, W, Cout,
+    _lib.check(lib.wmh_conv3d_k3_fwd_bf16x3(cfg, P(x0d), P(ss0d), C0, P(x1d), P(ss1d), C1, P(wfd), P(bd), P(y), P(part), P(ws), N, D, H, W, Cout,
                                             0.01, None), 'wmh_conv3d_k3_fwd_bf16x3')
     torch.cuda.synchronize()
     got = y.cpu().double()

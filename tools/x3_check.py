@@ -31,7 +31,7 @@ def run(N, S, C0, C1, Cout, check=True, reps=5):
     part = torch.empty(N, Cout, npart, 4, device='cuda')
 
     def x3():
-        _lib.check(lib.wmh_conv3d_k3_fwd_bf16x3(cfg, P(x0), P(ss0), C0, P(x1), P(ss1), C1, P(wfd), P(bias), P(y), P(part), N, S, S, S, Cout, 0.01, None), 'x3')
+        _lib.check(lib.wmh_conv3d_k3_fwd_bf16x3(cfg, P(x0), P(ss0), C0, P(x1), P(ss1), C1, P(wfd), P(bias), P(y), P(part), None, N, S, S, S, Cout, 0.01, None), 'x3')
     # the exact-fp32 kernel
     wf32 = np.empty(lib.wmh_conv3d_k3_packed_floats(cfg0, Cin, Cout), np.float32)
     lib.wmh_conv3d_k3_pack_weights(cfg0, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf32.ctypes.data_as(C.c_void_p))
