@@ -21,17 +21,27 @@ def build_library(force=False, verbose=True):
     objdir = os.path.join(LIBDIR, 'obj')
     os.makedirs(objdir, exist_ok=True)
     deps = [os.path.join(CSRC, 'wmh_common.h'), os.path.join(CSRC, 'conv3d_common.h'), os.path.join(CSRC, 'cl_common.h'), os.path.join(HERE, '..', 'include', 'deepwmh_amd.h')]
-    objs, relink = [], force or not os.path.exists(LIB)
+    objs, relink, jobs = [], force or not os.path.exists(LIB), []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         if force or _newer(s, o) or any(_newer(d, o) for d in deps):
-            cmd = [HIPCC] + FLAGS + ['-c', s, '-o', o]
-            if verbose:
-                print(' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append([HIPCC] + FLAGS + ['-c', s, '-o', o])
             relink = True
         objs.append(o)
+    # the translation units are independent: a few compilers side by side (WMH_BUILD_JOBS, default 4 -- each hipcc peaks at ~1.5 GB)
+    width, running = max(1, int(os.environ.get('WMH_BUILD_JOBS', '4'))), []
+    while jobs or running:
+        while jobs and len(running) < width:
+            cmd = jobs.pop(0)
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            running.append((cmd, subprocess.Popen(cmd)))
+        cmd, proc = running.pop(0)
+        if proc.wait() != 0:
+            for _, other in running:
+                other.kill()
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
     if relink:
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
