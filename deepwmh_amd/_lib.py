@@ -26,6 +26,7 @@ SIGNATURES = {
     'wmh_conv3d_k3_packed_halfs_bf16': (_sz, [_i, _i, _i]),
     'wmh_conv3d_k3_pack_weights_bf16': (_i, [_i, _vp, _i, _i, _vp]),
     'wmh_conv3d_k3_num_partials_bf16': (_i, [_i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_num_partials_bf16x3': (_i, [_i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_pack_weights_bf16_device': (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'wmh_conv3d_k3_bf16x3_supported': (_i, [_i]),
     'wmh_conv3d_k3_packed_halfs_bf16x3': (_sz, [_i, _i, _i]),

@@ -52,6 +52,32 @@ def build_parser():
     return ap
 
 
+def count_gpus_without_runtime(topology='/sys/class/kfd/kfd/topology/nodes'):
+    """Number of GPUs from the KFD topology in sysfs (nodes with simd_count > 0; CPU nodes have 0), narrowed by a
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES list when one is set.  torch.cuda.device_count() can fall back to
+    hipGetDeviceCount, which initialises the HIP runtime -- the fan-out parent must not (it only starts children)."""
+    n = 0
+    try:
+        nodes = sorted(os.listdir(topology), key=lambda v: int(v) if v.isdigit() else 0)
+    except OSError:
+        nodes = []
+    for node in nodes:
+        try:
+            with open(os.path.join(topology, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get('simd_count', '0')) > 0:
+            n += 1
+    for var in ('HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        vis = os.environ.get(var)
+        if vis is not None and vis.strip() != '':
+            n = min(n, len([v for v in vis.split(',') if v.strip()]))
+    if n < 1:
+        raise RuntimeError('MI355WMH_GPUS=all: no GPU in %s; list the ids explicitly (e.g. MI355WMH_GPUS=0-7)' % topology)
+    return n
+
+
 def parse_gpu_list(spec):
     """'0-7' -> [0..7]; '0,2,5' -> [0,2,5]; '1' -> [1]; 'all' -> every visible device; ''/None -> [].  An id may repeat
     ('0,0'): that many processes then share the GPU."""
@@ -59,8 +85,7 @@ def parse_gpu_list(spec):
         return []
     spec = spec.strip()
     if spec == 'all':
-        import torch                                   # counting devices does not initialise the HIP runtime
-        return list(range(torch.cuda.device_count()))
+        return list(range(count_gpus_without_runtime()))
     ids = []
     for part in spec.split(','):
         part = part.strip()

@@ -138,12 +138,12 @@ def main(argv=None):
         if rank == 0:
             print('epoch %d/%d: lr %.6f train loss %.4f val loss %.4f (%.1f s)'
                   % (epoch + 1, args.epochs, lr, float(np.mean(losses)), v, time.time() - t0), flush=True)
-        save('model_latest', epoch + 1)
         if best is None or ma > best:
             best = ma
             save('model_best', epoch + 1)
         if args.save_every_epoch:
             save('model_ep_%04d' % (epoch + 1), epoch + 1)
+        save('model_latest', epoch + 1)                  # last: carries this epoch's `best`, so a `-c` run cannot overwrite a better model_best
     save('model_final_checkpoint', args.epochs)
     loader.close()
     if world > 1:

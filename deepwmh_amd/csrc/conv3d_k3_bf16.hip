@@ -261,6 +261,13 @@ extern "C" int wmh_conv3d_k3_num_partials_bf16(int cfg, int N, int Do, int Ho, i
     const BGeo ge = bf16_geo(cfg, w8);
     return cdiv(Wo, ge.TX) * cdiv(Ho, ge.TY) * cdiv(Do, ge.TZ) * ge.WPS;
 }
+// ... and by wmh_conv3d_k3_fwd_bf16x3, which always runs the four-consumer-wave geometry (WMH_BF16_WAVES8 does not apply to it)
+extern "C" int wmh_conv3d_k3_num_partials_bf16x3(int cfg, int N, int Do, int Ho, int Wo) {
+    if (!bf16_nt(cfg)) return wmh_fail(WMH_EINVAL, "num_partials_bf16x3: configuration has no bf16x3 kernel");
+    (void)N;
+    const BGeo ge = bf16_geo(cfg, false);
+    return cdiv(Wo, ge.TX) * cdiv(Ho, ge.TY) * cdiv(Do, ge.TZ) * ge.WPS;
+}
 extern "C" size_t wmh_conv3d_k3_packed_halfs_bf16(int cfg, int Cin, int Cout) {
     const int NT = bf16_nt(cfg);
     if (!NT) return 0;

@@ -1,7 +1,8 @@
 """Training data side of `nnUNet_plan_and_preprocess` / `nnUNet_train`: dataset fingerprint and plan, preprocessed
 case storage, random patch sampling with foreground oversampling [nnU-Net, not in tree:
 experiment_planning/experiment_planner_baseline_3DUNet_v21.py, preprocessing/, training/dataloading/dataset_loading.py
-DataLoader3D].  Host CPU numpy: the reference's data path is host code too; only the patches go to the GPU.
+DataLoader3D].  Crop / resampling / normalisation of the cases run on the GPU (preprocess.py -> libdeepwmh_amd.so; no host
+form in the product); file IO, the planner and the patch sampler are host code.
 Directory contract: /root/reference/deepwmh/pipeline/DCNN_multistage.py:50-93 (raw), :620-631 (preprocessed)."""
 import json
 import os
@@ -62,19 +63,17 @@ def plan_and_preprocess(raw_base, preprocessed_base, task, verify=True, log=prin
             if not set(u.astype(int).tolist()) <= set(range(nclass)):
                 raise ValueError('dataset integrity: %s has labels %s outside dataset.json' % (c, u))
         data = np.stack(imgs).astype(np.float32)
-        cropped, nz, bbox = preprocess.crop_to_nonzero(data)
-        sl = tuple(slice(a, b) for a, b in bbox)
-        seg = lab[sl].astype(np.int8)
-        seg[~nz] = -1                                    # nnU-Net marks outside-of-body voxels with -1
+        cropped, seg, nz, bbox = preprocess.crop_training_case_device(data, lab)
         loaded.append((c, cropped, seg, nz, bbox, meta, data.shape[1:]))
         spacings.append(meta['spacing'])
         shapes.append(cropped.shape[1:])
     # ExperimentPlanner3D_v21 (deepwmh_amd/planner.py): target spacing, axis order, pooling / kernel sizes per stage, patch, batch
-    target_spacing, tf, tb, stage = plan_3d_fullres(spacings, shapes, nmod, nclass)
+    target_spacing, tf, tb, stage = plan_3d_fullres(spacings, shapes, nmod, nclass, log)
     patch, num_pool = [int(v) for v in stage['patch_size']], len(stage['pool_op_kernel_sizes'])
     median_shape = stage['median_patient_size_in_voxels']
     crop_frac = np.median([np.prod(sh) / np.prod(full) for (_, _, _, _, _, _, full), sh in zip(loaded, shapes)])
     plan = UNetPlan(nmod, 32, nclass, stage['pool_op_kernel_sizes'], stage['conv_kernel_sizes'], 2, 320, patch)
+    plan.check_supported()          # before any case is preprocessed or written: an unrunnable plan is a failed command
     plans = make_plans(plan, tuple(float(v) for v in stage['current_spacing']), use_mask_for_norm=bool(crop_frac < 0.75),
                        batch_size=int(stage['batch_size']))
     plans['transpose_forward'], plans['transpose_backward'] = list(tf), list(tb)
@@ -93,13 +92,8 @@ def plan_and_preprocess(raw_base, preprocessed_base, task, verify=True, log=prin
         cropped_t = cropped.transpose([0] + [i + 1 for i in tf])
         seg_t, nz_t = seg.transpose(tf), nz.transpose(tf)
         sp_t = np.asarray(meta['spacing'], float)[tf]
-        res = preprocess.resample_to_spacing(cropped_t, sp_t, target_t, 3)
-        if res.shape[1:] != seg_t.shape:
-            seg_r = preprocess.resample_segmentation(seg_t, res.shape[1:], preprocess.separate_z_axis(sp_t, target_t))
-            nz_r = seg_r >= 0
-        else:
-            seg_r, nz_r = seg_t, nz_t
-        norm = preprocess.normalize_noncT(res, nz_r, use_mask)
+        norm, seg_r = preprocess.resample_normalize_training_case_device(cropped_t, seg_t, nz_t, sp_t, target_t, use_mask)
+        res = norm
         allc = np.concatenate([norm, seg_r[None].astype(np.float32)], 0)
         np.savez_compressed(os.path.join(stage_dir, c + '.npz'), data=allc)
         fg = np.argwhere(seg_r > 0)
@@ -120,10 +114,6 @@ def plan_and_preprocess(raw_base, preprocessed_base, task, verify=True, log=prin
     log('planned %s: %d cases, axis order %s, median shape %s, target spacing %s, patch %s, batch %d, poolings %s, kernels %s, '
         'use_mask_for_norm %s' % (task, len(cases), tf, np.asarray(median_shape).tolist(), np.round(target_t, 3).tolist(), patch,
                                   int(stage['batch_size']), stage['pool_op_kernel_sizes'], stage['conv_kernel_sizes'], use_mask))
-    try:
-        plan.check_supported()
-    except (NotImplementedError, ValueError) as e:
-        log('WARNING: this plan is outside what the HIP kernels implement (%s); nnUNet_predict / nnUNet_train will refuse it' % e)
     return task, plans
 
 

@@ -189,7 +189,9 @@ class UNetEngine:
             cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
         if use_bf16 and not (in16 or out16):       # wide tile for >= 64 output channels (bf16 kernel only)
             cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
-        if use_bf16 or use_x3:
+        if use_x3:
+            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16x3(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials_bf16x3')
+        elif use_bf16:
             npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials_bf16')
         else:
             npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials')

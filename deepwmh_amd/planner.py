@@ -46,9 +46,11 @@ def transpose_for(target_spacing):
     return tf, [int(np.argwhere(np.array(tf) == i)[0][0]) for i in range(3)]
 
 
-def get_pool_and_conv_props(spacing, patch_size, min_feature_map_size=MIN_EDGE, max_numpool=MAX_POOL):
+def get_pool_and_conv_props(spacing, patch_size, min_feature_map_size=MIN_EDGE, max_numpool=MAX_POOL, in_plane_together=False):
     """common_utils.get_pool_and_conv_props: pool an axis while its spacing is within a factor 2 of the finest one and its extent
-    stays >= 2 * min size; 3-wide kernels along the largest group of axes whose spacings are within a factor 2 of each other."""
+    stays >= 2 * min size; 3-wide kernels along the largest group of axes whose spacings are within a factor 2 of each other.
+    in_plane_together (not upstream; `plan_stage`'s supported-plan constraint): stop pooling as soon as the two in-plane axes
+    cannot both be pooled, so every pooling is [2,2,2] or [1,2,2]."""
     dim = len(spacing)
     cur_sp, cur_sz = [float(s) for s in spacing], [float(s) for s in patch_size]
     pools, kernels, num_pool = [], [], [0] * dim
@@ -63,7 +65,7 @@ def get_pool_and_conv_props(spacing, patch_size, min_feature_map_size=MIN_EDGE, 
         kernel = [3 if i in axes else 1 for i in range(dim)]
         valid = [i for i in valid if cur_sz[i] >= 2 * min_feature_map_size]
         valid = [i for i in valid if num_pool[i] < max_numpool]
-        if not valid:
+        if not valid or (in_plane_together and not (1 in valid and 2 in valid)):
             break
         pool = [1] * dim
         for v in valid:
@@ -93,7 +95,35 @@ def approx_vram(patch, num_pool_per_axis, base, max_feat, nmod, nclass, pools, c
     return int(tmp)
 
 
-def plan_stage(current_spacing, original_spacing, original_shape, num_cases, nmod, nclass):
+def poolings_supported(pools, kernels):
+    """What libdeepwmh_amd.so implements (UNetPlan.check_supported): the two in-plane axes pool together, the first axis with
+    them or not at all; 3-wide kernels in plane."""
+    return all(list(p) in ([2, 2, 2], [1, 2, 2]) for p in pools) and all(list(k) in ([3, 3, 3], [1, 3, 3]) for k in kernels)
+
+
+def plan_stage(current_spacing, original_spacing, original_shape, num_cases, nmod, nclass, log=None):
+    """`_plan_stage` as upstream plans it; when that plan is outside what the HIP kernels implement (an in-plane axis that
+    runs out of voxels one pooling before the other: [2,2,1], or the first axis pooling alone: [2,1,1]) the stage is
+    re-planned with pooling stopped where the two in-plane axes can no longer both be halved -- a shallower network on the same
+    budget, every pooling [2,2,2] or [1,2,2].  The deviation from upstream is logged.  Raises ValueError if that still is not
+    a supported plan (in-plane spacings a factor 2 or more apart)."""
+    st = _plan_stage(current_spacing, original_spacing, original_shape, num_cases, nmod, nclass, False)
+    if poolings_supported(st['pool_op_kernel_sizes'], st['conv_kernel_sizes']):
+        return st
+    first = st
+    st = _plan_stage(current_spacing, original_spacing, original_shape, num_cases, nmod, nclass, True)
+    if st['pool_op_kernel_sizes'] and poolings_supported(st['pool_op_kernel_sizes'], st['conv_kernel_sizes']):
+        if log:
+            log('WARNING: upstream\'s plan (patch %s, poolings %s) is outside the HIP kernels\' repertoire; re-planned with the in-plane '
+                'axes pooled together: patch %s, poolings %s' % ([int(v) for v in first['patch_size']], first['pool_op_kernel_sizes'],
+                                                                [int(v) for v in st['patch_size']], st['pool_op_kernel_sizes']))
+        return st
+    raise ValueError('no plan with [2,2,2] / [1,2,2] poolings for spacing %s, median shape %s (upstream plans %s)'
+                     % (np.asarray(current_spacing).tolist(), np.asarray(first['median_patient_size_in_voxels']).tolist(),
+                        first['pool_op_kernel_sizes']))
+
+
+def _plan_stage(current_spacing, original_spacing, original_shape, num_cases, nmod, nclass, together):
     """ExperimentPlanner3D_v21.get_properties_for_stage (spacing / shape already in the transposed axis order).
     nclass = number of foreground classes + 1."""
     current_spacing = np.asarray(current_spacing, float)
@@ -104,15 +134,15 @@ def plan_stage(current_spacing, original_spacing, original_shape, num_cases, nmo
     p *= 1.0 / min(p) * 512
     p = np.round(p).astype(int)
     p = [min(int(i), int(j)) for i, j in zip(p, median)]
-    npa, pools, kernels, shp, div = get_pool_and_conv_props(current_spacing, p)
+    npa, pools, kernels, shp, div = get_pool_and_conv_props(current_spacing, p, MIN_EDGE, MAX_POOL, together)
     here = approx_vram(shp, npa, BASE_FEATURES, MAX_FEATURES, nmod, nclass, pools)
     while here > REF_VOXELS:
         ax = int(np.argsort(np.array(shp) / median)[-1])
         tmp = deepcopy(shp)
         tmp[ax] -= div[ax]
-        _, _, _, _, div_new = get_pool_and_conv_props(current_spacing, tmp)
+        _, _, _, _, div_new = get_pool_and_conv_props(current_spacing, tmp, MIN_EDGE, MAX_POOL, together)
         shp[ax] -= div_new[ax]
-        npa, pools, kernels, shp, div = get_pool_and_conv_props(current_spacing, shp)
+        npa, pools, kernels, shp, div = get_pool_and_conv_props(current_spacing, shp, MIN_EDGE, MAX_POOL, together)
         here = approx_vram(shp, npa, BASE_FEATURES, MAX_FEATURES, nmod, nclass, pools)
     batch = int(np.floor(max(REF_VOXELS / here, 1) * DEFAULT_BATCH))
     max_batch = max(int(np.round(BATCH_COVERS * dataset_voxels / float(np.prod(shp, dtype=np.float64)))), MIN_BATCH)
@@ -122,12 +152,12 @@ def plan_stage(current_spacing, original_spacing, original_shape, num_cases, nmo
                 do_dummy_2D_data_aug=bool(max(shp) / shp[0] > ANISO_THRESHOLD), pool_op_kernel_sizes=pools, conv_kernel_sizes=kernels)
 
 
-def plan_3d_fullres(spacings, sizes, nmod, nclass):
+def plan_3d_fullres(spacings, sizes, nmod, nclass, log=None):
     """spacings / sizes: per training case, after cropping, in the image's own axis order.  Returns
     (target_spacing [image order], transpose_forward, transpose_backward, stage dict [transposed order])."""
     target = target_spacing_v21(spacings, sizes)
     new_shapes = [np.asarray(sp, float) / target * np.asarray(sz, float) for sp, sz in zip(spacings, sizes)]
     tf, tb = transpose_for(target)
     median = np.median(np.vstack(new_shapes), 0)
-    stage = plan_stage(target[tf], target[tf], median[tf], len(spacings), nmod, nclass)
+    stage = plan_stage(target[tf], target[tf], median[tf], len(spacings), nmod, nclass, log)
     return target, tf, tb, stage

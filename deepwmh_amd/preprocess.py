@@ -1,52 +1,11 @@
-"""Host-side pre/post steps either side of the network inside `nnUNet_predict`
-[nnU-Net, not in tree: preprocessing.GenericPreprocessor.preprocess_test_case, cropping.crop_to_nonzero,
-inference.segmentation_export.save_segmentation_nifti_from_softmax].
-Two forms: `preprocess_case` / `export_prediction` are the numpy/scipy restatement (used when a case needs resampling
-or an axis transpose, and as the checker of the device form in the tests); `preprocess_case_device` /
-`export_segmentation_device` run crop / z-score / un-crop in libdeepwmh_amd.so and are what `nnUNet_predict` uses for
-volumes already at the plan's spacing.  Parity unpinned: restated from upstream nnU-Net v1."""
+"""Pre/post steps either side of the network inside `nnUNet_predict` / `nnUNet_plan_and_preprocess`, on the GPU
+[nnU-Net, not in tree: preprocessing.GenericPreprocessor.preprocess_test_case / resample_and_normalize,
+cropping.crop_to_nonzero, inference.segmentation_export.save_segmentation_nifti_from_softmax]:
+crop to the non-zero box, spacing resampling (order 3 data, label-wise order 1 segmentations, order 1 softmax on
+export; the low-resolution axis on its own for thick slices), z-score, un-crop -- all in libdeepwmh_amd.so
+(`volume_ops.hip`, `resample.hip`).  There is no host (numpy / scipy) form in the product: the CPU restatement these are
+checked against lives in oracle/preprocess.py.  Parity unpinned: restated from upstream nnU-Net v1."""
 import numpy as np
-from scipy.ndimage import binary_fill_holes, zoom
-
-
-def create_nonzero_mask(data):
-    mask = np.zeros(data.shape[1:], dtype=bool)
-    for c in range(data.shape[0]):
-        mask |= data[c] != 0
-    return binary_fill_holes(mask)
-
-
-def crop_to_nonzero(data):
-    """data [C,z,y,x] -> (cropped data, nonzero mask cropped (bool), bbox [[z0,z1],[y0,y1],[x0,x1]])."""
-    mask = create_nonzero_mask(data)
-    idx = np.where(mask)
-    if len(idx[0]) == 0:
-        bbox = [[0, s] for s in data.shape[1:]]
-    else:
-        bbox = [[int(i.min()), int(i.max()) + 1] for i in idx]
-    sl = tuple(slice(a, b) for a, b in bbox)
-    return data[(slice(None),) + sl], mask[sl], bbox
-
-
-def normalize_noncT(data, nonzero_mask, use_mask_for_norm):
-    """nnU-Net non-CT scheme: per-channel z-score (inside the non-zero mask when use_mask_for_norm)."""
-    out = data.astype(np.float32, copy=True)
-    for c in range(out.shape[0]):
-        if use_mask_for_norm:
-            v = out[c][nonzero_mask]
-            out[c][nonzero_mask] = (v - v.mean()) / (v.std() + 1e-8)
-            out[c][~nonzero_mask] = 0
-        else:
-            out[c] = (out[c] - out[c].mean()) / (out[c].std() + 1e-8)
-    return out
-
-
-def _resize(vol, new_shape, order):
-    """skimage.transform.resize(order, mode='edge', anti_aliasing=False) == pixel-area-aligned spline zoom."""
-    if tuple(vol.shape) == tuple(new_shape):
-        return vol
-    factors = [n / o for n, o in zip(new_shape, vol.shape)]
-    return zoom(vol, factors, order=order, mode='nearest', grid_mode=True, prefilter=order > 1)
 
 
 SEPARATE_Z_ANISO_THRESHOLD = 3.0     # nnU-Net RESAMPLING_SEPARATE_Z_ANISO_THRESHOLD [preprocessing.py, not in tree]
@@ -66,116 +25,6 @@ def separate_z_axis(spacing_a, spacing_b):
             return int(axis[0]) if len(axis) == 1 else None
     return None
 
-
-def _resize_separate_z(vol, new_shape, order, axis):
-    """`resample_data_or_seg(do_separate_z=True, order_z=0)`: every slice across `axis` resized in its plane (order), then
-    nearest neighbour along `axis` at the pixel-centre coordinates (o + 0.5) * in / out - 0.5 (map_coordinates order 0)."""
-    from scipy.ndimage import map_coordinates
-    new_shape = tuple(int(v) for v in new_shape)
-    plane = tuple(n for i, n in enumerate(new_shape) if i != axis)
-    slices = [_resize(np.take(vol, k, axis=axis), plane, order) for k in range(vol.shape[axis])]
-    out = np.stack(slices, axis)
-    if out.shape[axis] == new_shape[axis]:
-        return out
-    grids = np.mgrid[tuple(slice(0, n) for n in new_shape)].astype(np.float64)
-    grids[axis] = (grids[axis] + 0.5) * (out.shape[axis] / new_shape[axis]) - 0.5
-    return map_coordinates(out, grids, order=0, mode='nearest')
-
-
-def resample_volume(vol, new_shape, order, axis=None):
-    """One channel to new_shape: jointly (axis None) or with the low-resolution axis on its own."""
-    if tuple(vol.shape) == tuple(int(v) for v in new_shape):
-        return vol
-    return _resize(vol, new_shape, order) if axis is None else _resize_separate_z(vol, new_shape, order, axis)
-
-
-def _resize_labels(seg, new_shape):
-    """batchgenerators `resize_segmentation(order=1)` [not in tree]: every label's indicator resized linearly, the label set
-    where that is >= 0.5 (labels in ascending order, so the larger label wins a tie)."""
-    if tuple(seg.shape) == tuple(int(v) for v in new_shape):
-        return seg
-    out = np.zeros(tuple(int(v) for v in new_shape), seg.dtype)
-    for c in np.unique(seg):
-        out[_resize((seg == c).astype(np.float64), new_shape, 1) >= 0.5] = c
-    return out
-
-
-def resample_segmentation(seg, new_shape, axis=None):
-    """`resample_patient`'s segmentation branch (order_seg=1, order_z_seg=0): label-wise linear jointly, or in the plane of every
-    slice across `axis` followed by nearest neighbour along it."""
-    from scipy.ndimage import map_coordinates
-    new_shape = tuple(int(v) for v in new_shape)
-    if tuple(seg.shape) == new_shape:
-        return seg
-    if axis is None:
-        return _resize_labels(seg, new_shape)
-    plane = tuple(n for i, n in enumerate(new_shape) if i != axis)
-    out = np.stack([_resize_labels(np.take(seg, k, axis=axis), plane) for k in range(seg.shape[axis])], axis)
-    if out.shape[axis] == new_shape[axis]:
-        return out
-    grids = np.mgrid[tuple(slice(0, n) for n in new_shape)].astype(np.float64)
-    grids[axis] = (grids[axis] + 0.5) * (out.shape[axis] / new_shape[axis]) - 0.5
-    return map_coordinates(out, grids, order=0, mode='nearest').astype(seg.dtype)
-
-
-def resample_to_spacing(data, spacing, target_spacing, order=3):
-    spacing, target_spacing = np.asarray(spacing, float), np.asarray(target_spacing, float)
-    new_shape = np.round(spacing / target_spacing * np.array(data.shape[1:])).astype(int)
-    if np.all(new_shape == np.array(data.shape[1:])):
-        return data
-    axis = separate_z_axis(spacing, target_spacing)
-    return np.stack([resample_volume(data[c].astype(np.float64), new_shape, order, axis).astype(np.float32) for c in range(data.shape[0])])
-
-
-def preprocess_case(volume_zyx, spacing, plans, stage=None):
-    """volume_zyx: float32 [z,y,x] (one modality) or [C,z,y,x].  Returns (data [C,...] for the network, props)."""
-    data = volume_zyx[None] if volume_zyx.ndim == 3 else volume_zyx
-    data = data.astype(np.float32)
-    orig_shape = data.shape[1:]
-    cropped, nzmask, bbox = crop_to_nonzero(data)
-    stages = plans['plans_per_stage']
-    st = stages[stage if stage is not None else (max(stages.keys()) if isinstance(stages, dict) else len(stages) - 1)]
-    tf = list(plans.get('transpose_forward', [0, 1, 2]))
-    target = np.asarray(st['current_spacing'], float)
-    cropped = cropped.transpose([0] + [i + 1 for i in tf])
-    nzmask = nzmask.transpose(tf)
-    sp = np.asarray(spacing, float)[tf]
-    shape_after_crop = cropped.shape[1:]
-    res = resample_to_spacing(cropped, sp, target, order=3)
-    if res.shape[1:] != nzmask.shape:
-        nzmask = _resize(nzmask.astype(np.float64), res.shape[1:], 0) > 0.5
-    umn = plans.get('use_mask_for_norm', {0: False})
-    use_mask = bool(umn[0] if isinstance(umn, dict) else umn)
-    out = normalize_noncT(res, nzmask, use_mask)
-    props = dict(original_shape=orig_shape, bbox=bbox, shape_after_crop=tuple(shape_after_crop), transpose_forward=tf,
-                 transpose_backward=list(plans.get('transpose_backward', [0, 1, 2])),
-                 original_spacing=tuple(float(v) for v in np.asarray(spacing, float)), spacing_after_resampling=tuple(float(v) for v in target))
-    return np.ascontiguousarray(out), props
-
-
-def export_prediction(prob, props):
-    """prob [K, ...] in network geometry -> (segmentation uint8, probabilities [K]) in the input's geometry:
-    transpose back, resample to the cropped shape (order 1), argmax, un-crop into zeros."""
-    tb = props['transpose_backward']
-    prob = prob.transpose([0] + [i + 1 for i in tb])
-    tgt = props['shape_after_crop']
-    tgt = tuple(np.array(tgt)[[props['transpose_forward'].index(i) for i in range(3)]]) if tb != [0, 1, 2] else tuple(tgt)
-    if prob.shape[1:] != tgt:
-        # save_segmentation_nifti_from_softmax [nnU-Net, not in tree]: order 1, and the low-resolution axis on its own (order 0)
-        # when the case's spacing (original axis order) or the resampled spacing is anisotropic
-        axis = _export_axis(props)
-        prob = np.stack([resample_volume(prob[k].astype(np.float64), tgt, 1, axis).astype(np.float32) for k in range(prob.shape[0])])
-    seg_c = prob.argmax(0).astype(np.uint8)
-    full = np.zeros(props['original_shape'], dtype=np.uint8)
-    bb = props['bbox']
-    sl = tuple(slice(a, b) for a, b in bb)
-    full[sl] = seg_c
-    pfull = np.zeros((prob.shape[0],) + tuple(props['original_shape']), dtype=np.float32)
-    pfull[0] = 1.0                                  # outside the crop everything is background
-    pfull[(slice(None),) + sl] = prob
-    return full, pfull
-
-
 def _export_axis(props):
     """Low-resolution axis (in the input's axis order) for the export resampling, or None."""
     if 'original_spacing' not in props:
@@ -183,7 +32,6 @@ def _export_axis(props):
     tb = props['transpose_backward']
     after = np.asarray(props['spacing_after_resampling'], float)[tb]          # back to the input's axis order
     return separate_z_axis(props['original_spacing'], after)
-
 
 # ---- device path: crop-to-nonzero + z-score on the GPU (no resampling: volumes already at the plan's spacing) ----------
 def needs_resampling(shape_zyx, spacing, plans, stage=None):
@@ -316,3 +164,84 @@ def export_prediction_device(seg_d, prob_d, props, want_prob0=False):
 def export_segmentation_device(seg_crop, props):
     """Label map only (no resampling / transpose case)."""
     return export_prediction_device(seg_crop, None, props, False)[0]
+
+
+# ---- training cases (`nnUNet_plan_and_preprocess`): image + segmentation ------------------------------------------------
+def crop_training_case_device(data, seg, device='cuda:0'):
+    """cropping.crop_to_nonzero for a training case: data [C,z,y,x] float32 and its label map [z,y,x] -> (cropped data,
+    cropped segmentation int8 with -1 outside the filled non-zero mask, cropped mask (bool), bbox).  The mask, hole filling
+    and box come from the device kernels `preprocess_case_device` uses; numpy only slices."""
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(device)
+    Cn, D, H, W = (int(v) for v in x.shape)
+    n = D * H * W
+    st = _lib.current_stream()
+    raw = torch.empty(n, dtype=torch.uint8, device=device)
+    mask = torch.empty((D, H, W), dtype=torch.uint8, device=device)
+    labels = torch.empty(n, dtype=torch.int32, device=device)
+    flags = torch.empty(n, dtype=torch.int32, device=device)
+    bbox_d = torch.empty(6, dtype=torch.int32, device=device)
+    _lib.check(lib.wmh_nonzero_mask(_lib.ptr(x), _lib.ptr(raw), Cn, D, H, W, st), 'wmh_nonzero_mask')
+    _lib.check(lib.wmh_fill_holes(_lib.ptr(raw), _lib.ptr(mask), _lib.ptr(labels), _lib.ptr(flags), D, H, W, st), 'wmh_fill_holes')
+    _lib.check(lib.wmh_mask_bbox(_lib.ptr(mask), _lib.ptr(bbox_d), D, H, W, st), 'wmh_mask_bbox')
+    bb = [int(v) for v in bbox_d.cpu().tolist()]
+    bbox = [[bb[0], bb[1]], [bb[2], bb[3]], [bb[4], bb[5]]]
+    sl = tuple(slice(a, b) for a, b in bbox)
+    nz = mask.cpu().numpy()[sl] != 0
+    seg_c = np.asarray(seg)[sl].astype(np.int8)
+    seg_c[~nz] = -1                                      # nnU-Net marks outside-of-body voxels with -1
+    return np.asarray(data, dtype=np.float32)[(slice(None),) + sl], seg_c, nz, bbox
+
+
+def _resample_labels_device(seg_d, new_shape, axis):
+    """batchgenerators `resize_segmentation(order=1)` as `resample_patient` calls it (order_seg=1, order_z_seg=0): every
+    label's indicator resampled linearly (in the plane of the slices across `axis` when the low-resolution axis goes on its
+    own), the label set where that is >= 0.5 in ascending label order, then nearest neighbour along `axis`.
+    seg_d: device float32 [D,H,W] holding integer labels.  Returns device float32 [*new_shape]."""
+    import torch
+    new_shape = tuple(int(v) for v in new_shape)
+    if tuple(seg_d.shape) == new_shape:
+        return seg_d
+    mid = list(new_shape)
+    if axis is not None:
+        mid[axis] = int(seg_d.shape[axis])
+    out = torch.zeros(tuple(mid), dtype=torch.float32, device=seg_d.device)
+    for c in torch.unique(seg_d).cpu().tolist():
+        ind = (seg_d == c).to(torch.float32)[None].contiguous()
+        out[_resample_device(ind, mid, 1)[0] >= 0.5] = c
+    if tuple(mid) != new_shape:
+        out = _resample_device(out[None].contiguous(), new_shape, 0)[0]
+    return out
+
+
+def resample_normalize_training_case_device(cropped_t, seg_t, nz_t, spacing_t, target_t, use_mask, device='cuda:0'):
+    """GenericPreprocessor.resample_and_normalize for one training case, everything in network axis order: order-3 resampling
+    of the data (`wmh_resample`), label-wise linear resampling of the segmentation, z-score inside seg >= 0 (or the whole
+    volume) by `wmh_zscore_crop`.  Returns (data [C,...] float32, segmentation [...] int8) as numpy arrays."""
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    spacing_t, target_t = np.asarray(spacing_t, float), np.asarray(target_t, float)
+    shape_t = tuple(int(v) for v in cropped_t.shape[1:])
+    new_shape = tuple(int(v) for v in np.round(spacing_t / target_t * np.array(shape_t)).astype(int))
+    x = torch.from_numpy(np.ascontiguousarray(cropped_t, dtype=np.float32)).to(device)
+    if new_shape != shape_t:
+        axis = separate_z_axis(spacing_t, target_t)
+        x = _resample_device(x, new_shape, 3, axis)
+        seg_d = _resample_labels_device(torch.from_numpy(np.ascontiguousarray(seg_t, dtype=np.float32)).to(device), new_shape, axis)
+        seg_r = seg_d.cpu().numpy().astype(np.int8)
+        mask = (seg_d >= 0).to(torch.uint8).contiguous()
+    else:
+        seg_r = np.asarray(seg_t, dtype=np.int8)
+        mask = torch.from_numpy(np.ascontiguousarray(nz_t, dtype=np.uint8)).to(device)
+    Cn = int(x.shape[0])
+    st = _lib.current_stream()
+    full = torch.tensor([0, new_shape[0], 0, new_shape[1], 0, new_shape[2]], dtype=torch.int32, device=device)
+    out = torch.empty((Cn,) + new_shape, dtype=torch.float32, device=device)
+    stats = torch.empty(Cn, 2, dtype=torch.float32, device=device)
+    ws = torch.empty(max(1, lib.wmh_zscore_crop_workspace_doubles(Cn)), dtype=torch.float64, device=device)
+    _lib.check(lib.wmh_zscore_crop(_lib.ptr(x.contiguous()), _lib.ptr(mask), _lib.ptr(full), _lib.ptr(out), None, _lib.ptr(stats), _lib.ptr(ws),
+                                   Cn, new_shape[0], new_shape[1], new_shape[2], int(bool(use_mask)), st), 'wmh_zscore_crop')
+    return out.cpu().numpy(), seg_r

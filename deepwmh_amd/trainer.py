@@ -175,7 +175,7 @@ class UNetTrainer:
         y = self._buf(key + '.y', (N, cout, D, H, W))
         part, npart = None, 0
         if want_stats:
-            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, D, H, W), 'num_partials_bf16')
+            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16x3(cfg, N, D, H, W), 'num_partials_bf16x3')
             part = self._buf(key + '.part', (N, cout, npart, 4))
         nws = self.lib.wmh_conv3d_k3_bf16x3_workspace_floats(cfg, C0 + C1, N, D, H, W, cout)
         ws = self._buf('splitk.ws', (nws,)) if nws else None
@@ -515,6 +515,19 @@ def ds_pick_indices(in_size, factor):
     return np.clip(np.floor((o + 0.5) * in_size / out).astype(np.int64), 0, in_size - 1)
 
 
+_DS_INDEX_CACHE = {}
+
+
+def _ds_index_tensor(in_size, factor, device):
+    """The pick indices as a device tensor, built once per (length, factor, device): rebuilding them per iteration was a dozen
+    pageable, host-synchronous H2D copies per training step."""
+    key = (int(in_size), int(factor), str(device))
+    t = _DS_INDEX_CACHE.get(key)
+    if t is None:
+        t = _DS_INDEX_CACHE[key] = torch.from_numpy(ds_pick_indices(in_size, factor)).to(device)
+    return t
+
+
 def downsample_targets(seg, num_scales, pool_op_kernel_sizes=None):
     """Deep-supervision targets (nnUNetTrainerV2: scales 1 / cumprod(pooling kernels), order 0).  seg: uint8 tensor
     [N, X, Y, Z] on any device; returns one [N, voxels] tensor per scale."""
@@ -524,7 +537,7 @@ def downsample_targets(seg, num_scales, pool_op_kernel_sizes=None):
         cum = [c * int(p) for c, p in zip(cum, pools[s - 1])]
         t = seg
         for ax in range(3):
-            idx = torch.from_numpy(ds_pick_indices(seg.shape[1 + ax], cum[ax])).to(seg.device)
-            t = t.index_select(1 + ax, idx)
+            if cum[ax] != 1:
+                t = t.index_select(1 + ax, _ds_index_tensor(seg.shape[1 + ax], cum[ax], seg.device))
         out.append(t.contiguous().view(seg.shape[0], -1))
     return out

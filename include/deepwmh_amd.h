@@ -88,6 +88,8 @@ int wmh_conv3d_k3_bf16_supported(int cfg);
 /* InstanceNorm partial records per (n, c) row written by wmh_conv3d_k3_fwd_bf16 (its wave split differs from the fp32
  * kernel's, so this replaces wmh_conv3d_k3_num_partials for that call). */
 int wmh_conv3d_k3_num_partials_bf16(int cfg, int N, int Do, int Ho, int Wo);
+/* ... and by wmh_conv3d_k3_fwd_bf16x3 (always the four-consumer-wave geometry). */
+int wmh_conv3d_k3_num_partials_bf16x3(int cfg, int N, int Do, int Ho, int Wo);
 size_t wmh_conv3d_k3_packed_halfs_bf16(int cfg, int Cin, int Cout);
 int wmh_conv3d_k3_pack_weights_bf16(int cfg, const float* w, int Cin, int Cout, uint16_t* wf);
 /* The same image written on the device, with the channel sub-range / data-gradient modes of

@@ -12,9 +12,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from oracle import postprocess as opp, stage1 as o1, stage2 as o2   # noqa: E402
+from oracle import postprocess as opp, preprocess, stage1 as o1, stage2 as o2   # noqa: E402
 from stage1_cases import make_case                                    # noqa: E402
-from deepwmh_amd import preprocess                                    # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_nnunet_predict_cli_end_to_end(tmp_path, tiny_net, tiny_io):
     from deepwmh_amd import checkpoint as ck
-    from deepwmh_amd import nifti, preprocess
+    from deepwmh_amd import nifti
+    from oracle import preprocess
     from oracle import sliding_window as osw
     plan, net, sd = tiny_net
     model_dir = str(tmp_path / 'model')

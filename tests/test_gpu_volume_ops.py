@@ -102,6 +102,7 @@ def test_full_size_volume_remove_sparks_exact(lib):
 @pytest.mark.parametrize('use_mask', [True, False])
 def test_preprocess_case_device_matches_host(lib, use_mask):
     from deepwmh_amd import checkpoint as ck, preprocess
+    from oracle import preprocess as opre
     from deepwmh_amd.plan import tiny_plan
     plans = ck.make_plans(tiny_plan(), spacing=(1.0, 1.0, 1.0), use_mask_for_norm=use_mask)
     rng = np.random.default_rng(3)
@@ -109,7 +110,7 @@ def test_preprocess_case_device_matches_host(lib, use_mask):
     vol[3:43, 2:50, 5:42] = rng.standard_normal((40, 48, 37)).astype(np.float32) * 40 + 200
     vol[10:14, 20:25, 20:26] = 0                             # a hole inside the head: filled by the mask, kept in the statistics
     vol[0, 0, 0] = 0
-    ref, props_ref = preprocess.preprocess_case(vol, (1.0, 1.0, 1.0), plans)
+    ref, props_ref = opre.preprocess_case(vol, (1.0, 1.0, 1.0), plans)
     got, props = preprocess.preprocess_case_device(vol, (1.0, 1.0, 1.0), plans)
     torch.cuda.synchronize()
     assert props['bbox'] == props_ref['bbox'] and tuple(props['shape_after_crop']) == tuple(props_ref['shape_after_crop'])
@@ -119,17 +120,18 @@ def test_preprocess_case_device_matches_host(lib, use_mask):
     seg = (torch.rand(props['shape_after_crop'], device='cuda') < 0.3).to(torch.uint8)
     full = preprocess.export_segmentation_device(seg, props)
     prob = np.stack([1 - seg.cpu().numpy().astype(np.float32), seg.cpu().numpy().astype(np.float32)])
-    full_ref, _ = preprocess.export_prediction(prob, props_ref)
+    full_ref, _ = opre.export_prediction(prob, props_ref)
     assert np.array_equal(full, full_ref)
 
 
 def test_preprocess_device_all_zero_volume(lib):
     from deepwmh_amd import checkpoint as ck, preprocess
+    from oracle import preprocess as opre
     from deepwmh_amd.plan import tiny_plan
     plans = ck.make_plans(tiny_plan(), spacing=(1.0, 1.0, 1.0), use_mask_for_norm=True)
     vol = np.zeros((8, 9, 10), np.float32)
     got, props = preprocess.preprocess_case_device(vol, (1.0, 1.0, 1.0), plans)
-    ref, props_ref = preprocess.preprocess_case(vol, (1.0, 1.0, 1.0), plans)
+    ref, props_ref = opre.preprocess_case(vol, (1.0, 1.0, 1.0), plans)
     assert props['bbox'] == props_ref['bbox'] and np.array_equal(got.cpu().numpy(), ref)
 
 
@@ -138,12 +140,13 @@ def test_resample_matches_scipy_zoom(lib, order):
     """wmh_resample against the host restatement of skimage's resize (scipy zoom, float64): up- and down-sampling,
     anisotropic factors, an axis left untouched, tiny extents."""
     from deepwmh_amd import preprocess
+    from oracle import preprocess as opre
     rng = np.random.default_rng(11)
     for shp, new in [((20, 24, 18), (31, 24, 13)), ((9, 10, 11), (18, 25, 7)), ((3, 40, 5), (4, 33, 5)), ((16, 16, 16), (16, 16, 16)),
                      ((2, 3, 30), (5, 2, 41))]:
         x = (rng.standard_normal((2,) + shp) * 30 + 100).astype(np.float32)
         got = preprocess._resample_device(torch.from_numpy(x).cuda(), new, order).cpu().numpy()
-        ref = np.stack([preprocess._resize(x[c].astype(np.float64), new, order).astype(np.float32) for c in range(2)]) \
+        ref = np.stack([opre._resize(x[c].astype(np.float64), new, order).astype(np.float32) for c in range(2)]) \
             if tuple(new) != shp else x
         if tuple(new) == shp and order == 3:
             tol = 2e-5 * float(np.abs(x).max())          # identity zoom still runs the spline round trip on the device
@@ -158,6 +161,7 @@ def test_resample_matches_scipy_zoom(lib, order):
                                         ((5.0, 1.1, 1.1), [0, 1, 2]), ((0.9, 0.9, 4.0), [0, 1, 2]), ((1.0, 0.8, 3.6), [2, 0, 1])])
 def test_preprocess_and_export_device_with_resampling(lib, spacing, tf):
     from deepwmh_amd import checkpoint as ck, preprocess
+    from oracle import preprocess as opre
     from deepwmh_amd.plan import tiny_plan
     plans = ck.make_plans(tiny_plan(), spacing=(1.0, 1.0, 1.0), use_mask_for_norm=True)
     plans['transpose_forward'] = tf
@@ -167,7 +171,7 @@ def test_preprocess_and_export_device_with_resampling(lib, spacing, tf):
     vol = np.zeros((40, 46, 38), np.float32)
     vol[4:37, 3:44, 5:35] = (gaussian_filter(rng.standard_normal((33, 41, 30)), 1.5) * 200 + 300).astype(np.float32)
     vol[15:18, 20:24, 18:22] = 0
-    ref, props_ref = preprocess.preprocess_case(vol, spacing, plans)
+    ref, props_ref = opre.preprocess_case(vol, spacing, plans)
     got, props = preprocess.preprocess_case_device(vol, spacing, plans)
     assert props['bbox'] == props_ref['bbox'] and tuple(props['shape_after_crop']) == tuple(props_ref['shape_after_crop'])
     assert tuple(got.shape) == ref.shape
@@ -178,7 +182,44 @@ def test_preprocess_and_export_device_with_resampling(lib, spacing, tf):
     prob = torch.softmax(logits, 0).contiguous()
     seg = prob.argmax(0).to(torch.uint8)
     full, p0 = preprocess.export_prediction_device(seg, prob, props, True)
-    full_ref, pfull_ref = preprocess.export_prediction(prob.cpu().numpy(), props_ref)
+    full_ref, pfull_ref = opre.export_prediction(prob.cpu().numpy(), props_ref)
     assert float(np.abs(p0 - pfull_ref[0]).max()) <= 2e-6
     sure = np.abs(pfull_ref[1] - pfull_ref[0]) > 1e-5
     assert full.shape == full_ref.shape and int((full != full_ref)[sure].sum()) == 0
+
+
+@pytest.mark.parametrize('spacing,target,use_mask', [((1.0, 1.0, 1.0), (1.0, 1.0, 1.0), True), ((0.8, 1.0, 1.3), (1.0, 1.0, 1.0), True),
+                                                    ((1.0, 1.0, 1.0), (1.5, 0.75, 1.2), False), ((4.0, 0.9, 0.9), (3.0, 1.0, 1.0), True)])
+def test_training_case_preprocessing_device_matches_host(lib, spacing, target, use_mask):
+    """`nnUNet_plan_and_preprocess` per case (crop, order-3 data / label-wise order-1 segmentation resampling incl. the thick-slice
+    branch, z-score) on the device against the host restatement in oracle/preprocess.py."""
+    from deepwmh_amd import preprocess
+    from oracle import preprocess as opre
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(17)
+    vol = np.zeros((1, 30, 44, 40), np.float32)
+    vol[0, 3:28, 4:41, 5:36] = (gaussian_filter(rng.standard_normal((25, 37, 31)), 1.5) * 200 + 300).astype(np.float32)
+    vol[0, 10:13, 20:24, 18:22] = 0
+    lab = np.zeros((30, 44, 40), np.float32)
+    lab[8:14, 10:22, 9:20] = 1
+    lab[18:22, 25:33, 22:30] = 1
+    cropped, seg, nz, bbox = preprocess.crop_training_case_device(vol, lab)
+    c_ref, nz_ref, bbox_ref = opre.crop_to_nonzero(vol)
+    assert bbox == bbox_ref and np.array_equal(cropped, c_ref) and np.array_equal(nz, nz_ref)
+    seg_ref = lab[tuple(slice(a, b) for a, b in bbox)].astype(np.int8)
+    seg_ref[~nz_ref] = -1
+    assert np.array_equal(seg, seg_ref) and (seg == -1).any()
+    got, seg_r = preprocess.resample_normalize_training_case_device(cropped, seg, nz, spacing, target, use_mask)
+    res = opre.resample_to_spacing(c_ref, spacing, target, 3)
+    if res.shape[1:] != seg_ref.shape:
+        sr = opre.resample_segmentation(seg_ref, res.shape[1:], opre.separate_z_axis(np.asarray(spacing, float), np.asarray(target, float)))
+        nzr = sr >= 0
+    else:
+        sr, nzr = seg_ref, nz_ref
+    ref = opre.normalize_noncT(res, nzr, use_mask)
+    assert got.shape == ref.shape and seg_r.shape == sr.shape and seg_r.dtype == np.int8
+    # labels: identical except where a label's linear indicator sits on the 0.5 threshold to rounding (none expected; allow 1e-4)
+    assert float((seg_r != sr).mean()) <= 1e-4, float((seg_r != sr).mean())
+    same = seg_r == sr
+    mask_same = (seg_r >= 0) == (sr >= 0)
+    assert float(np.abs(got - ref)[:, mask_same & same].max()) <= 5e-5 * (1 + float(np.abs(ref).max()))

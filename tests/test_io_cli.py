@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 from deepwmh_amd import checkpoint as ck
-from deepwmh_amd import nifti, preprocess
+from deepwmh_amd import nifti
+from oracle import preprocess
 from deepwmh_amd.cli.predict import build_parser
 from deepwmh_amd.plan import tiny_plan
 

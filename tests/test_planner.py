@@ -62,3 +62,27 @@ def test_transposes_are_inverse():
         tf, tb = planner.transpose_for(np.array(t))
         assert [tf[i] for i in tb] == [0, 1, 2]
         assert np.argmax(np.array(t)[tf]) == 0
+
+
+def test_every_emitted_plan_is_one_the_hip_path_runs():
+    """upstream's planner lets an in-plane axis run out of voxels one pooling before the other ([2,2,1]) or the first
+    axis pool alone ([2,1,1]); `plan_stage` re-plans those (logged) so that `nnUNet_train` / `nnUNet_predict` never meet a plan
+    they refuse after the cohort has been preprocessed."""
+    import itertools
+    from deepwmh_amd.plan import UNetPlan
+    msgs = []
+    for shape in itertools.product([40, 96, 120, 170, 256], [96, 150, 224], [64, 118, 190, 256]):
+        for sp in [(1.2, 1.0, 1.2), (1, 1, 1), (3.0, 0.9, 0.9), (5.0, 0.5, 0.5), (0.9, 0.9, 4.0), (1.0, 2.5, 1.0)]:
+            _, _, _, st = planner.plan_3d_fullres([sp] * 20, [shape] * 20, 1, 2, log=msgs.append)
+            UNetPlan(1, 32, 2, st['pool_op_kernel_sizes'], st['conv_kernel_sizes'], 2, 320, [int(v) for v in st['patch_size']]).check_supported()
+            assert len(st['pool_op_kernel_sizes']) >= 1
+    # the advisor's reproduction: 120x150x118 at (1.2, 1.0, 1.2) -> upstream ends with [2,2,1]
+    _, _, _, st = planner.plan_3d_fullres([(1.2, 1.0, 1.2)] * 20, [(120, 150, 118)] * 20, 1, 2, log=msgs.append)
+    assert list(st['patch_size']) == [128, 160, 112] and st['pool_op_kernel_sizes'] == [[2, 2, 2]] * 4
+    assert any('re-planned' in m for m in msgs)
+
+
+def test_unplannable_dataset_fails_before_preprocessing():
+    import pytest
+    with pytest.raises(ValueError):
+        planner.plan_3d_fullres([(5.0, 1.0, 2.5)] * 4, [(30, 200, 90)] * 4, 1, 2)      # in-plane spacings 2.5 x apart: [1,3,1] kernels

@@ -22,8 +22,7 @@ def test_oracle_reproduces_postprocess_and_stage2_vectors():
 
 
 def test_oracle_reproduces_resample_and_stage1_vectors():
-    from deepwmh_amd import preprocess
-    from oracle import stage1 as o1
+    from oracle import preprocess, stage1 as o1
     for order in (0, 1, 3):
         got = preprocess._resize(G['rs_in'].astype(np.float64), (15, 9, 13), order).astype(np.float32)
         assert np.array_equal(got, G['rs_out_o%d' % order])

@@ -1,10 +1,11 @@
 """nnU-Net's separate-z resampling [preprocessing.resample_patient / resample_data_or_seg, not in tree], restated in
-deepwmh_amd/preprocess.py (thick-slice FLAIR -- the case /root/reference/deepwmh/analysis/image_ops.py:354-359
+oracle/preprocess.py (host restatement; the device form in deepwmh_amd/preprocess.py is compared with it in tests/test_gpu_volume_ops.py) (thick-slice FLAIR -- the case /root/reference/deepwmh/analysis/image_ops.py:354-359
 handles explicitly -- was resampled isotropically with a cubic spline along the slice axis)."""
 import numpy as np
 from scipy.ndimage import zoom
 
-from deepwmh_amd import checkpoint as ck, preprocess as pp
+from deepwmh_amd import checkpoint as ck, preprocess as dpp
+from oracle import preprocess as pp
 from deepwmh_amd.plan import tiny_plan
 
 
@@ -13,6 +14,8 @@ def test_axis_rule():
     assert pp.separate_z_axis((1, 1, 1), (1, 1, 4)) == 2            # else the plan's
     assert pp.separate_z_axis((3, 1, 1), (1, 1, 1)) is None         # threshold is strictly greater than 3
     assert pp.separate_z_axis((1, 1, 1), (1, 1, 1)) is None
+    for a, b in (((5, 1, 1), (1, 1, 1)), ((1, 1, 1), (1, 1, 4)), ((3, 1, 1), (1, 1, 1)), ((0.24, 1.25, 1.25), (1, 1, 1)), ((1, 6, 1), (2, 2, 2))):
+        assert dpp.separate_z_axis(a, b) == pp.separate_z_axis(a, b)      # the product's copy of the rule
     assert pp.separate_z_axis((0.24, 1.25, 1.25), (1, 1, 1)) is None   # two low-resolution axes: joint resampling
 
 

@@ -35,11 +35,13 @@ def make_raw_dataset(raw_base, task='Task001_LabelDenoising', n=4, shape=(40, 48
     return task
 
 
+@pytest.mark.gpu
 def test_plan_and_preprocess_thick_slices(tmp_path):
     """Thick-slice FLAIR (reference image_ops.py:354-359 accepts anisotropy > 3): the slice axis goes first, the stage is stored in
     that order with [1,3,3] / [1,2,2] first levels, and inference preprocessing lands on the same grid as the training data."""
-    from deepwmh_amd import nifti, preprocess
+    from deepwmh_amd import nifti
     from deepwmh_amd.data import DATA_ID, plan_and_preprocess
+    from oracle import preprocess
     from deepwmh_amd.plan import UNetPlan
     raw, pre = str(tmp_path / 'raw'), str(tmp_path / 'pre')
     # nifti.write takes [z,y,x] arrays and (z,y,x) spacing: 12 slices of 4 mm, 1 mm in plane; slice axis in the MIDDLE here
@@ -78,6 +80,7 @@ def test_cli_accepts_reference_training_commands():
     assert e.value.code == 0
 
 
+@pytest.mark.gpu
 def test_plan_and_preprocess_and_loader(tmp_path):
     from deepwmh_amd.data import DATA_ID, PatchLoader, plan_and_preprocess
     raw, pre = str(tmp_path / 'raw'), str(tmp_path / 'pre')
