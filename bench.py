@@ -4,7 +4,8 @@ Gaussian aggregation) on N MI355X.  One "step" = one whole volume through the ho
 volume H2D -> extract patches -> Generic_UNet forward -> seg head + softmax + mirror average + Gaussian
 accumulate -> normalise + argmax -> label-map D2H (SURVEY.md 8d's timing protocol).  Prints ONE JSON line.
 
-  python bench.py                         # N=1, configs[1] (fp32, mirroring on): the headline
+  python bench.py                         # N=1, configs[1] (fp32 tensors / accumulate, products from fp16 pairs; mirroring on): the headline
+  python bench.py --precision fp32        # the exact-fp32 kernels (v_mfma_f32_32x32x2_f32)
   python bench.py --gpus N                # spawns the N ranks itself (fresh child processes, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N    # or under torchrun
   python bench.py --precision bf16 --storage bf16      # configs[2]: bf16 forward, a step = 8 volumes
@@ -28,23 +29,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (dense peaks)
-# bf16x3: a product is four bf16 matrix instructions (both operands split into two bf16 numbers), so the mode's ceiling in
+# f16x2: a product is four bf16 matrix instructions (both operands split into two bf16 numbers), so the mode's ceiling in
 # ALGORITHMIC flops is a quarter of the bf16 peak
-PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 625.0}
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'f16x2': 625.0}
 HBM_PEAK_GBS = 8000.0
 FWD_GFLOP_PER_PATCH = 954.46     # BASELINE.md section 2 (the engine's own count of what it queued is reported next to it)
 AGG_GBYTES_PER_VOLUME = 0.46     # aggregation read-modify-write + volume in / label map out
 KERNEL_NAME = {
     'fp32': 'conv3d_k3_ws_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM, wave-specialised)',
     'bf16': 'conv3d_k3_bf16_ws_kernel<cfg0> (v_mfma_f32_32x32x16_bf16 implicit GEMM, wave-specialised)',
-    'bf16x3': 'conv3d_k3_bf16_ws_kernel<cfg0, X3> (fp32 tensors; operands split into bf16 pairs, 4 x v_mfma_f32_32x32x16_bf16 per '
-              '16 channels and tap, fp32 accumulate; peak = bf16 peak / 4)',
+    'f16x2': 'conv3d_k3_bf16_ws_kernel<cfg0, PAIR> (fp32 tensors; operands split into fp16 pairs, 4 x v_mfma_f32_32x32x16_f16 per '
+              '16 channels and tap, fp32 accumulate; peak = 16-bit MFMA peak / 4)',
     'bf16_storage': 'cl_conv3_kernel<ClGeo<4,4>> (channels-last bf16 tensors, v_mfma_f32_32x32x16_bf16, LDS-DMA staging, every stride-1 launch)',
 }
 
 
 def mode_key(precision, storage):
-    return precision if precision in ('fp32', 'bf16x3') else ('bf16_storage' if storage == 'bf16' else 'bf16')
+    return precision if precision in ('fp32', 'f16x2') else ('bf16_storage' if storage == 'bf16' else 'bf16')
 
 
 def parse_args(argv=None):
@@ -58,9 +59,10 @@ def parse_args(argv=None):
                     help='auto: time the oracle on the WHOLE volume without mirroring when a probe says that fits in '
                          '~60 s (it does on the GPU box), else on one patch; full / sample force one of the two')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='same as --cpu-baseline off')
-    ap.add_argument('--precision', choices=['fp32', 'bf16', 'bf16x3'], default='fp32',
-                    help='bf16 = BASELINE.json configs[2] (bf16 matrix-core operands, fp32 accumulate); bf16x3 = fp32 tensors, '
-                         'products from bf16 pairs (fp32-grade results on the bf16 instruction); neither is the headline')
+    ap.add_argument('--precision', choices=['fp32', 'bf16', 'f16x2'], default='f16x2',
+                    help='f16x2 (default, the headline): fp32 tensors and accumulation, every product from fp16 pairs (21-22 significant '
+                         'bits per operand; softmax within 1e-5 of the fp32 CPU oracle at full size); fp32 = the exact-fp32 kernels; '
+                         'bf16 = BASELINE.json configs[2] (bf16 matrix-core operands, fp32 accumulate)')
     ap.add_argument('--storage', choices=['fp32', 'bf16'], default='fp32',
                     help='bf16 (with --precision bf16): activation tensors are kept as bf16; not the headline')
     ap.add_argument('--volumes-per-step', type=int, default=0,
@@ -68,6 +70,9 @@ def parse_args(argv=None):
     ap.add_argument('--shard', choices=['volumes', 'patches'], default='volumes',
                     help='volumes: one volume per rank per step (weak scaling, no collective); patches: ONE volume per '
                          'step, its patches split over the ranks with an RCCL all-gather of the weighted tiles (strong)')
+    ap.add_argument('--also', choices=['auto', 'off'], default='auto',
+                    help='auto (N=1, fp32 headline only): after the headline, measure configs[2] (channels-last bf16, 8 volumes per '
+                         'step), the f16x2 mode and one training iteration (fp32, bf16) and report them in an "also" object')
     ap.add_argument('--dry-run', action='store_true',
                     help='launch plumbing only (CPU test of --gpus N): gloo process group, no kernels, value null')
     args = ap.parse_args(argv)
@@ -100,12 +105,14 @@ def self_launch(argv):
 # ------------------------------------------------------------------------------------------------------------
 # CPU baseline (the oracle as the checker and as the reported baseline; never in the timed GPU region)
 # ------------------------------------------------------------------------------------------------------------
-def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits):
+def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits, extra_notta=None):
     """Times the CPU oracle (kind 'port': our torch-CPU restatement of nnU-Net; the reference's own nnU-Net
     fork is not available).  'full': the whole volume without mirroring -- 8 patch forwards + Gaussian
     aggregation + argmax, after one warm-up forward -- which is the complete path at 1/8 of the mirrored
     forward count; the mirrored figure is that time with the forward part x8.  'sample': one patch forward.
-    gpu_notta: (seg, prob) numpy of the HIP path on the same volume without mirroring, or None."""
+    gpu_notta: (seg, prob) numpy of the HIP path on the same volume without mirroring, or None.
+    extra_notta: {mode name: (seg, prob)} of other fp32-grade modes to check against the same oracle run (returned as a
+    third value, {mode name: parity dict})."""
     import torch
     from oracle import sliding_window as osw
     from oracle.generic_unet import unet_from_plan
@@ -116,7 +123,7 @@ def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits):
     P = plan.patch_size
     x = torch.from_numpy(np.ascontiguousarray(vol[None, :, :P[0], :P[1], :P[2]]))
     sub = x[:, :, :P[0] // 2, :P[1] // 2, :P[2] // 2]
-    npatch, mirrors, parity = 8, (8 if tta else 1), None
+    npatch, mirrors, parity, parity_extra = 8, (8 if tta else 1), None, {}
     with torch.no_grad():
         net(sub)                                    # cold: oneDNN primitive creation
         t0 = time.time()
@@ -161,14 +168,17 @@ def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits):
                           % (vol.shape[1], vol.shape[2], vol.shape[3], t_full, npatch, fwd_s[0], t_full - fwd_s[0],
                              1.0 / t_full, t_est, cores),
                    timed_no_mirroring=dict(value=1.0 / t_full, seconds=round(t_full, 2), forward_seconds=round(fwd_s[0], 2)))
+        margin = np.abs(prob_o[1] - prob_o[0])
+
+        def versus_oracle(seg_g, prob_g):
+            return dict(sample='whole volume, 8 tiles, Gaussian aggregation, no mirroring: HIP path vs oracle',
+                        max_abs_softmax_err=float(np.abs(prob_g - prob_o).max()),
+                        argmax_mismatches=int(((seg_g != seg_o) & (margin > 2e-4)).sum()),
+                        argmax_mismatches_any_margin=int((seg_g != seg_o).sum()),
+                        dice_vs_oracle_mask=float(osw.hard_dice_binary(seg_o, seg_g)))
         if gpu_notta is not None:
-            seg_g, prob_g = gpu_notta
-            margin = np.abs(prob_o[1] - prob_o[0])
-            parity = dict(sample='whole volume, 8 tiles, Gaussian aggregation, no mirroring: HIP path vs oracle',
-                          max_abs_softmax_err=float(np.abs(prob_g - prob_o).max()),
-                          argmax_mismatches=int(((seg_g != seg_o) & (margin > 2e-4)).sum()),
-                          argmax_mismatches_any_margin=int((seg_g != seg_o).sum()),
-                          dice_vs_oracle_mask=float(osw.hard_dice_binary(seg_o, seg_g)))
+            parity = versus_oracle(*gpu_notta)
+        parity_extra = {k: versus_oracle(*v) for k, v in (extra_notta or {}).items()}
     else:
         if t_patch is not None:
             t, frac = t_patch, 1.0
@@ -185,7 +195,7 @@ def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits):
         parity = dict(sample='first patch, no mirroring',
                       max_abs_softmax_err=float(np.abs(sm(gpu_patch_logits) - sm(ref_patch)).max()),
                       argmax_mismatches=int(((gpu_patch_logits.argmax(1) != ref_patch.argmax(1)) & (margin > 4e-4)).sum()))
-    return out, parity
+    return out, parity, parity_extra
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -231,17 +241,151 @@ def workload_string(args, tta, forwards, world):
     shp = '%dx%dx%d' % tuple(args.shape)
     mir = 'mirroring (TTA x8) %s' % ('on' if tta else 'off')
     if args.precision == 'fp32':
-        return ('configs[1]: one %s FLAIR volume per GPU, 128^3 patches, step 0.5, fp32, Gaussian aggregation, %s; '
+        return ('configs[1] on the exact-fp32 kernels: one %s FLAIR volume per GPU, 128^3 patches, step 0.5, fp32, Gaussian aggregation, %s; '
                 '%d patch forwards per volume' % (shp, mir, forwards))
-    if args.precision == 'bf16x3':
-        return ('configs[1] workload in the opt-in bf16x3 mode: one %s FLAIR volume per GPU, 128^3 patches, step 0.5, fp32 tensors, '
-                'stride-1 3x3x3 products from bf16 pairs (16 mantissa bits per operand, fp32 accumulate), Gaussian aggregation, %s; '
+    if args.precision == 'f16x2':
+        return ('configs[1]: one %s FLAIR volume per GPU, 128^3 patches, step 0.5, fp32 tensors and accumulation, 3x3x3 products '
+                'formed from fp16 pairs (21-22 significant bits per operand; all other layers exact fp32), Gaussian aggregation, %s; '
                 '%d patch forwards per volume' % (shp, mir, forwards))
     return ('configs[2]: bf16 forward (bf16 matrix-core operands, fp32 accumulate, %s activation tensors, fused '
             'InstanceNorm+LeakyReLU), batch of %d synthetic %s volumes per step per GPU, 128^3 patches, step 0.5, Gaussian '
             'aggregation, %s; %d patch forwards per volume'
             % ('bf16' if args.storage == 'bf16' else 'fp32', args.volumes_per_step, shp, mir, forwards))
 
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the other modes, on the same record (N = 1): exact fp32, configs[2], one training iteration
+# ------------------------------------------------------------------------------------------------------------
+TRAIN_TFLOP_PER_ITER = 5.727       # batch 2 x 128^3, forward + backward = 3 x 2 x 954.55 GFLOP
+
+
+def measure_inference_mode(plan, sd, device, precision, storage, V, steps, warmup, tta, shape, ref32=None):
+    """One more inference mode with the headline's timing protocol (H2D + hot path + D2H per volume, HIP events on the
+    dominant kernel's launches).  ref32: (seg, prob) device tensors of the fp32 HIP path on volume 0, for the accuracy figures."""
+    import torch
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    from deepwmh_amd.synthetic import synthetic_flair
+    eng = UNetEngine(plan, sd, device, precision=precision, storage=storage)
+    pred = SlidingWindowPredictor(eng, do_mirroring=tta, batch=8)
+    vols_h = [torch.from_numpy(synthetic_flair(tuple(shape), seed=v)).pin_memory() for v in range(V)]
+    seg_h = torch.empty(tuple(shape), dtype=torch.uint8).pin_memory()
+    vol_d = torch.empty((1,) + tuple(shape), dtype=torch.float32, device=device)
+
+    def run_step():
+        for v in range(V):
+            vol_d.copy_(vols_h[v], non_blocking=True)
+            out = pred.predict_device(vol_d, return_prob=True)
+            seg_h.copy_(out[0], non_blocking=True)
+        return out
+
+    for _ in range(warmup):
+        run_step()
+    eng.timed_cfgs, eng.timings, eng.acct = {0}, [], dict(flop=0.0, bytes=0.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.timed_cfgs = set()
+    acct, eng.acct = eng.acct, None
+    forwards = 8 * (8 if tta else 1)
+    nvol = steps * V
+    gb_vol = acct['bytes'] / nvol / 1e9 + AGG_GBYTES_PER_VOLUME
+    out = dict(volumes_per_step=V, steps=steps, warmup=warmup, ms_per_step=round(1e3 * dt / steps, 3), value=round(nvol / dt, 4),
+               unit='volumes/s', end_to_end_tflops=round(forwards * FWD_GFLOP_PER_PATCH / 1e3 * nvol / dt, 2),
+               hbm_whole_path=dict(algorithmic_gbytes_per_volume=round(gb_vol, 2), achieved_gbs=round(gb_vol * nvol / dt, 1),
+                                   peak_gbs=HBM_PEAK_GBS, frac=round(gb_vol * nvol / dt / HBM_PEAK_GBS, 4)),
+               roofline=roofline_block(eng.timings, precision, storage, dt))
+    if ref32 is not None:
+        vol_d.copy_(vols_h[0])
+        s16, p16 = pred.predict_device(vol_d, return_prob=True)
+        s32, p32 = ref32
+        inter = float(((s16 > 0) & (s32 > 0)).sum())
+        out['parity_vs_fp32_path'] = dict(
+            max_abs_softmax_diff=float((p16 - p32).abs().max()), voxels_changing_class=int((s16 != s32).sum()), voxels=int(s32.numel()),
+            dice_vs_fp32_mask=2 * inter / (float((s16 > 0).sum()) + float((s32 > 0).sum()) + 1e-6))
+    return out, eng, vol_d, vols_h
+
+
+def measure_training_mode(plan, sd, device, precision, iters, warmup):
+    """One nnUNetTrainerV2 iteration (forward with deep supervision, Dice+CE, backward, clip, SGD-Nesterov) at batch 2 x 128^3,
+    BASELINE plan, synthetic patches and labels resident in HBM."""
+    import torch
+    from deepwmh_amd.trainer import UNetTrainer, downsample_targets
+    tr = UNetTrainer(plan, sd, device, precision=precision)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    x = torch.randn(2, 1, 128, 128, 128, generator=g).to(device)
+    lab = (torch.rand(2, 128, 128, 128, generator=g) < 0.05).to(torch.uint8).to(device)
+    td = downsample_targets(lab, plan.num_pool, plan.pool_op_kernel_sizes)
+    losses = []
+    for _ in range(warmup):
+        losses.append(tr.run_iteration(x, td, 1e-2).clone())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        losses.append(tr.run_iteration(x, td, 1e-2).clone())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tflops = TRAIN_TFLOP_PER_ITER * iters / dt
+    peak = PEAK_TFLOPS['fp32' if precision == 'fp32' else 'bf16']
+    losses = [float(v) for v in torch.stack(losses).cpu()]
+    del tr
+    return dict(workload='one nnUNetTrainerV2 iteration, batch 2 x 128^3, BASELINE plan (31.2 M parameters), deep supervision, Dice+CE, '
+                         'clip 12, SGD-Nesterov; %s' % ('fp32 throughout' if precision == 'fp32' else
+                                                        'bf16 matrix-core operands for the stride-1 convolutions of the wide levels '
+                                                        '(forward, data and weight gradients), fp32 master weights / statistics / optimizer'),
+                steps=iters, warmup=warmup, ms_per_step=round(1e3 * dt / iters, 3), value=round(2 * iters / dt, 3), unit='patches/s',
+                loss_first_to_last=[round(losses[0], 6), round(losses[-1], 6)],
+                roofline=dict(bound='mfma', kernel='whole iteration (every launch of the step)', achieved=round(tflops, 2), peak=peak,
+                              unit='TFLOP/s', frac=round(tflops / peak, 4), algorithmic_tflop_per_step=TRAIN_TFLOP_PER_ITER,
+                              note='fp32: v_mfma_f32_32x32x2_f32 peak; bf16: priced against the bf16 peak although the stride-2 layers, '
+                                   'statistics and reductions of this mode stay fp32'))
+
+
+def training_parity_tiny():
+    """The training step against torch autograd (the oracle's restatement of nnUNetTrainerV2.run_iteration) on the committed tiny
+    network: loss and every parameter gradient of one iteration, fp32 and bf16 modes.  The checker, not the thing measured."""
+    import copy
+    import torch
+    from deepwmh_amd.plan import tiny_plan
+    from deepwmh_amd.trainer import UNetTrainer, downsample_targets
+    from oracle import training as ot
+    from oracle.generic_unet import unet_from_plan
+    plan = tiny_plan(patch=32, base=4, num_pool=3, max_feat=32)
+    sd = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'tiny_net_weights.npz')))
+    io = np.load(os.path.join(ROOT, 'tests', 'golden', 'tiny_net_io.npz'))
+    vol = io['volume'][0]
+    data = np.stack([vol[4:36, 8:40, 4:36], vol[8:40, 0:32, 2:34][::-1].copy()])[:, None].astype(np.float32)
+    labels = np.stack([(io['seg_tta'][4:36, 8:40, 4:36] > 0), np.random.default_rng(5).random((32, 32, 32)) < 0.2]).astype(np.uint8)
+    net = unet_from_plan(plan)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net = copy.deepcopy(net).train()
+    net.do_ds = True
+    weights = ot.deep_supervision_weights(plan.num_pool)
+    x = torch.from_numpy(data)
+    tgt = ot.downsample_targets(torch.from_numpy(labels[:, None].astype(np.float32)), plan.num_pool)
+    loss = ot.multiple_output_loss(net(x), tgt, weights)
+    loss.backward()
+    out = {}
+    for precision in ('fp32', 'bf16'):
+        tr = UNetTrainer(plan, sd, 'cuda:0', precision=precision)
+        tr.forward(x.cuda())
+        l = float(tr.backward(downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)).cpu())
+        num = den = worst = 0.0
+        for name, p in net.named_parameters():
+            ref = p.grad if p.grad is not None else torch.zeros_like(p)
+            got = tr.g[name].cpu()
+            num += float(((got - ref) ** 2).sum())
+            den += float((ref ** 2).sum())
+            if float(ref.abs().max()) > 1e-5:
+                worst = max(worst, float((got - ref).abs().max()) / float(ref.abs().max()))
+        out[precision] = dict(sample='tiny net (tests/golden), batch 2 x 32^3, one iteration vs torch autograd on the CPU',
+                              loss=l, oracle_loss=float(loss.detach()), gradient_rel_l2_err=(num / max(den, 1e-30)) ** 0.5,
+                              worst_parameter_rel_max_err=worst)
+    return out
 
 # ------------------------------------------------------------------------------------------------------------
 def run_rank(args):
@@ -341,7 +485,7 @@ def run_rank(args):
         vols_rank = args.steps * V                      # volumes this rank queued in the timed region
         gb_vol = acct['bytes'] / vols_rank / 1e9 + AGG_GBYTES_PER_VOLUME
         dtype = ('f32' if args.precision == 'fp32' else
-                 'f32 tensors and accumulate / bf16x3 products (two bf16 per operand)' if args.precision == 'bf16x3' else
+                 'f32 tensors and accumulate / f16x2 products (two bf16 per operand)' if args.precision == 'f16x2' else
                  'bf16 operands / f32 accumulate+storage' if args.storage == 'fp32' else
                  'bf16 operands and activation tensors / f32 accumulate')
         res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=nvol / dt,
@@ -361,8 +505,8 @@ def run_rank(args):
                                        achieved_gbs=round(gb_vol * nvol / dt, 1), peak_gbs=HBM_PEAK_GBS,
                                        frac=round(gb_vol * nvol / dt / HBM_PEAK_GBS, 4)),
                    roofline=roofline)
-        if args.precision != 'fp32':
-            # accuracy of the reduced-precision mode against the fp32 HIP path on the same volume (same weights)
+        if args.precision == 'bf16' or (args.precision == 'f16x2' and args.also == 'off'):
+            # accuracy of the mode against the exact-fp32 HIP path on the same volume (same weights)
             eng32 = UNetEngine(plan, sd, device)
             pred32 = SlidingWindowPredictor(eng32, do_mirroring=tta, batch=8)
             vol_d.copy_(vols_h[0])
@@ -375,17 +519,58 @@ def run_rank(args):
                 voxels_changing_class=int((s16 != s32).sum()), voxels=int(s32.numel()),
                 dice_vs_fp32_mask=2 * inter / (float((s16 > 0).sum()) + float((s32 > 0).sum()) + 1e-6))
             del eng32, pred32
+        also_on = args.also == 'auto' and world == 1 and args.precision == 'f16x2' and not by_patch
+        extra_nt = {}
+        if also_on:
+            # every other mode on the driver's record: short runs, same protocol, after the headline's timed region
+            also = {}
+            m, e32, vd32, vh32 = measure_inference_mode(plan, sd, device, 'fp32', 'fp32', 1, 3, 1, tta, args.shape, None)
+            m['workload'] = 'configs[1] on the exact-fp32 kernels (v_mfma_f32_32x32x2_f32), mirroring %s' % ('on' if tta else 'off')
+            m['dtype'] = 'f32'
+            also['fp32_exact'] = m
+            p32 = SlidingWindowPredictor(e32, do_mirroring=tta, batch=8)
+            vd32.copy_(vh32[0])
+            s32, q32 = p32.predict_device(vd32, return_prob=True)
+            ref32 = (s32.clone(), q32.clone())
+            vol_d.copy_(vols_h[0])
+            sh, ph = pred.predict_device(vol_d, return_prob=True)
+            inter = float(((sh > 0) & (ref32[0] > 0)).sum())
+            res['parity_vs_fp32_path'] = dict(
+                max_abs_softmax_diff=float((ph - ref32[1]).abs().max()), voxels_changing_class=int((sh != ref32[0]).sum()), voxels=int(sh.numel()),
+                dice_vs_fp32_mask=2 * inter / (float((sh > 0).sum()) + float((ref32[0] > 0).sum()) + 1e-6))
+            if args.cpu_baseline != 'off':
+                s3, p3 = SlidingWindowPredictor(e32, do_mirroring=False, batch=8).predict_device(vd32, return_prob=True)
+                extra_nt['fp32_exact'] = (s3.cpu().numpy(), p3.cpu().numpy())
+            del e32, p32
+            torch.cuda.empty_cache()
+            m, e16, _, _ = measure_inference_mode(plan, sd, device, 'bf16', 'bf16', 8, 2, 1, tta, args.shape, ref32)
+            m['workload'] = ('configs[2]: bf16 forward on channels-last bf16 tensors (wide levels), fused InstanceNorm+LeakyReLU, batch of 8 '
+                             'synthetic volumes per step, mirroring %s' % ('on' if tta else 'off'))
+            m['dtype'] = 'bf16 operands and activation tensors / f32 accumulate'
+            also['configs2_bf16_storage'] = m
+            del e16, ref32
+            torch.cuda.empty_cache()
+            for prec in ('fp32', 'bf16'):
+                also['train_' + prec] = measure_training_mode(plan, sd, device, prec, 5, 2)
+                torch.cuda.empty_cache()
+            if args.cpu_baseline != 'off':
+                tp = training_parity_tiny()
+                for prec in ('fp32', 'bf16'):
+                    also['train_' + prec]['parity'] = tp[prec]
+            res['also'] = also
         if world == 1 and args.cpu_baseline != 'off':
             P = plan.patch_size
             vol_d.copy_(vols_h[0])
-            # the oracle check runs on the engine of the mode when the mode claims fp32-grade results (fp32, bf16x3)
-            eng32 = eng if args.precision in ('fp32', 'bf16x3') else UNetEngine(plan, sd, device)
+            # the oracle check runs on the engine of the mode when the mode claims fp32-grade results (fp32, f16x2)
+            eng32 = eng if args.precision in ('fp32', 'f16x2') else UNetEngine(plan, sd, device)
             x = vol_d[None, :, :P[0], :P[1], :P[2]].contiguous()
             lg = eng32.forward_logits(x).cpu().numpy()
             p_nt = SlidingWindowPredictor(eng32, do_mirroring=False, batch=8)
             seg_nt, prob_nt = p_nt.predict_device(vol_d, return_prob=True)
             gpu_nt = (seg_nt.cpu().numpy(), prob_nt.cpu().numpy())
-            res['cpu_baseline'], res['parity'] = cpu_baseline(plan, sd, vols_h[0].numpy(), tta, args.cpu_baseline, gpu_nt, lg)
+            res['cpu_baseline'], res['parity'], px = cpu_baseline(plan, sd, vols_h[0].numpy(), tta, args.cpu_baseline, gpu_nt, lg, extra_nt)
+            for k, v in px.items():
+                res['also'][k]['parity_vs_oracle'] = v
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

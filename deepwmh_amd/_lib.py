@@ -26,14 +26,14 @@ SIGNATURES = {
     'wmh_conv3d_k3_packed_halfs_bf16': (_sz, [_i, _i, _i]),
     'wmh_conv3d_k3_pack_weights_bf16': (_i, [_i, _vp, _i, _i, _vp]),
     'wmh_conv3d_k3_num_partials_bf16': (_i, [_i, _i, _i, _i, _i]),
-    'wmh_conv3d_k3_num_partials_bf16x3': (_i, [_i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_num_partials_f16x2': (_i, [_i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_pack_weights_bf16_device': (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    'wmh_conv3d_k3_bf16x3_supported': (_i, [_i]),
-    'wmh_conv3d_k3_packed_halfs_bf16x3': (_sz, [_i, _i, _i]),
-    'wmh_conv3d_k3_pack_weights_bf16x3': (_i, [_i, _vp, _i, _i, _vp]),
-    'wmh_conv3d_k3_pack_weights_bf16x3_device': (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    'wmh_conv3d_k3_bf16x3_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
-    'wmh_conv3d_k3_fwd_bf16x3': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_conv3d_k3_f16x2_supported': (_i, [_i]),
+    'wmh_conv3d_k3_packed_halfs_f16x2': (_sz, [_i, _i, _i]),
+    'wmh_conv3d_k3_pack_weights_f16x2': (_i, [_i, _vp, _i, _i, _vp]),
+    'wmh_conv3d_k3_pack_weights_f16x2_device': (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'wmh_conv3d_k3_f16x2_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_fwd_f16x2': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_bf16_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_fwd_bf16_splitk': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_fwd_bf16': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),

@@ -84,8 +84,8 @@ def main(argv=None):
 
     bs = int(plans['plans_per_stage'][max(plans['plans_per_stage'].keys())]['batch_size'])
     precision = 'bf16' if (args.bf16 or os.environ.get('WMH_TRAIN_PRECISION', '') == 'bf16') and not args.fp32 else 'fp32'
-    if os.environ.get('WMH_TRAIN_PRECISION', '') == 'bf16x3' and not args.fp32 and not args.bf16:
-        precision = 'bf16x3'                            # fp32-grade products from bf16 pairs in the forward / data-gradient convolutions
+    if os.environ.get('WMH_TRAIN_PRECISION', '') == 'f16x2' and not args.fp32 and not args.bf16:
+        precision = 'f16x2'                            # fp32-grade products from fp16 pairs in the forward / data-gradient convolutions
     start_epoch, best, ma_resume = 0, None, None
     latest = os.path.join(fdir, 'model_latest.model')
     if args.continue_training and os.path.isfile(latest):

@@ -7,6 +7,9 @@
 #include "wmh_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// the "pair" mode (fp16 hi + lo per operand): the weights are split after scaling by this power of two (their low parts then stay
+// in fp16's normal range down to |w| ~ 5e-4), the accumulators are scaled back before the epilogue
+#define WMH_PAIR_WSCALE 256.f
 
 struct ConvArgs {
     const float* x0; const float* ss0; int C0;

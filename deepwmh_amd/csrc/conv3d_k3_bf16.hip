@@ -29,11 +29,11 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {     // v_c
     return __builtin_bit_cast(unsigned, b);
 }
 
-// X3: the bf16x3 form (conv3d_k3_bf16_ws.hip): chunks of 8 channels staged as [hi | lo] bf16 pairs, every tap issued with the
+// PAIR: the f16x2 form (conv3d_k3_bf16_ws.hip): chunks of 8 channels staged as [hi | lo] bf16 pairs, every tap issued with the
 // high and with the low parts of the weights (a fragment's lanes 0-31 / 32-63)
-template <class C, int RIT, bool X3 = false>
+template <class C, int RIT, bool PAIR = false>
 __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d_k3_bf16_kernel(const ConvArgs a) {
-    constexpr int S = C::S, MT = C::MT, NT = C::NT, NIT = C::NIT, THREADS = C::THREADS, APF = 4, CKB = X3 ? 8 : 16, NA = X3 ? 2 : 1;
+    constexpr int S = C::S, MT = C::MT, NT = C::NT, NIT = C::NIT, THREADS = C::THREADS, APF = 4, CKB = PAIR ? 8 : 16, NA = PAIR ? 2 : 1;
     static_assert(C::TN == 1, "one sample per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];      // [CS voxels][2]
 
@@ -91,20 +91,20 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = (g * NT + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const float bv = (a.KS == 1 && a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+            const float bv = (a.KS == 1 && a.bias != nullptr && co < a.Cout) ? a.bias[co] * (PAIR ? WMH_PAIR_WSCALE : 1.f) : 0.f;
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[nt][m][r] = bv;
         }
 
-    const bf16x8* wl = reinterpret_cast<const bf16x8*>(a.wf) + (size_t)g * a.nchunks * 27 * NT * 64 + (X3 ? j : lane);
+    const bf16x8* wl = reinterpret_cast<const bf16x8*>(a.wf) + (size_t)g * a.nchunks * 27 * NT * 64 + (PAIR ? j : lane);
     const int Tlast = ch_hi * 27 - 1;
-    bf16x8 aring[APF][NT * NA];                                   // X3: [nt] = high parts, [NT + nt] = low parts, both lane halves alike
+    bf16x8 aring[APF][NT * NA];                                   // PAIR: [nt] = high parts, [NT + nt] = low parts, both lane halves alike
     auto loadA = [&](int T, bf16x8 (&dst)[NT * NA]) {
         T = min(T, Tlast);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             dst[nt] = wl[((size_t)T * NT + nt) * 64];
-            if constexpr (X3) dst[NT + nt] = wl[((size_t)T * NT + nt) * 64 + 32];
+            if constexpr (PAIR) dst[NT + nt] = wl[((size_t)T * NT + nt) * 64 + 32];
         }
     };
 #pragma unroll
@@ -155,10 +155,16 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
                     float t1 = fmaf(v[ii][c + 1], scv[c + 1], shv[c + 1]);
                     t0 = fmaxf(t0, t0 * slope_eff);
                     t1 = fmaxf(t1, t1 * slope_eff);
-                    const unsigned u = pack_bf16x2(t0, t1);
-                    w[c >> 1] = u & keep;
-                    if constexpr (X3)                      // words 4-7: what is left after the high parts, rounded to bf16 again
-                        w[4 + (c >> 1)] = pack_bf16x2(t0 - __uint_as_float(u << 16), t1 - __uint_as_float(u & 0xFFFF0000u)) & keep;
+                    if constexpr (PAIR) {                    // fp16 pair (conv3d_k3_bf16_ws.hip): words 0-3 high parts (toward zero), 4-7 the remainders (nearest)
+                        const auto h2 = __builtin_amdgcn_cvt_pkrtz(t0, t1);
+                        w[c >> 1] = __builtin_bit_cast(unsigned, h2) & keep;
+                        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                        const f32x2_t lo2 = {t0 - (float)h2[0], t1 - (float)h2[1]};
+                        w[4 + (c >> 1)] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo2, f16x2_t)) & keep;
+                    } else {
+                        w[c >> 1] = pack_bf16x2(t0, t1) & keep;
+                    }
                 }
                 const int e = tid + it * THREADS;
                 const int key = (keymask >> it) & 1u;
@@ -182,8 +188,13 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
                 const bf16x8 bv = *reinterpret_cast<const bf16x8*>(ldsb + badr[kw][m] + rowoff);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[0][nt], bv, acc[nt][m], 0, 0, 0);
-                    if constexpr (X3) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[0][NT + nt], bv, acc[nt][m], 0, 0, 0);
+                    if constexpr (PAIR) {
+                        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aring[0][nt]), __builtin_bit_cast(f16x8, bv), acc[nt][m], 0, 0, 0);
+                        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aring[0][NT + nt]), __builtin_bit_cast(f16x8, bv), acc[nt][m], 0, 0, 0);
+                    } else {
+                        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[0][nt], bv, acc[nt][m], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
@@ -196,6 +207,12 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
         if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mfma += t - t_mark; }
     }
     if (a.stamps) t_mark = __builtin_amdgcn_s_memtime();
+    if constexpr (PAIR) {                                   // undo the weights' 2^8 (exact; split-K slabs hold unscaled partial sums)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[nt][m] *= (1.f / WMH_PAIR_WSCALE);
+    }
     if (!(abl & 2)) conv_epilogue<C>(a, acc, g, ks, n0, wave, j, kh, dx, dy, dz, ts0, oz0, oy0, ox0, (tz * a.nty + ty) * a.ntx + tx);
     if (a.stamps && tid == 0) {
         unsigned long long* o = a.stamps + (size_t)blockIdx.x * 4;
@@ -261,9 +278,9 @@ extern "C" int wmh_conv3d_k3_num_partials_bf16(int cfg, int N, int Do, int Ho, i
     const BGeo ge = bf16_geo(cfg, w8);
     return cdiv(Wo, ge.TX) * cdiv(Ho, ge.TY) * cdiv(Do, ge.TZ) * ge.WPS;
 }
-// ... and by wmh_conv3d_k3_fwd_bf16x3, which always runs the four-consumer-wave geometry (WMH_BF16_WAVES8 does not apply to it)
-extern "C" int wmh_conv3d_k3_num_partials_bf16x3(int cfg, int N, int Do, int Ho, int Wo) {
-    if (!bf16_nt(cfg)) return wmh_fail(WMH_EINVAL, "num_partials_bf16x3: configuration has no bf16x3 kernel");
+// ... and by wmh_conv3d_k3_fwd_f16x2, which always runs the four-consumer-wave geometry (WMH_BF16_WAVES8 does not apply to it)
+extern "C" int wmh_conv3d_k3_num_partials_f16x2(int cfg, int N, int Do, int Ho, int Wo) {
+    if (!bf16_nt(cfg)) return wmh_fail(WMH_EINVAL, "num_partials_f16x2: configuration has no f16x2 kernel");
     (void)N;
     const BGeo ge = bf16_geo(cfg, false);
     return cdiv(Wo, ge.TX) * cdiv(Ho, ge.TY) * cdiv(Do, ge.TZ) * ge.WPS;
@@ -292,19 +309,21 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16(int cfg, const float* w, int Cin,
     return WMH_OK;
 }
 
-// ---- bf16x3 (conv3d_k3_bf16_ws.hip, X3): chunks of 8 input channels, a lane's 16 bytes are the HIGH bf16 parts of its output
-// channel's 8 weights (lanes 0-31) or the LOW parts (lanes 32-63): w = hi + lo + O(2^-17 w)
-extern "C" int wmh_conv3d_k3_bf16x3_supported(int cfg) { return cfg == 0 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE || cfg == 3 || cfg == 4 || cfg == 5; }
-extern "C" size_t wmh_conv3d_k3_packed_halfs_bf16x3(int cfg, int Cin, int Cout) {
+// ---- the "pair" mode (entry points keep round 2's f16x2 names; conv3d_k3_bf16_ws.hip, PAIR): chunks of 8 input channels, a lane's
+// 16 bytes are the HIGH fp16 parts of its output channel's 8 weights (lanes 0-31) or the LOW parts (lanes 32-63), of the
+// weights scaled by 2^8: 256 w = hi + lo + O(2^-22 w).  |w| must stay below 255 (fp16's range after the scaling).
+extern "C" int wmh_conv3d_k3_f16x2_supported(int cfg) { return cfg == 0 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE || cfg == 3 || cfg == 4 || cfg == 5; }
+extern "C" size_t wmh_conv3d_k3_packed_halfs_f16x2(int cfg, int Cin, int Cout) {
     const int NT = bf16_nt(cfg);
-    if (!NT || !wmh_conv3d_k3_bf16x3_supported(cfg)) return 0;
+    if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg)) return 0;
     return (size_t)cdiv(Cout, 32 * NT) * cdiv(Cin, 8) * 27 * NT * 64 * 8;
 }
-static inline float bf2f(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline uint16_t f2h(float v) { const _Float16 h = (_Float16)v; uint16_t u; memcpy(&u, &h, 2); return u; }     // nearest even
+static inline float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
 // w: host fp32 torch layout [Cout][Cin][27]; wf: host uint16 out, [G][cin/8][tap][NT][lane][8]
-extern "C" int wmh_conv3d_k3_pack_weights_bf16x3(int cfg, const float* w, int Cin, int Cout, uint16_t* wf) {
+extern "C" int wmh_conv3d_k3_pack_weights_f16x2(int cfg, const float* w, int Cin, int Cout, uint16_t* wf) {
     const int NT = bf16_nt(cfg);
-    if (!NT || !wmh_conv3d_k3_bf16x3_supported(cfg) || !w || !wf) return wmh_fail(WMH_EINVAL, "pack_weights_bf16x3: unsupported cfg or null");
+    if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg) || !w || !wf) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2: unsupported cfg or null");
     const int G = cdiv(Cout, 32 * NT), NCH = cdiv(Cin, 8);
     for (int g = 0; g < G; ++g)
         for (int ch = 0; ch < NCH; ++ch)
@@ -314,9 +333,10 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16x3(int cfg, const float* w, int Ci
                         for (int e = 0; e < 8; ++e) {
                             const int co = (g * NT + nt) * 32 + (lane & 31), ci = ch * 8 + e;
                             float v = 0.f;
-                            if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 27 + tap];
-                            const uint16_t hi = f2bf(v);
-                            wf[(((((size_t)g * NCH + ch) * 27 + tap) * NT + nt) * 64 + lane) * 8 + e] = (lane >> 5) ? f2bf(v - bf2f(hi)) : hi;
+                            if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 27 + tap] * WMH_PAIR_WSCALE;
+                            if (!(v > -65000.f && v < 65000.f)) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2: a weight is not finite or exceeds +-253 (fp16 pair range)");
+                            const uint16_t hi = f2h(v);
+                            wf[(((((size_t)g * NCH + ch) * 27 + tap) * NT + nt) * 64 + lane) * 8 + e] = (lane >> 5) ? f2h(v - h2f(hi)) : hi;
                         }
     return WMH_OK;
 }
@@ -355,9 +375,9 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16_device(int cfg, const float* w, i
     return wmh_check_launch("pack_bf16_kernel");
 }
 
-// The bf16x3 image on the device (training: weights change every step): modes as above, chunks of 8 input channels,
+// The f16x2 image on the device (training: weights change every step): modes as above, chunks of 8 input channels,
 // high parts on lanes 0-31 and low parts on lanes 32-63 of every fragment.
-__global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* w, uint16_t* wf, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
+__global__ __launch_bounds__(256) void pack_f16x2_kernel(const float* w, uint16_t* wf, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
                                                            int NT, int NCH, size_t total) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         size_t r = idx;
@@ -371,31 +391,31 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* w, uint16
         float v = 0.f;
         if (mode == 0) { if (eco < Cout && eci < ci_cnt) v = w[((size_t)eco * Cin_total + ci_off + eci) * 27 + tap]; }
         else           { if (eco < ci_cnt && eci < Cout) v = w[((size_t)eci * Cin_total + ci_off + eco) * 27 + (26 - tap)]; }
-        const unsigned u = __float_as_uint(v);
-        const unsigned hi = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-        const unsigned ul = __float_as_uint(v - __uint_as_float(hi << 16));
-        wf[idx] = (uint16_t)((lane >> 5) ? (ul + 0x7FFFu + ((ul >> 16) & 1u)) >> 16 : hi);
+        v = fminf(fmaxf(v * WMH_PAIR_WSCALE, -65000.f), 65000.f);          // (training: a weight beyond +-253 saturates instead of overflowing)
+        const _Float16 hi = (_Float16)v;
+        const _Float16 out = (lane >> 5) ? (_Float16)(v - (float)hi) : hi;
+        wf[idx] = __builtin_bit_cast(uint16_t, out);
     }
 }
-extern "C" int wmh_conv3d_k3_pack_weights_bf16x3_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
+extern "C" int wmh_conv3d_k3_pack_weights_f16x2_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
                                                         uint16_t* wf, void* stream) {
     const int NT = bf16_nt(cfg);
-    if (!NT || !wmh_conv3d_k3_bf16x3_supported(cfg) || !w || !wf || ci_off < 0 || ci_cnt < 1 || ci_off + ci_cnt > Cin_total || (mode != 0 && mode != 1))
-        return wmh_fail(WMH_EINVAL, "pack_weights_bf16x3_device: bad args or configuration without a bf16x3 kernel");
+    if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg) || !w || !wf || ci_off < 0 || ci_cnt < 1 || ci_off + ci_cnt > Cin_total || (mode != 0 && mode != 1))
+        return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: bad args or configuration without a f16x2 kernel");
     const int eCin = mode == 0 ? ci_cnt : Cout, eCout = mode == 0 ? Cout : ci_cnt;
     const int NCH = cdiv(eCin, 8);
     const size_t total = (size_t)cdiv(eCout, 32 * NT) * NCH * 27 * NT * 64 * 8;
     unsigned nb = (unsigned)((total + 255) / 256); if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wf, Cin_total, Cout, ci_off, ci_cnt, mode, NT, NCH, total);
-    return wmh_check_launch("pack_bf16x3_kernel");
+    hipLaunchKernelGGL(pack_f16x2_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wf, Cin_total, Cout, ci_off, ci_cnt, mode, NT, NCH, total);
+    return wmh_check_launch("pack_f16x2_kernel");
 }
 
-template <class C, int RIT, bool X3 = false>
+template <class C, int RIT, bool PAIR = false>
 static int launch_bf16(const ConvArgs& a, unsigned nblk, hipStream_t st) {
     const int lds = C::CS * 32;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_kernel<C, RIT, X3>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_kernel<C, RIT, PAIR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((conv3d_k3_bf16_kernel<C, RIT, X3>), dim3(nblk), dim3(C::THREADS), lds, st, a);
+    hipLaunchKernelGGL((conv3d_k3_bf16_kernel<C, RIT, PAIR>), dim3(nblk), dim3(C::THREADS), lds, st, a);
     return wmh_check_launch("conv3d_k3_bf16_kernel");
 }
 
@@ -491,29 +511,29 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     return launch_bf16<BCfg2, 3>(a, (unsigned)nblk, st);
 }
 
-int wmh_launch_conv_bf16x3_ws(int cfg, const ConvArgs& a, hipStream_t st);
+int wmh_launch_conv_f16x2_ws(int cfg, const ConvArgs& a, hipStream_t st);
 // y = conv3x3x3 with both operands split into two bf16 numbers each and all four partial products accumulated in fp32
-// (16 mantissa bits per operand): fp32 tensors in and out, stride 1, wf from wmh_conv3d_k3_pack_weights_bf16x3.  Same
+// (16 mantissa bits per operand): fp32 tensors in and out, stride 1, wf from wmh_conv3d_k3_pack_weights_f16x2.  Same
 // geometry, moments records (wmh_conv3d_k3_num_partials_bf16) and epilogue as wmh_conv3d_k3_fwd_bf16.
-extern "C" size_t wmh_conv3d_k3_bf16x3_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout) {
+extern "C" size_t wmh_conv3d_k3_f16x2_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout) {
     if (!(cfg == 3 || cfg == 4 || cfg == 5)) return 0;
     const int S = bf16_stride(cfg);
     const int ks = bf16_ksplit(bf16_small_blocks(cfg, N, D, H, W, Cout), cdiv(Cin, 8));
     return ks > 1 ? (size_t)ks * N * Cout * ((D - 1) / S + 1) * ((H - 1) / S + 1) * ((W - 1) / S + 1) : 0;
 }
-extern "C" int wmh_conv3d_k3_fwd_bf16x3(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
+extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
                                         const uint16_t* wf, const float* bias, float* y, float* partials, float* workspace,
                                         int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream) {
     const int NT = bf16_nt(cfg);
-    if (!NT || !wmh_conv3d_k3_bf16x3_supported(cfg)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: configuration has no bf16x3 kernel");
-    if (!x0 || !wf || !y || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: null/empty argument");
+    if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: configuration has no f16x2 kernel");
+    if (!x0 || !wf || !y || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: null/empty argument");
     if (x1 == nullptr) C1 = 0;
-    if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: LeakyReLU slope must be in [0, 1]");
-    if (C1 > 0 && (C0 % 8) != 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: C0 must be a multiple of 8 with two sources");
+    if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: LeakyReLU slope must be in [0, 1]");
+    if (C1 > 0 && (C0 % 8) != 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: C0 must be a multiple of 8 with two sources");
     const bool small = cfg == 3 || cfg == 4 || cfg == 5;
     if (!small && ((W % 4) != 0 || (size_t)16 * D * H * W * 4 >= ((size_t)1 << 32) || (reinterpret_cast<uintptr_t>(x0) & 15) != 0 ||
                    (x1 && (reinterpret_cast<uintptr_t>(x1) & 15) != 0)))
-        return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: needs W % 4 == 0 and 16-byte aligned sources");
+        return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: needs W % 4 == 0 and 16-byte aligned sources");
     ConvArgs a;
     a.x0 = x0; a.ss0 = ss0; a.C0 = C0; a.x1 = x1; a.ss1 = ss1; a.C1 = C1;
     a.wf = reinterpret_cast<const float*>(wf); a.bias = bias; a.y = y; a.part = partials;
@@ -530,10 +550,10 @@ extern "C" int wmh_conv3d_k3_fwd_bf16x3(int cfg, const float* x0, const float* s
     a.xcd_swizzle = swz_env & 1;
     a.stamps = g_conv_stamps;
     hipStream_t st = (hipStream_t)stream;
-    if (!small) return wmh_launch_conv_bf16x3_ws(cfg, a, st);
+    if (!small) return wmh_launch_conv_f16x2_ws(cfg, a, st);
     // rows of 16 / 8 voxels (stride 1 and 2): the one-role kernel, split-K when slab memory is given (wmh_conv3d_k3_fwd_bf16_splitk)
     const long long nblk = (long long)a.ntx * a.nty * a.ntz * N * a.G;
-    if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16x3: grid too large");
+    if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: grid too large");
     a.KS = workspace != nullptr ? bf16_ksplit(nblk, a.nchunks) : 1;
     if (a.KS > 1) a.y = workspace;
     const unsigned nb = (unsigned)(nblk * a.KS);

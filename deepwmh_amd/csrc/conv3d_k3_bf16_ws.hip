@@ -25,6 +25,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned ws_pack_bf16x2(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
@@ -54,8 +55,14 @@ __device__ __forceinline__ float ld_uniform(const float* p) {
 #endif
 
 // IN16: both sources are bf16 tensors (a quad is one 8-byte load per channel, widened by a shift); OUT16: y is stored as bf16.
-// X3 ("bf16x3", fp32 tensors): every operand is split into two bf16 numbers, x = x_hi + x_lo with x_hi = bf16(x), x_lo = bf16(x -
-// x_hi) (16 mantissa bits together), and the product is formed from all four partial products on the bf16 instruction.  A
+// PAIR (the "pair" mode, fp32 tensors): every operand is split into TWO FP16 numbers, x = x_hi + x_lo with x_hi = fp16(x) (round
+// toward zero: saturates instead of overflowing), x_lo = fp16(x - x_hi) (nearest) -- 21-22 significant bits together, against
+// fp32's 24 -- and the product is formed from all four partial products on v_mfma_f32_32x32x16_f16 (same rate as the bf16
+// instruction).  Round 2 split into bf16 pairs (16 bits together): 3.4e-6 relative error per layer against 0.5-1.4e-6 for
+// the exact-fp32 kernel; fp16 pairs are at the fp32 kernel's level.  fp16's narrow exponent is no obstacle here: activations
+// behind InstanceNorm + LeakyReLU are O(1) (a low part below fp16's normal range only loses bits that are < 2^-25 absolute),
+// and the weights are scaled by 2^8 before the split (wmh_conv3d_k3_pack_weights_f16x2; |w| < 255 required), undone exactly
+// on the accumulators before the epilogue.  A
 // chunk is 8 input channels; the 16 k slots of an MFMA carry B = [x_hi | x_lo] of those channels (the bf16 kernel's LDS image:
 // 32 bytes per voxel, the hi piece where channels 0-7 were, the lo piece where channels 8-15 were -- ONE operand read per
 // voxel tile and tap, as before), and the tap is issued twice, with A = [w_hi | w_hi] and A = [w_lo | w_lo]:
@@ -63,10 +70,10 @@ __device__ __forceinline__ float ld_uniform(const float* p) {
 // MFMA, and with one 32-channel output tile per wave that is exactly the LDS bandwidth: 4.3 instead of 3.x ms per layer.)
 // 4 MFMAs per 16 channels and tap instead of 1 -- still 4x fewer cycles than the fp32 instruction -- with fp32 accumulation,
 // fp32 tensors and the fp32 epilogue.
-template <class C, bool IN16 = false, bool OUT16 = false, bool X3 = false>
+template <class C, bool IN16 = false, bool OUT16 = false, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArgs a, const int T /*tiles*/) {
-    constexpr int S = C::S, MT = C::MT, NT = C::NT, CKB = X3 ? 8 : 16;
-    static_assert(!(X3 && (IN16 || OUT16)), "bf16x3 works on fp32 tensors");
+    constexpr int S = C::S, MT = C::MT, NT = C::NT, CKB = PAIR ? 8 : 16;
+    static_assert(!(PAIR && (IN16 || OUT16)), "f16x2 works on fp32 tensors");
     constexpr int LTH = 256;                                   // loader threads
     constexpr int NIT = (C::SP + LTH - 1) / LTH;
     constexpr int CS = NIT * LTH;                              // padded voxel count: every loader store in range
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         // chunk go through a ring of RS register sets: while one set is normalised, packed and written, RS-1 are in flight.
         // bf16 sources: a set is half the registers, and with half the bytes per load the same ring would keep half the bytes
         // in flight -- the whole chunk rides in the ring instead
-        constexpr int HPS = X3 ? 1 : 2;                           // half-slots per quad slot (X3: the 8 channels of a chunk are one)
+        constexpr int HPS = PAIR ? 1 : 2;                           // half-slots per quad slot (PAIR: the 8 channels of a chunk are one)
         constexpr int NHS = HPS * NSL, RS = IN16 ? WMH_BF16_WS_RING16(NHS) : WMH_BF16_WS_RING(NHS);   // RS must divide NHS (static ring indices)
         f32x4_t v[IN16 ? 1 : RS][8];
         uint2 v16[IN16 ? RS : 1][8];
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             // be pushed out to scratch (their reload sits between the two barriers, where every wave of the workgroup waits,
             // and a scratch reload waits for ALL loads in flight -- the whole prefetch ring)
             unsigned w[4][4];                                      // [voxel of the quad][channel pair]
-            unsigned wlo[X3 ? 4 : 1][4];                           // X3: the low parts
+            unsigned wlo[PAIR ? 4 : 1][4];                           // PAIR: the low parts
 #pragma unroll
             for (int c = 0; c < 8; c += 2) {
                 f32x4_t t[2];
@@ -244,12 +251,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const unsigned u = ws_pack_bf16x2(t[0][k], t[1][k]);
-                    w[k][c >> 1] = u & keep;
-                    if constexpr (X3) {                            // remainder after the high part, rounded to bf16 again
-                        const f32x2_t hi2 = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xFFFF0000u)};
-                        const f32x2_t lo2 = f32x2_t{t[0][k], t[1][k]} - hi2;
-                        wlo[k][c >> 1] = ws_pack_bf16x2(lo2[0], lo2[1]) & keep;
+                    if constexpr (PAIR) {                            // fp16 pair: high part toward zero, the remainder to nearest
+                        const auto h2 = __builtin_amdgcn_cvt_pkrtz(t[0][k], t[1][k]);
+                        w[k][c >> 1] = __builtin_bit_cast(unsigned, h2) & keep;
+                        const f32x2_t lo2 = f32x2_t{t[0][k], t[1][k]} - f32x2_t{(float)h2[0], (float)h2[1]};
+                        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                        wlo[k][c >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo2, f16x2_t)) & keep;
+                    } else {
+                        w[k][c >> 1] = ws_pack_bf16x2(t[0][k], t[1][k]) & keep;
                     }
                 }
             }
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 if (sidx < NQ && x >= 0 && x < C::IX) {
                     const int e = row * C::IX + x;
                     dst[e * 2 + (half ^ ((x >> 3) & 1))] = make_uint4(w[k][0], w[k][1], w[k][2], w[k][3]);
-                    if constexpr (X3) dst[e * 2 + (1 ^ ((x >> 3) & 1))] = make_uint4(wlo[k][0], wlo[k][1], wlo[k][2], wlo[k][3]);
+                    if constexpr (PAIR) dst[e * 2 + (1 ^ ((x >> 3) & 1))] = make_uint4(wlo[k][0], wlo[k][1], wlo[k][2], wlo[k][3]);
                 }
             }
         };
@@ -347,11 +356,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             const int tyi = ts % C::MY, tzi = ts / C::MY;
             const int e0 = (tzi * C::LZ + dz) * C::ZS + (tyi * C::LY + dy) * C::YS + dx;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) badr[kw][m] = (e0 + kw) * 32 + 16 * (kh ^ (((dx + kw) >> 3) & 1));   // X3: hi piece (kh 0) / lo piece (kh 1)
+            for (int kw = 0; kw < 3; ++kw) badr[kw][m] = (e0 + kw) * 32 + 16 * (kh ^ (((dx + kw) >> 3) & 1));   // PAIR: hi piece (kh 0) / lo piece (kh 1)
         }
         const char* ldsb = reinterpret_cast<const char*>(ldsq);
-        // X3: a fragment's 64 pieces are [hi of cout 0..31 | lo of cout 0..31]; both lane halves read the same piece
-        const bf16x8* wl = reinterpret_cast<const bf16x8*>(wlds) + (X3 ? j : lane);
+        // PAIR: a fragment's 64 pieces are [hi of cout 0..31 | lo of cout 0..31]; both lane halves read the same piece
+        const bf16x8* wl = reinterpret_cast<const bf16x8*>(wlds) + (PAIR ? j : lane);
         int g, tx, ty, tz, n0;
         __syncthreads();
         int it = 0;
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = (g * NT + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+                    const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] * (PAIR ? WMH_PAIR_WSCALE : 1.f) : 0.f;
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[nt][m][r] = bv;
                 }
@@ -375,22 +384,26 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 for (int tap = 0; tap < 27; ++tap) {
                     const int kw = tap % 3;
                     const int rowoff = ((tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS) * 32;
-                    bf16x8 av[NT], al[X3 ? NT : 1];
+                    bf16x8 av[NT], al[PAIR ? NT : 1];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         av[nt] = wl[(tap * NT + nt) * 64];
-                        if constexpr (X3) al[nt] = wl[(tap * NT + nt) * 64 + 32];
+                        if constexpr (PAIR) al[nt] = wl[(tap * NT + nt) * 64 + 32];
                     }
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const bf16x8 bv = *reinterpret_cast<const bf16x8*>(cur + badr[kw][m] + rowoff);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[nt], bv, acc[nt][m], 0, 0, 0);
-                        if constexpr (X3) {                        // the low parts of the weights against the same operand
+                        if constexpr (PAIR) {                        // high, then low parts of the weights against the same operand
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[nt], bv, acc[nt][m], 0, 0, 0);
+                                acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[nt]), __builtin_bit_cast(f16x8, bv), acc[nt][m], 0, 0, 0);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[nt]), __builtin_bit_cast(f16x8, bv), acc[nt][m], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[nt], bv, acc[nt][m], 0, 0, 0);
                         }
                     }
                 }
@@ -400,6 +413,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 if (a.stamps) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; tb += d; if (ch == 0) tbl += d; }
             }
             if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+            if constexpr (PAIR) {                               // undo the weights' 2^8 (exact)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[nt][m] *= (1.f / WMH_PAIR_WSCALE);
+            }
             conv_epilogue<C, OUT16>(a, acc, g, 0, n0, wave, j, kh, dx, dy, dz, ts0, tz * C::TZ, ty * C::TY, tx * C::TX,
                              (tz * a.nty + ty) * a.ntx + tx);
             if (a.stamps) te += __builtin_amdgcn_s_memtime() - t0;
@@ -415,7 +434,7 @@ typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> WBCfg0;
 typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> WBCfg2;
 typedef ConvCfg<1, 32, 1, 4, 4, 1, 4, 2, 4, 6> WBCfgW;      // configuration 21: 4 x 4 x 32 voxels x 64 output channels
 
-template <class C, bool IN16 = false, bool OUT16 = false, bool X3 = false>
+template <class C, bool IN16 = false, bool OUT16 = false, bool PAIR = false>
 static int launch_bf16_ws(const ConvArgs& a, hipStream_t st) {
     static int ncu = 0;
     if (!ncu) {
@@ -428,11 +447,11 @@ static int launch_bf16_ws(const ConvArgs& a, hipStream_t st) {
     constexpr int NITL = (C::SP + 255) / 256;
     constexpr int lds = 2 * NITL * 256 * 32 + 27 * C::NT * 64 * 16;
     static_assert(lds <= 160 * 1024, "LDS");
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_ws_kernel<C, IN16, OUT16, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_ws_kernel<C, IN16, OUT16, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const long long T = (long long)a.ntx * a.nty * a.ntz * a.N * a.G;
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 bf16 (wave-specialised): too many tiles");
     const int grid = T < ncu ? (int)T : ncu;
-    hipLaunchKernelGGL((conv3d_k3_bf16_ws_kernel<C, IN16, OUT16, X3>), dim3(grid), dim3(512), lds, st, a, (int)T);
+    hipLaunchKernelGGL((conv3d_k3_bf16_ws_kernel<C, IN16, OUT16, PAIR>), dim3(grid), dim3(512), lds, st, a, (int)T);
     return wmh_check_launch("conv3d_k3_bf16_ws_kernel");
 }
 // a: fully prepared by wmh_conv3d_k3_fwd_bf16 (one-role geometry: npart, nchunks, G ... are the same)
@@ -447,10 +466,10 @@ int wmh_launch_conv_bf16_ws(int cfg, const ConvArgs& a, hipStream_t st, int in16
     return cfg == 0 ? launch_bf16_ws<WBCfg0>(a, st) : launch_bf16_ws<WBCfg2>(a, st);
 }
 
-// bf16x3: the same geometry, chunks of 8 input channels (a: prepared by wmh_conv3d_k3_fwd_bf16x3)
-int wmh_launch_conv_bf16x3_ws(int cfg, const ConvArgs& a, hipStream_t st) {
+// f16x2: the same geometry, chunks of 8 input channels (a: prepared by wmh_conv3d_k3_fwd_f16x2)
+int wmh_launch_conv_f16x2_ws(int cfg, const ConvArgs& a, hipStream_t st) {
     if (cfg == 21) return launch_bf16_ws<WBCfgW, false, false, true>(a, st);
     if (cfg == 0) return launch_bf16_ws<WBCfg0, false, false, true>(a, st);
     if (cfg == 2) return launch_bf16_ws<WBCfg2, false, false, true>(a, st);
-    return wmh_fail(WMH_EINVAL, "conv3d_k3 bf16x3: configurations 0, 2 and 21");
+    return wmh_fail(WMH_EINVAL, "conv3d_k3 f16x2: configurations 0, 2 and 21");
 }

@@ -50,14 +50,14 @@ class _ConvLayer:
             self._packed_bf16[cfg] = torch.from_numpy(wf.view(np.int16)).to(self.device)
         return self._packed_bf16[cfg]
 
-    def packed_bf16x3(self, cfg):
+    def packed_f16x2(self, cfg):
         key = ('x3', cfg)
         if key not in self._packed_bf16:
-            n = self.lib.wmh_conv3d_k3_packed_halfs_bf16x3(cfg, self.cin, self.cout)
+            n = self.lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, self.cin, self.cout)
             wf = np.empty(n, dtype=np.uint16)
-            _lib.check(self.lib.wmh_conv3d_k3_pack_weights_bf16x3(
+            _lib.check(self.lib.wmh_conv3d_k3_pack_weights_f16x2(
                 cfg, self.w_host.ctypes.data_as(C.c_void_p), self.cin, self.cout,
-                wf.ctypes.data_as(C.c_void_p)), 'wmh_conv3d_k3_pack_weights_bf16x3')
+                wf.ctypes.data_as(C.c_void_p)), 'wmh_conv3d_k3_pack_weights_f16x2')
             self._packed_bf16[key] = torch.from_numpy(wf.view(np.int16)).to(self.device)
         return self._packed_bf16[key]
 
@@ -81,8 +81,8 @@ class UNetEngine:
         InstanceNorm statistics, heads and softmax stay fp32).  storage 'bf16' (with precision 'bf16' only) also
         keeps the five full-resolution activation tensors -- where the HBM bytes are -- as bf16, like the fp16
         tensors of nnU-Net's autocast predict; everything below the first pooling stays fp32."""
-        if precision not in ('fp32', 'bf16', 'bf16x3'):
-            raise ValueError('precision must be fp32, bf16 or bf16x3')
+        if precision not in ('fp32', 'bf16', 'f16x2'):
+            raise ValueError('precision must be fp32, bf16 or f16x2')
         if storage not in ('fp32', 'bf16', 'bf16_ncdhw') or (storage != 'fp32' and precision != 'bf16'):
             raise ValueError("storage must be 'fp32', or 'bf16' / 'bf16_ncdhw' together with precision='bf16'")
         self.precision = precision
@@ -179,18 +179,18 @@ class UNetEngine:
         plain = not (in16 or out16)
         use_bf16 = (self.precision == 'bf16' and layer.kz == 3 and layer.sz == s and (C1 == 0 or C0 % 16 == 0)
                     and bool(self.lib.wmh_conv3d_k3_bf16_supported(cfg)) and (plain or (cfg == 0 and s == 1)))
-        # 'bf16x3': the 3x3x3 convolutions that have a bf16 kernel (stride 1: rows of >= 8 voxels; stride 2: output rows of 8 or 16) form their products from bf16
-        # pairs (x = hi + lo, 16 mantissa bits per operand, all four partial products, fp32 accumulation): fp32-grade results at
-        # 2-2.7x the fp32 instruction's speed.  Everything else is the exact-fp32 path.
+        # 'f16x2': the 3x3x3 convolutions that have a 16-bit-operand kernel (stride 1: rows of >= 8 voxels; stride 2: output rows of 8 or 16)
+        # form their products from fp16 pairs (x = hi + lo, 21-22 significant bits per operand, all four partial products, fp32
+        # accumulation): results at the exact-fp32 kernel's error level at 2-2.7x its speed.  Everything else is the exact-fp32 path.
         cfg_x = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
-        use_x3 = (self.precision == 'bf16x3' and layer.kz == 3 and layer.sz == s and (C1 == 0 or C0 % 8 == 0)
-                  and bool(self.lib.wmh_conv3d_k3_bf16x3_supported(cfg_x)) and (cfg_x in (3, 4, 5) or W % 4 == 0))
+        use_x3 = (self.precision == 'f16x2' and layer.kz == 3 and layer.sz == s and (C1 == 0 or C0 % 8 == 0)
+                  and bool(self.lib.wmh_conv3d_k3_f16x2_supported(cfg_x)) and (cfg_x in (3, 4, 5) or W % 4 == 0))
         if use_x3:
             cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
         if use_bf16 and not (in16 or out16):       # wide tile for >= 64 output channels (bf16 kernel only)
             cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
         if use_x3:
-            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16x3(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials_bf16x3')
+            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_f16x2(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials_f16x2')
         elif use_bf16:
             npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, Do, Ho, Wo), 'wmh_conv3d_k3_num_partials_bf16')
         else:
@@ -199,23 +199,23 @@ class UNetEngine:
         part = self._buf(key + '.part', (N, layer.cout, npart, 4))
         ss = self._buf(key + '.ss', (N, layer.cout, 2))
         if use_x3:
-            nws = self.lib.wmh_conv3d_k3_bf16x3_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout)
+            nws = self.lib.wmh_conv3d_k3_f16x2_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout)
         elif use_bf16:
             nws = self.lib.wmh_conv3d_k3_bf16_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout)
         else:
             nws = self.lib.wmh_conv3d_k3_workspace_floats(cfg, layer.cin, N, D, H, W, layer.cout, s)
         ws = self._buf('splitk.ws', (nws,)) if nws else None      # shared: layers run one after another
         st = self._stream()
-        wf = layer.packed_bf16x3(cfg) if use_x3 else layer.packed_bf16(cfg) if use_bf16 else layer.packed(cfg)
+        wf = layer.packed_f16x2(cfg) if use_x3 else layer.packed_bf16(cfg) if use_bf16 else layer.packed(cfg)
         timed = cfg in self.timed_cfgs
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if use_x3:
-            _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16x3(
+            _lib.check(self.lib.wmh_conv3d_k3_fwd_f16x2(
                 cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,
                 _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws),
-                N, D, H, W, layer.cout, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd_bf16x3')
+                N, D, H, W, layer.cout, LRELU_SLOPE, st), 'wmh_conv3d_k3_fwd_f16x2')
         elif (in16 or out16) and use_bf16:
             _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16_st(
                 cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1,

@@ -45,13 +45,13 @@ class UNetTrainer:
         fp16=True]: the stride-1 convolutions of the >= 16-wide levels (forward and data gradient) multiply bf16-rounded
         operands with fp32 accumulation; weights, activations, statistics, weight gradients, loss and optimizer stay fp32
         (bf16 keeps fp32's exponent range, so no loss scaling)."""
-        if precision not in ('fp32', 'bf16', 'bf16x3'):
-            raise ValueError('precision must be fp32, bf16 or bf16x3')
+        if precision not in ('fp32', 'bf16', 'f16x2'):
+            raise ValueError('precision must be fp32, bf16 or f16x2')
         self.precision = precision
         self.bf16_forward = self.bf16_dgrad = self.bf16_wgrad = precision == 'bf16'      # diagnostic switches (tools/diag_bf16_train.py)
-        # 'bf16x3': forward and stride-1 data-gradient convolutions with rows of >= 16 voxels form their products from bf16 pairs
+        # 'f16x2': forward and stride-1 data-gradient convolutions with rows of >= 16 voxels form their products from fp16 pairs
         # (network.py, DESIGN.md 3.3d: fp32-grade, 2-2.7x the fp32 instruction's speed); weight gradients and everything else fp32
-        self.x3 = precision == 'bf16x3'
+        self.x3 = precision == 'f16x2'
         plan.check_supported()
         self.plan, self.device = plan, torch.device(device)
         if self.device.type != 'cuda':
@@ -153,7 +153,7 @@ class UNetTrainer:
                 and (C1 == 0 or C0 % 16 == 0))
 
     def _use_x3(self, cfg_b, stride, C0, C1, W):
-        return (self.x3 and stride == 1 and (C1 == 0 or C0 % 8 == 0) and (W % 4 == 0 or cfg_b == 4) and bool(self.lib.wmh_conv3d_k3_bf16x3_supported(cfg_b)))
+        return (self.x3 and stride == 1 and (C1 == 0 or C0 % 8 == 0) and (W % 4 == 0 or cfg_b == 4) and bool(self.lib.wmh_conv3d_k3_f16x2_supported(cfg_b)))
 
     def _pack_x3(self, conv, cfg, mode, ci_off, ci_cnt):
         key = (conv.name, cfg, mode, ci_off, ci_cnt, 'x3')
@@ -161,11 +161,11 @@ class UNetTrainer:
         if hit is not None and hit[0] == self._version:
             return hit[1]
         ecin, ecout = (ci_cnt, conv.cout) if mode == 0 else (conv.cout, ci_cnt)
-        n = self.lib.wmh_conv3d_k3_packed_halfs_bf16x3(cfg, ecin, ecout)
+        n = self.lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, ecin, ecout)
         wf = hit[1] if hit is not None else torch.empty(n, dtype=torch.int16, device=self.device)
-        _lib.check(self.lib.wmh_conv3d_k3_pack_weights_bf16x3_device(cfg, _lib.ptr(self.p[conv.name + '.conv.weight']), conv.cin, conv.cout,
+        _lib.check(self.lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, _lib.ptr(self.p[conv.name + '.conv.weight']), conv.cin, conv.cout,
                                                                      ci_off, ci_cnt, mode, _lib.ptr(wf), self._st()),
-                   'wmh_conv3d_k3_pack_weights_bf16x3_device')
+                   'wmh_conv3d_k3_pack_weights_f16x2_device')
         self._packed[key] = (self._version, wf)
         return wf
 
@@ -175,14 +175,14 @@ class UNetTrainer:
         y = self._buf(key + '.y', (N, cout, D, H, W))
         part, npart = None, 0
         if want_stats:
-            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16x3(cfg, N, D, H, W), 'num_partials_bf16x3')
+            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_f16x2(cfg, N, D, H, W), 'num_partials_f16x2')
             part = self._buf(key + '.part', (N, cout, npart, 4))
-        nws = self.lib.wmh_conv3d_k3_bf16x3_workspace_floats(cfg, C0 + C1, N, D, H, W, cout)
+        nws = self.lib.wmh_conv3d_k3_f16x2_workspace_floats(cfg, C0 + C1, N, D, H, W, cout)
         ws = self._buf('splitk.ws', (nws,)) if nws else None
-        _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16x3(cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wf),
+        _lib.check(self.lib.wmh_conv3d_k3_fwd_f16x2(cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wf),
                                                      _lib.ptr(bias), _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws), N, D, H, W, cout, LRELU_SLOPE,
                                                      self._st()),
-                   'wmh_conv3d_k3_fwd_bf16x3')
+                   'wmh_conv3d_k3_fwd_f16x2')
         return y, part, npart
 
     def _pack_bf16(self, conv, cfg, mode, ci_off, ci_cnt):

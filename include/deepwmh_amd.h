@@ -88,8 +88,8 @@ int wmh_conv3d_k3_bf16_supported(int cfg);
 /* InstanceNorm partial records per (n, c) row written by wmh_conv3d_k3_fwd_bf16 (its wave split differs from the fp32
  * kernel's, so this replaces wmh_conv3d_k3_num_partials for that call). */
 int wmh_conv3d_k3_num_partials_bf16(int cfg, int N, int Do, int Ho, int Wo);
-/* ... and by wmh_conv3d_k3_fwd_bf16x3 (always the four-consumer-wave geometry). */
-int wmh_conv3d_k3_num_partials_bf16x3(int cfg, int N, int Do, int Ho, int Wo);
+/* ... and by wmh_conv3d_k3_fwd_f16x2 (always the four-consumer-wave geometry). */
+int wmh_conv3d_k3_num_partials_f16x2(int cfg, int N, int Do, int Ho, int Wo);
 size_t wmh_conv3d_k3_packed_halfs_bf16(int cfg, int Cin, int Cout);
 int wmh_conv3d_k3_pack_weights_bf16(int cfg, const float* w, int Cin, int Cout, uint16_t* wf);
 /* The same image written on the device, with the channel sub-range / data-gradient modes of
@@ -104,22 +104,25 @@ int wmh_conv3d_k3_bf16_config(int cfg, int Cout, int W);
 int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1,
                            int C1, const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D,
                            int H, int W, int Cout, float lrelu_slope, void* stream);
-/* "bf16x3": fp32-grade products on the bf16 matrix instruction.  Every operand is split into two bf16
- * numbers (x = x_hi + x_lo, 16 mantissa bits together) and all four partial products are accumulated in fp32: 4 bf16 MFMAs
- * per 16 input channels and tap instead of 1, still a quarter of the fp32 instruction's cycles.  fp32 NCDHW tensors in and
- * out, configurations 0 / 2 / 21 (stride 1, rows of >= 16 voxels) and 3 / 4 / 5; geometry, epilogue and moments records of
- * wmh_conv3d_k3_fwd_bf16 (wmh_conv3d_k3_num_partials_bf16).  wf: wmh_conv3d_k3_pack_weights_bf16x3 ([G][cin/8][27][NT][64][8]
- * bf16: lanes 0-31 the high parts, lanes 32-63 the low parts of an output channel's 8 weights). */
-int wmh_conv3d_k3_bf16x3_supported(int cfg);
-size_t wmh_conv3d_k3_packed_halfs_bf16x3(int cfg, int Cin, int Cout);
-int wmh_conv3d_k3_pack_weights_bf16x3(int cfg, const float* w, int Cin, int Cout, uint16_t* wf);
+/* "f16x2": fp32-grade products on the 16-bit matrix instruction.  Every operand is split into two FP16 numbers
+ * (x = x_hi + x_lo: 21-22 significant bits together; round 2 used bf16 pairs, 16 bits) and all four partial products are
+ * accumulated in fp32: 4 v_mfma_f32_32x32x16_f16 per 16 input channels and tap instead of 1, still a quarter of the fp32
+ * instruction's cycles.  Measured against float64, a layer's error is below the exact-fp32 kernel's (tools/f16x2_check.py).
+ * fp32 NCDHW tensors in and out, configurations 0 / 2 / 21 (stride 1, rows of >= 16 voxels) and 3 / 4 / 5; geometry and
+ * epilogue of wmh_conv3d_k3_fwd_bf16, moments records: wmh_conv3d_k3_num_partials_f16x2.  wf: wmh_conv3d_k3_pack_weights_f16x2
+ * ([G][cin/8][27][NT][64][8] fp16 of the weights x 2^8: lanes 0-31 the high parts, lanes 32-63 the low parts of an output
+ * channel's 8 weights; the kernel scales the accumulators back.  Weights must be finite and below 253 in magnitude:
+ * WMH_EINVAL otherwise; the device packer saturates). */
+int wmh_conv3d_k3_f16x2_supported(int cfg);
+size_t wmh_conv3d_k3_packed_halfs_f16x2(int cfg, int Cin, int Cout);
+int wmh_conv3d_k3_pack_weights_f16x2(int cfg, const float* w, int Cin, int Cout, uint16_t* wf);
 /* the same image from weights in HBM (training); modes as wmh_conv3d_k3_pack_weights_bf16_device */
-int wmh_conv3d_k3_pack_weights_bf16x3_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
+int wmh_conv3d_k3_pack_weights_f16x2_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
                                              uint16_t* wf, void* stream);
 /* Configurations 3 / 4 / 5 (rows of 16 / 8 voxels, stride 2 / 1 / 2; D, H, W = the INPUT extent) run the one-role kernel and
- * take split-K slab memory like wmh_conv3d_k3_fwd_bf16_splitk (workspace >= wmh_conv3d_k3_bf16x3_workspace_floats floats, or NULL). */
-size_t wmh_conv3d_k3_bf16x3_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout);
-int wmh_conv3d_k3_fwd_bf16x3(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
+ * take split-K slab memory like wmh_conv3d_k3_fwd_bf16_splitk (workspace >= wmh_conv3d_k3_f16x2_workspace_floats floats, or NULL). */
+size_t wmh_conv3d_k3_f16x2_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout);
+int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
                              const uint16_t* wf, const float* bias, float* y, float* partials, float* workspace,
                              int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
 /* The same with split-K for the small-row configurations (rows of 16 / 8 voxels: the 16^3 / 8^3 levels): the channel reduction

@@ -92,28 +92,34 @@ def test_engine_refuses_cpu(tiny_net):
         UNetEngine(plan, sd, device='cpu')
 
 
-def test_bf16x3_weight_image_is_a_two_term_split():
-    """Host-side packing of the bf16x3 mode (no GPU needed): every fragment holds the high bf16 parts of an output channel's 8 weights
-    on lanes 0-31 and the low parts on lanes 32-63, and hi + lo reproduces the weight to 16 mantissa bits."""
+def test_f16x2_weight_image_is_a_two_term_split():
+    """Host-side packing of the f16x2 mode (no GPU needed): every fragment holds the high fp16 parts of an output channel's 8 weights
+    (scaled by 2^8) on lanes 0-31 and the low parts on lanes 32-63; hi + lo reproduces 256 w to 21-22 significant bits while the
+    low part is a normal fp16 number, and to 2^-25 absolute below that; out-of-range weights are refused."""
     import ctypes as C
     import numpy as np
     from deepwmh_amd import _lib
     lib = _lib.load()
     Cin, Cout, cfg = 20, 40, 0                       # ragged: 3 chunks of 8 channels, 2 groups of 32 output channels
-    assert lib.wmh_conv3d_k3_bf16x3_supported(cfg) and not lib.wmh_conv3d_k3_bf16x3_supported(8)
+    assert lib.wmh_conv3d_k3_f16x2_supported(cfg) and not lib.wmh_conv3d_k3_f16x2_supported(8)
     rng = np.random.default_rng(0)
-    w = (rng.standard_normal((Cout, Cin, 27)) * np.exp(rng.uniform(-6, 6, (Cout, Cin, 27)))).astype(np.float32)
-    n = lib.wmh_conv3d_k3_packed_halfs_bf16x3(cfg, Cin, Cout)
+    w = (rng.standard_normal((Cout, Cin, 27)) * np.exp(rng.uniform(-9, 3, (Cout, Cin, 27)))).astype(np.float32)
+    w = np.clip(w, -200, 200)
+    n = lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cin, Cout)
     assert n == 2 * 3 * 27 * 1 * 64 * 8
     wf = np.zeros(n, np.uint16)
-    _lib.check(lib.wmh_conv3d_k3_pack_weights_bf16x3(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
-    img = (wf.astype(np.uint32) << 16).view(np.float32).reshape(2, 3, 27, 1, 64, 8)       # [g][chunk][tap][nt][lane][e]
+    _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
+    img = wf.view(np.float16).astype(np.float64).reshape(2, 3, 27, 1, 64, 8)              # [g][chunk][tap][nt][lane][e]
     hi, lo = img[:, :, :, 0, :32, :], img[:, :, :, 0, 32:, :]
     full = np.zeros((2 * 32, 3 * 8, 27), np.float32)
     full[:Cout, :Cin] = w
-    ref = full.reshape(2, 32, 3, 8, 27).transpose(0, 2, 4, 1, 3)                        # [g][chunk][tap][cout lane][e]
-    rec = hi.astype(np.float64) + lo.astype(np.float64)
-    err = np.abs(rec - ref) / np.maximum(np.abs(ref), 1e-30)
-    assert float(err[ref != 0].max()) <= 2.0 ** -16                                      # two bf16 terms: <= 2^-17 typical, 2^-16 worst
+    ref = 256.0 * full.reshape(2, 32, 3, 8, 27).transpose(0, 2, 4, 1, 3).astype(np.float64)   # [g][chunk][tap][cout lane][e]
+    rec = hi + lo
+    assert np.all(np.isfinite(rec))
+    err = np.abs(rec - ref)
+    assert np.all(err <= np.maximum(2.0 ** -21 * np.abs(ref), 2.0 ** -25))               # two fp16 terms (nearest, nearest)
     assert np.all(rec[ref == 0] == 0)                                                    # padding channels / rows are zero
-    assert np.array_equal(hi, (hi.view(np.uint32) & 0xFFFF0000).view(np.float32))        # both parts are bf16 values
+    assert np.array_equal(hi, ref.astype(np.float16).astype(np.float64))                 # the high part is fp16(256 w)
+    w[3, 4, 5] = 300.0                                                                   # 256 w beyond fp16's range
+    with __import__('pytest').raises(_lib.WMHError):
+        _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')

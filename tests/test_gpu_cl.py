@@ -376,3 +376,48 @@ def test_configs2_full_width_patch_against_the_fp32_path():
     # one un-mirrored, un-aggregated forward (the bench's mirrored + Gaussian-aggregated volume agrees to 0.018 / Dice 0.9986);
     # measured here: max 0.095, Dice 0.9965, 0.5 % of voxels
     assert d < 0.15 and mean_d < 1e-2 and dice > 0.99 and flips < 1e-2
+
+
+def test_configs2_stress_eight_volumes_three_repetitions():
+    """BASELINE.json configs[2] at the size its LDS-DMA ordering race showed at (garbage tiles "only at full size",
+    every small test green): 8 volumes of 160x192x160, each 8 tiles x 8 mirrors = 64 batch-8 forwards of the 31 M-parameter net on
+    channels-last bf16 tensors, three repetitions.  Every result finite, all three repetitions bit-equal, masks against the fp32
+    path."""
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.plan import baseline_plan
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    from deepwmh_amd.synthetic import he_init_state_dict, synthetic_flair
+    plan = baseline_plan()
+    sd = he_init_state_dict(plan, seed=0)
+    vols = [torch.from_numpy(synthetic_flair((160, 192, 160), seed=v)).cuda() for v in range(8)]
+    eng = UNetEngine(plan, sd, 'cuda:0', precision='bf16', storage='bf16')
+    assert eng.ncl == 3
+    pred = SlidingWindowPredictor(eng, do_mirroring=True, batch=8)
+    first = None
+    for rep in range(3):
+        outs = []
+        for v in vols:
+            seg, prob = pred.predict_device(v, return_prob=True)
+            outs.append((seg.clone(), prob.clone()))
+        torch.cuda.synchronize()
+        for i, (seg, prob) in enumerate(outs):
+            assert bool(torch.isfinite(prob).all()), 'repetition %d volume %d: non-finite softmax' % (rep, i)
+            assert float((prob.sum(0) - 1).abs().max()) <= 1e-5
+        if first is None:
+            first = outs
+        else:
+            for i, ((s0, p0), (s1, p1)) in enumerate(zip(first, outs)):
+                assert torch.equal(p0, p1) and torch.equal(s0, s1), 'repetition %d volume %d differs from repetition 0' % (rep, i)
+    del eng, pred
+    eng32 = UNetEngine(plan, sd, 'cuda:0')
+    pred32 = SlidingWindowPredictor(eng32, do_mirroring=True, batch=8)
+    worst_dice, worst_diff = 1.0, 0.0
+    for i in (0, 3, 7):
+        s32, p32 = pred32.predict_device(vols[i], return_prob=True)
+        s16, p16 = first[i]
+        inter = float(((s16 > 0) & (s32 > 0)).sum())
+        dice = 2 * inter / (float((s16 > 0).sum()) + float((s32 > 0).sum()) + 1e-6)
+        worst_dice, worst_diff = min(worst_dice, dice), max(worst_diff, float((p16 - p32).abs().max()))
+    print('configs[2] stress: 3 x 8 volumes bit-equal and finite; vs the fp32 path on volumes 0, 3, 7: worst Dice %.5f, max |softmax diff| %.3g'
+          % (worst_dice, worst_diff))
+    assert worst_dice > 0.99 and worst_diff < 5e-2

@@ -310,8 +310,8 @@ def test_convtranspose_122_wgrad_vs_autograd(shape):
     assert err <= 2e-4 * float(ref.abs().max()) + 1e-5, err
 
 
-def test_bf16x3_training_step_matches_autograd_oracle(tiny_net, tiny_io):
-    """precision='bf16x3': forward and stride-1 data-gradient products from bf16 pairs (fp32-grade); the same bounds as the fp32 step."""
+def test_f16x2_training_step_matches_autograd_oracle(tiny_net, tiny_io):
+    """precision='f16x2': forward and stride-1 data-gradient products from bf16 pairs (fp32-grade); the same bounds as the fp32 step."""
     import copy
     from oracle import training as ot
     from deepwmh_amd.trainer import UNetTrainer, downsample_targets
@@ -325,7 +325,7 @@ def test_bf16x3_training_step_matches_autograd_oracle(tiny_net, tiny_io):
     out = net(x)
     loss = ot.multiple_output_loss(out, tgt, weights)
     loss.backward()
-    tr = UNetTrainer(plan, sd, 'cuda:0', precision='bf16x3')
+    tr = UNetTrainer(plan, sd, 'cuda:0', precision='f16x2')
     xd, td = x.cuda(), downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
     lg = tr.forward(xd)
     for i, (a, b) in enumerate(zip(lg, out)):
@@ -343,14 +343,14 @@ def test_bf16x3_training_step_matches_autograd_oracle(tiny_net, tiny_io):
         rows.append((rel, name))
         worst = max(worst, rel)
     rows.sort(reverse=True)
-    print('bf16x3 step: largest relative gradient errors (max-norm): ' + ', '.join('%s %.2g' % (n.replace('conv_blocks_', ''), r) for r, n in rows[:5])
+    print('f16x2 step: largest relative gradient errors (max-norm): ' + ', '.join('%s %.2g' % (n.replace('conv_blocks_', ''), r) for r, n in rows[:5])
           + '; median %.2g' % rows[len(rows) // 2][0])
     # 16-bit operand mantissas against fp32 autograd: the InstanceNorm backward's cancellations amplify the per-product 2^-17 to
     # a few 1e-3 on the first layers of this 4-feature net (fp32's own distance to float64 autograd at full width is 2.8e-3,
     # test_full_width_backward_matches_autograd); the bf16 mode's figure on the same net is 9e-2
     assert worst <= 1e-2 and rows[len(rows) // 2][0] <= 2e-3
     # bit-reproducible like the other modes
-    tr2 = UNetTrainer(plan, sd, 'cuda:0', precision='bf16x3')
+    tr2 = UNetTrainer(plan, sd, 'cuda:0', precision='f16x2')
     tr2.forward(xd); tr2.backward(td)
     torch.cuda.synchronize()
     assert torch.equal(tr.grads, tr2.grads)

@@ -1,4 +1,4 @@
-"""bf16x3 convolution (wmh_conv3d_k3_fwd_bf16x3): error against a float64 reference next to the exact-fp32 kernel's, and timing at the
+"""f16x2 convolution (wmh_conv3d_k3_fwd_f16x2): error against a float64 reference next to the exact-fp32 kernel's, and timing at the
 BASELINE shapes.  python tools/x3_check.py"""
 import ctypes as C
 import os
@@ -22,16 +22,16 @@ def run(N, S, C0, C1, Cout, check=True, reps=5):
     bias = torch.randn(Cout, device='cuda', generator=g) * 0.1
     cfg0 = lib.wmh_conv3d_k3_config(Cin, Cout, S, S, S, 1)
     cfg = lib.wmh_conv3d_k3_bf16_config(cfg0, Cout, S)
-    assert lib.wmh_conv3d_k3_bf16x3_supported(cfg), cfg
-    wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_bf16x3(cfg, Cin, Cout), np.uint16)
-    _lib.check(lib.wmh_conv3d_k3_pack_weights_bf16x3(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
+    assert lib.wmh_conv3d_k3_f16x2_supported(cfg), cfg
+    wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cin, Cout), np.uint16)
+    _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
     wfd = torch.from_numpy(wf.view(np.int16)).cuda()
     y = torch.empty(N, Cout, S, S, S, device='cuda')
     npart = lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, S, S, S)
     part = torch.empty(N, Cout, npart, 4, device='cuda')
 
     def x3():
-        _lib.check(lib.wmh_conv3d_k3_fwd_bf16x3(cfg, P(x0), P(ss0), C0, P(x1), P(ss1), C1, P(wfd), P(bias), P(y), P(part), None, N, S, S, S, Cout, 0.01, None), 'x3')
+        _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(x0), P(ss0), C0, P(x1), P(ss1), C1, P(wfd), P(bias), P(y), P(part), None, N, S, S, S, Cout, 0.01, None), 'x3')
     # the exact-fp32 kernel
     wf32 = np.empty(lib.wmh_conv3d_k3_packed_floats(cfg0, Cin, Cout), np.float32)
     lib.wmh_conv3d_k3_pack_weights(cfg0, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf32.ctypes.data_as(C.c_void_p))

@@ -1,6 +1,6 @@
 """profiles/pmc_traffic.json from the rocprofv3 --pmc passes over tools/pmc_traffic.py:
    python tools/make_pmc_traffic.py <root> <label>
-expects <root>/pmc_<mode>_FETCH_SIZE and <root>/pmc_<mode>_WRITE_SIZE for mode in fp32, bf16, bf16_storage, bf16x3 (missing modes are
+expects <root>/pmc_<mode>_FETCH_SIZE and <root>/pmc_<mode>_WRITE_SIZE for mode in fp32, bf16, bf16_storage, f16x2 (missing modes are
 skipped).  Per mode: the dominant convolution kernel's mean FETCH_SIZE / WRITE_SIZE per launch (KiB), FETCH_SIZE corrected by the
 calibration launch of the same run (a streaming kernel over 1 GiB in + 1 GiB out: MI355X_MICROARCH.md, HBM section)."""
 import csv
@@ -10,7 +10,7 @@ import os
 import sys
 
 KERNEL = {'fp32': 'conv3d_k3_ws_kernel<ConvCfg<1, 32, 1, 4, 8', 'bf16': 'conv3d_k3_bf16_ws_kernel<ConvCfg<1, 32',
-          'bf16_storage': 'cl_conv3_kernel', 'bf16x3': '1, 8, 1, 4, 6, 3, 1>, false, false, true>'}      # bf16x3: the X3 instance of the 32-row configuration (the bench's timed launches)
+          'bf16_storage': 'cl_conv3_kernel', 'f16x2': '1, 8, 1, 4, 6, 3, 1>, false, false, true>'}      # f16x2: the X3 instance of the 32-row configuration (the bench's timed launches)
 CAL = 'instnorm_lrelu_apply_kernel'
 CAL_KIB = 1024 * 1024
 

@@ -12,8 +12,8 @@ from deepwmh_amd.plan import baseline_plan  # noqa: E402
 from deepwmh_amd.synthetic import he_init_state_dict  # noqa: E402
 
 plan = baseline_plan()
-MODE = os.environ.get('WMH_PMC_MODE', 'fp32')           # fp32 | bf16 (bf16 operands, fp32 tensors) | bf16_storage (channels-last bf16) | bf16x3
-eng = UNetEngine(plan, he_init_state_dict(plan, 0), 'cuda:0', precision=MODE if MODE in ('fp32', 'bf16x3') else 'bf16',
+MODE = os.environ.get('WMH_PMC_MODE', 'fp32')           # fp32 | bf16 (bf16 operands, fp32 tensors) | bf16_storage (channels-last bf16) | f16x2
+eng = UNetEngine(plan, he_init_state_dict(plan, 0), 'cuda:0', precision=MODE if MODE in ('fp32', 'f16x2') else 'bf16',
                  storage='bf16' if MODE == 'bf16_storage' else 'fp32')
 lib = eng.lib
 n = 256 * 1024 * 1024                      # 1 GiB read + 1 GiB written, far beyond the 256 MiB Infinity Cache

@@ -11,7 +11,7 @@ python3 bench.py --precision bf16 --storage bf16 > $out/bench_bf16_storage.json 
 python3 bench.py --precision bf16 > $out/bench_bf16.json 2> $out/bench_bf16.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_default -o s -- python3 bench.py --cpu-baseline off > $out/stats_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_bf16_storage -o s -- python3 bench.py --precision bf16 --storage bf16 --cpu-baseline off > $out/stats_bf16_storage.log 2>&1
-for mode in fp32 bf16 bf16_storage bf16x3; do
+for mode in fp32 bf16 bf16_storage f16x2; do
   for c in FETCH_SIZE WRITE_SIZE; do
     WMH_PMC_MODE=$mode rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${mode}_$c -o p -- python3 tools/pmc_traffic.py > $out/pmc_${mode}_$c.log 2>&1
   done

@@ -1,5 +1,5 @@
 """Time one nnUNetTrainerV2 iteration (BASELINE plan, batch 2 of 128^3 patches) on the HIP kernels.
-env: WMH_BATCH (2), WMH_ITERS (4), WMH_PRECISION (fp32 | bf16 | bf16x3)."""
+env: WMH_BATCH (2), WMH_ITERS (4), WMH_PRECISION (fp32 | bf16 | f16x2)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
