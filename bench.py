@@ -330,19 +330,22 @@ def measure_training_mode(plan, sd, device, precision, iters, warmup):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tflops = TRAIN_TFLOP_PER_ITER * iters / dt
-    peak = PEAK_TFLOPS['fp32' if precision == 'fp32' else 'bf16']
+    peak = PEAK_TFLOPS[precision]
     losses = [float(v) for v in torch.stack(losses).cpu()]
     del tr
     return dict(workload='one nnUNetTrainerV2 iteration, batch 2 x 128^3, BASELINE plan (31.2 M parameters), deep supervision, Dice+CE, '
                          'clip 12, SGD-Nesterov; %s' % ('fp32 throughout' if precision == 'fp32' else
+                                                        'forward and stride-1 data-gradient convolutions from fp16 pairs (fp32 tensors and '
+                                                        'accumulation), weight gradients / statistics / optimizer exact fp32' if precision == 'f16x2' else
                                                         'bf16 matrix-core operands for the stride-1 convolutions of the wide levels '
                                                         '(forward, data and weight gradients), fp32 master weights / statistics / optimizer'),
                 steps=iters, warmup=warmup, ms_per_step=round(1e3 * dt / iters, 3), value=round(2 * iters / dt, 3), unit='patches/s',
                 loss_first_to_last=[round(losses[0], 6), round(losses[-1], 6)],
                 roofline=dict(bound='mfma', kernel='whole iteration (every launch of the step)', achieved=round(tflops, 2), peak=peak,
                               unit='TFLOP/s', frac=round(tflops / peak, 4), algorithmic_tflop_per_step=TRAIN_TFLOP_PER_ITER,
-                              note='fp32: v_mfma_f32_32x32x2_f32 peak; bf16: priced against the bf16 peak although the stride-2 layers, '
-                                   'statistics and reductions of this mode stay fp32'))
+                              note='fp32: v_mfma_f32_32x32x2_f32 peak; f16x2: 16-bit MFMA peak / 4 although its weight gradients run on the fp32 '
+                                   'instruction; bf16: priced against the bf16 peak although the stride-2 layers, statistics and reductions '
+                                   'of this mode stay fp32'))
 
 
 def training_parity_tiny():
@@ -370,7 +373,7 @@ def training_parity_tiny():
     loss = ot.multiple_output_loss(net(x), tgt, weights)
     loss.backward()
     out = {}
-    for precision in ('fp32', 'bf16'):
+    for precision in ('fp32', 'f16x2', 'bf16'):
         tr = UNetTrainer(plan, sd, 'cuda:0', precision=precision)
         tr.forward(x.cuda())
         l = float(tr.backward(downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)).cpu())
@@ -485,7 +488,7 @@ def run_rank(args):
         vols_rank = args.steps * V                      # volumes this rank queued in the timed region
         gb_vol = acct['bytes'] / vols_rank / 1e9 + AGG_GBYTES_PER_VOLUME
         dtype = ('f32' if args.precision == 'fp32' else
-                 'f32 tensors and accumulate / f16x2 products (two bf16 per operand)' if args.precision == 'f16x2' else
+                 'f32 tensors and accumulate / products from fp16 pairs (two fp16 per operand, 21-22 significant bits)' if args.precision == 'f16x2' else
                  'bf16 operands / f32 accumulate+storage' if args.storage == 'fp32' else
                  'bf16 operands and activation tensors / f32 accumulate')
         res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=nvol / dt,
@@ -550,12 +553,12 @@ def run_rank(args):
             also['configs2_bf16_storage'] = m
             del e16, ref32
             torch.cuda.empty_cache()
-            for prec in ('fp32', 'bf16'):
+            for prec in ('fp32', 'f16x2', 'bf16'):
                 also['train_' + prec] = measure_training_mode(plan, sd, device, prec, 5, 2)
                 torch.cuda.empty_cache()
             if args.cpu_baseline != 'off':
                 tp = training_parity_tiny()
-                for prec in ('fp32', 'bf16'):
+                for prec in ('fp32', 'f16x2', 'bf16'):
                     also['train_' + prec]['parity'] = tp[prec]
             res['also'] = also
         if world == 1 and args.cpu_baseline != 'off':

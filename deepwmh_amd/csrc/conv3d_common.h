@@ -18,6 +18,7 @@ struct ConvArgs {
     int N, D, H, W, Do, Ho, Wo, Cout;
     int nchunks, ntx, nty, ntz, npart;
     int G, KS, xcd_swizzle;
+    int by, bz;                     // supertile of the persistent kernels' tile order (wmh_tile_coords); 1, 1 = plain x -> y -> z order
     float slope;
     unsigned long long* stamps;     // diagnostics only (NULL in production): per-workgroup cycle counts
 };
@@ -65,6 +66,36 @@ __device__ __forceinline__ float sum32(float v) {   // sum over the 32 lanes of 
     v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4);
     v += __shfl_xor(v, 2);  v += __shfl_xor(v, 1);
     return v;
+}
+
+// Tile index (after the XCD-aware permutation) -> (cout group, tile coordinates, sample).  Tiles are enumerated supertile by
+// supertile -- the ntx tiles of a row, a.by rows, a.bz slices -- instead of row by row through the whole slice: the ~32
+// workgroups an XCD runs at one time then work on a compact block of the volume (128 x 16 x 16 voxels for the 128^3 layers)
+// instead of half a slab (128 x 64 x 4), and the halos they share are found in that XCD's L2 instead of being fetched again.
+// Placement only: results and moment records do not depend on it.  a.by | a.nty and a.bz | a.ntz (wmh_pick_supertile).
+__device__ __forceinline__ void wmh_tile_coords(const ConvArgs& a, int t, int& g, int& tx, int& ty, int& tz, int& n0) {
+    g = t % a.G; t /= a.G;
+    const int per_sample = a.ntx * a.nty * a.ntz;
+    n0 = t / per_sample;
+    const int s = t - n0 * per_sample;
+    const int blk = a.ntx * a.by * a.bz;
+    const int q = s / blk;
+    int r = s - q * blk;
+    tx = r % a.ntx; r /= a.ntx;
+    const int nby = a.nty / a.by;
+    ty = (q % nby) * a.by + r % a.by;
+    tz = (q / nby) * a.bz + r / a.by;
+}
+// by, bz: powers of two dividing nty / ntz with ntx * by * bz <= the workgroups an XCD runs at a time, grown towards a cube
+// (TY, TZ: the tile's extent in voxels)
+static inline void wmh_pick_supertile(ConvArgs& a, int TY, int TZ, int per_xcd) {
+    a.by = a.bz = 1;
+    for (;;) {
+        const bool cy = a.nty % (2 * a.by) == 0, cz = a.ntz % (2 * a.bz) == 0;
+        if (a.ntx * a.by * a.bz * 2 > per_xcd || (!cy && !cz)) break;
+        const bool grow_y = cy && (!cz || a.by * TY <= a.bz * TZ);
+        if (grow_y) a.by *= 2; else a.bz *= 2;
+    }
 }
 
 // wave-specialised persistent form for the large-layer configuration (conv3d_k3_ws.hip)

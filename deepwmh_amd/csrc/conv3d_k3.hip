@@ -604,6 +604,7 @@ static int conv_fwd(int cfg, const float* x0, const float* ss0, int C0, const fl
     static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
     a.xcd_swizzle = swz_env;
     a.stamps = g_conv_stamps;
+    a.by = a.bz = 1;
     long long nblk = (long long)a.ntx * a.nty * a.ntz * cdiv(N, c.TN) * a.G;
     const long long tiles = nblk;
     a.KS = pick_ksplit(c, nblk, a.nchunks);

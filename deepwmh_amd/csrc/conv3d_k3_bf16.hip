@@ -472,6 +472,7 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     static const int abl_env = env_int("WMH_BF16_ABL", 0);
     a.xcd_swizzle = (swz_env & 1) | (abl_env << 4);
     a.stamps = g_conv_stamps;
+    a.by = a.bz = 1;
     const long long nblk = (long long)a.ntx * a.nty * a.ntz * N * a.G;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: grid too large");
     hipStream_t st = (hipStream_t)stream;
@@ -549,6 +550,7 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
     a.xcd_swizzle = swz_env & 1;
     a.stamps = g_conv_stamps;
+    a.by = a.bz = 1;
     hipStream_t st = (hipStream_t)stream;
     if (!small) return wmh_launch_conv_f16x2_ws(cfg, a, st);
     // rows of 16 / 8 voxels (stride 1 and 2): the one-role kernel, split-K when slab memory is given (wmh_conv3d_k3_fwd_bf16_splitk)

@@ -93,11 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
     auto tile_of = [&](int v, int& g, int& tx, int& ty, int& tz, int& n0) {
         const int q = T >> 3, r = T & 7, xcd = v & 7;
         int t = (a.xcd_swizzle & 1) ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3) : v;
-        g = t % a.G; t /= a.G;
-        tx = t % a.ntx; t /= a.ntx;
-        ty = t % a.nty; t /= a.nty;
-        tz = t % a.ntz; t /= a.ntz;
-        n0 = t;
+        wmh_tile_coords(a, t, g, tx, ty, tz, n0);
     };
     int ntiles_mine = 0;
     for (int v = blockIdx.x; v < T; v += gridDim.x) ++ntiles_mine;
@@ -435,7 +431,7 @@ typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> WBCfg2;
 typedef ConvCfg<1, 32, 1, 4, 4, 1, 4, 2, 4, 6> WBCfgW;      // configuration 21: 4 x 4 x 32 voxels x 64 output channels
 
 template <class C, bool IN16 = false, bool OUT16 = false, bool PAIR = false>
-static int launch_bf16_ws(const ConvArgs& a, hipStream_t st) {
+static int launch_bf16_ws(const ConvArgs& a_in, hipStream_t st) {
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
@@ -448,9 +444,12 @@ static int launch_bf16_ws(const ConvArgs& a, hipStream_t st) {
     constexpr int lds = 2 * NITL * 256 * 32 + 27 * C::NT * 64 * 16;
     static_assert(lds <= 160 * 1024, "LDS");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_ws_kernel<C, IN16, OUT16, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    const long long T = (long long)a.ntx * a.nty * a.ntz * a.N * a.G;
+    const long long T = (long long)a_in.ntx * a_in.nty * a_in.ntz * a_in.N * a_in.G;
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 bf16 (wave-specialised): too many tiles");
     const int grid = T < ncu ? (int)T : ncu;
+    ConvArgs a = a_in;
+    static const int supertile = getenv("WMH_SUPERTILE") ? atoi(getenv("WMH_SUPERTILE")) : 1;
+    if (supertile && (a.xcd_swizzle & 1)) wmh_pick_supertile(a, C::TY, C::TZ, grid / 8 > 0 ? grid / 8 : 1);
     hipLaunchKernelGGL((conv3d_k3_bf16_ws_kernel<C, IN16, OUT16, PAIR>), dim3(grid), dim3(512), lds, st, a, (int)T);
     return wmh_check_launch("conv3d_k3_bf16_ws_kernel");
 }

@@ -71,11 +71,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
     auto tile_of = [&](int v, int& g, int& tx, int& ty, int& tz, int& n0) {
         const int q = T >> 3, r = T & 7, xcd = v & 7;
         int t = a.xcd_swizzle ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3) : v;
-        g = t % a.G; t /= a.G;
-        tx = t % a.ntx; t /= a.ntx;
-        ty = t % a.nty; t /= a.nty;
-        tz = t % a.ntz; t /= a.ntz;
-        n0 = t;
+        wmh_tile_coords(a, t, g, tx, ty, tz, n0);
     };
     int ntiles_mine = 0;
     for (int v = blockIdx.x; v < T; v += gridDim.x) ++ntiles_mine;
@@ -177,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
                     const f32x2_t lo = __builtin_elementwise_fma(xlo, sc2, sh2);
                     const f32x2_t hi = __builtin_elementwise_fma(xhi, sc2, sh2);
                     const f32x2_t lo_s = lo * slope_eff, hi_s = hi * slope_eff;
-                    // LeakyReLU as max(t, slope t) for 0 <= slope <= 1; bit-identical to the select form
+                    // LeakyReLU as max(t, slope t) for 0 <= slope <= 1
                     const f32x4_t v = {fmaxf(lo[0], lo_s[0]), fmaxf(lo[1], lo_s[1]), fmaxf(hi[0], hi_s[0]), fmaxf(hi[1], hi_s[1])};
                     if (NSL * LTH == NQ || sidx < NQ) *reinterpret_cast<f32x4_t*>(xb + cc * CS + 4 * sidx) = v;   // row * RSX + 4 q = 4 sidx
                 }
@@ -298,15 +294,18 @@ static int ws_num_cus() {
     return ncu;
 }
 template <class C, bool IN16 = false>
-static int launch_ws(const ConvArgs& a, hipStream_t st) {
+static int launch_ws(const ConvArgs& a_in, hipStream_t st) {
     constexpr int CSL = C::IY * C::IZ * (4 * ((C::IX + 6) / 4));            // channel stride of the quad-aligned LDS tile
     constexpr int lds = (2 * C::CK * CSL + 2 * 27 * C::NT * 64 * (C::CK / 2)) * 4;
     static_assert(lds <= 160 * 1024, "LDS");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_ws_kernel<C, IN16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    const long long T = (long long)a.ntx * a.nty * a.ntz * a.N * a.G;
+    const long long T = (long long)a_in.ntx * a_in.nty * a_in.ntz * a_in.N * a_in.G;
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 (wave-specialised): too many tiles");
     const int ncu = ws_num_cus();
     const int grid = T < ncu ? (int)T : ncu;
+    ConvArgs a = a_in;
+    static const int supertile = getenv("WMH_SUPERTILE") ? atoi(getenv("WMH_SUPERTILE")) : 1;
+    if (supertile && a.xcd_swizzle) wmh_pick_supertile(a, C::TY, C::TZ, grid / 8 > 0 ? grid / 8 : 1);
 #ifdef WMH_DIAG_ABLATIONS
     static const int dbg = getenv("WMH_WS_DBG") ? atoi(getenv("WMH_WS_DBG")) : 0;
 #else

@@ -122,25 +122,31 @@ def test_engine_f16x2_full_width_patch_vs_fp32_path():
     assert d <= 5e-5 and mism == 0
 
 
-def test_activation_overflow_saturates_and_large_weights_are_refused(lib):
-    """fp16's range: an activation beyond 65504 saturates (the high part is rounded toward zero) instead of becoming inf, and the
-    host packer refuses weights whose 2^8 multiple does not fit."""
+def test_activation_range_of_the_fp16_pair(lib):
+    """fp16's range.  The high part is rounded toward zero, so it saturates at 65504 and the low part carries the rest: activations
+    up to 131008 in magnitude stay finite (with fp16's coarse spacing up there); beyond that the low part overflows and the output
+    is non-finite -- loud, like nnU-Net's own fp16 autocast at 65504, not silently wrong.  (Behind InstanceNorm + LeakyReLU an
+    activation is bounded by sqrt(voxels) ~ 1.4e3 times the affine scale.)"""
     from deepwmh_amd import _lib
     P = _lib.ptr
     N, Cin, Cout, D, H, W = 1, 8, 32, 4, 8, 32
-    x = torch.ones(N, Cin, D, H, W)
-    x[0, 0, 1, 2, 3] = 3.0e5
     w = np.zeros((Cout, Cin, 27), np.float32)
     w[:, :, 13] = 1.0 / Cin
     cfg = lib.wmh_conv3d_k3_bf16_config(_lib.check(lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, 1), 'config'), Cout, W)
     wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cin, Cout), np.uint16)
     _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
     wfd = torch.from_numpy(wf.view(np.int16)).cuda()
-    y = torch.empty(N, Cout, D, H, W, device='cuda')
-    xd = x.cuda()
-    _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(xd), None, Cin, None, None, 0, P(wfd), None, P(y), None, None, N, D, H, W, Cout, 0.01, None), 'fwd')
-    torch.cuda.synchronize()
-    got = y.cpu()
-    assert bool(torch.isfinite(got).all())
-    assert float(got[0, 0, 0, 0, 0]) == pytest.approx(1.0, abs=1e-6)
-    assert 1.0e4 < float(got[0, 0, 1, 2, 3]) < 3.0e5 / Cin + 1       # saturated, finite (2 x 65504 / 8 + 7/8)
+    for big, finite in ((1.0e5, True), (-1.0e5, True), (3.0e5, False)):
+        x = torch.ones(N, Cin, D, H, W)
+        x[0, 0, 1, 2, 3] = big
+        y = torch.empty(N, Cout, D, H, W, device='cuda')
+        xd = x.cuda()
+        _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(xd), None, Cin, None, None, 0, P(wfd), None, P(y), None, None, N, D, H, W, Cout, 0.01, None), 'fwd')
+        torch.cuda.synchronize()
+        got = y.cpu()
+        assert float(got[0, 0, 0, 0, 0]) == pytest.approx(1.0, abs=1e-6)
+        if finite:
+            assert bool(torch.isfinite(got).all())
+            assert float(got[0, 0, 1, 2, 3]) == pytest.approx(big / Cin + 7.0 / 8, rel=2e-4)
+        else:
+            assert not bool(torch.isfinite(got[0, :, 1, 2, 3]).all())

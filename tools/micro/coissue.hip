@@ -10,9 +10,10 @@ typedef short s8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum { K_FMA = 0, K_PKFMA, K_CVTPK, K_INT, K_DSREAD, K_DSWRITE, K_TRANSFORM, K_MAX3, K_NKINDS };
+enum { K_FMA = 0, K_PKFMA, K_CVTPK, K_INT, K_DSREAD, K_DSWRITE, K_TRANSFORM, K_MAX3, K_BFI, K_CNDMASK, K_ADD3, K_PERM, K_CVTF32F16, K_CVTPKRTZ, K_MOV, K_ADDF, K_NKINDS };
 static const char* kind_name[K_NKINDS] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_pk_bf16_f32", "v_lshl/v_and", "ds_read_b128", "ds_write_b128",
-                                          "transform (rd+28valu+wr)/30", "v_med3_f32"};
+                                          "transform (rd+28valu+wr)/30", "v_med3_f32", "v_bfi_b32", "v_cmp_gt_i32+v_cndmask", "v_add3_u32", "v_perm_b32", "v_cvt_f32_f16",
+                                          "v_cvt_pkrtz_f16_f32", "v_mov_b32", "v_add_f32"};
 
 template <int KIND, int PER>      // PER loader instructions per block of 8 MFMAs
 __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, int iters, int run_mfma, int run_loader, int prio) {
@@ -52,6 +53,14 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, i
                 if (KIND == K_CVTPK) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[r]) : "v"(x[r]), "v"(x[(r + 1) & 7]));
                 if (KIND == K_INT) { if (j & 1) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(u[r])); else asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(u[r])); }
                 if (KIND == K_MAX3) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[r]) : "v"(c1), "v"(c2));
+                if (KIND == K_BFI) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(u[r]) : "v"(u[(r + 1) & 7]), "v"(u[(r + 2) & 7]));
+                if (KIND == K_CNDMASK) { if (j & 1) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[r]) : "v"(u[(r + 1) & 7]) : "vcc"); else asm volatile("v_cmp_gt_i32 vcc, 0, %0" :: "v"(u[r]) : "vcc"); }
+                if (KIND == K_ADD3) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[r]) : "v"(u[(r + 1) & 7]), "v"(u[(r + 2) & 7]));
+                if (KIND == K_PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[r]) : "v"(u[(r + 1) & 7]), "v"(0x07060302u));
+                if (KIND == K_CVTF32F16) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(x[r]) : "v"(u[r]));
+                if (KIND == K_CVTPKRTZ) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[r]) : "v"(x[r]), "v"(x[(r + 1) & 7]));
+                if (KIND == K_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(u[r]) : "v"(u[(r + 1) & 7]));
+                if (KIND == K_ADDF) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[r]) : "v"(c2));
                 if (KIND == K_DSREAD) {
                     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[j & 3]) : "v"(addr), "n"((j & 7) * 1024));
                     if ((j & 3) == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -119,9 +128,10 @@ static void run(int iters) {
            kind_name[KIND], PER / 8.0, res[0][0], ms[0], res[1][1], ms[1], res[2][0], res[2][1], ms[2]);
 }
 
-int main() {
+int main(int argc, char**) {
     hipMalloc(&d_out, 256 * 8 * 8); hipMalloc(&d_sink, 256 * 512 * 4);
     const int iters = 4000;
+    if (argc > 1) {           // the first table (round 3, profiles/r03_coissue.txt)
     run<K_FMA, 4>(iters); run<K_FMA, 8>(iters); run<K_FMA, 16>(iters); run<K_FMA, 32>(iters); run<K_FMA, 64>(iters);
     run<K_PKFMA, 8>(iters); run<K_PKFMA, 16>(iters); run<K_PKFMA, 32>(iters);
     run<K_CVTPK, 8>(iters); run<K_CVTPK, 32>(iters);
@@ -129,6 +139,10 @@ int main() {
     run<K_MAX3, 8>(iters); run<K_MAX3, 32>(iters);
     run<K_DSREAD, 8>(iters); run<K_DSREAD, 16>(iters); run<K_DSREAD, 32>(iters);
     run<K_DSWRITE, 8>(iters); run<K_DSWRITE, 16>(iters);
+    }
     run<K_TRANSFORM, 30>(iters); run<K_TRANSFORM, 60>(iters); run<K_TRANSFORM, 120>(iters);
+    run<K_INT, 64>(iters); run<K_INT, 128>(iters);
+    run<K_BFI, 32>(iters); run<K_CNDMASK, 32>(iters); run<K_ADD3, 32>(iters); run<K_PERM, 32>(iters); run<K_MOV, 32>(iters);
+    run<K_CVTF32F16, 32>(iters); run<K_CVTPKRTZ, 32>(iters); run<K_ADDF, 32>(iters);
     return 0;
 }
