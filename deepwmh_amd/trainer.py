@@ -52,6 +52,11 @@ class UNetTrainer:
         # 'f16x2': forward and stride-1 data-gradient convolutions with rows of >= 16 voxels form their products from fp16 pairs
         # (network.py, DESIGN.md 3.3d: fp32-grade, 2-2.7x the fp32 instruction's speed); weight gradients and everything else fp32
         self.x3 = precision == 'f16x2'
+        # fp16's exponent range: the data gradients (dLoss/dy ~ 1e-8 .. 1e-2 at 2 x 128^3 voxels) sit below fp16's normal range, so in
+        # this mode the backward pass runs on the loss scaled by 2^16 -- the static form of the GradScaler nnU-Net's own fp16 AMP
+        # training uses -- and loss and gradient arena are scaled back (exactly: a power of two) at the end of backward().  Without it
+        # the full-size gradients were 7 % off (tools/grad_compare.py); the forward pass (O(1) activations) needs nothing.
+        self.loss_scale = 65536.0 if self.x3 else 1.0
         plan.check_supported()
         self.plan, self.device = plan, torch.device(device)
         if self.device.type != 'cuda':
@@ -427,7 +432,7 @@ class UNetTrainer:
                 self._ready([self.dec[u]['seg'] + '.weight'])
                 continue
             dl = self._buf('b.dl%d' % u, lg.shape)
-            _lib.check(lib.wmh_dice_ce_loss_fwd_bwd(_lib.ptr(lg), _lib.ptr(targets[s]), N, self.K, S, w, 1e-5, _lib.ptr(dl),
+            _lib.check(lib.wmh_dice_ce_loss_fwd_bwd(_lib.ptr(lg), _lib.ptr(targets[s]), N, self.K, S, w * self.loss_scale, 1e-5, _lib.ptr(dl),
                                                     _lib.ptr(self.loss_acc), _lib.ptr(self.ws_d), st), 'wmh_dice_ce_loss_fwd_bwd')
             dls[u] = dl
         g_next = None                                        # gradient arriving from the stage above (via its convT)
@@ -464,6 +469,9 @@ class UNetTrainer:
             outs = self._block_bwd(tape['enc'][i], g, g2, None, None, i > 0)
             g = outs[0] if outs else None
         self._avg.finish()
+        if self.loss_scale != 1.0:                           # exact: power of two
+            self.grads.mul_(1.0 / self.loss_scale)
+            self.loss_acc.mul_(1.0 / self.loss_scale)
         return self.loss_acc
 
     # ---- optimizer -----------------------------------------------------------------------------------------------
