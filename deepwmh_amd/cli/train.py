@@ -28,10 +28,13 @@ def build_parser():
     ap.add_argument('--disable_postprocessing_on_folds', action='store_true')
     ap.add_argument('--custom_val_cases', nargs='*', default=None)            # fork-only
     ap.add_argument('--npz', action='store_true')
-    ap.add_argument('--fp32', action='store_true')                            # nnU-Net: disable mixed precision (already the default here)
+    ap.add_argument('--fp32', action='store_true',                            # nnU-Net: disable mixed precision
+                    help='exact-fp32 kernels throughout (also WMH_TRAIN_PRECISION=fp32).  The default is f16x2: fp32 tensors, statistics, '
+                         'weight gradients and optimizer; forward and data-gradient products from fp16 pairs with a 2^16 loss scale -- '
+                         'gradients at the fp32 step\'s level (nnU-Net itself defaults to fp16 AMP with a GradScaler)')
     ap.add_argument('--bf16', action='store_true',
-                    help='mixed precision: bf16 operands in the forward/data-gradient convolutions of the wide levels (extension; '
-                         'also WMH_TRAIN_PRECISION=bf16).  nnU-Net itself defaults to fp16 AMP; here fp32 is the default')
+                    help='mixed precision: bf16 operands in the forward/data-gradient/weight-gradient convolutions of the wide levels '
+                         '(extension; also WMH_TRAIN_PRECISION=bf16)')
     ap.add_argument('--val_batches', type=int, default=None)
     ap.add_argument('--seed', type=int, default=12345)
     return ap
@@ -83,9 +86,13 @@ def main(argv=None):
     os.makedirs(fdir, exist_ok=True)
 
     bs = int(plans['plans_per_stage'][max(plans['plans_per_stage'].keys())]['batch_size'])
-    precision = 'bf16' if (args.bf16 or os.environ.get('WMH_TRAIN_PRECISION', '') == 'bf16') and not args.fp32 else 'fp32'
-    if os.environ.get('WMH_TRAIN_PRECISION', '') == 'f16x2' and not args.fp32 and not args.bf16:
-        precision = 'f16x2'                            # fp32-grade products from fp16 pairs in the forward / data-gradient convolutions
+    precision = os.environ.get('WMH_TRAIN_PRECISION', 'f16x2')
+    if args.fp32:
+        precision = 'fp32'
+    elif args.bf16:
+        precision = 'bf16'
+    if precision not in ('fp32', 'f16x2', 'bf16'):
+        sys.exit('nnUNet_train (deepwmh_amd): WMH_TRAIN_PRECISION must be fp32, f16x2 or bf16, got %r' % precision)
     start_epoch, best, ma_resume = 0, None, None
     latest = os.path.join(fdir, 'model_latest.model')
     if args.continue_training and os.path.isfile(latest):

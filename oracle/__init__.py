@@ -5,7 +5,9 @@ This package is a torch-CPU / numpy / scipy restatement of what the
 (/root/reference/deepwmh/main/predict.py:153-156,
 /root/reference/deepwmh/pipeline/DCNN_multistage.py:331-336,531-533).
 
-PARITY UNPINNED.  The arithmetic of this path lives in the un-vendored, un-pinned
+PARITY UNPINNED for the nnU-Net rows (generic_unet, sliding_window, training, preprocess); the rows whose code IS in
+/root/reference (postprocess, stage1, stage2's Dice) are pinned to the reference's own function bodies through
+tests/golden/rows_ref.npz (tests/golden/make_golden_ref.py, tests/test_rows_ref.py).  The arithmetic of the network path lives in the un-vendored, un-pinned
 nnU-Net fork `lchdl/nnUNet_for_DeepWMH` (README.md:69-72 of the reference; absent
 from its setup.py:32-46), which is not present in /root/reference, not installed
 and not fetchable.  The reference has no tests, golden vectors or sample weights

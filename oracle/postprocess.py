@@ -4,8 +4,10 @@ remove_sparks / remove_3mm_sparks restate /root/reference/deepwmh/analysis/image
 primitive the reference imports (scipy.ndimage.label, default 6-connectivity, image_ops.py:8); the reference's
 per-component Python loop is replaced by a bincount of the label image (same set of kept voxels).
 fill_holes is scipy.ndimage.binary_fill_holes, as nnU-Net's create_nonzero_mask calls it [not in tree].
-Parity unpinned: the reference holds no tests or fixtures for these functions and is not executed here; the
-arithmetic is scipy's own on both sides.  Only tests/, smoke() and bench.py's cpu_baseline leg may import this.
+Pinned: tests/golden/rows_ref.npz holds the outputs of the REFERENCE's own remove_sparks / remove_3mm_sparks / connected_components
+bodies (executed from /root/reference in the build container by tests/golden/make_golden_ref.py); tests/test_rows_ref.py holds
+these functions to them bit for bit.  fill_holes (nnU-Net, not in tree) stays unpinned.  Only tests/, smoke() and bench.py's
+cpu_baseline leg may import this.
 """
 import numpy as np
 from scipy.ndimage import binary_fill_holes, label

@@ -11,8 +11,10 @@ z-score), the reference functions:
   nll, hist_curve, histogram_analysis, nll_analysis   /root/reference/deepwmh/analysis/lesion_analysis.py:40-113,115-278
 threshold_otsu is scikit-image's (an unpinned dependency of the reference, absent here): restated from its published
 algorithm (256-bin histogram over [min, max], float32 counts, maximum between-class variance, returns the bin centre).
-Array-in / array-out (the reference reads NIfTI paths).  Parity unpinned: no reference tests or fixtures exist for these
-functions and the reference is not executed here.  Only tests/, smoke() and bench.py's cpu_baseline leg may import this.
+Array-in / array-out (the reference reads NIfTI paths).  Pinned: every function above except threshold_otsu and the nll_analysis
+driver is held bit for bit to the outputs of the REFERENCE's own function bodies (tests/golden/rows_ref.npz, made by
+tests/golden/make_golden_ref.py from /root/reference; tests/test_rows_ref.py).  threshold_otsu (scikit-image, absent) and therefore
+nll(use_mask=True) and the composition in nll_analysis_arrays stay unpinned.  Only tests/, smoke() and bench.py's cpu_baseline leg may import this.
 """
 import warnings
 

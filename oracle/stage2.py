@@ -4,8 +4,10 @@ softmax_masking:   /root/reference/deepwmh/pipeline/DCNN_multistage.py:102-109
 ensembling:        /root/reference/deepwmh/pipeline/DCNN_multistage.py:111-125
 hard_dice_binary:  /root/reference/deepwmh/analysis/metrics.py:26-32
 validation split:  /root/reference/deepwmh/pipeline/DCNN_multistage.py:426-446
-Parity unpinned (the reference has no tests/fixtures for these and is not executed here); the expressions are
-copied operation for operation onto float32 numpy arrays, which is what load_nifti_simple returns (data_io.py:288-290).
+hard_dice_binary and remove_3mm_sparks are pinned to the reference's own code (tests/golden/rows_ref.npz, tests/test_rows_ref.py).
+The masking / ensembling / split expressions live inside NIfTI file workers and a method of the reference (nibabel is absent: they
+cannot be executed here) and stay unpinned; they are restated operation for operation on float32 numpy arrays, which is what
+load_nifti_simple returns (data_io.py:288-290).
 Only tests/, smoke() and bench.py's cpu_baseline leg may import this.
 """
 import numpy as np
