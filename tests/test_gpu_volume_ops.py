@@ -199,9 +199,10 @@ def test_training_case_preprocessing_device_matches_host(lib, spacing, target, u
     rng = np.random.default_rng(17)
     vol = np.zeros((1, 30, 44, 40), np.float32)
     vol[0, 3:28, 4:41, 5:36] = (gaussian_filter(rng.standard_normal((25, 37, 31)), 1.5) * 200 + 300).astype(np.float32)
-    vol[0, 10:13, 20:24, 18:22] = 0
+    vol[0, 10:13, 20:24, 18:22] = 0                      # a hole: filled by the mask
+    vol[0, 3:9, 4:12, 5:36] = 0                          # a notch open to the outside: stays outside the mask (segmentation -1)
     lab = np.zeros((30, 44, 40), np.float32)
-    lab[8:14, 10:22, 9:20] = 1
+    lab[9:14, 13:22, 9:20] = 1
     lab[18:22, 25:33, 22:30] = 1
     cropped, seg, nz, bbox = preprocess.crop_training_case_device(vol, lab)
     c_ref, nz_ref, bbox_ref = opre.crop_to_nonzero(vol)
