@@ -40,11 +40,9 @@ __device__ __forceinline__ cl_u32x4 cl_transform8(const cl_u32x4 u, const float 
     cl_u32x4 w;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const cl_f32x2 x = {__builtin_bit_cast(float, u[p] << 16), __builtin_bit_cast(float, u[p] & 0xFFFF0000u)};
-        const cl_f32x2 s = {sc[2 * p], sc[2 * p + 1]}, t = {sh[2 * p], sh[2 * p + 1]};
-        const cl_f32x2 z = __builtin_elementwise_fma(x, s, t);
-        const cl_f32x2 zs = z * slope;
-        w[p] = cl_pack2(cl_vmax(z[0], zs[0]), cl_vmax(z[1], zs[1]));
+        // unpacked fp32 instructions: v_pk_fma_f32 / v_pk_mul_f32 of a staging wave do not overlap with the consumers' MFMAs (conv3d_common.h)
+        const float x0 = __builtin_bit_cast(float, u[p] << 16), x1 = __builtin_bit_cast(float, u[p] & 0xFFFF0000u);
+        w[p] = cl_pack2(wmh_norm_lrelu(x0, sc[2 * p], sh[2 * p], slope), wmh_norm_lrelu(x1, sc[2 * p + 1], sh[2 * p + 1], slope));
     }
     return w;
 }

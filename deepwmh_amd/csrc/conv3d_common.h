@@ -68,6 +68,19 @@ __device__ __forceinline__ float sum32(float v) {   // sum over the 32 lanes of 
     return v;
 }
 
+// lrelu(x * sc + sh) with UNPACKED fp32 instructions.  Measured (tools/micro/coissue.hip, profiles/r03_coissue.txt): a loader wave's
+// v_pk_fma_f32 / v_pk_mul_f32 do not overlap at all with the MFMA stream of the consumer wave on the same SIMD (the kernel's wall
+// time is the SUM of the two streams), while v_fma_f32 / v_mul_f32 / v_max_f32, the conversions and integer instructions do (wall =
+// the longer stream): the packed form halves the instruction count and costs matrix time one for one.  Inline asm so that the
+// compiler does not fuse neighbouring elements back into packed instructions; same roundings as the packed form (bit-identical).
+__device__ __forceinline__ float wmh_norm_lrelu(float x, float sc, float sh, float slope) {
+    float z, zs, r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(z) : "v"(x), "v"(sc), "v"(sh));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(zs) : "v"(z), "v"(slope));
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(z), "v"(zs));
+    return r;
+}
+
 // Tile index (after the XCD-aware permutation) -> (cout group, tile coordinates, sample).  Tiles are enumerated supertile by
 // supertile -- the ntx tiles of a row, a.by rows, a.bz slices -- instead of row by row through the whole slice: the ~32
 // workgroups an XCD runs at one time then work on a compact block of the volume (128 x 16 x 16 voxels for the 128^3 layers)

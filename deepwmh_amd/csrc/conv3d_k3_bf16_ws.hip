@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             const int sidx = lt + i * LTH;
             const int row = sidx / QPR, q = sidx - row * QPR;
             const unsigned keep = okh[r] ? 0xFFFFFFFFu : 0u;      // quad outside the volume: zeros
-            // InstanceNorm + LeakyReLU in packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: two voxels per instruction), two
+            // InstanceNorm + LeakyReLU (unpacked fp32 instructions, conv3d_common.h), two
             // channels at a time straight into the packed words: the staging registers of the next chunk's weights must not
             // be pushed out to scratch (their reload sits between the two barriers, where every wave of the workgroup waits,
             // and a scratch reload waits for ALL loads in flight -- the whole prefetch ring)
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int cc = c + e;
-                    const f32x2_t sc2 = {scv[8 * half + cc], scv[8 * half + cc]}, sh2 = {shv[8 * half + cc], shv[8 * half + cc]};
+                    const float sc1 = scv[8 * half + cc], sh1 = shv[8 * half + cc];
                     f32x2_t xlo, xhi;
                     if constexpr (IN16) {
                         const unsigned u0 = v16[r][cc].x, u1 = v16[r][cc].y;
@@ -240,19 +240,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                         xlo = f32x2_t{v[r][cc][0], v[r][cc][1]};
                         xhi = f32x2_t{v[r][cc][2], v[r][cc][3]};
                     }
-                    const f32x2_t lo = __builtin_elementwise_fma(xlo, sc2, sh2);
-                    const f32x2_t hi = __builtin_elementwise_fma(xhi, sc2, sh2);
-                    const f32x2_t lo_s = lo * slope_eff, hi_s = hi * slope_eff;
-                    t[e] = f32x4_t{ws_vmax(lo[0], lo_s[0]), ws_vmax(lo[1], lo_s[1]), ws_vmax(hi[0], hi_s[0]), ws_vmax(hi[1], hi_s[1])};
+                    // unpacked fp32 instructions: packed ones do not overlap with the consumer's MFMAs (conv3d_common.h)
+                    t[e] = f32x4_t{wmh_norm_lrelu(xlo[0], sc1, sh1, slope_eff), wmh_norm_lrelu(xlo[1], sc1, sh1, slope_eff),
+                                   wmh_norm_lrelu(xhi[0], sc1, sh1, slope_eff), wmh_norm_lrelu(xhi[1], sc1, sh1, slope_eff)};
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if constexpr (PAIR) {                            // fp16 pair: high part toward zero, the remainder to nearest
                         const auto h2 = __builtin_amdgcn_cvt_pkrtz(t[0][k], t[1][k]);
                         w[k][c >> 1] = __builtin_bit_cast(unsigned, h2) & keep;
-                        const f32x2_t lo2 = f32x2_t{t[0][k], t[1][k]} - f32x2_t{(float)h2[0], (float)h2[1]};
+                        float l0, l1;                                // (unpacked subtraction, see above)
+                        asm("v_sub_f32 %0, %1, %2" : "=v"(l0) : "v"(t[0][k]), "v"((float)h2[0]));
+                        asm("v_sub_f32 %0, %1, %2" : "=v"(l1) : "v"(t[1][k]), "v"((float)h2[1]));
                         typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-                        wlo[k][c >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo2, f16x2_t)) & keep;
+                        wlo[k][c >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{l0, l1}, f16x2_t)) & keep;
                     } else {
                         w[k][c >> 1] = ws_pack_bf16x2(t[0][k], t[1][k]) & keep;
                     }

@@ -10,10 +10,10 @@ typedef short s8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum { K_FMA = 0, K_PKFMA, K_CVTPK, K_INT, K_DSREAD, K_DSWRITE, K_TRANSFORM, K_MAX3, K_BFI, K_CNDMASK, K_ADD3, K_PERM, K_CVTF32F16, K_CVTPKRTZ, K_MOV, K_ADDF, K_NKINDS };
+enum { K_FMA = 0, K_PKFMA, K_CVTPK, K_INT, K_DSREAD, K_DSWRITE, K_TRANSFORM, K_MAX3, K_BFI, K_CNDMASK, K_ADD3, K_PERM, K_CVTF32F16, K_CVTPKRTZ, K_MOV, K_ADDF, K_TRANSFORM_PLAIN, K_PKMUL, K_NKINDS };
 static const char* kind_name[K_NKINDS] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_pk_bf16_f32", "v_lshl/v_and", "ds_read_b128", "ds_write_b128",
                                           "transform (rd+28valu+wr)/30", "v_med3_f32", "v_bfi_b32", "v_cmp_gt_i32+v_cndmask", "v_add3_u32", "v_perm_b32", "v_cvt_f32_f16",
-                                          "v_cvt_pkrtz_f16_f32", "v_mov_b32", "v_add_f32"};
+                                          "v_cvt_pkrtz_f16_f32", "v_mov_b32", "v_add_f32", "transform, plain fp32 (rd+36valu+wr)/38", "v_pk_mul_f32"};
 
 template <int KIND, int PER>      // PER loader instructions per block of 8 MFMAs
 __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, int iters, int run_mfma, int run_loader, int prio) {
@@ -69,6 +69,27 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, i
                     asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(q[j & 3]), "n"((j & 7) * 1024) : "memory");
                     if ((j & 3) == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                if (KIND == K_PKMUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[r]) : "v"(pc));
+                if (KIND == K_TRANSFORM_PLAIN && (j % 38) == 0) {
+                    // one 16-byte piece with unpacked float instructions: read, 4 x (shl, and, 4 x v_fma (z, z', slope z, slope z'), med3, med3, cvt_pk), write
+                    u32x4 w;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(addr + ((j / 38) & 7) * 1024) : "memory");
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {
+                        unsigned lo, hi; float z0, z1, y0, y1, m0, m1; unsigned o;
+                        asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(lo) : "v"(w[pp]));
+                        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(hi) : "v"(w[pp]));
+                        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(z0) : "v"(lo), "v"(c1), "v"(c2));
+                        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y0) : "v"(lo), "v"(c2), "v"(c1));
+                        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(z1) : "v"(hi), "v"(c1), "v"(c2));
+                        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y1) : "v"(hi), "v"(c2), "v"(c1));
+                        asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(z0), "v"(y0), "v"(c1));
+                        asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(z1), "v"(y1), "v"(c1));
+                        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o) : "v"(m0), "v"(m1));
+                        w[pp] = o;
+                    }
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(addr + ((j / 38) & 7) * 1024), "v"(w) : "memory");
+                }
                 if (KIND == K_TRANSFORM && (j % 30) == 0) {
                     // one 16-byte piece: read, 4 x (shl, and, pk_fma, pk_mul, med3, med3, cvt_pk), write = 30 instructions
                     u32x4 w;
@@ -102,7 +123,7 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, i
 
 static unsigned long long* d_out; static float* d_sink;
 template <int KIND, int PER>
-static void run(int iters) {
+static void run(int iters, int prio = 0) {
     unsigned long long h[256 * 8];
     double res[3][2];
     float ms[3];
@@ -112,7 +133,7 @@ static void run(int iters) {
         for (int rep = 0; rep < 2; ++rep) {
             hipMemset(d_out, 0, sizeof(h));
             hipEventRecord(e0);
-            hipLaunchKernelGGL((k<KIND, PER>), dim3(256), dim3(512), 0, 0, d_out, d_sink, iters, modes[md][0], modes[md][1], 0);
+            hipLaunchKernelGGL((k<KIND, PER>), dim3(256), dim3(512), 0, 0, d_out, d_sink, iters, modes[md][0], modes[md][1], prio);
             hipEventRecord(e1);
             hipDeviceSynchronize();
         }
@@ -124,13 +145,23 @@ static void run(int iters) {
         res[md][1] = sl / (256 * 4) / ((double)iters * PER);
     }
     // s_memtime ticks -> shader cycles: the MFMA-only run issues one MFMA per 32 cycles... report raw ticks and wall time
+    if (prio) printf("[loader at s_setprio 3] ");
     printf("%-30s %4.1f per MFMA | alone: mfma %6.2f ticks (%.3f ms), loader %6.2f ticks/instr (%.3f ms) | together: mfma %6.2f, loader %6.2f (%.3f ms)\n",
            kind_name[KIND], PER / 8.0, res[0][0], ms[0], res[1][1], ms[1], res[2][0], res[2][1], ms[2]);
 }
 
-int main(int argc, char**) {
+int main(int argc, char** argv) {
     hipMalloc(&d_out, 256 * 8 * 8); hipMalloc(&d_sink, 256 * 512 * 4);
     const int iters = 4000;
+    if (argc > 1 && argv[1][0] == 'p') {      // loaders at raised priority, as in the real kernels
+        run<K_FMA, 8>(iters, 1); run<K_FMA, 16>(iters, 1); run<K_FMA, 32>(iters, 1); run<K_PKFMA, 16>(iters, 1); run<K_CVTPK, 8>(iters, 1);
+        run<K_INT, 32>(iters, 1); run<K_TRANSFORM, 30>(iters, 1); run<K_TRANSFORM, 60>(iters, 1); run<K_TRANSFORM, 120>(iters, 1);
+        run<K_TRANSFORM_PLAIN, 38>(iters, 1); run<K_TRANSFORM_PLAIN, 76>(iters, 1); run<K_TRANSFORM_PLAIN, 152>(iters, 1);
+        run<K_TRANSFORM_PLAIN, 38>(iters, 0);
+        run<K_PKMUL, 16>(iters, 1); run<K_PKFMA, 8>(iters, 1); run<K_PKFMA, 32>(iters, 1); run<K_MAX3, 32>(iters, 1); run<K_CVTPK, 32>(iters, 1);
+        run<K_CVTF32F16, 32>(iters, 1); run<K_CVTPKRTZ, 32>(iters, 1); run<K_DSREAD, 16>(iters, 1); run<K_DSWRITE, 8>(iters, 1);
+        return 0;
+    }
     if (argc > 1) {           // the first table (round 3, profiles/r03_coissue.txt)
     run<K_FMA, 4>(iters); run<K_FMA, 8>(iters); run<K_FMA, 16>(iters); run<K_FMA, 32>(iters); run<K_FMA, 64>(iters);
     run<K_PKFMA, 8>(iters); run<K_PKFMA, 16>(iters); run<K_PKFMA, 32>(iters);
