@@ -81,6 +81,12 @@ __device__ __forceinline__ float wmh_norm_lrelu(float x, float sc, float sh, flo
     return r;
 }
 
+// The 16-bit-operand kernels (conv3d_k3_bf16.hip, conv3d_k3_bf16_ws.hip) walk the 27 taps in the order (kd, kw, kr): step p is tap
+// wmh_tap_of(p) of the weight image (whose layout stays torch's kd, kr, kw).  The three kr taps of a (kd, kw) group read the same
+// input rows shifted by one output row, which the wave-specialised kernel exploits; both kernels use the order so that their results
+// stay bit-identical to each other.
+__host__ __device__ constexpr int wmh_tap_of(int p) { return (p / 9) * 9 + (p % 3) * 3 + (p / 3) % 3; }
+
 // Tile index (after the XCD-aware permutation) -> (cout group, tile coordinates, sample).  Tiles are enumerated supertile by
 // supertile -- the ntx tiles of a row, a.by rows, a.bz slices -- instead of row by row through the whole slice: the ~32
 // workgroups an XCD runs at one time then work on a compact block of the volume (128 x 16 x 16 voxels for the 128^3 layers)

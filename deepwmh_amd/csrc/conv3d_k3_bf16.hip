@@ -97,10 +97,13 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
         }
 
     const bf16x8* wl = reinterpret_cast<const bf16x8*>(a.wf) + (size_t)g * a.nchunks * 27 * NT * 64 + (PAIR ? j : lane);
-    const int Tlast = ch_hi * 27 - 1;
     bf16x8 aring[APF][NT * NA];                                   // PAIR: [nt] = high parts, [NT + nt] = low parts, both lane halves alike
-    auto loadA = [&](int T, bf16x8 (&dst)[NT * NA]) {
-        T = min(T, Tlast);
+    // fragments of step `st` (0..26, or beyond: the next chunk's) of chunk `chn`; the steps walk the taps in the order (kd, kw, kr)
+    // (wmh_tap_of: the wave-specialised kernel's order).  Past the last chunk: the last fragment again (never used).
+    auto loadA = [&](int chn, int st, bf16x8 (&dst)[NT * NA]) {
+        if (st >= 27) { st -= 27; ++chn; }
+        const bool past = chn >= ch_hi;
+        const int T = (past ? ch_hi - 1 : chn) * 27 + (past ? 26 : wmh_tap_of(st));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             dst[nt] = wl[((size_t)T * NT + nt) * 64];
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
         }
     };
 #pragma unroll
-    for (int d = 0; d < APF; ++d) loadA(ch_lo * 27 + d, aring[d]);
+    for (int d = 0; d < APF; ++d) loadA(ch_lo, d, aring[d]);
 
     const char* ldsb = reinterpret_cast<const char*>(ldsq);
     unsigned long long t_stage = 0, t_mfma = 0, t_mark = 0;          // diagnostics (a.stamps != NULL only)
@@ -177,11 +180,12 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
         // ---- 27 taps x MT x NT MFMAs -----------------------------------------------------------------------------
         if (!(abl & 1))
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
+        for (int step = 0; step < 27; ++step) {
+            const int tap = wmh_tap_of(step);
             const int kw = tap % 3;
             const int rowoff = ((tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS) * 32;
             bf16x8 anew[NT * NA];
-            loadA(ch * 27 + tap + APF, anew);
+            loadA(ch, step + APF, anew);
             __builtin_amdgcn_sched_barrier(0x38F);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {

@@ -377,16 +377,27 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             for (int ch = 0; ch < nch; ++ch, ++it) {
                 const char* cur = ldsb + (size_t)(it & 1) * CS * 32;
                 if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+                // Taps are processed in the order (kd, kw, kr) -- wmh_tap_of(), the one-role kernel's order too -- three kr taps per
+                // (kd, kw) group: their weight fragments are read together (9 exposed LDS latencies per chunk instead of 27: the
+                // compiler reads a tap's fragments right in front of its first MFMA), and an input row is read once for the up to
+                // three (kr, output row) pairs that use it.
 #pragma unroll
-                for (int tap = 0; tap < 27; ++tap) {
-                    const int kw = tap % 3;
-                    const int rowoff = ((tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS) * 32;
-                    bf16x8 av[NT], al[PAIR ? NT : 1];
+                for (int grp = 0; grp < 9; ++grp) {
+                    const int kw = grp % 3;
+                    bf16x8 av3[3][NT], al3[3][PAIR ? NT : 1];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        av[nt] = wl[(tap * NT + nt) * 64];
-                        if constexpr (PAIR) al[nt] = wl[(tap * NT + nt) * 64 + 32];
-                    }
+                    for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const int tap = (grp / 3) * 9 + kr * 3 + kw;
+                            av3[kr][nt] = wl[(tap * NT + nt) * 64];
+                            if constexpr (PAIR) al3[kr][nt] = wl[(tap * NT + nt) * 64 + 32];
+                        }
+#pragma unroll
+                  for (int kr = 0; kr < 3; ++kr) {
+                    const int rowoff = ((grp / 3) * C::ZS + kr * C::YS) * 32;
+                    bf16x8 (&av)[NT] = av3[kr];
+                    bf16x8 (&al)[PAIR ? NT : 1] = al3[kr];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const bf16x8 bv = *reinterpret_cast<const bf16x8*>(cur + badr[kw][m] + rowoff);
@@ -403,6 +414,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                                 acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[nt], bv, acc[nt][m], 0, 0, 0);
                         }
                     }
+                  }
                 }
                 if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
                 __syncthreads();
