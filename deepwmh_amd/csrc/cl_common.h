@@ -36,13 +36,25 @@ __device__ __forceinline__ float cl_ld_uniform(const float* p) {
 
 // One 16-byte piece = 8 consecutive channels of one voxel: lrelu(x * scale + shift), back to bf16.
 // sc / sh: the 8 channels' scale and shift; slope 1 with scale 1 / shift 0 = identity (a source without pending norm).
+// UNPACKED: plain v_fma_f32 / v_mul_f32 / v_max_f32 (conv3d_common.h::wmh_norm_lrelu) -- for a staging wave that shares its SIMD with a
+// consumer wave's MFMA stream: packed fp32 instructions do not overlap with it (cl_conv3_kernel's stride-1 layers 3-8 % faster,
+// round 3).  The one-role kernels (stride 2, first layer, transposed convolution), where the same wave issues the MFMAs afterwards,
+// keep the packed form: half the instructions (measured: 0.69 against 0.71 ms on the first strided layer).  Same roundings either way.
+template <bool UNPACKED = false>
 __device__ __forceinline__ cl_u32x4 cl_transform8(const cl_u32x4 u, const float (&sc)[8], const float (&sh)[8], float slope) {
     cl_u32x4 w;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        // unpacked fp32 instructions: v_pk_fma_f32 / v_pk_mul_f32 of a staging wave do not overlap with the consumers' MFMAs (conv3d_common.h)
-        const float x0 = __builtin_bit_cast(float, u[p] << 16), x1 = __builtin_bit_cast(float, u[p] & 0xFFFF0000u);
-        w[p] = cl_pack2(wmh_norm_lrelu(x0, sc[2 * p], sh[2 * p], slope), wmh_norm_lrelu(x1, sc[2 * p + 1], sh[2 * p + 1], slope));
+        if constexpr (UNPACKED) {
+            const float x0 = __builtin_bit_cast(float, u[p] << 16), x1 = __builtin_bit_cast(float, u[p] & 0xFFFF0000u);
+            w[p] = cl_pack2(wmh_norm_lrelu(x0, sc[2 * p], sh[2 * p], slope), wmh_norm_lrelu(x1, sc[2 * p + 1], sh[2 * p + 1], slope));
+        } else {
+            const cl_f32x2 x = {__builtin_bit_cast(float, u[p] << 16), __builtin_bit_cast(float, u[p] & 0xFFFF0000u)};
+            const cl_f32x2 s = {sc[2 * p], sc[2 * p + 1]}, t = {sh[2 * p], sh[2 * p + 1]};
+            const cl_f32x2 z = __builtin_elementwise_fma(x, s, t);
+            const cl_f32x2 zs = z * slope;
+            w[p] = cl_pack2(cl_vmax(z[0], zs[0]), cl_vmax(z[1], zs[1]));
+        }
     }
     return w;
 }

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
                         const unsigned keep = ((keep_tr >> k) & 1u) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const cl_u32x4 w = cl_transform8(raw[k][h], sc[h], sh[h], slope_tr);
+                            const cl_u32x4 w = cl_transform8<true>(raw[k][h], sc[h], sh[h], slope_tr);
                             *reinterpret_cast<cl_u32x4*>(buf + (h * NVP + k * LTH) * 16) = cl_u32x4{w[0] & keep, w[1] & keep, w[2] & keep, w[3] & keep};
                         }
                     }
