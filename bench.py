@@ -349,8 +349,11 @@ def measure_training_mode(plan, sd, device, precision, iters, warmup):
 
 
 def training_parity_tiny():
-    """The training step against torch autograd (the oracle's restatement of nnUNetTrainerV2.run_iteration) on the committed tiny
-    network: loss and every parameter gradient of one iteration, fp32 and bf16 modes.  The checker, not the thing measured."""
+    """The training step against FLOAT64 torch autograd (the oracle's restatement of nnUNetTrainerV2.run_iteration) on the committed tiny
+    network: loss and every parameter gradient of one iteration, per mode.  The checker, not the thing measured.  Median and worst
+    parameter error in max-norm and the cosine of the whole gradient: the fixture has a voxel whose pre-activation is ~1e-6 from a
+    LeakyReLU kink, so an evaluation that rounds it to the other side is 5 % off on that channel's parameters without being wrong
+    (tests/test_gpu_trainer.py::test_f16x2_training_step_matches_autograd_oracle); the median is the robust figure."""
     import copy
     import torch
     from deepwmh_amd.plan import tiny_plan
@@ -365,29 +368,34 @@ def training_parity_tiny():
     labels = np.stack([(io['seg_tta'][4:36, 8:40, 4:36] > 0), np.random.default_rng(5).random((32, 32, 32)) < 0.2]).astype(np.uint8)
     net = unet_from_plan(plan)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
-    net = copy.deepcopy(net).train()
+    net = copy.deepcopy(net).double().train()
     net.do_ds = True
     weights = ot.deep_supervision_weights(plan.num_pool)
     x = torch.from_numpy(data)
-    tgt = ot.downsample_targets(torch.from_numpy(labels[:, None].astype(np.float32)), plan.num_pool)
-    loss = ot.multiple_output_loss(net(x), tgt, weights)
+    tgt = [t.double() for t in ot.downsample_targets(torch.from_numpy(labels[:, None].astype(np.float32)), plan.num_pool)]
+    loss = ot.multiple_output_loss(net(x.double()), tgt, weights)
     loss.backward()
     out = {}
     for precision in ('fp32', 'f16x2', 'bf16'):
         tr = UNetTrainer(plan, sd, 'cuda:0', precision=precision)
         tr.forward(x.cuda())
         l = float(tr.backward(downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)).cpu())
-        num = den = worst = 0.0
+        num = den = dot = 0.0
+        rows = []
         for name, p in net.named_parameters():
             ref = p.grad if p.grad is not None else torch.zeros_like(p)
-            got = tr.g[name].cpu()
+            got = tr.g[name].double().cpu()
             num += float(((got - ref) ** 2).sum())
             den += float((ref ** 2).sum())
+            dot += float((got * ref).sum())
             if float(ref.abs().max()) > 1e-5:
-                worst = max(worst, float((got - ref).abs().max()) / float(ref.abs().max()))
-        out[precision] = dict(sample='tiny net (tests/golden), batch 2 x 32^3, one iteration vs torch autograd on the CPU',
+                rows.append(float((got - ref).abs().max()) / float(ref.abs().max()))
+        rows.sort()
+        gn = float(torch.cat([tr.g[n].double().cpu().reshape(-1) for n, _ in net.named_parameters()]).norm())
+        out[precision] = dict(sample='tiny net (tests/golden), batch 2 x 32^3, one iteration vs float64 torch autograd on the CPU',
                               loss=l, oracle_loss=float(loss.detach()), gradient_rel_l2_err=(num / max(den, 1e-30)) ** 0.5,
-                              worst_parameter_rel_max_err=worst)
+                              gradient_cosine=dot / max(gn * den ** 0.5, 1e-30),
+                              median_parameter_rel_max_err=rows[len(rows) // 2], worst_parameter_rel_max_err=rows[-1])
     return out
 
 # ------------------------------------------------------------------------------------------------------------

