@@ -254,11 +254,17 @@ typedef ConvCfg<1, 32, 1, 4, 4, 1, 4, 2, 4, 6> BCfgW;
 typedef ConvCfg<2, 16, 2, 2, 8, 1, 2, 2, 2, 6> BCfg3;     // stride 2, 16-wide output, 2 x 8 x 16 outputs x 64 channels
 typedef ConvCfg<1, 8, 4, 4, 8, 1, 2, 1, 8, 6> BCfg4;      // stride 1, 8-wide
 typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 1, 2, 6> BCfg5;      // stride 2, 8-wide output
-static int bf16_nt(int cfg) { return (cfg == 0 || cfg == 4 || cfg == 5) ? 1 : (cfg == 2 || cfg == 3 || cfg == WMH_BF16_CFG_WIDE) ? 2 : 0; }
-static int bf16_stride(int cfg) { return (cfg == 3 || cfg == 5) ? 2 : 1; }
+// Stride 2 with output rows of 32 voxels and more (the first convolution of the 64^3 and 32^3 stages; f16x2 mode only: round 3).  A
+// tile of 2 x 2 x 32 outputs x 64 channels reads a 5 x 5 x 65 input box: 57 KB as [voxel][hi | lo of 8 channels], two workgroups
+// per CU, so that one stages while the other multiplies (12.7 input voxels are staged per output voxel: the layer is loader-bound,
+// the fp32-instruction kernel it replaces ran 2.4 / 0.9 ms for the two layers at batch 8).
+typedef ConvCfg<2, 32, 1, 2, 2, 1, 1, 2, 2, 6> BCfg1;
+static int bf16_nt(int cfg) { return (cfg == 0 || cfg == 4 || cfg == 5) ? 1 : (cfg == 1 || cfg == 2 || cfg == 3 || cfg == WMH_BF16_CFG_WIDE) ? 2 : 0; }
+static int bf16_stride(int cfg) { return (cfg == 1 || cfg == 3 || cfg == 5) ? 2 : 1; }
 struct BGeo { int TX, TY, TZ, WPS; };
 static BGeo bf16_geo(int cfg, bool w8) {
     if (cfg == WMH_BF16_CFG_WIDE) return BGeo{BCfgW::TX, BCfgW::TY, BCfgW::TZ, BCfgW::WPS};
+    if (cfg == 1) return BGeo{BCfg1::TX, BCfg1::TY, BCfg1::TZ, BCfg1::WPS};
     if (cfg == 3) return BGeo{BCfg3::TX, BCfg3::TY, BCfg3::TZ, BCfg3::WPS};
     if (cfg == 4) return BGeo{BCfg4::TX, BCfg4::TY, BCfg4::TZ, BCfg4::WPS};
     if (cfg == 5) return BGeo{BCfg5::TX, BCfg5::TY, BCfg5::TZ, BCfg5::WPS};
@@ -273,7 +279,7 @@ extern "C" int wmh_conv3d_k3_bf16_config(int cfg, int Cout, int W) {
     return cfg;
 }
 
-extern "C" int wmh_conv3d_k3_bf16_supported(int cfg) { return bf16_nt(cfg) > 0; }
+extern "C" int wmh_conv3d_k3_bf16_supported(int cfg) { return cfg != 1 && bf16_nt(cfg) > 0; }      // configuration 1: f16x2 only
 // InstanceNorm partial records per (n, c) row the bf16 kernel writes (its wave split differs from the fp32 kernel's)
 extern "C" int wmh_conv3d_k3_num_partials_bf16(int cfg, int N, int Do, int Ho, int Wo) {
     if (!bf16_nt(cfg)) return wmh_fail(WMH_EINVAL, "num_partials_bf16: configuration has no bf16 kernel");
@@ -316,7 +322,7 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16(int cfg, const float* w, int Cin,
 // ---- the "pair" mode (entry points keep round 2's f16x2 names; conv3d_k3_bf16_ws.hip, PAIR): chunks of 8 input channels, a lane's
 // 16 bytes are the HIGH fp16 parts of its output channel's 8 weights (lanes 0-31) or the LOW parts (lanes 32-63), of the
 // weights scaled by 2^8: 256 w = hi + lo + O(2^-22 w).  |w| must stay below 255 (fp16's range after the scaling).
-extern "C" int wmh_conv3d_k3_f16x2_supported(int cfg) { return cfg == 0 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE || cfg == 3 || cfg == 4 || cfg == 5; }
+extern "C" int wmh_conv3d_k3_f16x2_supported(int cfg) { return cfg == 0 || cfg == 1 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE || cfg == 3 || cfg == 4 || cfg == 5; }
 extern "C" size_t wmh_conv3d_k3_packed_halfs_f16x2(int cfg, int Cin, int Cout) {
     const int NT = bf16_nt(cfg);
     if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg)) return 0;
@@ -521,7 +527,7 @@ int wmh_launch_conv_f16x2_ws(int cfg, const ConvArgs& a, hipStream_t st);
 // (16 mantissa bits per operand): fp32 tensors in and out, stride 1, wf from wmh_conv3d_k3_pack_weights_f16x2.  Same
 // geometry, moments records (wmh_conv3d_k3_num_partials_bf16) and epilogue as wmh_conv3d_k3_fwd_bf16.
 extern "C" size_t wmh_conv3d_k3_f16x2_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout) {
-    if (!(cfg == 3 || cfg == 4 || cfg == 5)) return 0;
+    if (!(cfg == 1 || cfg == 3 || cfg == 4 || cfg == 5)) return 0;
     const int S = bf16_stride(cfg);
     const int ks = bf16_ksplit(bf16_small_blocks(cfg, N, D, H, W, Cout), cdiv(Cin, 8));
     return ks > 1 ? (size_t)ks * N * Cout * ((D - 1) / S + 1) * ((H - 1) / S + 1) * ((W - 1) / S + 1) : 0;
@@ -535,7 +541,7 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     if (x1 == nullptr) C1 = 0;
     if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: LeakyReLU slope must be in [0, 1]");
     if (C1 > 0 && (C0 % 8) != 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: C0 must be a multiple of 8 with two sources");
-    const bool small = cfg == 3 || cfg == 4 || cfg == 5;
+    const bool small = cfg == 1 || cfg == 3 || cfg == 4 || cfg == 5;           // the one-role kernel
     if (!small && ((W % 4) != 0 || (size_t)16 * D * H * W * 4 >= ((size_t)1 << 32) || (reinterpret_cast<uintptr_t>(x0) & 15) != 0 ||
                    (x1 && (reinterpret_cast<uintptr_t>(x1) & 15) != 0)))
         return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: needs W % 4 == 0 and 16-byte aligned sources");
@@ -564,7 +570,8 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     if (a.KS > 1) a.y = workspace;
     const unsigned nb = (unsigned)(nblk * a.KS);
     int rc;
-    if (cfg == 3) rc = launch_bf16<BCfg3, 4, true>(a, nb, st);
+    if (cfg == 1) rc = launch_bf16<BCfg1, 4, true>(a, nb, st);
+    else if (cfg == 3) rc = launch_bf16<BCfg3, 4, true>(a, nb, st);
     else if (cfg == 4) rc = launch_bf16<BCfg4, 3, true>(a, nb, st);
     else rc = launch_bf16<BCfg5, 4, true>(a, nb, st);
     if (rc != WMH_OK || a.KS == 1) return rc;

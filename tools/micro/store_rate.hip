@@ -5,6 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -o store_rate store_rate.hip && ./store_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
@@ -37,8 +38,9 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* ticks, 
     if (lane == 0) ticks[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int iters = 512;
+    const int grid = argc > 1 ? atoi(argv[1]) : 256;      // fewer workgroups than CUs: the per-CU store path instead of the HBM write rate
     const size_t plane = (size_t)256 * 4 * iters * 32;          // floats per channel plane
     float* out; unsigned long long* ticks;
     hipMalloc(&out, plane * 32 * sizeof(float)); hipMalloc(&ticks, 1024 * 8);
@@ -49,14 +51,14 @@ int main() {
         float ms = 0;
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
-            if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, out, ticks, iters, plane);
-            if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), 0, 0, out, ticks, iters, plane);
-            if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, out, ticks, iters, plane);
+            if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, out, ticks, iters, plane);
+            if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, out, ticks, iters, plane);
+            if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, out, ticks, iters, plane);
             hipEventRecord(e1); hipDeviceSynchronize();
             hipEventElapsedTime(&ms, e0, e1);
         }
-        const double bytes = (double)256 * 4 * iters * 32 * 32 * 4;
-        printf("%-62s %.3f ms  %.0f GB/s  = %.1f B per 2.4 GHz clock per CU\n", names[mode], ms, bytes / ms / 1e6, bytes / (ms * 1e-3) / 2.4e9 / 256);
+        const double bytes = (double)grid * 4 * iters * 32 * 32 * 4;
+        printf("%-62s %.3f ms  %.0f GB/s  = %.1f B per 2.4 GHz clock per CU\n", names[mode], ms, bytes / ms / 1e6, bytes / (ms * 1e-3) / 2.4e9 / grid);
     }
     return 0;
 }
