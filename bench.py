@@ -392,7 +392,9 @@ def training_parity_tiny():
                 rows.append(float((got - ref).abs().max()) / float(ref.abs().max()))
         rows.sort()
         gn = float(torch.cat([tr.g[n].double().cpu().reshape(-1) for n, _ in net.named_parameters()]).norm())
-        out[precision] = dict(sample='tiny net (tests/golden), batch 2 x 32^3, one iteration vs float64 torch autograd on the CPU',
+        out[precision] = dict(sample='tiny net (tests/golden), batch 2 x 32^3, one iteration vs float64 torch autograd on the CPU; the fixture has a '
+                                     'pre-activation 1.8e-6 from a LeakyReLU kink in a 512-voxel channel: an evaluation that rounds it to the other side '
+                                     'is ~5 % off on the parameters behind it (tests/test_gpu_trainer.py), the cosine is the robust figure',
                               loss=l, oracle_loss=float(loss.detach()), gradient_rel_l2_err=(num / max(den, 1e-30)) ** 0.5,
                               gradient_cosine=dot / max(gn * den ** 0.5, 1e-30),
                               median_parameter_rel_max_err=rows[len(rows) // 2], worst_parameter_rel_max_err=rows[-1])

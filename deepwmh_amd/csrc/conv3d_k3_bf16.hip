@@ -459,7 +459,7 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
                          float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope,
                          int in16, int out16, void* stream, float* workspace = nullptr) {
     const int NT = bf16_nt(cfg);
-    if (!NT) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: configuration has no bf16 kernel");
+    if (!NT || cfg == 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: configuration has no bf16 kernel");
     if (!x0 || !wf || !y || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: null/empty argument");
     if (x1 == nullptr) C1 = 0;
     if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: LeakyReLU slope must be in [0, 1]");

@@ -25,6 +25,9 @@ CASES = [  # N, D, H, W, C0, C1, Cout, pending norm on source 0 / 1 [, stride]
     (2, 16, 16, 16, 32, 0, 64, True, False, 2),   # stride 2, output rows of 8 (configuration 5)
     (2, 8, 32, 32, 32, 0, 128, True, False, 2),   # stride 2, output rows of 16 (configuration 3)
     (1, 7, 20, 27, 16, 0, 64, False, False, 2),   # ... odd extents
+    (2, 8, 16, 64, 32, 0, 64, True, False, 2),    # stride 2, output rows of 32 (configuration 1: the first convolution of the 64^3 / 32^3 stages)
+    (1, 7, 9, 50, 16, 0, 40, True, False, 2),     # ... ragged tiles, channel counts that are not multiples of the chunk / the tile
+    (1, 6, 6, 128, 8, 0, 128, False, False, 2),   # ... two tiles per row, no pending norm
     (1, 5, 9, 36, 12, 0, 40, True, False),        # channel counts that are not multiples of the chunk / the tile; ragged tiles
     (1, 6, 10, 32, 16, 24, 32, False, True),      # two sources (the decoder's concatenation), the second one normalised
     (2, 4, 12, 64, 64, 64, 64, True, True),       # the 64-channel tile (configuration 21)
