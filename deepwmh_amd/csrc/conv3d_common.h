@@ -247,6 +247,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
             continue;
         }
         float* ych = ybase + ((size_t)n * a.Cout + cob) * DoHoWo;          // channel cob of sample n
+        // A store's address is the wave-uniform base of the 32-channel group plus a 32-bit lane offset that walks the channel planes by
+        // addition (the launchers check 32 planes < 4 GB): `global_store_dword v_off, v_data, s[base]`.  With 64-bit per-row offsets the
+        // compiler kept sixteen scalar pairs, spilled them into vector lanes and read them back with two v_readlane per store.
+        char* const ychb = reinterpret_cast<char*>(ych);
+        const unsigned plane = 4u * (unsigned)DoHoWo;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int ts = ts0 + m;
@@ -254,10 +259,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
             if ((vmask >> m) & 1u) {
                 float* yp = ych + (size_t)(4 * kh) * DoHoWo + (size_t)oz * HoWo + oy * a.Wo + ox;
                 if (nrows == 32) {                  // uniform: all 32 output channels of this tile exist
+                    unsigned off = (unsigned)(4 * kh) * plane + 4u * (unsigned)(oz * HoWo + oy * a.Wo + ox);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if constexpr (NTS) __builtin_nontemporal_store(acc[nt][m][r], yp + (size_t)((r & 3) + 8 * (r >> 2)) * DoHoWo);
-                        else yp[(size_t)((r & 3) + 8 * (r >> 2)) * DoHoWo] = acc[nt][m][r];
+                    for (int r = 0; r < 16; ++r) {                    // rows (r & 3) + 8 (r >> 2): +1, +1, +1, +5 planes
+                        float* p = reinterpret_cast<float*>(ychb + off);
+                        if constexpr (NTS) __builtin_nontemporal_store(acc[nt][m][r], p);
+                        else *p = acc[nt][m][r];
+                        off += (r & 3) == 3 ? 5u * plane : plane;
                     }
                 } else {
 #pragma unroll

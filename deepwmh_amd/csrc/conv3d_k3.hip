@@ -599,6 +599,7 @@ static int conv_fwd(int cfg, const float* x0, const float* ss0, int C0, const fl
     a.nchunks = (C1 > 0) ? (C0 / c.CK + cdiv(C1, c.CK)) : cdiv(C0, c.CK);
     a.ntx = cdiv(a.Wo, c.TX); a.nty = cdiv(a.Ho, c.TY); a.ntz = cdiv(a.Do, c.TZ);
     a.npart = a.ntx * a.nty * a.ntz * c.WPS;
+    if ((size_t)a.Do * a.Ho * a.Wo * 4 * 32 >= ((size_t)1 << 32)) return wmh_fail(WMH_EINVAL, "conv3d_k3: 32 output channel planes must stay below 4 GB (epilogue lane offsets are 32-bit)");
     a.slope = lrelu_slope;
     a.G = cdiv(Cout, 32 * c.NT);
     static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);

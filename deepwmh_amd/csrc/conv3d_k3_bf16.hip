@@ -475,6 +475,7 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     const BGeo ge = bf16_geo(cfg, w8);
     a.ntx = cdiv(a.Wo, ge.TX); a.nty = cdiv(a.Ho, ge.TY); a.ntz = cdiv(a.Do, ge.TZ);
     a.npart = a.ntx * a.nty * a.ntz * ge.WPS;
+    if ((size_t)a.Do * a.Ho * a.Wo * 4 * 32 >= ((size_t)1 << 32)) return wmh_fail(WMH_EINVAL, "conv3d_k3: 32 output channel planes must stay below 4 GB (epilogue lane offsets are 32-bit)");
     a.slope = lrelu_slope;
     a.G = cdiv(Cout, 32 * NT);
     a.KS = 1;
@@ -554,6 +555,7 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     const BGeo ge = bf16_geo(cfg, false);
     a.ntx = cdiv(a.Wo, ge.TX); a.nty = cdiv(a.Ho, ge.TY); a.ntz = cdiv(a.Do, ge.TZ);
     a.npart = a.ntx * a.nty * a.ntz * ge.WPS;
+    if ((size_t)a.Do * a.Ho * a.Wo * 4 * 32 >= ((size_t)1 << 32)) return wmh_fail(WMH_EINVAL, "conv3d_k3: 32 output channel planes must stay below 4 GB (epilogue lane offsets are 32-bit)");
     a.slope = lrelu_slope;
     a.G = cdiv(Cout, 32 * NT);
     a.KS = 1;
