@@ -335,15 +335,15 @@ def measure_training_mode(plan, sd, device, precision, iters, warmup):
     del tr
     return dict(workload='one nnUNetTrainerV2 iteration, batch 2 x 128^3, BASELINE plan (31.2 M parameters), deep supervision, Dice+CE, '
                          'clip 12, SGD-Nesterov; %s' % ('fp32 throughout' if precision == 'fp32' else
-                                                        'forward and stride-1 data-gradient convolutions from fp16 pairs (fp32 tensors and '
-                                                        'accumulation), weight gradients / statistics / optimizer exact fp32' if precision == 'f16x2' else
+                                                        'forward, stride-1 data-gradient and weight-gradient convolutions from fp16 pairs (fp32 tensors '
+                                                        'and accumulation), stride-2 layers / statistics / optimizer exact fp32' if precision == 'f16x2' else
                                                         'bf16 matrix-core operands for the stride-1 convolutions of the wide levels '
                                                         '(forward, data and weight gradients), fp32 master weights / statistics / optimizer'),
                 steps=iters, warmup=warmup, ms_per_step=round(1e3 * dt / iters, 3), value=round(2 * iters / dt, 3), unit='patches/s',
                 loss_first_to_last=[round(losses[0], 6), round(losses[-1], 6)],
                 roofline=dict(bound='mfma', kernel='whole iteration (every launch of the step)', achieved=round(tflops, 2), peak=peak,
                               unit='TFLOP/s', frac=round(tflops / peak, 4), algorithmic_tflop_per_step=TRAIN_TFLOP_PER_ITER,
-                              note='fp32: v_mfma_f32_32x32x2_f32 peak; f16x2: 16-bit MFMA peak / 4 although its weight gradients run on the fp32 '
+                              note='fp32: v_mfma_f32_32x32x2_f32 peak; f16x2: 16-bit MFMA peak / 4 although its stride-2 layers run on the fp32 '
                                    'instruction; bf16: priced against the bf16 peak although the stride-2 layers, statistics and reductions '
                                    'of this mode stay fp32'))
 

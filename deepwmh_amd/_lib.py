@@ -75,6 +75,11 @@ SIGNATURES = {
     'wmh_conv3d_k3_wgrad_bf16_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_wgrad_bf16_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_wgrad_bf16': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_conv3d_k3_wgrad_f16x2_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_wgrad_f16x2_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_wgrad_f16x2': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_conv3d_k3_wgrad_f16x2_stamp_count': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_wgrad_f16x2_stamped': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     'wmh_conv3d_k3s2_dgrad_packed_floats': (_sz, [_i, _i]),
     'wmh_conv3d_k3s2_dgrad_pack_weights_device': (_i, [_vp, _i, _i, _vp, _vp]),
     'wmh_conv3d_k3s2_dgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -349,6 +349,13 @@ class UNetTrainer:
             _lib.check(lib.wmh_conv3d_wgrad(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
                                             _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, conv.kz, conv.sz,
                                             conv.stride, LRELU_SLOPE, st), 'wmh_conv3d_wgrad')
+        elif self.x3 and lib.wmh_conv3d_k3_wgrad_f16x2_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
+            # pair form (fp16 hi + lo of dy and of the activated input): the loss scale keeps dy inside fp16's range
+            nws = lib.wmh_conv3d_k3_wgrad_f16x2_workspace_floats(C0 + C1, Cc, N, D, H, W)
+            ws = self._buf('b.wgrad.ws', (nws,))
+            _lib.check(lib.wmh_conv3d_k3_wgrad_f16x2(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
+                                                     _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, LRELU_SLOPE, st),
+                       'wmh_conv3d_k3_wgrad_f16x2')
         elif self.bf16_wgrad and lib.wmh_conv3d_k3_wgrad_bf16_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
             nws = lib.wmh_conv3d_k3_wgrad_bf16_workspace_floats(C0 + C1, Cc, N, D, H, W)
             ws = self._buf('b.wgrad.ws', (nws,))

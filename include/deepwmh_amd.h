@@ -268,6 +268,21 @@ int wmh_conv3d_k3_wgrad_bf16_supported(int Cin, int Cout, int N, int D, int H, i
 size_t wmh_conv3d_k3_wgrad_bf16_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
 int wmh_conv3d_k3_wgrad_bf16(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
                              float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
+/* The same weight gradient in the f16x2 "pair" mode (fp32-grade training, the default of nnUNet_train): dy and the activated input
+ * are each split into two fp16 numbers (hi toward zero, lo = the remainder: 21-22 significant bits) and kept as one dword per voxel;
+ * two v_mfma_f32_32x32x16_f16 per 8 voxels and channel form dy_hi (x_hi + x_lo) + dy_lo (x_hi + x_lo) in fp32 accumulators.
+ * |dy|, |x'| up to 131008 (callers scale the loss, as the f16x2 data gradient needs).  Stride 1, rows of >= 12 voxels
+ * (wmh_conv3d_k3_wgrad_f16x2_supported); workspace >= wmh_conv3d_k3_wgrad_f16x2_workspace_floats(...) floats.  The _stamped form
+ * also writes wmh_conv3d_k3_wgrad_f16x2_stamp_count(...) cycle counters (4 per workgroup: consumer work / wait, loader work /
+ * wait) -- diagnostics (tools/wgrad_check.py). */
+int wmh_conv3d_k3_wgrad_f16x2_supported(int Cin, int Cout, int N, int D, int H, int W, int stride);
+size_t wmh_conv3d_k3_wgrad_f16x2_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
+int wmh_conv3d_k3_wgrad_f16x2(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
+                              float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
+size_t wmh_conv3d_k3_wgrad_f16x2_stamp_count(int Cin, int Cout, int N, int D, int H, int W);
+int wmh_conv3d_k3_wgrad_f16x2_stamped(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
+                                      float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope,
+                                      unsigned long long* stamps, void* stream);
 /* Data gradient of the stride-2 3x3x3 convolution in gather form (each of the 27 taps feeds exactly one of the 8 output
  * parity classes: the ideal MFMA count, 1/8 of the zero-insert route below).  w = torch layout [Cout][Cin][27] in HBM;
  * wp = its image, wmh_conv3d_k3s2_dgrad_packed_floats(Cin, Cout) floats; dy = [N][Cout][Do][Ho][Wo] with Do = (D-1)/2+1;

@@ -300,6 +300,50 @@ def test_conv3d_wgrad_bf16_operands(lib, shape):
     assert float((outs[0] - g32).norm() / g32.norm()) <= 1e-2
 
 
+F16X2_WG = [(2, 16, 0, 8, 8, 8, 32), (1, 32, 24, 40, 5, 9, 45), (2, 20, 0, 36, 6, 16, 16), (1, 8, 8, 72, 3, 17, 20), (2, 1, 0, 32, 4, 8, 32),
+            (2, 64, 0, 128, 8, 32, 32), (1, 128, 0, 256, 6, 32, 32), (2, 32, 0, 32, 16, 32, 64), (3, 16, 0, 32, 4, 24, 40)]
+
+
+@pytest.mark.parametrize('shape', F16X2_WG, ids=[str(c) for c in F16X2_WG])
+def test_conv3d_wgrad_f16x2_pairs(lib, shape):
+    """Pair-form weight gradient (fp16 hi + lo per operand, conv3d_k3_wgrad_f16x2.hip) against float64 autograd: fp32-grade (the exact-fp32
+    kernel's own distance to float64 is printed beside it); two sources, channel tails, ragged tiles, both tile geometries, the three
+    tile orders (plain / part of a plane per step / several planes per step), bit-reproducible."""
+    N, C0, C1, Cout, D, H, W = shape
+    Cin = C0 + C1
+    g = torch.Generator().manual_seed(92)
+    x0 = torch.randn(N, C0, D, H, W, generator=g); s0 = torch.stack([0.5 + torch.rand(N, C0, generator=g), 0.3 * torch.randn(N, C0, generator=g)], -1)
+    x1 = torch.randn(N, C1, D, H, W, generator=g) if C1 else None
+    s1 = torch.stack([0.5 + torch.rand(N, C1, generator=g), 0.3 * torch.randn(N, C1, generator=g)], -1) if C1 else None
+    dy = torch.randn(N, Cout, D, H, W, generator=g) * torch.exp(torch.empty(N, Cout, 1, 1, 1).uniform_(-4, 3, generator=g))
+    act = torch.cat([_act(x0, s0)] + ([_act(x1, s1)] if C1 else []), 1)            # fp32, as the kernel forms it
+    w = torch.zeros(Cout, Cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(act.double(), w, None, padding=1).backward(dy.double())
+    ref = w.grad.reshape(Cout, Cin, 27)
+    assert lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, W, 1) == 1
+    assert lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, 8, 1) == 0 and lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, W, 2) == 0
+    d = [t.cuda() if t is not None else None for t in (x0, s0, x1, s1, dy)]
+    ws = torch.full((lib.wmh_conv3d_k3_wgrad_f16x2_workspace_floats(Cin, Cout, N, D, H, W),), float('nan'), device='cuda')
+    outs = []
+    for _ in range(2):
+        dW = torch.full((Cout, Cin, 27), float('nan'), device='cuda')
+        check(lib.wmh_conv3d_k3_wgrad_f16x2(P(d[0]), P(d[1]), C0, P(d[2]), P(d[3]), C1, P(d[4]), P(dW), P(ws), N, D, H, W, Cout, SLOPE, None), 'wgrad f16x2')
+        torch.cuda.synchronize()
+        outs.append(dW.cpu())
+    assert torch.equal(outs[0], outs[1])                                          # fixed-order reduction
+    assert not torch.isnan(outs[0]).any()
+    dW32 = torch.full((Cout, Cin, 27), float('nan'), device='cuda')
+    ws32 = torch.empty(lib.wmh_conv3d_k3_wgrad_workspace_floats(Cin, Cout, N, D, H, W, 1), device='cuda')
+    check(lib.wmh_conv3d_k3_wgrad(P(d[0]), P(d[1]), C0, P(d[2]), P(d[3]), C1, P(d[4]), P(dW32), P(ws32), N, D, H, W, Cout, 1, SLOPE, None), 'wgrad')
+    torch.cuda.synchronize()
+    # per output channel: dy's scale varies over 7 e-folds between channels
+    scale = ref.abs().amax((1, 2), keepdim=True)
+    e16 = float(((outs[0].double() - ref).abs() / scale).max()); e32 = float(((dW32.cpu().double() - ref).abs() / scale).max())
+    r16 = float((outs[0].double() - ref).norm() / ref.norm())
+    print('f16x2 max err / channel max %.2e (exact-fp32 kernel %.2e), rel. L2 %.2e' % (e16, e32, r16))
+    assert e16 <= 4e-6 and r16 <= 1e-6, (e16, e32, r16)
+
+
 def test_clip_and_sgd_nesterov(lib):
     g = torch.Generator().manual_seed(71)
     n = 100003
