@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 # f16x2: a product is four bf16 matrix instructions (both operands split into two bf16 numbers), so the mode's ceiling in
 # ALGORITHMIC flops is a quarter of the bf16 peak
 PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'f16x2': 625.0}
+NOMINAL_SCLK_MHZ = 2400            # the clock the guide's peaks are quoted at
 HBM_PEAK_GBS = 8000.0
 FWD_GFLOP_PER_PATCH = 954.46     # BASELINE.md section 2 (the engine's own count of what it queued is reported next to it)
 AGG_GBYTES_PER_VOLUME = 0.46     # aggregation read-modify-write + volume in / label map out
@@ -199,6 +200,76 @@ def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits, extra_no
 
 
 # ------------------------------------------------------------------------------------------------------------
+# shader clock and socket power over a timed region (the 16-bit MFMA modes run below the nominal clock: DESIGN.md 3.3e)
+# ------------------------------------------------------------------------------------------------------------
+class ClockSampler:
+    """Reads the device's hwmon `freq1_input` (shader clock, Hz) and `power1_input` (socket power, uW) every 50 ms from a thread
+    while a timed region runs.  Plain sysfs reads: no GPU call, no child process.  Reports medians; None where the files are absent."""
+
+    def __init__(self, device_index=0):
+        import glob
+        self.freq = self.power = None
+        want = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            want = '%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        cands = []
+        for f in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input')):
+            dev = os.path.realpath(os.path.join(os.path.dirname(f), '..', '..'))
+            cands.append((os.path.basename(dev), f))
+        pick = [f for (d, f) in cands if want and d.startswith(want)]
+        if not pick and len(cands) == 1:
+            pick = [cands[0][1]]
+        if pick:
+            self.freq = pick[0]
+            pw = os.path.join(os.path.dirname(pick[0]), 'power1_input')
+            self.power = pw if os.path.exists(pw) else None
+        self.f, self.w, self._stop, self._th = [], [], False, None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                self.f.append(int(open(self.freq).read()) / 1e6)
+                if self.power:
+                    self.w.append(int(open(self.power).read()) / 1e6)
+            except Exception:
+                pass
+            time.sleep(0.05)
+
+    def __enter__(self):
+        if self.freq:
+            import threading
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th:
+            self._th.join(timeout=1.0)
+
+    def report(self):
+        if not self.f:
+            return None
+        med = lambda v: sorted(v)[len(v) // 2]
+        return dict(sclk_mhz_median=round(med(self.f)), sclk_mhz_min=round(min(self.f)), sclk_mhz_nominal=NOMINAL_SCLK_MHZ,
+                    socket_power_w_median=round(med(self.w)) if self.w else None, samples=len(self.f),
+                    source='hwmon freq1_input / power1_input of the device, every 50 ms over the timed region')
+
+
+def add_sustained(roofline, clock):
+    """roofline.frac stays priced against the guide's peak (2.4 GHz); this adds what the fraction is at the clock the chip held."""
+    if clock and roofline and roofline.get('bound') == 'mfma' and clock['sclk_mhz_median'] > 0:
+        k = min(1.0, clock['sclk_mhz_median'] / NOMINAL_SCLK_MHZ)
+        roofline['frac_at_sustained_clock'] = round(roofline['frac'] / k, 4)
+        roofline['sustained_clock_note'] = ('peak x %d / %d MHz: the shader clock the power management held during the timed region '
+                                            '(median); frac itself is priced against the nominal peak' % (clock['sclk_mhz_median'], NOMINAL_SCLK_MHZ))
+
+
+# ------------------------------------------------------------------------------------------------------------
 # roofline block of the dominant kernel, per precision mode
 # ------------------------------------------------------------------------------------------------------------
 def roofline_block(timings, precision, storage, dt):
@@ -284,11 +355,12 @@ def measure_inference_mode(plan, sd, device, precision, storage, V, steps, warmu
         run_step()
     eng.timed_cfgs, eng.timings, eng.acct = {0}, [], dict(flop=0.0, bytes=0.0)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        run_step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with ClockSampler(torch.cuda.current_device()) as cs:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     eng.timed_cfgs = set()
     acct, eng.acct = eng.acct, None
     forwards = 8 * (8 if tta else 1)
@@ -298,7 +370,8 @@ def measure_inference_mode(plan, sd, device, precision, storage, V, steps, warmu
                unit='volumes/s', end_to_end_tflops=round(forwards * FWD_GFLOP_PER_PATCH / 1e3 * nvol / dt, 2),
                hbm_whole_path=dict(algorithmic_gbytes_per_volume=round(gb_vol, 2), achieved_gbs=round(gb_vol * nvol / dt, 1),
                                    peak_gbs=HBM_PEAK_GBS, frac=round(gb_vol * nvol / dt / HBM_PEAK_GBS, 4)),
-               roofline=roofline_block(eng.timings, precision, storage, dt))
+               roofline=roofline_block(eng.timings, precision, storage, dt), clock=cs.report())
+    add_sustained(out['roofline'], out['clock'])
     if ref32 is not None:
         vol_d.copy_(vols_h[0])
         s16, p16 = pred.predict_device(vol_d, return_prob=True)
@@ -324,28 +397,31 @@ def measure_training_mode(plan, sd, device, precision, iters, warmup):
     for _ in range(warmup):
         losses.append(tr.run_iteration(x, td, 1e-2).clone())
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        losses.append(tr.run_iteration(x, td, 1e-2).clone())
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with ClockSampler(torch.cuda.current_device()) as cs:
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            losses.append(tr.run_iteration(x, td, 1e-2).clone())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     tflops = TRAIN_TFLOP_PER_ITER * iters / dt
     peak = PEAK_TFLOPS[precision]
     losses = [float(v) for v in torch.stack(losses).cpu()]
     del tr
-    return dict(workload='one nnUNetTrainerV2 iteration, batch 2 x 128^3, BASELINE plan (31.2 M parameters), deep supervision, Dice+CE, '
+    out = dict(workload='one nnUNetTrainerV2 iteration, batch 2 x 128^3, BASELINE plan (31.2 M parameters), deep supervision, Dice+CE, '
                          'clip 12, SGD-Nesterov; %s' % ('fp32 throughout' if precision == 'fp32' else
                                                         'forward, stride-1 data-gradient and weight-gradient convolutions from fp16 pairs (fp32 tensors '
                                                         'and accumulation), stride-2 layers / statistics / optimizer exact fp32' if precision == 'f16x2' else
                                                         'bf16 matrix-core operands for the stride-1 convolutions of the wide levels '
                                                         '(forward, data and weight gradients), fp32 master weights / statistics / optimizer'),
                 steps=iters, warmup=warmup, ms_per_step=round(1e3 * dt / iters, 3), value=round(2 * iters / dt, 3), unit='patches/s',
-                loss_first_to_last=[round(losses[0], 6), round(losses[-1], 6)],
+                loss_first_to_last=[round(losses[0], 6), round(losses[-1], 6)], clock=cs.report(),
                 roofline=dict(bound='mfma', kernel='whole iteration (every launch of the step)', achieved=round(tflops, 2), peak=peak,
                               unit='TFLOP/s', frac=round(tflops / peak, 4), algorithmic_tflop_per_step=TRAIN_TFLOP_PER_ITER,
                               note='fp32: v_mfma_f32_32x32x2_f32 peak; f16x2: 16-bit MFMA peak / 4 although its stride-2 layers run on the fp32 '
                                    'instruction; bf16: priced against the bf16 peak although the stride-2 layers, statistics and reductions '
                                    'of this mode stay fp32'))
+    add_sustained(out['roofline'], out['clock'])
+    return out
 
 
 def training_parity_tiny():
@@ -478,11 +554,13 @@ def run_rank(args):
     # (a layer reads its input once, writes its output once, + weights; fp32 mode: 4.17 GB per patch forward)
     eng.acct = dict(flop=0.0, bytes=0.0)
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        seg, prob = run_step()
-    barrier()
-    dt = time.perf_counter() - t0
+    with ClockSampler(torch.cuda.current_device()) as cs:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            seg, prob = run_step()
+        barrier()
+        dt = time.perf_counter() - t0
+    clock = cs.report()
     eng.timed_cfgs = set()
     acct, eng.acct = eng.acct, None
     if world > 1:
@@ -491,6 +569,7 @@ def run_rank(args):
         dt = float(t.item())
 
     roofline = roofline_block(eng.timings, args.precision, args.storage, dt)
+    add_sustained(roofline, clock)
 
     if rank == 0:
         forwards = 8 * (8 if tta else 1)
@@ -517,7 +596,7 @@ def run_rank(args):
                    hbm_whole_path=dict(algorithmic_gbytes_per_volume=round(gb_vol, 2),
                                        achieved_gbs=round(gb_vol * nvol / dt, 1), peak_gbs=HBM_PEAK_GBS,
                                        frac=round(gb_vol * nvol / dt / HBM_PEAK_GBS, 4)),
-                   roofline=roofline)
+                   roofline=roofline, clock=clock)
         if args.precision == 'bf16' or (args.precision == 'f16x2' and args.also == 'off'):
             # accuracy of the mode against the exact-fp32 HIP path on the same volume (same weights)
             eng32 = UNetEngine(plan, sd, device)
@@ -564,7 +643,7 @@ def run_rank(args):
             del e16, ref32
             torch.cuda.empty_cache()
             for prec in ('fp32', 'f16x2', 'bf16'):
-                also['train_' + prec] = measure_training_mode(plan, sd, device, prec, 5, 2)
+                also['train_' + prec] = measure_training_mode(plan, sd, device, prec, 8, 2)
                 torch.cuda.empty_cache()
             if args.cpu_baseline != 'off':
                 tp = training_parity_tiny()

@@ -157,8 +157,12 @@ class UNetTrainer:
         return ((self.bf16_forward if which == 'fwd' else self.bf16_dgrad) and stride == 1 and cfg in (0, 2) and bool(self.lib.wmh_conv3d_k3_bf16_supported(cfg))
                 and (C1 == 0 or C0 % 16 == 0))
 
-    def _use_x3(self, cfg_b, stride, C0, C1, W):
-        return (self.x3 and stride == 1 and (C1 == 0 or C0 % 8 == 0) and (W % 4 == 0 or cfg_b == 4) and bool(self.lib.wmh_conv3d_k3_f16x2_supported(cfg_b)))
+    def _use_x3(self, cfg_b, stride, C0, C1, W, fwd=False):
+        # the forward pass also has pair kernels for the strided layers (configurations 1, 3, 5: as the inference engine uses them);
+        # their data gradients stay on the fp32 gather kernel
+        if stride == 2 and not (fwd and cfg_b in (1, 3, 5)):
+            return False
+        return (self.x3 and (C1 == 0 or C0 % 8 == 0) and (W % 4 == 0 or cfg_b in (1, 3, 4, 5)) and bool(self.lib.wmh_conv3d_k3_f16x2_supported(cfg_b)))
 
     def _pack_x3(self, conv, cfg, mode, ci_off, ci_cnt):
         key = (conv.name, cfg, mode, ci_off, ci_cnt, 'x3')
@@ -174,13 +178,14 @@ class UNetTrainer:
         self._packed[key] = (self._version, wf)
         return wf
 
-    def _run_conv_x3(self, key, cfg, x0, ss0, x1, ss1, wf, bias, cout, want_stats):
+    def _run_conv_x3(self, key, cfg, x0, ss0, x1, ss1, wf, bias, cout, want_stats, stride=1):
         N, C0, D, H, W = x0.shape
         C1 = 0 if x1 is None else x1.shape[1]
-        y = self._buf(key + '.y', (N, cout, D, H, W))
+        Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = self._buf(key + '.y', (N, cout, Do, Ho, Wo))
         part, npart = None, 0
         if want_stats:
-            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_f16x2(cfg, N, D, H, W), 'num_partials_f16x2')
+            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_f16x2(cfg, N, Do, Ho, Wo), 'num_partials_f16x2')
             part = self._buf(key + '.part', (N, cout, npart, 4))
         nws = self.lib.wmh_conv3d_k3_f16x2_workspace_floats(cfg, C0 + C1, N, D, H, W, cout)
         ws = self._buf('splitk.ws', (nws,)) if nws else None
@@ -239,9 +244,9 @@ class UNetTrainer:
         cfg = _lib.check(self.lib.wmh_conv3d_config(conv.cin, conv.cout, D, H, W, conv.kz, conv.sz, conv.stride), 'config')
         C1 = 0 if x1 is None else x1.shape[1]
         cfg_x3 = self.lib.wmh_conv3d_k3_bf16_config(cfg, conv.cout, W) if (self.x3 and conv.iso) else -1
-        if cfg_x3 >= 0 and self._use_x3(cfg_x3, conv.stride, x0.shape[1], C1, W):
+        if cfg_x3 >= 0 and self._use_x3(cfg_x3, conv.stride, x0.shape[1], C1, W, fwd=True):
             wf = self._pack_x3(conv, cfg_x3, 0, 0, conv.cin)
-            y, part, npart = self._run_conv_x3(key, cfg_x3, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout, True)
+            y, part, npart = self._run_conv_x3(key, cfg_x3, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout, True, conv.stride)
         elif conv.iso and self._use_bf16(cfg, conv.stride, x0.shape[1], C1):
             cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, conv.cout, W)          # wide tile for >= 64 output channels
             wf = self._pack_bf16(conv, cfg, 0, 0, conv.cin)

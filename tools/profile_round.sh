@@ -21,6 +21,12 @@ for mode in f16x2 fp32 bf16_storage; do
     WMH_PMC_MODE=$mode rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${mode}_$c -o p -- python3 tools/pmc_traffic.py > $out/pmc_${mode}_$c.log 2>&1
   done
 done
+# the pair weight-gradient kernel: traffic with its z-first tile order and with the plain order, per-layer times and stamps
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_wgrad_$c -o p -- python3 tools/pmc_wgrad.py > $out/pmc_wgrad_$c.log 2>&1
+done
+WMH_WGRAD_PLAIN_ORDER=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_wgrad_plain_order_FETCH_SIZE -o p -- python3 tools/pmc_wgrad.py > $out/pmc_wgrad_plain_order.log 2>&1
+WMH_STAMPS=1 python3 tools/wgrad_check.py > $out/wgrad_check_per_layer.txt 2>&1
 find $out -name '*.db' -delete; find $out -name '*_agent_info.csv' -delete
 # keep the CSVs small enough to travel: drop the per-dispatch kernel traces of the stats runs (the stats tables stay)
 find $out -name '*kernel_trace.csv' -path '*stats_*' -delete

@@ -87,7 +87,7 @@ def main():
             for _ in range(2):
                 run(lib, mode, d, C0, C1, Cout, N, D, H, W, dW, ws)
             torch.cuda.synchronize()
-            reps = 10
+            reps = int(os.environ.get('WMH_REPS', '10'))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
