@@ -123,3 +123,24 @@ def test_f16x2_weight_image_is_a_two_term_split():
     w[3, 4, 5] = 300.0                                                                   # 256 w beyond fp16's range
     with __import__('pytest').raises(_lib.WMHError):
         _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2(cfg, w.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
+
+
+def test_wgrad_f16x2_plan_host_side(lib):
+    """Host-side planning of the pair weight gradient (no GPU): which layers it serves, and the slab workspace it asks for
+    (P slabs of Cout x Cin x 27 floats, P = the power of two that brings the grid of 32 co x 16 ci workgroups closest to 256 from below)."""
+    sup, ws = lib.wmh_conv3d_k3_wgrad_f16x2_supported, lib.wmh_conv3d_k3_wgrad_f16x2_workspace_floats
+    assert sup(32, 32, 2, 128, 128, 128, 1) == 1 and sup(256, 256, 2, 16, 16, 16, 1) == 1
+    assert sup(320, 320, 2, 8, 8, 8, 1) == 0            # rows shorter than 12 voxels: the fp32 kernel
+    assert sup(32, 64, 2, 128, 128, 128, 2) == 0        # strided layers: the fp32 kernel
+    assert ws(320, 320, 2, 8, 8, 8) == 0
+    # 32 -> 32 at 2 x 128^3: 1 x 2 channel groups -> P = 128
+    assert ws(32, 32, 2, 128, 128, 128) == 128 * 32 * 32 * 27
+    # 256 -> 128 at 2 x 32^3: 4 x 16 groups -> P = 4
+    assert ws(256, 128, 2, 32, 32, 32) == 4 * 128 * 256 * 27
+    # more groups than CUs: one slab
+    assert ws(640, 320, 1, 16, 16, 16) == 1 * 320 * 640 * 27
+    # a single tile: P cannot exceed the tile count
+    assert ws(16, 32, 1, 2, 4, 32) == 1 * 32 * 16 * 27
+    assert lib.wmh_conv3d_k3_wgrad_f16x2_stamp_count(32, 32, 2, 128, 128, 128) == 256 * 4
+    # argument checks fail loudly
+    assert lib.wmh_conv3d_k3_wgrad_f16x2(None, None, 32, None, None, 0, None, None, None, 2, 128, 128, 128, 32, 0.01, None) == -1
