@@ -108,9 +108,14 @@ class UNetEngine:
             _lib.check(self.lib.wmh_convtranspose3d_pack_weights(tu_host.ctypes.data_as(C.c_void_p), cdown, cskip, kt,
                                                                  wf.ctypes.data_as(C.c_void_p)), 'convT pack')
             tu_wf = torch.from_numpy(wf).to(dev)
+            tu_wf_x3 = None
+            if precision == 'f16x2':                       # pair image of the same weights (split on the device)
+                tu_wf_x3 = torch.empty(self.lib.wmh_convtranspose3d_packed_dwords_f16x2(cdown, cskip, kt), dtype=torch.int32, device=dev)
+                _lib.check(self.lib.wmh_convtranspose3d_pack_weights_f16x2_device(_lib.ptr(tu_w), cdown, cskip, kt, _lib.ptr(tu_wf_x3), None),
+                           'wmh_convtranspose3d_pack_weights_f16x2_device')
             convs = [_ConvLayer(self.lib, sd, c.name, c.cin, c.cout, 1, dev, c.kz, c.sz) for c in st['convs']]
             seg_w = torch.from_numpy(_np(sd[st['seg'] + '.weight']).reshape(plan.num_classes, cskip)).contiguous().to(dev)
-            self.dec.append(dict(tu_w=tu_w, tu_wf=tu_wf, kt=kt, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
+            self.dec.append(dict(tu_w=tu_w, tu_wf=tu_wf, tu_wf_x3=tu_wf_x3, kt=kt, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
         if storage == 'bf16_ncdhw':
             self._check_storage_supported()
         self.ncl = 0                                   # resolution levels held as channels-last bf16 tensors
@@ -252,7 +257,7 @@ class UNetEngine:
             N, layer.cout, st), 'wmh_instnorm_finalize')
         return y, ss
 
-    def _convT(self, key, w, wf, x, ss, cout, kt=2, out16=False):
+    def _convT(self, key, w, wf, x, ss, cout, kt=2, out16=False, wf_x3=None):
         N, Cin, D, H, W = x.shape
         if self.acct is not None:
             self.acct['flop'] += 2.0 * Cin * cout * N * D * H * W * 4 * kt
@@ -267,6 +272,11 @@ class UNetEngine:
                 self._stream()), 'wmh_convtranspose3d_mfma_fwd_st')
             return y
         y = self._buf(key + '.y', (N, cout, kt * D, 2 * H, 2 * W))
+        if wf_x3 is not None and x.dtype == torch.float32:      # 'f16x2': products from fp16 pairs, bound by its tensors instead of the fp32 MFMA
+            _lib.check(self.lib.wmh_convtranspose3d_fwd_f16x2(
+                _lib.ptr(x), _lib.ptr(ss), _lib.ptr(wf_x3), _lib.ptr(y), N, Cin, cout, D, H, W, kt, LRELU_SLOPE,
+                self._stream()), 'wmh_convtranspose3d_fwd_f16x2')
+            return y
         if (D * H * W) % 4 == 0:           # matrix-core kernel (16-byte staging loads)
             _lib.check(self.lib.wmh_convtranspose3d_mfma_fwd(
                 _lib.ptr(x), _lib.ptr(ss), _lib.ptr(wf), _lib.ptr(y), N, Cin, cout, D, H, W, kt, LRELU_SLOPE,
@@ -430,7 +440,7 @@ class UNetEngine:
                 cur, cur_ss = self._cl_conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss)
                 cur, cur_ss = self._cl_conv('dec%d.1' % u, st['convs'][1], cur, cur_ss)
             else:
-                up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt'])
+                up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt'], wf_x3=st['tu_wf_x3'])
                 cur, cur_ss = self._conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss)
                 cur, cur_ss = self._conv('dec%d.1' % u, st['convs'][1], cur, cur_ss)
             if u == nd - 1:
@@ -456,7 +466,7 @@ class UNetEngine:
         outs = []
         for u, st in enumerate(self.dec):
             o16 = st16 and u == len(self.dec) - 1
-            up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt'], out16=o16)
+            up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt'], out16=o16, wf_x3=st['tu_wf_x3'])
             skip, skip_ss = skips[-(u + 1)]
             cur, cur_ss = self._conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss, out16=o16)
             cur, cur_ss = self._conv('dec%d.1' % u, st['convs'][1], cur, cur_ss, out16=o16)

@@ -281,7 +281,11 @@ class UNetTrainer:
             kt = st['kt']
             up = self._buf('t.tu%d.y' % u, (N, st['cskip'], kt * D, 2 * H, 2 * W))
             wtu = self.p[st['tu'] + '.weight']
-            if (D * H * W) % 4 == 0:
+            if self.x3:                                      # pair form (any voxel count), image re-split on the device each step
+                wf = self._pack_tu_x3(u, wtu, st)
+                _lib.check(self.lib.wmh_convtranspose3d_fwd_f16x2(_lib.ptr(cur), _lib.ptr(cur_ss), _lib.ptr(wf), _lib.ptr(up), N,
+                                                                  Cin, st['cskip'], D, H, W, kt, LRELU_SLOPE, self._st()), 'convT fwd f16x2')
+            elif (D * H * W) % 4 == 0:
                 wf = self._pack_tu(u, wtu, st)
                 _lib.check(self.lib.wmh_convtranspose3d_mfma_fwd(_lib.ptr(cur), _lib.ptr(cur_ss), _lib.ptr(wf), _lib.ptr(up), N,
                                                                  Cin, st['cskip'], D, H, W, kt, LRELU_SLOPE, self._st()), 'convT fwd')
@@ -312,6 +316,18 @@ class UNetTrainer:
         wf = hit[1] if hit is not None else torch.empty(n, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.wmh_convtranspose3d_pack_weights_device(_lib.ptr(wtu), st['cdown'], st['cskip'], st['kt'], _lib.ptr(wf), self._st()),
                    'wmh_convtranspose3d_pack_weights_device')
+        self._packed[key] = (self._version, wf)
+        return wf
+
+    def _pack_tu_x3(self, u, wtu, st):
+        key = ('tu.x3', u)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == self._version:
+            return hit[1]
+        n = self.lib.wmh_convtranspose3d_packed_dwords_f16x2(st['cdown'], st['cskip'], st['kt'])
+        wf = hit[1] if hit is not None else torch.empty(n, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.wmh_convtranspose3d_pack_weights_f16x2_device(_lib.ptr(wtu), st['cdown'], st['cskip'], st['kt'], _lib.ptr(wf), self._st()),
+                   'wmh_convtranspose3d_pack_weights_f16x2_device')
         self._packed[key] = (self._version, wf)
         return wf
 

@@ -197,6 +197,14 @@ int wmh_convtranspose3d_pack_weights(const float* w, int Cin, int Cout, int kt, 
 int wmh_convtranspose3d_pack_weights_device(const float* w, int Cin, int Cout, int kt, float* wf, void* stream);
 int wmh_convtranspose3d_mfma_fwd(const float* x, const float* ss, const float* wf, float* y, int N, int Cin,
                                  int Cout, int D, int H, int W, int kt, float lrelu_slope, void* stream);
+/* The transposed convolution in the f16x2 "pair" mode (fp32 tensors and accumulation, products from fp16 pairs: the forward kernels'
+ * scheme, two v_mfma_f32_32x32x16_f16 per 8 input channels; any D*H*W).  wf = wmh_convtranspose3d_packed_dwords_f16x2(Cin, Cout, kt)
+ * dwords written by wmh_convtranspose3d_pack_weights_f16x2_device from the torch-layout weights [Cin][Cout][kt][2][2] in HBM
+ * (|w| is clamped to 253.9). */
+size_t wmh_convtranspose3d_packed_dwords_f16x2(int Cin, int Cout, int kt);
+int wmh_convtranspose3d_pack_weights_f16x2_device(const float* w, int Cin, int Cout, int kt, void* wf, void* stream);
+int wmh_convtranspose3d_fwd_f16x2(const float* x, const float* ss, const void* wf, float* y, int N, int Cin, int Cout,
+                                  int D, int H, int W, int kt, float lrelu_slope, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sliding-window glue [nnU-Net neural_network.py::_internal_predict_3D_3Dconv_tiled and

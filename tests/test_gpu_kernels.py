@@ -318,6 +318,42 @@ def test_convtranspose3d_k2s2_mfma(lib, shape):
     assert float((yh - ref).abs().max()) <= 1e-5 * (1 + float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 8, 4, 4, 4, True, 2), (1, 8, 4, 2, 6, 8, False, 2), (2, 24, 20, 3, 16, 32, True, 2), (3, 64, 32, 8, 8, 8, True, 2),
+                                   (1, 40, 72, 4, 4, 5, True, 2), (1, 33, 9, 3, 5, 7, True, 2), (2, 64, 32, 4, 8, 16, True, 1)])
+def test_convtranspose3d_f16x2_pairs(lib, shape):
+    """Transposed convolution from fp16 pairs against float64: fp32-grade (the exact-fp32 MFMA kernel's own distance is printed), channel
+    tails (Cin not a multiple of 8 / 32), odd voxel counts, the (1,2,2) form, weights over four decades."""
+    from deepwmh_amd import _lib
+    N, Cin, Cout, D, H, W, use_ss, kt = shape
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cin, Cout, kt, 2, 2, generator=g) * torch.exp(torch.empty(Cin, Cout, 1, 1, 1).uniform_(-7, 1, generator=g))
+    ss = torch.stack([0.5 + torch.rand(N, Cin, generator=g), 0.3 * torch.randn(N, Cin, generator=g)], -1) if use_ss else None
+    act = _lrelu_affine(x, ss)                                   # fp32, as the kernel forms it
+    ref = F.conv_transpose3d(act.double(), w.double(), None, stride=(kt, 2, 2))
+    xd, ssd, wd = x.cuda(), (ss.cuda() if use_ss else None), w.cuda()
+    wf = torch.zeros(lib.wmh_convtranspose3d_packed_dwords_f16x2(Cin, Cout, kt), dtype=torch.int32, device='cuda')
+    _lib.check(lib.wmh_convtranspose3d_pack_weights_f16x2_device(P(wd), Cin, Cout, kt, P(wf), None), 'convT pack f16x2')
+    y = torch.full((N, Cout, kt * D, 2 * H, 2 * W), float('nan'), device='cuda')
+    _lib.check(lib.wmh_convtranspose3d_fwd_f16x2(P(xd), P(ssd), P(wf), P(y), N, Cin, Cout, D, H, W, kt, SLOPE, None), 'convT f16x2')
+    torch.cuda.synchronize()
+    yh = y.cpu().double()
+    assert not torch.isnan(yh).any()
+    scale = float(ref.abs().max())
+    e16 = float((yh - ref).abs().max()) / scale
+    r16 = float((yh - ref).norm() / ref.norm())
+    line = 'f16x2 max err / max|ref| %.2e, rel. L2 %.2e' % (e16, r16)
+    if (D * H * W) % 4 == 0:
+        wf32 = torch.empty(lib.wmh_convtranspose3d_packed_floats(Cin, Cout, kt), device='cuda')
+        _lib.check(lib.wmh_convtranspose3d_pack_weights_device(P(wd), Cin, Cout, kt, P(wf32), None), 'pack')
+        y32 = torch.empty_like(y)
+        _lib.check(lib.wmh_convtranspose3d_mfma_fwd(P(xd), P(ssd), P(wf32), P(y32), N, Cin, Cout, D, H, W, kt, SLOPE, None), 'convT mfma')
+        torch.cuda.synchronize()
+        line += '  (exact-fp32 kernel: %.2e / %.2e)' % (float((y32.cpu().double() - ref).abs().max()) / scale, float((y32.cpu().double() - ref).norm() / ref.norm()))
+    print(line)
+    assert e16 <= 2e-6 and r16 <= 1e-6, line
+
+
 def test_extract_patches_flips_and_padding(lib):
     from deepwmh_amd import _lib
     rng = np.random.default_rng(2)
