@@ -20,6 +20,7 @@
 // Stands in for Generic_UNet.tu[u] = torch.nn.ConvTranspose3d [nnU-Net, not in tree].
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "wmh_common.h"
 
 typedef float ctp_f32x16 __attribute__((ext_vector_type(16)));
@@ -45,8 +46,9 @@ __device__ __forceinline__ unsigned ctp_split(float v) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(ctp_f32x2{hi, lo}, ctp_f16x2));
 }
 
-template <int NT, int MT, int CKC, int KT>
-__global__ __launch_bounds__(256, 2) void convT_k2s2_f16x2_kernel(const ConvTPArgs a) {
+// NTS: streaming stores (an output far larger than the 256 MB Infinity Cache: conv3d_common.h::conv_epilogue)
+template <int NT, int MT, int CKC, int KT, bool NTS = false>
+__global__ __launch_bounds__(256, MT <= 2 ? 4 : 2) void convT_k2s2_f16x2_kernel(const ConvTPArgs a) {
     constexpr int NTAP = 4 * KT;                  // rows per output channel
     constexpr int VT = MT * 32;                   // voxels per workgroup tile
     constexpr int NG = CKC / 4;                   // 4-channel groups per chunk
@@ -172,8 +174,15 @@ __global__ __launch_bounds__(256, 2) void convT_k2s2_f16x2_kernel(const ConvTPAr
                 const int co = co0 + (KT == 2 ? c : 2 * c + kh);
                 if (co >= a.Cout) continue;
                 float* yp = a.y + ((size_t)n * a.Cout + co) * O + base;
-                *reinterpret_cast<float2*>(yp) = make_float2(acc[nt][m][4 * c + 0] * inv, acc[nt][m][4 * c + 1] * inv);
-                *reinterpret_cast<float2*>(yp + W2) = make_float2(acc[nt][m][4 * c + 2] * inv, acc[nt][m][4 * c + 3] * inv);
+                typedef float ctp_st2 __attribute__((ext_vector_type(2)));
+                const ctp_st2 v0 = {acc[nt][m][4 * c + 0] * inv, acc[nt][m][4 * c + 1] * inv}, v1 = {acc[nt][m][4 * c + 2] * inv, acc[nt][m][4 * c + 3] * inv};
+                if constexpr (NTS) {
+                    __builtin_nontemporal_store(v0, reinterpret_cast<ctp_st2*>(yp));
+                    __builtin_nontemporal_store(v1, reinterpret_cast<ctp_st2*>(yp + W2));
+                } else {
+                    *reinterpret_cast<ctp_st2*>(yp) = v0;
+                    *reinterpret_cast<ctp_st2*>(yp + W2) = v1;
+                }
             }
         }
     }
@@ -218,7 +227,10 @@ extern "C" int wmh_convtranspose3d_fwd_f16x2(const float* x, const float* ss, co
         return wmh_fail(WMH_EINVAL, "convtranspose3d_fwd_f16x2: bad args");
     if (reinterpret_cast<uintptr_t>(y) & 7) return wmh_fail(WMH_EINVAL, "convtranspose3d_fwd_f16x2: y must be 8-byte aligned");
     const long long DHW = (long long)D * H * W;
-    constexpr int NT = 2, MT = 4, CKC = 32;
+    constexpr int NT = 2, CKC = 32;
+    // 64 voxels per workgroup, four workgroups per CU (measured: 0.78 / 0.22 / 0.09 ms for the three wide levels at batch 8 against
+    // 0.82 / 0.26 / 0.10 with 128 voxels and two workgroups; WMH_CONVT_MT=4 selects the latter)
+    static const int MT = (getenv("WMH_CONVT_MT") && atoi(getenv("WMH_CONVT_MT")) == 4) ? 4 : 2;
     ConvTPArgs a;
     a.x = x; a.ss = ss; a.wf = static_cast<const unsigned*>(wf); a.y = y; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     a.nrg = ctp_cdiv((long long)Cout * 4 * kt, 256);
@@ -227,7 +239,13 @@ extern "C" int wmh_convtranspose3d_fwd_f16x2(const float* x, const float* ss, co
     const long long nblk = (long long)ctp_cdiv(a.nvox, MT * 32) * a.nrg;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "convtranspose3d_fwd_f16x2: grid too large");
     const int lds = 2 * (CKC / 4) * MT * 32 * 16;
-    if (kt == 2) hipLaunchKernelGGL((convT_k2s2_f16x2_kernel<NT, MT, CKC, 2>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
-    else         hipLaunchKernelGGL((convT_k2s2_f16x2_kernel<NT, MT, CKC, 1>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    // streaming stores: 0.82 -> 0.78 ms for the 2 GB output of the full-resolution level in isolation, nothing in the network (the
+    // next convolution's loaders wait for HBM either way): off unless WMH_CONVT_NTS=1
+    static const bool nts = getenv("WMH_CONVT_NTS") && atoi(getenv("WMH_CONVT_NTS")) != 0;
+    if (kt == 2 && MT == 4 && nts) hipLaunchKernelGGL((convT_k2s2_f16x2_kernel<NT, 4, CKC, 2, true>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    else if (kt == 2 && MT == 2 && nts) hipLaunchKernelGGL((convT_k2s2_f16x2_kernel<NT, 2, CKC, 2, true>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    else if (kt == 2 && MT == 2) hipLaunchKernelGGL((convT_k2s2_f16x2_kernel<NT, 2, CKC, 2>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    else if (kt == 2) hipLaunchKernelGGL((convT_k2s2_f16x2_kernel<NT, 4, CKC, 2>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
+    else         hipLaunchKernelGGL((convT_k2s2_f16x2_kernel<NT, 4, CKC, 1>), dim3((unsigned)ctp_cdiv(a.nvox, 128) * a.nrg), dim3(256), 2 * (CKC / 4) * 128 * 16, (hipStream_t)stream, a);
     return wmh_check_launch("convT_k2s2_f16x2_kernel");
 }
