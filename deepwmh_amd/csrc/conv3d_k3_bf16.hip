@@ -33,7 +33,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {     // v_c
 // high and with the low parts of the weights (a fragment's lanes 0-31 / 32-63)
 template <class C, int RIT, bool PAIR = false>
 __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d_k3_bf16_kernel(const ConvArgs a) {
-    constexpr int S = C::S, MT = C::MT, NT = C::NT, NIT = C::NIT, THREADS = C::THREADS, APF = 4, CKB = PAIR ? 8 : 16, NA = PAIR ? 2 : 1;
+    constexpr int S = C::S, MT = C::MT, NT = C::NT, NIT = C::NIT, THREADS = C::THREADS, APF = 4, CKB = PAIR ? 8 : 16;
     static_assert(C::TN == 1, "one sample per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];      // [CS voxels][2]
 
@@ -96,19 +96,21 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
             for (int m = 0; m < MT; ++m) acc[nt][m][r] = bv;
         }
 
-    const bf16x8* wl = reinterpret_cast<const bf16x8*>(a.wf) + (size_t)g * a.nchunks * 27 * NT * 64 + (PAIR ? j : lane);
-    bf16x8 aring[APF][NT * NA];                                   // PAIR: [nt] = high parts, [NT + nt] = low parts, both lane halves alike
+    // PAIR: a fragment of the image holds the high parts of its 32 rows on lanes 0-31 and the low parts on lanes 32-63.  ONE 16-byte
+    // load per lane fetches both; v_permlane32_swap_b32 turns it into the two operands [w_hi | w_hi] and [w_lo | w_lo] when the tap is
+    // issued.  (Loading the two halves separately, each into all 64 lanes, doubled the bytes through the vector-memory pipe: with
+    // one voxel tile per wave the strided 32-row configuration moved 432 KB of weight fragments per chunk and CU at that pipe's
+    // 64 bytes per clock -- twice its MFMA time.)
+    const bf16x8* wl = reinterpret_cast<const bf16x8*>(a.wf) + (size_t)g * a.nchunks * 27 * NT * 64 + lane;
+    bf16x8 aring[APF][NT];
     // fragments of step `st` (0..26, or beyond: the next chunk's) of chunk `chn`; the steps walk the taps in the order (kd, kw, kr)
     // (wmh_tap_of: the wave-specialised kernel's order).  Past the last chunk: the last fragment again (never used).
-    auto loadA = [&](int chn, int st, bf16x8 (&dst)[NT * NA]) {
+    auto loadA = [&](int chn, int st, bf16x8 (&dst)[NT]) {
         if (st >= 27) { st -= 27; ++chn; }
         const bool past = chn >= ch_hi;
         const int T = (past ? ch_hi - 1 : chn) * 27 + (past ? 26 : wmh_tap_of(st));
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            dst[nt] = wl[((size_t)T * NT + nt) * 64];
-            if constexpr (PAIR) dst[NT + nt] = wl[((size_t)T * NT + nt) * 64 + 32];
-        }
+        for (int nt = 0; nt < NT; ++nt) dst[nt] = wl[((size_t)T * NT + nt) * 64];
     };
 #pragma unroll
     for (int d = 0; d < APF; ++d) loadA(ch_lo, d, aring[d]);
@@ -184,18 +186,31 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
             const int tap = wmh_tap_of(step);
             const int kw = tap % 3;
             const int rowoff = ((tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS) * 32;
-            bf16x8 anew[NT * NA];
+            bf16x8 anew[NT];
             loadA(ch, step + APF, anew);
             __builtin_amdgcn_sched_barrier(0x38F);
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t ahi[PAIR ? NT : 1], alo[PAIR ? NT : 1];
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const u32x4_t raw = __builtin_bit_cast(u32x4_t, aring[0][nt]);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {                        // lanes 32-63 of r[0] <- lanes 0-31, lanes 0-31 of r[1] <- lanes 32-63
+                        const auto r = __builtin_amdgcn_permlane32_swap(raw[d], raw[d], false, false);
+                        ahi[nt][d] = r[0]; alo[nt][d] = r[1];
+                    }
+                }
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const bf16x8 bv = *reinterpret_cast<const bf16x8*>(ldsb + badr[kw][m] + rowoff);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     if constexpr (PAIR) {
-                        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-                        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aring[0][nt]), __builtin_bit_cast(f16x8, bv), acc[nt][m], 0, 0, 0);
-                        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aring[0][NT + nt]), __builtin_bit_cast(f16x8, bv), acc[nt][m], 0, 0, 0);
+                        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ahi[nt]), __builtin_bit_cast(f16x8, bv), acc[nt][m], 0, 0, 0);
+                        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, alo[nt]), __builtin_bit_cast(f16x8, bv), acc[nt][m], 0, 0, 0);
                     } else {
                         acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[0][nt], bv, acc[nt][m], 0, 0, 0);
                     }
@@ -204,9 +219,9 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
 #pragma unroll
             for (int d = 0; d + 1 < APF; ++d)
 #pragma unroll
-                for (int nt = 0; nt < NT * NA; ++nt) aring[d][nt] = aring[d + 1][nt];
+                for (int nt = 0; nt < NT; ++nt) aring[d][nt] = aring[d + 1][nt];
 #pragma unroll
-            for (int nt = 0; nt < NT * NA; ++nt) aring[APF - 1][nt] = anew[nt];
+            for (int nt = 0; nt < NT; ++nt) aring[APF - 1][nt] = anew[nt];
         }
         if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mfma += t - t_mark; }
     }
