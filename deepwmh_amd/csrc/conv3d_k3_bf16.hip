@@ -180,15 +180,26 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
         __syncthreads();
         if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
         // ---- 27 taps x MT x NT MFMAs -----------------------------------------------------------------------------
+        // The B operands of step + 1 are read BEFORE the MFMAs of step are issued (sched_barrier pins them): a wave issues in order and
+        // an MFMA holds the issue until the pipe takes it, so a read placed in front of its own use -- the compiler's schedule -- waits
+        // out the LDS latency with the matrix pipe empty.  With one voxel tile per wave (the strided 32-row configuration) that was
+        // 356 cycles per tap against 128 of MFMA issue.
+        auto loadB = [&](int st, bf16x8 (&dst)[MT]) __attribute__((always_inline)) {
+            const int tap = wmh_tap_of(st < 27 ? st : 26);
+            const int kw = tap % 3;
+            const int rowoff = ((tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS) * 32;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(ldsb + badr[kw][m] + rowoff);
+        };
+        bf16x8 bbuf[2][MT];                                  // static indices: the step loop is fully unrolled
+        if (!(abl & 1)) loadB(0, bbuf[0]);
         if (!(abl & 1))
 #pragma unroll
         for (int step = 0; step < 27; ++step) {
-            const int tap = wmh_tap_of(step);
-            const int kw = tap % 3;
-            const int rowoff = ((tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS) * 32;
             bf16x8 anew[NT];
             loadA(ch, step + APF, anew);
-            __builtin_amdgcn_sched_barrier(0x38F);
+            if (step + 1 < 27) loadB(step + 1, bbuf[(step + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
             typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
             typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
             u32x4_t ahi[PAIR ? NT : 1], alo[PAIR ? NT : 1];
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(ldsb + badr[kw][m] + rowoff);
+                const bf16x8 bv = bbuf[step & 1][m];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     if constexpr (PAIR) {
@@ -222,6 +233,7 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
                 for (int nt = 0; nt < NT; ++nt) aring[d][nt] = aring[d + 1][nt];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) aring[APF - 1][nt] = anew[nt];
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mfma += t - t_mark; }
     }
@@ -575,7 +587,8 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     a.G = cdiv(Cout, 32 * NT);
     a.KS = 1;
     static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
-    a.xcd_swizzle = swz_env & 1;
+    static const int abl_x = env_int("WMH_BF16_ABL", 0);      // diagnostics (timing only): see the one-role kernel
+    a.xcd_swizzle = (swz_env & 1) | (small ? abl_x << 4 : 0);
     a.stamps = g_conv_stamps;
     a.by = a.bz = 1;
     hipStream_t st = (hipStream_t)stream;
