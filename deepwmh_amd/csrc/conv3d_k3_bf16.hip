@@ -281,10 +281,9 @@ typedef ConvCfg<1, 32, 1, 4, 4, 1, 4, 2, 4, 6> BCfgW;
 typedef ConvCfg<2, 16, 2, 2, 8, 1, 2, 2, 2, 6> BCfg3;     // stride 2, 16-wide output, 2 x 8 x 16 outputs x 64 channels
 typedef ConvCfg<1, 8, 4, 4, 8, 1, 2, 1, 8, 6> BCfg4;      // stride 1, 8-wide
 typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 1, 2, 6> BCfg5;      // stride 2, 8-wide output
-// Stride 2 with output rows of 32 voxels and more (the first convolution of the 64^3 and 32^3 stages; f16x2 mode only: round 3).  A
-// tile of 2 x 2 x 32 outputs x 64 channels reads a 5 x 5 x 65 input box: 57 KB as [voxel][hi | lo of 8 channels], two workgroups
-// per CU, so that one stages while the other multiplies (12.7 input voxels are staged per output voxel: the layer is loader-bound,
-// the fp32-instruction kernel it replaces ran 2.4 / 0.9 ms for the two layers at batch 8).
+// Stride 2 with output rows of 32 voxels and more (the first convolution of the 64^3 and 32^3 stages; f16x2 mode only: round 3): tile
+// geometry only -- the kernel is the wave-specialised one of conv3d_k3s2_f16x2_ws.hip (a 2 x 2 x 32 output tile x 64 channels reads a
+// 5 x 5 x 65 input box; the one-role form that first served these layers spent half its time in its in-order staging).
 typedef ConvCfg<2, 32, 1, 2, 2, 1, 1, 2, 2, 6> BCfg1;
 static int bf16_nt(int cfg) { return (cfg == 0 || cfg == 4 || cfg == 5) ? 1 : (cfg == 1 || cfg == 2 || cfg == 3 || cfg == WMH_BF16_CFG_WIDE) ? 2 : 0; }
 static int bf16_stride(int cfg) { return (cfg == 1 || cfg == 3 || cfg == 5) ? 2 : 1; }
@@ -374,6 +373,17 @@ extern "C" int wmh_conv3d_k3_pack_weights_f16x2(int cfg, const float* w, int Cin
                             if (!(v > -65000.f && v < 65000.f)) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2: a weight is not finite or exceeds +-253 (fp16 pair range)");
                             const uint16_t hi = f2h(v);
                             wf[(((((size_t)g * NCH + ch) * 27 + tap) * NT + nt) * 64 + lane) * 8 + e] = (lane >> 5) ? f2h(v - h2f(hi)) : hi;
+                            if (cfg == 1) {
+                                // the strided 32-row configuration (conv3d_k3s2_f16x2_ws.hip): a lane holds 4 channels x (hi, lo) -- channel
+                                // 4 (lane >> 5) + (e >> 1) of the chunk, half e & 1; hi = the value cut to 11 significant bits
+                                const int ci2 = ch * 8 + 4 * (lane >> 5) + (e >> 1);
+                                float v2 = 0.f;
+                                if (co < Cout && ci2 < Cin) v2 = w[((size_t)co * Cin + ci2) * 27 + tap] * WMH_PAIR_WSCALE;
+                                if (!(v2 > -65000.f && v2 < 65000.f)) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2: a weight is not finite or exceeds +-253 (fp16 pair range)");
+                                unsigned u; memcpy(&u, &v2, 4); u &= 0xFFFFE000u;
+                                float h; memcpy(&h, &u, 4);
+                                wf[(((((size_t)g * NCH + ch) * 27 + tap) * NT + nt) * 64 + lane) * 8 + e] = (e & 1) ? f2h(v2 - h) : f2h(h);
+                            }
                         }
     return WMH_OK;
 }
@@ -414,8 +424,9 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16_device(int cfg, const float* w, i
 
 // The f16x2 image on the device (training: weights change every step): modes as above, chunks of 8 input channels,
 // high parts on lanes 0-31 and low parts on lanes 32-63 of every fragment.
+// il: the interleaved image of the strided 32-row configuration (a lane holds 4 channels x (hi, lo); conv3d_k3s2_f16x2_ws.hip)
 __global__ __launch_bounds__(256) void pack_f16x2_kernel(const float* w, uint16_t* wf, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
-                                                           int NT, int NCH, size_t total) {
+                                                           int NT, int NCH, size_t total, int il) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         size_t r = idx;
         const int e = (int)(r % 8); r /= 8;
@@ -424,11 +435,17 @@ __global__ __launch_bounds__(256) void pack_f16x2_kernel(const float* w, uint16_
         const int tap = (int)(r % 27); r /= 27;
         const int ch = (int)(r % NCH);
         const int g = (int)(r / NCH);
-        const int eco = (g * NT + nt) * 32 + (lane & 31), eci = ch * 8 + e;
+        const int eco = (g * NT + nt) * 32 + (lane & 31), eci = il ? ch * 8 + 4 * (lane >> 5) + (e >> 1) : ch * 8 + e;
         float v = 0.f;
         if (mode == 0) { if (eco < Cout && eci < ci_cnt) v = w[((size_t)eco * Cin_total + ci_off + eci) * 27 + tap]; }
         else           { if (eco < ci_cnt && eci < Cout) v = w[((size_t)eci * Cin_total + ci_off + eco) * 27 + (26 - tap)]; }
         v = fminf(fmaxf(v * WMH_PAIR_WSCALE, -65000.f), 65000.f);          // (training: a weight beyond +-253 saturates instead of overflowing)
+        if (il) {
+            const float h = __uint_as_float(__float_as_uint(v) & 0xFFFFE000u);
+            const _Float16 out = (e & 1) ? (_Float16)(v - h) : (_Float16)h;
+            wf[idx] = __builtin_bit_cast(uint16_t, out);
+            continue;
+        }
         const _Float16 hi = (_Float16)v;
         const _Float16 out = (lane >> 5) ? (_Float16)(v - (float)hi) : hi;
         wf[idx] = __builtin_bit_cast(uint16_t, out);
@@ -439,11 +456,12 @@ extern "C" int wmh_conv3d_k3_pack_weights_f16x2_device(int cfg, const float* w, 
     const int NT = bf16_nt(cfg);
     if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg) || !w || !wf || ci_off < 0 || ci_cnt < 1 || ci_off + ci_cnt > Cin_total || (mode != 0 && mode != 1))
         return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: bad args or configuration without a f16x2 kernel");
+    if (cfg == 1 && mode != 0) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: configuration 1 (stride 2) has a forward image only");
     const int eCin = mode == 0 ? ci_cnt : Cout, eCout = mode == 0 ? Cout : ci_cnt;
     const int NCH = cdiv(eCin, 8);
     const size_t total = (size_t)cdiv(eCout, 32 * NT) * NCH * 27 * NT * 64 * 8;
     unsigned nb = (unsigned)((total + 255) / 256); if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(pack_f16x2_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wf, Cin_total, Cout, ci_off, ci_cnt, mode, NT, NCH, total);
+    hipLaunchKernelGGL(pack_f16x2_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wf, Cin_total, Cout, ci_off, ci_cnt, mode, NT, NCH, total, cfg == 1 ? 1 : 0);
     return wmh_check_launch("pack_f16x2_kernel");
 }
 
@@ -519,7 +537,7 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     const bool quad_ok = (W % 4) == 0 && (size_t)16 * D * H * W * 4 < ((size_t)1 << 32) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && (!x1 || (reinterpret_cast<uintptr_t>(x1) & 15) == 0);
     if (small) {
         if (in16 || out16) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16_st: bf16 storage is served for configurations 0 and 21");
-        a.KS = workspace != nullptr ? bf16_ksplit(nblk, a.nchunks) : 1;
+        a.KS = (workspace != nullptr && cfg != 1) ? bf16_ksplit(nblk, a.nchunks) : 1;
         if (a.KS > 1) a.y = workspace;                       // slabs [KS][N][Cout][Do][Ho][Wo]; bias and moments come with the reduce
         const unsigned nb = (unsigned)(nblk * a.KS);
         int rc;
@@ -555,7 +573,7 @@ int wmh_launch_conv_f16x2_ws(int cfg, const ConvArgs& a, hipStream_t st);
 // (16 mantissa bits per operand): fp32 tensors in and out, stride 1, wf from wmh_conv3d_k3_pack_weights_f16x2.  Same
 // geometry, moments records (wmh_conv3d_k3_num_partials_bf16) and epilogue as wmh_conv3d_k3_fwd_bf16.
 extern "C" size_t wmh_conv3d_k3_f16x2_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout) {
-    if (!(cfg == 1 || cfg == 3 || cfg == 4 || cfg == 5)) return 0;
+    if (!(cfg == 3 || cfg == 4 || cfg == 5)) return 0;           // (configuration 1: wave-specialised, no split-K)
     const int S = bf16_stride(cfg);
     const int ks = bf16_ksplit(bf16_small_blocks(cfg, N, D, H, W, Cout), cdiv(Cin, 8));
     return ks > 1 ? (size_t)ks * N * Cout * ((D - 1) / S + 1) * ((H - 1) / S + 1) * ((W - 1) / S + 1) : 0;
@@ -569,6 +587,7 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     if (x1 == nullptr) C1 = 0;
     if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: LeakyReLU slope must be in [0, 1]");
     if (C1 > 0 && (C0 % 8) != 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: C0 must be a multiple of 8 with two sources");
+    if (cfg == 1 && C1 > 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: the strided 32-row configuration takes one source");
     const bool small = cfg == 1 || cfg == 3 || cfg == 4 || cfg == 5;           // the one-role kernel
     if (!small && ((W % 4) != 0 || (size_t)16 * D * H * W * 4 >= ((size_t)1 << 32) || (reinterpret_cast<uintptr_t>(x0) & 15) != 0 ||
                    (x1 && (reinterpret_cast<uintptr_t>(x1) & 15) != 0)))
@@ -596,12 +615,13 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     // rows of 16 / 8 voxels (stride 1 and 2): the one-role kernel, split-K when slab memory is given (wmh_conv3d_k3_fwd_bf16_splitk)
     const long long nblk = (long long)a.ntx * a.nty * a.ntz * N * a.G;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: grid too large");
-    a.KS = workspace != nullptr ? bf16_ksplit(nblk, a.nchunks) : 1;
+    a.KS = (workspace != nullptr && cfg != 1) ? bf16_ksplit(nblk, a.nchunks) : 1;
     if (a.KS > 1) a.y = workspace;
     const unsigned nb = (unsigned)(nblk * a.KS);
     int rc;
-    if (cfg == 1) rc = launch_bf16<BCfg1, 4, true>(a, nb, st);
-    else if (cfg == 3) rc = launch_bf16<BCfg3, 4, true>(a, nb, st);
+    // stride 2, 32-voxel output rows: the wave-specialised kernel of conv3d_k3s2_f16x2_ws.hip (its own weight image: one source, no split-K)
+    if (cfg == 1) return wmh_launch_conv_s2_f16x2_ws(a, st);
+    if (cfg == 3) rc = launch_bf16<BCfg3, 4, true>(a, nb, st);
     else if (cfg == 4) rc = launch_bf16<BCfg4, 3, true>(a, nb, st);
     else rc = launch_bf16<BCfg5, 4, true>(a, nb, st);
     if (rc != WMH_OK || a.KS == 1) return rc;
