@@ -108,11 +108,13 @@ int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, c
  * (x = x_hi + x_lo: 21-22 significant bits together; round 2 used bf16 pairs, 16 bits) and all four partial products are
  * accumulated in fp32: 4 v_mfma_f32_32x32x16_f16 per 16 input channels and tap instead of 1, still a quarter of the fp32
  * instruction's cycles.  Measured against float64, a layer's error is below the exact-fp32 kernel's (tools/f16x2_check.py).
- * fp32 NCDHW tensors in and out, configurations 0 / 2 / 21 (stride 1, rows of >= 16 voxels) and 3 / 4 / 5; geometry and
+ * fp32 NCDHW tensors in and out, configurations 0 / 2 / 21 (stride 1, rows of >= 16 voxels), 1 (stride 2, output rows of 32 voxels:
+ * its own wave-specialised kernel; one source, no split-K workspace) and 3 / 4 / 5; geometry and
  * epilogue of wmh_conv3d_k3_fwd_bf16, moments records: wmh_conv3d_k3_num_partials_f16x2.  wf: wmh_conv3d_k3_pack_weights_f16x2
  * ([G][cin/8][27][NT][64][8] fp16 of the weights x 2^8: lanes 0-31 the high parts, lanes 32-63 the low parts of an output
- * channel's 8 weights; the kernel scales the accumulators back.  Weights must be finite and below 253 in magnitude:
- * WMH_EINVAL otherwise; the device packer saturates). */
+ * channel's 8 weights -- configuration 1: a lane holds 4 channels x (hi, lo), channels 0-3 of the chunk on lanes 0-31 and 4-7 on
+ * lanes 32-63, hi = the value cut to 11 significant bits; the kernel scales the accumulators back.  Weights must be finite and
+ * below 253 in magnitude: WMH_EINVAL otherwise; the device packer saturates). */
 int wmh_conv3d_k3_f16x2_supported(int cfg);
 size_t wmh_conv3d_k3_packed_halfs_f16x2(int cfg, int Cin, int Cout);
 int wmh_conv3d_k3_pack_weights_f16x2(int cfg, const float* w, int Cin, int Cout, uint16_t* wf);
