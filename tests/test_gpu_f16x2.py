@@ -28,6 +28,7 @@ CASES = [  # N, D, H, W, C0, C1, Cout, pending norm on source 0 / 1 [, stride]
     (2, 8, 16, 64, 32, 0, 64, True, False, 2),    # stride 2, output rows of 32 (configuration 1: the first convolution of the 64^3 / 32^3 stages)
     (1, 7, 9, 50, 16, 0, 40, True, False, 2),     # ... ragged tiles, channel counts that are not multiples of the chunk / the tile
     (1, 6, 6, 128, 8, 0, 128, False, False, 2),   # ... two tiles per row, no pending norm
+    (3, 9, 21, 70, 20, 0, 72, True, False, 2),    # ... a channel count that is no multiple of the chunk, two output-channel groups with a tail, many tiles per workgroup
     (1, 5, 9, 36, 12, 0, 40, True, False),        # channel counts that are not multiples of the chunk / the tile; ragged tiles
     (1, 6, 10, 32, 16, 24, 32, False, True),      # two sources (the decoder's concatenation), the second one normalised
     (2, 4, 12, 64, 64, 64, 64, True, True),       # the 64-channel tile (configuration 21)
