@@ -78,3 +78,29 @@ def test_workload_string_names_the_config():
     b = bench.parse_args(['--precision', 'bf16', '--storage', 'bf16'])
     w = bench.workload_string(b, True, 64, 1)
     assert w.startswith('configs[2]') and 'batch of 8' in w and b.volumes_per_step == 8
+
+
+def test_clock_sampler_without_a_device(tmp_path):
+    """bench.py's ClockSampler reads hwmon files when the device has them and reports None when it does not (this container)."""
+    import importlib.util
+    import os
+    import time
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with bench.ClockSampler(0) as cs:
+        time.sleep(0.06)
+    rep = cs.report()
+    assert rep is None or rep['sclk_mhz_median'] >= 0
+    # with files: medians of what was read
+    f = tmp_path / 'freq1_input'; f.write_text('1870000000\n')
+    w = tmp_path / 'power1_input'; w.write_text('1250000000\n')
+    cs = bench.ClockSampler(0)
+    cs.freq, cs.power = str(f), str(w)
+    with cs:
+        time.sleep(0.12)
+    rep = cs.report()
+    assert rep['sclk_mhz_median'] == 1870 and rep['socket_power_w_median'] == 1250 and rep['samples'] >= 1
+    r = dict(bound='mfma', frac=0.5, peak=bench.PEAK_TFLOPS['f16x2'])
+    bench.add_sustained(r, rep)
+    assert abs(r['frac_at_sustained_clock'] - 0.5 * 2400 / 1870) < 1e-3 and 'pure_mfma_stream' in r
