@@ -4,7 +4,7 @@
 // The one-role kernel that served these layers (conv3d_k3_bf16.hip, BCfg1) spends half its time staging: a 2 x 2 x 32 output tile reads
 // a 5 x 5 x 65 input box -- 12.7 staged voxels per output voxel -- and each of its four waves issues the 673 instructions of a chunk's
 // staging in order before it turns to the MFMAs (timing-only ablations: 0.85 of 1.74 ms for 32 -> 64 at 8 x 128^3 is the staging alone,
-// DESIGN.md section 5b).  Here the roles are split inside one workgroup of 12 waves per CU:
+// DESIGN.md section 3.3d).  Here the roles are split inside one workgroup of 12 waves per CU:
 //   waves 0-3   consumers: wave w owns output row w of the tile (32 voxels) x 64 output channels; per tap one B operand from LDS (read
 //               one tap ahead of its MFMAs) and two weight fragments straight from L2 (a ring four taps deep, one 16-byte load per lane and
 //               fragment), four v_mfma_f32_32x32x16_f16; then the shared epilogue (conv3d_common.h: bias, fp32 InstanceNorm moments, stores);
