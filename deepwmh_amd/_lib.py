@@ -83,6 +83,9 @@ SIGNATURES = {
     'wmh_convtranspose3d_packed_dwords_f16x2': (_sz, [_i, _i, _i]),
     'wmh_convtranspose3d_pack_weights_f16x2_device': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'wmh_convtranspose3d_fwd_f16x2': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_conv3d_k3s2_dgrad_packed_dwords_f16x2': (_sz, [_i, _i]),
+    'wmh_conv3d_k3s2_dgrad_pack_weights_f16x2_device': (_i, [_vp, _i, _i, _vp, _vp]),
+    'wmh_conv3d_k3s2_dgrad_f16x2': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'wmh_conv3d_k3s2_dgrad_packed_floats': (_sz, [_i, _i]),
     'wmh_conv3d_k3s2_dgrad_pack_weights_device': (_i, [_vp, _i, _i, _vp, _vp]),
     'wmh_conv3d_k3s2_dgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -8,6 +8,7 @@ Parameters, gradients and momentum live in three flat HBM arenas (one kernel lau
 the optimizer; one RCCL all-reduce for data parallelism).  Nothing here falls back to torch autograd.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -393,7 +394,21 @@ class UNetTrainer:
                     + ([wseg_name] if (wseg_name and dl is not None) else []))
         if not need_dx:
             return None
-        if conv.stride == 2 and conv.iso:                    # gather form: 27 MFMAs per channel pair for the 8 output parities
+        if conv.stride == 2 and conv.iso and self.x3 and os.environ.get('WMH_TRAIN_S2_DGRAD', 'f16x2') != 'fp32':   # gather form on fp16 pairs (dy is loss-scaled into fp16's range; the switch: diagnostics)
+            assert C1 == 0
+            key = ('dgrad.s2.x3', conv.name)
+            hit = self._packed.get(key)
+            if hit is None or hit[0] != self._version:
+                wp = hit[1] if hit is not None else torch.empty(lib.wmh_conv3d_k3s2_dgrad_packed_dwords_f16x2(C0, Cc), dtype=torch.int32,
+                                                                device=self.device)
+                _lib.check(lib.wmh_conv3d_k3s2_dgrad_pack_weights_f16x2_device(_lib.ptr(self.p[conv.name + '.conv.weight']), C0, Cc, _lib.ptr(wp), st),
+                           'wmh_conv3d_k3s2_dgrad_pack_weights_f16x2_device')
+                self._packed[key] = (self._version, wp)
+            wp = self._packed[key][1]
+            dx = self._buf('b.dx0.%s.y' % rec['key'], (N, C0, D, H, W))
+            _lib.check(lib.wmh_conv3d_k3s2_dgrad_f16x2(_lib.ptr(dy), _lib.ptr(wp), _lib.ptr(dx), N, C0, Cc, D, H, W, st), 'wmh_conv3d_k3s2_dgrad_f16x2')
+            return [dx]
+        if conv.stride == 2 and conv.iso:                  # gather form: 27 MFMAs per channel pair for the 8 output parities
             assert C1 == 0
             key = ('dgrad.s2', conv.name)
             hit = self._packed.get(key)

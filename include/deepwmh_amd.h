@@ -300,6 +300,12 @@ int wmh_conv3d_k3_wgrad_f16x2_stamped(const float* x0, const float* ss0, int C0,
 size_t wmh_conv3d_k3s2_dgrad_packed_floats(int Cin, int Cout);
 int wmh_conv3d_k3s2_dgrad_pack_weights_device(const float* w, int Cin, int Cout, float* wp, void* stream);
 int wmh_conv3d_k3s2_dgrad(const float* dy, const float* wp, float* dx, int N, int Cin, int Cout, int D, int H, int W, void* stream);
+/* The same data gradient in the f16x2 "pair" mode (products from fp16 pairs, fp32 accumulation; dy loss-scaled into fp16's range by the
+ * caller: |dy| < 65520).  wp = wmh_conv3d_k3s2_dgrad_packed_dwords_f16x2(Cin, Cout) dwords from
+ * wmh_conv3d_k3s2_dgrad_pack_weights_f16x2_device (w = torch layout [Cout][Cin][27] in HBM). */
+size_t wmh_conv3d_k3s2_dgrad_packed_dwords_f16x2(int Cin, int Cout);
+int wmh_conv3d_k3s2_dgrad_pack_weights_f16x2_device(const float* w, int Cin, int Cout, void* wp, void* stream);
+int wmh_conv3d_k3s2_dgrad_f16x2(const float* dy, const void* wp, float* dx, int N, int Cin, int Cout, int D, int H, int W, void* stream);
 /* up[n,c,z,2y,2x] = dy[n,c,z,y,x], zero elsewhere: the data gradient of a stride (1,2,2) convolution is the stride-1
  * convolution of `up` with the mode-1 weight image. */
 int wmh_upsample_zero_plane(const float* dy, float* up, int N, int C, int Ho, int Wo, int D, int H, int W, void* stream);

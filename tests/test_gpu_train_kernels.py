@@ -265,6 +265,37 @@ def test_conv3d_stride2_dgrad_gather(lib, shape):
     assert float((dX.cpu() - x.grad).abs().max()) <= 1e-5 * (1 + float(x.grad.abs().max()))
 
 
+@pytest.mark.parametrize('shape', [(2, 8, 16, 8, 8, 8), (1, 40, 20, 9, 11, 13), (1, 32, 64, 12, 10, 70), (2, 3, 5, 4, 6, 5), (2, 32, 64, 16, 16, 64)])
+def test_conv3d_stride2_dgrad_f16x2_pairs(lib, shape):
+    """dx of Conv3d(k3, s2, p1) from fp16 pairs against float64 autograd (even and odd extents, channel tails, several x tiles); the
+    exact-fp32 gather kernel's own distance is printed beside it."""
+    N, Cin, Cout, D, H, W = shape
+    g = torch.Generator().manual_seed(82)
+    x = torch.zeros(N, Cin, D, H, W, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * torch.exp(torch.empty(Cout, 1, 1, 1, 1).uniform_(-5, 0, generator=g))
+    y = F.conv3d(x, w.double(), None, stride=2, padding=1)
+    dY = torch.randn(y.shape, generator=g) * torch.exp(torch.empty(1, Cout, 1, 1, 1).uniform_(-3, 3, generator=g))
+    y.backward(dY.double())
+    ref = x.grad
+    wd, dYd = w.cuda(), dY.cuda()
+    wp = torch.zeros(lib.wmh_conv3d_k3s2_dgrad_packed_dwords_f16x2(Cin, Cout), dtype=torch.int32, device='cuda')
+    check(lib.wmh_conv3d_k3s2_dgrad_pack_weights_f16x2_device(P(wd), Cin, Cout, P(wp), None), 'dgrad pack f16x2')
+    dX = torch.full((N, Cin, D, H, W), float('nan'), device='cuda')
+    check(lib.wmh_conv3d_k3s2_dgrad_f16x2(P(dYd), P(wp), P(dX), N, Cin, Cout, D, H, W, None), 'k3s2 dgrad f16x2')
+    wp32 = torch.empty(lib.wmh_conv3d_k3s2_dgrad_packed_floats(Cin, Cout), device='cuda')
+    check(lib.wmh_conv3d_k3s2_dgrad_pack_weights_device(P(wd), Cin, Cout, P(wp32), None), 'dgrad pack')
+    dX32 = torch.full((N, Cin, D, H, W), float('nan'), device='cuda')
+    check(lib.wmh_conv3d_k3s2_dgrad(P(dYd), P(wp32), P(dX32), N, Cin, Cout, D, H, W, None), 'k3s2 dgrad')
+    torch.cuda.synchronize()
+    got = dX.cpu().double()
+    assert not torch.isnan(got).any()
+    sc = float(ref.abs().max())
+    e16, r16 = float((got - ref).abs().max()) / sc, float((got - ref).norm() / ref.norm())
+    e32, r32 = float((dX32.cpu().double() - ref).abs().max()) / sc, float((dX32.cpu().double() - ref).norm() / ref.norm())
+    print('f16x2 max err / max|ref| %.2e, rel. L2 %.2e  (exact-fp32 kernel %.2e / %.2e)' % (e16, r16, e32, r32))
+    assert e16 <= 2e-6 and r16 <= 1e-6
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 0, 8, 8, 8, 32), (1, 32, 24, 40, 5, 9, 45), (2, 20, 0, 36, 6, 16, 16), (1, 8, 8, 72, 3, 17, 20)])
 def test_conv3d_wgrad_bf16_operands(lib, shape):
     """bf16-operand weight gradient: against autograd on bf16-rounded dy and x' (tight: only the summation order differs) and
