@@ -413,8 +413,8 @@ def measure_training_mode(plan, sd, device, precision, iters, warmup):
     del tr
     out = dict(workload='one nnUNetTrainerV2 iteration, batch 2 x 128^3, BASELINE plan (31.2 M parameters), deep supervision, Dice+CE, '
                          'clip 12, SGD-Nesterov; %s' % ('fp32 throughout' if precision == 'fp32' else
-                                                        'forward, stride-1 data-gradient and weight-gradient convolutions from fp16 pairs (fp32 tensors '
-                                                        'and accumulation), stride-2 layers / statistics / optimizer exact fp32' if precision == 'f16x2' else
+                                                        'forward, data-gradient and stride-1 weight-gradient convolutions from fp16 pairs (fp32 tensors '
+                                                        'and accumulation), strided weight gradients / statistics / optimizer exact fp32' if precision == 'f16x2' else
                                                         'bf16 matrix-core operands for the stride-1 convolutions of the wide levels '
                                                         '(forward, data and weight gradients), fp32 master weights / statistics / optimizer'),
                 steps=iters, warmup=warmup, ms_per_step=round(1e3 * dt / iters, 3), value=round(2 * iters / dt, 3), unit='patches/s',
