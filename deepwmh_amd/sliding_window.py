@@ -76,7 +76,7 @@ class SlidingWindowPredictor:
         self.use_gaussian = use_gaussian
         self.do_mirroring = do_mirroring
         self.batch = int(batch)
-        assert 1 <= self.batch <= 16
+        assert 1 <= self.batch <= 64
         self._gauss = None
         self._cnt_cache = {}
         self._tmp = {}
@@ -138,10 +138,12 @@ class SlidingWindowPredictor:
 
         def extract(n, orgs, flips):
             patches = self._scratch('patches', (n, Cc) + P)
-            flat = [v for o in orgs for v in o]
-            _lib.check(lib.wmh_extract_patches(_lib.ptr(vol), _lib.ptr(patches), Cc, V[0], V[1], V[2],
-                                               _lib.iarr(pad_lo), P[0], P[1], P[2], n, _lib.iarr(flat),
-                                               _lib.iarr(flips), st), 'wmh_extract_patches')
+            for k in range(0, n, 16):                     # a patch list holds WMH_MAX_BATCH_ITEMS = 16 items
+                m = min(16, n - k)
+                flat = [v for o in orgs[k:k + m] for v in o]
+                _lib.check(lib.wmh_extract_patches(_lib.ptr(vol), _lib.ptr(patches[k:k + m]), Cc, V[0], V[1], V[2],
+                                                   _lib.iarr(pad_lo), P[0], P[1], P[2], m, _lib.iarr(flat),
+                                                   _lib.iarr(flips[k:k + m]), st), 'wmh_extract_patches')
             return patches
 
         def accumulate(y, ss, seg_w, origin, n, flips):
@@ -160,10 +162,16 @@ class SlidingWindowPredictor:
                 int(y.dtype == torch.bfloat16), st), 'wmh_seghead_softmax_accumulate_st')
 
         if self.do_mirroring:
-            for o in origins:
-                x = extract(8, [o] * 8, MIRROR_CODES)
+            # the 8 mirrored copies of a tile are one batch of 8; `batch` >= 16 puts several tiles' copies into one forward (bigger grids
+            # for the deep levels; the samples of a batch are independent, accumulation stays in tile order)
+            tpf = max(1, self.batch // 8)
+            for i in range(0, len(origins), tpf):
+                grp = origins[i:i + tpf]
+                n = 8 * len(grp)
+                x = extract(n, [o for o in grp for _ in range(8)], list(MIRROR_CODES) * len(grp))
                 y, ss, seg_w = self.engine.forward_features(x)[-1]
-                accumulate(y, ss, seg_w, o, 8, MIRROR_CODES)
+                for b, o in enumerate(grp):
+                    accumulate(y[8 * b:8 * b + 8], ss[8 * b:8 * b + 8], seg_w, o, 8, MIRROR_CODES)
         else:
             for i in range(0, len(origins), self.batch):
                 grp = origins[i:i + self.batch]
