@@ -438,6 +438,10 @@ __global__ __launch_bounds__(256) void pack_f16x2_kernel(const float* w, uint16_
         const int eco = (g * NT + nt) * 32 + (lane & 31), eci = il ? ch * 8 + 4 * (lane >> 5) + (e >> 1) : ch * 8 + e;
         float v = 0.f;
         if (mode == 0) { if (eco < Cout && eci < ci_cnt) v = w[((size_t)eco * Cin_total + ci_off + eci) * 27 + tap]; }
+        else if (mode == 2) {                    // w = ConvTranspose3d(k2, s2) weight [Cout][ci_cnt][2][2][2]: its 2-window embedded in the 3-window
+            const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+            if (eco < Cout && eci < ci_cnt && tz && ty && tx) v = w[((size_t)eco * Cin_total + ci_off + eci) * 8 + (tz - 1) * 4 + (ty - 1) * 2 + (tx - 1)];
+        }
         else           { if (eco < ci_cnt && eci < Cout) v = w[((size_t)eci * Cin_total + ci_off + eco) * 27 + (26 - tap)]; }
         v = fminf(fmaxf(v * WMH_PAIR_WSCALE, -65000.f), 65000.f);          // (training: a weight beyond +-253 saturates instead of overflowing)
         if (il) {
@@ -454,10 +458,11 @@ __global__ __launch_bounds__(256) void pack_f16x2_kernel(const float* w, uint16_
 extern "C" int wmh_conv3d_k3_pack_weights_f16x2_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
                                                         uint16_t* wf, void* stream) {
     const int NT = bf16_nt(cfg);
-    if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg) || !w || !wf || ci_off < 0 || ci_cnt < 1 || ci_off + ci_cnt > Cin_total || (mode != 0 && mode != 1))
+    if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg) || !w || !wf || ci_off < 0 || ci_cnt < 1 || ci_off + ci_cnt > Cin_total || (mode != 0 && mode != 1 && mode != 2))
         return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: bad args or configuration without a f16x2 kernel");
-    if (cfg == 1 && mode != 0) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: configuration 1 (stride 2) has a forward image only");
-    const int eCin = mode == 0 ? ci_cnt : Cout, eCout = mode == 0 ? Cout : ci_cnt;
+    if (cfg == 1 && mode == 1) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: configuration 1 (stride 2) has no data-gradient image");
+    if (mode == 2 && bf16_stride(cfg) != 2) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: mode 2 (transposed convolution's data gradient) is a stride-2 image");
+    const int eCin = mode == 1 ? Cout : ci_cnt, eCout = mode == 1 ? ci_cnt : Cout;
     const int NCH = cdiv(eCin, 8);
     const size_t total = (size_t)cdiv(eCout, 32 * NT) * NCH * 27 * NT * 64 * 8;
     unsigned nb = (unsigned)((total + 255) / 256); if (nb > 4096) nb = 4096;

@@ -499,8 +499,21 @@ class UNetTrainer:
             self._ready([tu])
             # (1,2,2): the window embedded in a (1,3,3) one, stride (1,2,2)
             cfg = _lib.check(lib.wmh_conv3d_config(cskip, Cin, kt * D, 2 * H, 2 * W, 3 if kt == 2 else 1, kt, 2), 'config')
-            wf = self._pack_tu_dgrad(u, self.p[tu], cfg, Cin, cskip)
-            g_in, _, _ = self._run_conv('b.tu%d.dx' % u, cfg, d_up, None, None, None, wf, None, Cin, 2, False, kt)
+            cfg_x3 = lib.wmh_conv3d_k3_bf16_config(cfg, Cin, 2 * W) if (self.x3 and kt == 2 and os.environ.get('WMH_TRAIN_TU_DGRAD') != 'fp32') else -1
+            if cfg_x3 in (1, 3, 5) and bool(lib.wmh_conv3d_k3_f16x2_supported(cfg_x3)):     # the strided pair kernels on the embedded image
+                key = ('tu.dgrad.x3', u, cfg_x3)
+                hit = self._packed.get(key)
+                if hit is None or hit[0] != self._version:
+                    wfx = hit[1] if hit is not None else torch.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg_x3, cskip, Cin), dtype=torch.int16,
+                                                                     device=self.device)
+                    _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg_x3, _lib.ptr(self.p[tu]), cskip, Cin, 0, cskip, 2, _lib.ptr(wfx), st),
+                               'wmh_conv3d_k3_pack_weights_f16x2_device')
+                    self._packed[key] = (self._version, wfx)
+                wfx = self._packed[key][1]
+                g_in, _, _ = self._run_conv_x3('b.tu%d.dx' % u, cfg_x3, d_up, None, None, None, wfx, None, Cin, False, 2)
+            else:
+                wf = self._pack_tu_dgrad(u, self.p[tu], cfg, Cin, cskip)
+                g_in, _, _ = self._run_conv('b.tu%d.dx' % u, cfg, d_up, None, None, None, wf, None, Cin, 2, False, kt)
             g_next = g_in
         # encoder: bottleneck back to the first layer; stage outputs also receive the decoder's skip gradient
         nenc = len(self.enc)

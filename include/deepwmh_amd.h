@@ -118,7 +118,8 @@ int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, c
 int wmh_conv3d_k3_f16x2_supported(int cfg);
 size_t wmh_conv3d_k3_packed_halfs_f16x2(int cfg, int Cin, int Cout);
 int wmh_conv3d_k3_pack_weights_f16x2(int cfg, const float* w, int Cin, int Cout, uint16_t* wf);
-/* the same image from weights in HBM (training); modes as wmh_conv3d_k3_pack_weights_bf16_device */
+/* the same image from weights in HBM (training); modes as wmh_conv3d_k3_pack_weights_bf16_device, and mode 2 (stride-2 configurations
+ * 1 / 3 / 5): w is a ConvTranspose3d(k2, s2) weight [Cout][ci_cnt][2][2][2] whose data gradient is a stride-2 convolution of dY */
 int wmh_conv3d_k3_pack_weights_f16x2_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
                                              uint16_t* wf, void* stream);
 /* Configurations 3 / 4 / 5 (rows of 16 / 8 voxels, stride 2 / 1 / 2; D, H, W = the INPUT extent) run the one-role kernel and

@@ -89,6 +89,41 @@ def test_conv_f16x2_against_float64(lib, case):
     assert float((ss.cpu().double() - ss_ref).abs().max()) <= 2e-4 * (1 + float(ss_ref.abs().max()))
 
 
+@pytest.mark.parametrize('shape', [(2, 32, 64, 8, 8, 32), (1, 24, 40, 5, 6, 16), (2, 64, 128, 4, 8, 8)], ids=str)
+def test_convtranspose_data_gradient_on_the_strided_pair_kernels(lib, shape):
+    """dX of ConvTranspose3d(k=2, s=2) = a stride-2 3x3x3 convolution of dY with the 2-window embedded at taps 1..2 of the
+    3-window (image mode 2 of wmh_conv3d_k3_pack_weights_f16x2_device), on the strided pair kernels; against float64 autograd."""
+    from deepwmh_amd import _lib
+    P = _lib.ptr
+    N, Cs, Ci, D, H, W = shape        # the transposed convolution maps Ci -> Cs channels, (D,H,W) -> twice that
+    g = torch.Generator().manual_seed(Cs + W)
+    w = torch.randn(Ci, Cs, 2, 2, 2, generator=g) / np.sqrt(8 * Ci)
+    dy = torch.randn(N, Cs, 2 * D, 2 * H, 2 * W, generator=g)
+    x = torch.zeros(N, Ci, D, H, W, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv_transpose3d(x, w.double(), None, stride=2).backward(dy.double())
+    ref = x.grad
+    cfg0 = _lib.check(lib.wmh_conv3d_k3_config(Cs, Ci, 2 * D, 2 * H, 2 * W, 2), 'config')
+    cfg = lib.wmh_conv3d_k3_bf16_config(cfg0, Ci, 2 * W)
+    assert cfg in (1, 3, 5) and lib.wmh_conv3d_k3_f16x2_supported(cfg)
+    wd = w.cuda()
+    wf = torch.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cs, Ci), dtype=torch.int16, device='cuda')
+    _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(wd), Cs, Ci, 0, Cs, 2, P(wf), None), 'pack')
+    dx = torch.full((N, Ci, D, H, W), float('nan'), device='cuda')
+    nws = lib.wmh_conv3d_k3_f16x2_workspace_floats(cfg, Cs, N, 2 * D, 2 * H, 2 * W, Ci)
+    ws = torch.empty(nws, device='cuda') if nws else None
+    dyd = dy.cuda()
+    _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(dyd), None, Cs, None, None, 0, P(wf), None, P(dx), None, P(ws), N, 2 * D, 2 * H, 2 * W, Ci,
+                                            0.01, None), 'wmh_conv3d_k3_fwd_f16x2')
+    torch.cuda.synchronize()
+    got = dx.cpu().double()
+    assert bool(torch.isfinite(got).all())
+    rel = float((got - ref).norm() / ref.norm())
+    assert rel <= 2e-6, rel
+    # mode 1 (the flipped, transposed image of a stride-1 layer) has no meaning for the interleaved image of configuration 1
+    if cfg == 1:
+        assert lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(wd), Cs, Ci, 0, Cs, 1, P(wf), None) != 0
+
+
 def test_engine_f16x2_meets_the_fp32_gate(tiny_net, tiny_io):
     """Tiny net, tiled + mirrored prediction: the same bounds tests/test_gpu_network.py puts on the fp32 path."""
     from deepwmh_amd.network import UNetEngine
