@@ -11,11 +11,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, 'deepwmh_amd', 'csrc')
 so = '/tmp/libcl_diag.so'
-subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-result', '-DWMH_CL_DIAG',
-                       '-shared', os.path.join(csrc, 'cl_conv3.hip'), os.path.join(csrc, 'wmh_kernels.hip'), '-o', so])
+ABL = int(os.environ.get('WMH_CL_ABL', '0'))                 # timing-only ablations: 1 no DMA, 4 no transform, 8 no MFMAs, 16 no epilogue, 64 no operand reloads
+ROLE = int(os.environ.get('WMH_CL_DIAG_ROLE', '0'))          # 1: stamps in the staging waves only, 2: in the consumer waves only, 0: both builds
+def build(role):
+    so = '/tmp/libcl_diag%d.so' % role
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-result', '-DWMH_CL_DIAG=%d' % role,
+                           '-DWMH_CL_ABL_MASK=%d' % (ABL << 1), '-shared', os.path.join(csrc, 'cl_conv3.hip'), os.path.join(csrc, 'wmh_kernels.hip'), '-o', so])
+    return so
 from deepwmh_amd import _lib
 plib = _lib.load()
-lib = C.CDLL(so)
 S, C0, C1, Cout = [int(v) for v in sys.argv[1:5]] if len(sys.argv) >= 5 else (128, 32, 0, 32)
 N, Cin = 8, C0 + C1
 x0 = torch.randn(N, S, S, S, C0, device='cuda').to(torch.bfloat16)
@@ -29,29 +33,41 @@ wfd = torch.from_numpy(wf.view(np.int16)).cuda()
 y = torch.empty(N, S, S, S, Cout, dtype=torch.bfloat16, device='cuda')
 npart = plib.wmh_cl_conv3_num_partials(S, S, S)
 part = torch.empty(N, Cout, npart, 4, device='cuda')
-stamps = torch.zeros(256 * 16, dtype=torch.int64, device='cuda')
-lib.wmh_cl_diag_stamps.argtypes = [C.c_void_p]
-lib.wmh_cl_conv3_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-import subprocess as _sp
-for rep in range(3):
-    stamps.zero_()
-    lib.wmh_cl_diag_stamps(P(stamps))
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    rc = lib.wmh_cl_conv3_fwd(P(x0), P(ss0), C0, P(x1), P(ss1), C1, P(wfd), None, P(y), P(part), N, S, S, S, Cout, 0.01, None)
-    e1.record()
-    torch.cuda.synchronize()
-    assert rc == 0
-st = stamps.cpu().numpy().reshape(256, 16).astype(np.float64)
+st = np.zeros((256, 16))
+for role in ((1, 2) if ROLE == 0 else (ROLE,)):
+    lib = C.CDLL(build(role))
+    stamps = torch.zeros(256 * 32, dtype=torch.int64, device='cuda')
+    lib.wmh_cl_diag_stamps.argtypes = [C.c_void_p]
+    lib.wmh_cl_conv3_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    for rep in range(3):
+        stamps.zero_()
+        lib.wmh_cl_diag_stamps(P(stamps))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = lib.wmh_cl_conv3_fwd(P(x0), P(ss0), C0, P(x1), P(ss1), C1, P(wfd), None, P(y), P(part), N, S, S, S, Cout, 0.01, None)
+        e1.record()
+        torch.cuda.synchronize()
+        assert rc == 0
+    allst = stamps.cpu().numpy().astype(np.float64)
+    got = allst[:256 * 16].reshape(256, 16)
+    if role == 2: perwave = allst[256 * 16:].reshape(256, 4, 4)
+    cols = list(range(0, 8)) + [13, 14, 15] if role == 1 else list(range(8, 13)) + ([6] if ROLE == 2 else [])
+    if role == 2: print('  shader clock over the run (s_memtime / s_memrealtime at 100 MHz): %.0f MHz' % float((got[:, 13] / np.maximum(got[:, 14], 1)).mean() * 100))
+    st[:, cols] = got[:, cols]
+    print('build %d (stamps in the %s waves): %.3f ms' % (role, 'staging' if role == 1 else 'consumer', e0.elapsed_time(e1)))
 it = st[:, 6]
 ok = it > 0
 per = lambda col: float((st[ok, col] / it[ok]).mean())
-print('%dx%d^3, %d+%d -> %d channels, WMH_CL_ABL=%s: %.3f ms (diagnostic build), %d iterations per workgroup'
-      % (N, S, C0, C1, Cout, os.environ.get('WMH_CL_ABL', '0'), e0.elapsed_time(e1), int(it[ok].mean())))
-print('  loader  : issue W+DMA %8.0f | wait DMA(it+1) %8.0f | transform %8.0f | barrier1 %8.0f | weights->LDS %8.0f | barrier2 %8.0f | sum %8.0f'
-      % (per(0), per(1), per(2), per(3), per(4), per(5), sum(per(c) for c in range(6))))
-print('  consumer: MFMA phase  %8.0f | barrier1 %8.0f | barrier2 %8.0f | epilogue/iter %8.0f | tile prologue/iter %8.0f | sum %8.0f'
-      % (per(8), per(9), per(10), per(11), per(12), sum(per(c) for c in range(8, 13))))
+print('%dx%d^3, %d+%d -> %d channels, WMH_CL_ABL=%d: %d iterations per workgroup' % (N, S, C0, C1, Cout, ABL, int(it[ok].mean())))
+print('  staging : table + poll + DMA-first issue %8.0f | wait DMA(it+1) %8.0f | transform + flag %8.0f | wait for the buffer (transform-first) %8.0f | late DMA %8.0f | share of transform-first iterations %.2f | sum %8.0f'
+      % (per(0), per(1), per(2), per(3), per(4), per(5), sum(per(c) for c in range(5))))
+print('  consumer: MFMA phase (with slice polls) %8.0f | chunk-start poll %8.0f (of it for the activations %8.0f) | epilogue/iter %8.0f | tile prologue/iter %8.0f | sum %8.0f'
+      % (per(8), per(9), per(10), per(11), per(12), sum(per(c) for c in (8, 9, 11, 12))))
+print('  weights : wait for slice 0 / 1 / 2 to be released %8.0f %8.0f %8.0f | load wait + 3 x 9 KB into LDS + flags %8.0f' % (per(7), per(13), per(14), per(15)))
+if ROLE in (0, 2):
+    for w in range(4):
+        v = perwave[ok, w, :] / it[ok, None]
+        print('  consumer wave %d: MFMA phase %8.0f | chunk-start poll %8.0f (activations %8.0f) | epilogue + rest %8.0f' % (w, v[:, 0].mean(), v[:, 1].mean(), v[:, 2].mean(), v[:, 3].mean()))
