@@ -280,6 +280,62 @@ def add_sustained(roofline, clock):
                                             '(median); frac itself is priced against the nominal peak' % (clock['sclk_mhz_median'], NOMINAL_SCLK_MHZ))
 
 
+def in_kernel_clock_f16x2(device, batch):
+    """One stamped launch of the dominant kernel on the dominant layer (32 -> 32 channels at 128^3, `batch` patches), outside the timed
+    region: the kernel's own s_memtime stamps (shader-clock cycles of a consumer wave's MFMA phases, barrier waits and epilogues, which
+    add up to the workgroup's life time) over the launch's duration give the clock the CUs actually ran at -- the hwmon figure in `clock`
+    is the power management's target, below which the clock is stretched while the matrix pipes are busy -- and the share of those
+    cycles in which an MFMA could issue at all."""
+    import ctypes as C
+    import torch
+    from deepwmh_amd import _lib
+    lib, P = _lib.load(), _lib.ptr
+    N, S, Cin, Cout = int(batch), 128, 32, 32
+    cfg = lib.wmh_conv3d_k3_bf16_config(lib.wmh_conv3d_k3_config(Cin, Cout, S, S, S, 1), Cout, S)
+    if not lib.wmh_conv3d_k3_f16x2_supported(cfg):
+        return None
+    g = torch.Generator(device=device).manual_seed(1)
+    x = torch.randn(N, Cin, S, S, S, device=device, generator=g)
+    ss = torch.stack([1 + 0.3 * torch.randn(N, Cin, device=device, generator=g), 0.2 * torch.randn(N, Cin, device=device, generator=g)], -1).contiguous()
+    w = (torch.randn(Cout, Cin, 27, device=device, generator=g) / (27 * Cin) ** 0.5).contiguous()
+    wf = torch.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cin, Cout), dtype=torch.int16, device=device)
+    _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(w), Cin, Cout, 0, Cin, 0, P(wf), None), 'pack')
+    y = torch.empty(N, Cout, S, S, S, device=device)
+    part = torch.empty(N, Cout, lib.wmh_conv3d_k3_num_partials_f16x2(cfg, N, S, S, S), 4, device=device)
+
+    def launch():
+        _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(x), P(ss), Cin, None, None, 0, P(wf), None, P(y), P(part), None, N, S, S, S, Cout, 0.01, None), 'f16x2')
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    stamps = torch.zeros(4096 * 8, dtype=torch.int64, device=device)
+    lib.wmh_debug_set_conv_stamps(C.c_void_p(stamps.data_ptr()))
+    try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); launch(); e1.record()
+        torch.cuda.synchronize()
+    finally:
+        lib.wmh_debug_set_conv_stamps(None)
+    ms = e0.elapsed_time(e1)
+    st = stamps.view(-1, 8).cpu().numpy().astype('float64')
+    st = st[st[:, 3] > 0]
+    if ms <= 0 or len(st) == 0:
+        return None
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    cycles = float((st[:, 0] + st[:, 1] + st[:, 2]).mean())
+    mhz = cycles / ms / 1e3
+    flop = 2.0 * 27 * Cin * Cout * N * S ** 3
+    issue = 4.0 * flop / 32768.0 / (4 * ncu) * 32.0             # four partial products; 32 cycles per v_mfma_f32_32x32x16_f16, per SIMD
+    tflops = flop / ms / 1e9
+    return dict(layer='32 -> 32 channels, %d x 128^3 (one stamped launch after the timed region)' % N, launch_ms=round(ms, 3), achieved=round(tflops, 1),
+                sclk_mhz=round(mhz), cycles_per_workgroup=round(cycles), mfma_issue_cycles=round(issue), mfma_issue_share=round(issue / cycles, 3),
+                phases=dict(mfma=round(float(st[:, 0].mean() / cycles), 3), barrier_wait=round(float(st[:, 1].mean() / cycles), 3),
+                            epilogue=round(float(st[:, 2].mean() / cycles), 3)),
+                frac_at_in_kernel_clock=round(tflops / (PEAK_TFLOPS['f16x2'] * mhz / NOMINAL_SCLK_MHZ), 3),
+                note='s_memtime counts shader-clock cycles: the consumer wave\'s phases over the launch duration = the clock the CUs ran at; '
+                     'mfma_issue_share = cycles in which the matrix pipe can be issuing (4 x 27 x channels/16 MFMAs of 32 cycles per voxel tile) / all cycles')
+
+
 # ------------------------------------------------------------------------------------------------------------
 # roofline block of the dominant kernel, per precision mode
 # ------------------------------------------------------------------------------------------------------------
@@ -581,6 +637,13 @@ def run_rank(args):
 
     roofline = roofline_block(eng.timings, args.precision, args.storage, dt)
     add_sustained(roofline, clock)
+    if rank == 0 and args.precision == 'f16x2' and roofline is not None:
+        try:
+            ik = in_kernel_clock_f16x2(device, patches_per_forward(args.storage))
+            if ik:
+                roofline['in_kernel'] = ik
+        except Exception as e:                          # diagnostics only
+            roofline['in_kernel'] = dict(error=str(e))
 
     if rank == 0:
         forwards = 8 * (8 if tta else 1)

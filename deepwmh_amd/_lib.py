@@ -79,6 +79,7 @@ SIGNATURES = {
     'wmh_conv3d_k3_wgrad_f16x2_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_wgrad_f16x2': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_wgrad_f16x2_stamp_count': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'wmh_debug_set_conv_stamps': (None, [_vp]),
     'wmh_conv3d_k3_wgrad_f16x2_stamped': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     'wmh_convtranspose3d_packed_dwords_f16x2': (_sz, [_i, _i, _i]),
     'wmh_convtranspose3d_pack_weights_f16x2_device': (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -1,11 +1,16 @@
 // cl_common.h -- shared pieces of the channels-last bf16 kernels (BASELINE.json configs[2], "bf16 forward").
 //
-// Tensor format "CL16": [n][z][y][x][c] with c fastest, bf16 bit patterns (round to nearest even), raw convolution
+// Tensor format "CL16": [n][c / 8][z][y][x][c % 8], bf16 bit patterns (round to nearest even), raw convolution
 // outputs; the InstanceNorm + LeakyReLU of the producing layer is still pending as a per-(n, c) {scale, shift} pair and
 // is applied by every consumer while it stages its operand (the normalised tensor is never written).
-// Why channels-last in this mode: a voxel's 8 consecutive channels are ONE 16-byte piece = one lane's B operand of
+// Why 8 channels innermost: a voxel's 8 consecutive channels are ONE 16-byte piece = one lane's B operand of
 // v_mfma_f32_32x32x16_bf16, so global -> LDS staging needs no transposition (LDS-DMA, no registers), and the epilogue
 // writes 16 bytes per lane (an NCDHW bf16 tensor can only be written 2 bytes per lane: the store path, not HBM, bounds it).
+// Why the 8-channel blocks are planes (round 3; rounds 1-2 kept all C channels of a voxel together, [n][z][y][x][c]): consecutive
+// lanes of a wave work on consecutive voxels, so a wave-instruction of the LDS-DMA or of the epilogue's stores then covers one
+// contiguous run of 16-byte pieces (a halo row of 34 voxels = 544 bytes, 5 cache lines) instead of one piece out of every voxel's
+// 2C bytes (64 cache lines per instruction at C >= 64): the texture addresser takes a cache line per cycle, and at 42 DMA
+// instructions per 16-channel chunk that was 2.7 k of the chunk's ~6 k cycles on the staging waves.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -80,9 +85,11 @@ __device__ __forceinline__ cl_u32x4 cl_transform8_plain(const cl_u32x4 u, const 
 // Channels of accumulator register r of v_mfma_f32_32x32x16_bf16's D tile: row (r&3) + 8*(r>>2) + 4*(lane>>5).
 // One M-tile (32 voxels on the lanes, 32 output channels in the 16 registers of both lane halves) -> CL16 rows:
 // registers pairwise to bf16, the two lane halves exchange 8-byte groups (v_permlane32_swap) so that every lane holds
-// 16 contiguous bytes, two 16-byte stores per lane.  yv: address of channel `cob` of this lane's voxel.
+// 16 contiguous bytes, two 16-byte stores per lane.  yv: address of this lane's voxel in the plane of channels cob .. cob+7
+// (cl_index), plane: halfs from one 8-channel plane to the next (8 x voxels of the sample).
+__device__ __forceinline__ size_t cl_index(size_t n, int C, size_t S, int c8, size_t v) { return ((n * (size_t)(C >> 3) + (size_t)c8) * S + v) * 8; }
 template <bool NTS = false>     // NTS: streaming stores (conv3d_common.h): the first layer only
-__device__ __forceinline__ void cl_store_mtile(const f32x16& acc, unsigned short* yv, int kh) {
+__device__ __forceinline__ void cl_store_mtile(const f32x16& acc, unsigned short* yv, int kh, size_t plane) {
     unsigned d[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) d[i] = cl_pack2(acc[2 * i], acc[2 * i + 1]);
@@ -93,8 +100,8 @@ __device__ __forceinline__ void cl_store_mtile(const f32x16& acc, unsigned short
         const auto r1 = __builtin_amdgcn_permlane32_swap(d[4 * gp + 1], d[4 * gp + 3], false, false);
         // lower half: channels 16gp .. 16gp+7, upper half: 16gp+8 .. 16gp+15
         const cl_u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
-        if constexpr (NTS) __builtin_nontemporal_store(v, reinterpret_cast<cl_u32x4*>(yv + 16 * gp + 8 * kh));
-        else *reinterpret_cast<cl_u32x4*>(yv + 16 * gp + 8 * kh) = v;
+        if constexpr (NTS) __builtin_nontemporal_store(v, reinterpret_cast<cl_u32x4*>(yv + (size_t)(2 * gp + kh) * plane));
+        else *reinterpret_cast<cl_u32x4*>(yv + (size_t)(2 * gp + kh) * plane) = v;
     }
 }
 

@@ -38,13 +38,14 @@ struct ClConvArgs {
 #endif
 };
 #ifdef WMH_CL_DIAG
-// timing-only ablations of the diagnostic build (results are wrong), compile-time (-DWMH_CL_ABL_MASK=m; run-time switches cost the
-// registers the kernel does not have): bit 1 = skip the activation DMA, 3 the transform, 4 the MFMAs, 5 the epilogue, 7 the operand reloads
+// Diagnostic build (tools/cl_diag.py).  -DWMH_CL_DIAG=1: s_memtime stamps in the staging waves, =2: in the consumer waves -- both at
+// once, or run-time ablation switches, cost registers this kernel does not have (244 bytes of scratch, an epilogue 10x slower).
+// Timing-only ablations, compile-time (-DWMH_CL_ABL_MASK=m; results are wrong): bit 1 = skip the activation DMA, 3 the transform,
+// 4 the MFMAs, 5 the epilogue, 7 the operand reloads, 8 the sliced weight hand-over.
 #ifndef WMH_CL_ABL_MASK
 #define WMH_CL_ABL_MASK 0
 #endif
 #define CL_ABL(bit) ((WMH_CL_ABL_MASK >> (bit)) & 1)
-// -DWMH_CL_DIAG=1: stamps in the staging waves, =2: in the consumer waves (both at once do not fit the register budget)
 #define CL_STAMP_(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define CL_STAMP_ADD_(acc, a, b) acc += (unsigned)((b) - (a))
 #if WMH_CL_DIAG == 2
@@ -94,47 +95,11 @@ __device__ __forceinline__ void cl_divmod(int t, int d, unsigned m, int& q, int&
     q = qq;
 }
 
-// Hand-over flags between the roles: monotonic counters in LDS, one lane of a wave adds 1 when the wave has done its part, the other
-// side polls.  LDS operations of a wave complete in order, so an add issued behind the wave's reads (writes) of a buffer lands after them.
-// Every poll is inline asm: a compiler-visible LDS read behind LDS-DMA in flight would get an s_waitcnt vmcnt(0) in front of it.
-__device__ __forceinline__ unsigned cl_flag_read(unsigned addr) {
-    unsigned v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-}
-__device__ __forceinline__ void cl_flag_wait(unsigned addr, int target) {
-    for (unsigned spin = 0; (int)(cl_flag_read(addr) - (unsigned)target) < 0; ++spin) {
-        __builtin_amdgcn_s_sleep(1);
-        if (spin > (1u << 24)) __builtin_trap();             // a lost hand-over aborts the launch instead of hanging the device
-    }
-}
-// (the weight wave's three copies of WR in one go)
-__device__ __forceinline__ void cl_flag_add3(unsigned addr) {
-    unsigned long long saved;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2 offset:4\n\tds_add_u32 %1, %2 offset:12\n\tds_add_u32 %1, %2 offset:20\n\ts_mov_b64 exec, %0"
-                 : "=&s"(saved) : "v"(addr), "v"(1u) : "memory");
-}
-__device__ __forceinline__ void cl_flag_add(unsigned addr) {
-    unsigned long long saved;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr), "v"(1u) : "memory");
-}
-// Counters (byte offsets from the counter base).  A counter must never mix two generations of what it counts, so everything that several
-// waves add to is kept PER BUFFER (per table slot): a wave cannot start the next use of a buffer before every wave of the other role has
-// finished with the current one, while waves of one role may well be a chunk apart.
-//   WDONE[sl]      weight slice sl: every fragment held by the consumer wave (4 adds per chunk)
-//   RW[b]          pairs {READY[b], WR}: buffer b normalised by the staging wave (7 adds per use); weight slices written (3 per chunk; the
-//                  single writer keeps a copy beside every READY so that a consumer reads both with one ds_read_b64)
-//   DONE[b]        buffer b: last operand read issued by the consumer wave (4 adds per use)
-//   TAB[slot]      scale/shift table slot written by the staging wave (7 adds per use)
-enum { CL_F_WDONE = 0, CL_F_RW = 16, CL_F_DONE = 40, CL_F_TAB = 52, CL_F_BYTES = 80 };
-constexpr int CL_TABLE_SLOTS = 4;
-
 template <class G>
 __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, const int T /*tiles*/) {
     constexpr int IY = G::IY, IX = G::IX, NV = G::NV, NSLOT = G::NSLOT, NVP = G::NVP, BUF = G::BUF, WQ = G::WQ, WIT = G::WIT, MT = G::MT, LTH = G::LTH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* wlds = lds + 3 * BUF;
-    const unsigned cbase = (unsigned)(G::LDS + CL_TABLE_SLOTS * (a.C0 + a.C1) * 8);     // hand-over counters (LDS byte address)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,61 +125,66 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
 
     if (wave == 11) {
         // ================================ weight wave ======================================================
-        // One wave moves the weight fragments: the next 27 KB ride in its registers (27 x 16 bytes per lane: chunk it+1's slices
-        // not yet written out, chunk it+2's behind them) and drop into the single LDS weight buffer slice by slice.  It issues ordinary
+        // One wave moves the weight fragments: chunk it+1's 27 KB ride in its registers (27 x 16 bytes per lane) while chunk it
+        // is consumed, and drop into the single LDS weight buffer between the two barriers of the chunk.  It issues ordinary
         // loads ONLY and the staging waves LDS-DMA ONLY: s_waitcnt vmcnt(N) counts the two kinds together but they do not
         // complete in one order, so a counted wait over a mix does not say which operations are still out (as one stream,
         // "all but the N youngest" let a chunk's DMA pass as landed while it was not -- rare garbage tiles at full size).
-        // The buffer is handed over in three kd-slices: the consumers count themselves out of a slice on an LDS counter as
-        // soon as their last fragment of the slice has arrived (half way through the slice's MFMAs), this wave refills it
-        // under the remaining MFMAs and counts the slice in (WR), which the consumers check before the slice's first read.
+        // The buffer is handed over in three kd-slices: the consumers count themselves out of slices 0 and 1 on an LDS counter as
+        // soon as their last fragment of the slice has arrived (half way through the slice's MFMAs), and this wave refills
+        // those two under the remaining MFMAs; only the last 9 KB are written between the barriers, where everybody waits.
+#ifndef CL_WPRIO
+#define CL_WPRIO 0
+#endif
+#ifndef CL_REL_IY
+#define CL_REL_IY 2
+#endif
+        if (CL_WPRIO) __builtin_amdgcn_s_setprio(CL_WPRIO);
         cl_u32x4 wst[WIT];
         int kw_ = 0, cw = 0, g_w = 0;
-        if (lane < CL_F_BYTES / 4) reinterpret_cast<unsigned*>(lds + G::LDS + CL_TABLE_SLOTS * (a.C0 + a.C1) * 8)[lane] = 0u;
+        const unsigned cnt_addr = (unsigned)(G::LDS + 2 * (a.C0 + a.C1) * 8);
+        if (lane < 4) reinterpret_cast<unsigned*>(lds + G::LDS + 2 * (a.C0 + a.C1) * 8)[lane] = 0u;
+        auto wait_slice = [&](int sl, unsigned target) __attribute__((always_inline)) {
+            for (;;) {
+                unsigned v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cnt_addr + 4u * sl) : "memory");
+                if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
         auto write_slice = [&](int sl) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) reinterpret_cast<cl_u32x4*>(wlds)[(sl * 9 + i) * 64 + lane] = wst[sl * 9 + i];
         };
         auto locate_w = [&]() __attribute__((always_inline)) { int tx, ty, tz, n0; tile_of(kw_, g_w, tx, ty, tz, n0); };
-        auto issue_slice = [&](int sl) __attribute__((always_inline)) {
+        auto issue_w = [&]() __attribute__((always_inline)) {
             const cl_u32x4* wsrc = reinterpret_cast<const cl_u32x4*>(a.wf) + ((size_t)g_w * nch + cw) * WQ + lane;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) wst[sl * 9 + i] = wsrc[(sl * 9 + i) * 64];
+            for (int i = 0; i < WIT; ++i) wst[i] = wsrc[i * 64];
         };
-        // the cursor moves one chunk ahead (it stays on the last chunk, whose weights are then fetched again for nobody)
-        auto advance_w = [&]() __attribute__((always_inline)) { if (kw_ * nch + cw + 1 < total && ++cw == nch) { cw = 0; ++kw_; locate_w(); } };
-        __builtin_amdgcn_s_setprio(3);                       // a few instructions per slice, and the consumers wait for them
-        locate_w();
-        CL_BARRIER();                                        // (the staging waves' table barrier; the counters are zero)
-        issue_slice(0); issue_slice(1); issue_slice(2);
-        write_slice(0); write_slice(1); write_slice(2);
-        CL_BARRIER();
-        advance_w();
-        issue_slice(0); issue_slice(1); issue_slice(2);      // chunk 1
-#ifdef WMH_CL_DIAG
-        unsigned w_wait[3] = {0, 0, 0}, w_write = 0;
-#endif
-        for (int it = 0; it < total; ++it) {
-            advance_w();                                     // chunk it+2: a slice's registers are refilled as soon as they have been written out
+        auto write_w = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int sl = 0; sl < 3; ++sl) {
-                CL_STAMP(q0);
-                cl_flag_wait(cbase + CL_F_WDONE + 4 * sl, 4 * (it + 1));     // the four consumers hold every fragment of slice sl of chunk `it`
-                CL_STAMP(q1);
-                write_slice(sl);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                cl_flag_add3(cbase + CL_F_RW);
-                issue_slice(sl);
-                CL_STAMP(q2);
-                CL_STAMP_ADD(w_wait[sl], q0, q1); CL_STAMP_ADD(w_write, q1, q2);
+            for (int i = 0; i < WIT; ++i) reinterpret_cast<cl_u32x4*>(wlds)[i * 64 + lane] = wst[i];
+        };
+        locate_w();
+        CL_BARRIER();                                        // (the staging waves' table barrier)
+        issue_w();
+        write_w();
+        CL_BARRIER();
+        for (int it = 0; it < total; ++it) {
+            if (kw_ * nch + cw + 1 < total && ++cw == nch) { cw = 0; ++kw_; locate_w(); }
+            issue_w();                                       // chunk it+1 (the last iteration repeats the last chunk)
+            if (!CL_ABL(8)) {
+                wait_slice(0, 4u * (unsigned)(it + 1)); write_slice(0);
+                wait_slice(1, 4u * (unsigned)(it + 1)); write_slice(1);
+                CL_BARRIER();                                // consumers are done with chunk `it`: the last slice may go
+                write_slice(2);
+            } else {
+                CL_BARRIER();
+                write_w();
             }
+            CL_BARRIER();
         }
-#if defined(WMH_CL_DIAG) && WMH_CL_DIAG == 1
-        if (a.stamps && lane == 0) {
-            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 16;
-            o[7] = w_wait[0]; o[13] = w_wait[1]; o[14] = w_wait[2]; o[15] = w_write;
-        }
-#endif
     } else if (loader) {
         // ================================ staging waves ====================================================
         if (!CL_ABL(6)) __builtin_amdgcn_s_setprio(2);       // ahead of the MFMA-issuing consumer on the same SIMD
@@ -235,7 +205,7 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         // Three streams run over this workgroup's chunk sequence (tile-major, chunk-minor), each with its own (tile, chunk)
         // counter -- no division in the loop: DMA (chunk it+2), transform and weights (chunk it+1).
         int gv[NSLOT];                                       // DMA: voxel index inside the sample, clamped when outside the volume
-        int n_dma = -1, n_tr = -1;
+        int n_dma = 0, n_tr = 0;
         unsigned keep_tr = 0;                                // transform: bit k = slot k's voxel is inside the volume
         int kd = 0, cd = 0, kt = 0, ct = 0;                  // (tile, chunk) of the DMA stream and of the transform / weight stream
         auto inside = [&](int k, int z0, int y0, int x0) __attribute__((always_inline)) {
@@ -246,11 +216,8 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         // Scale / shift of the pending InstanceNorm: kept in LDS for the sample being staged, one float4 {scale c, scale c+1,
         // shift c, shift c+1} per channel pair (the operand pairs of the packed FMAs), so that a chunk's 16 channels are 8
         // LDS reads into vector registers -- as scalar loads they cost 32 SGPRs, and the spills that followed put ~70
-        // v_readlane into every chunk iteration.  Four table slots, indexed by the count of sample changes along this workgroup's
-        // tiles ("runs"): the DMA stream, one chunk ahead of the transform, fills the slot of the run it enters and counts the wave
-        // in on TAB[slot]; the transform stream waits for the seven waves' counts when it enters the run.  (A slot is rewritten four
-        // runs later; the staging waves are never more than two chunks apart -- a DMA waits for the consumers, who wait for every
-        // staging wave's transform -- so nobody still reads it.)
+        // v_readlane into every chunk iteration.  Two tables (sample parity): the DMA stream, one chunk ahead of the transform
+        // and separated from it by the chunk's barriers, fills the table slot of the tile it enters when the sample changed.
         const int Ctot = a.C0 + a.C1;
         float4* tab = reinterpret_cast<float4*>(lds + 3 * BUF + WQ * 16 + G::SCR);
         auto write_table = [&](int n, int slot) __attribute__((always_inline)) {
@@ -264,36 +231,22 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
                 t[i] = v;
             }
         };
-        int run_d = 0, run_t = 0;                            // sample runs the two streams have entered
+        int n_tab0 = -1, n_tab1 = -1;                        // samples the two table slots hold (slot = tile counter parity)
         auto setup_dma = [&]() __attribute__((always_inline)) {
-            int g, tx, ty, tz, n_new;
-            tile_of(kd, g, tx, ty, tz, n_new);
-            if (n_new != n_dma) {                             // uniform; a handful of times per launch
-                const bool first = n_dma < 0;
-                if (!first) ++run_d;
-                n_dma = n_new;
-                write_table(n_dma, run_d & (CL_TABLE_SLOTS - 1));
-                if (!first) {                                 // (the first table is complete at the prologue's barrier)
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    cl_flag_add(cbase + CL_F_TAB + 4 * (run_d & (CL_TABLE_SLOTS - 1)));
-                }
-            }
+            int g, tx, ty, tz;
+            tile_of(kd, g, tx, ty, tz, n_dma);
+            // uniform; a handful of times per launch.  Slot = parity of the tile counter: the transform stream is at most one
+            // tile behind, so the slot of tile kd is not read any more by anyone when tile kd is entered here
+            if (kd & 1) { if (n_dma != n_tab1) { n_tab1 = n_dma; write_table(n_dma, 1); } }
+            else        { if (n_dma != n_tab0) { n_tab0 = n_dma; write_table(n_dma, 0); } }
             const int z0 = tz * G::TZ - 1, y0 = ty * G::TY - 1, x0 = tx * G::TX - 1;
             const int vb = (z0 * a.H + y0) * a.W + x0;
 #pragma unroll
             for (int k = 0; k < NSLOT; ++k) gv[k] = vb + (inside(k, z0, y0, x0) ? rel[k] : rel_center);
         };
         auto setup_tr = [&]() __attribute__((always_inline)) {
-            int g, tx, ty, tz, n_new;
-            tile_of(kt, g, tx, ty, tz, n_new);
-            if (n_new != n_tr) {
-                if (n_tr >= 0) {                                  // uses of the slot so far (run 0, slot 0, is the prologue's and not counted)
-                    ++run_t;
-                    const int slot = run_t & (CL_TABLE_SLOTS - 1);
-                    cl_flag_wait(cbase + CL_F_TAB + 4 * slot, 7 * (run_t / CL_TABLE_SLOTS + (slot != 0)));
-                }
-                n_tr = n_new;
-            }
+            int g, tx, ty, tz;
+            tile_of(kt, g, tx, ty, tz, n_tr);
             const int z0 = tz * G::TZ - 1, y0 = ty * G::TY - 1, x0 = tx * G::TX - 1;
             keep_tr = 0;
 #pragma unroll
@@ -308,16 +261,17 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         auto dma = [&](int b) __attribute__((always_inline)) {
             const uint16_t* xs; const float* ss; int Cs, c0;
             src_of(cd, xs, ss, Cs, c0);
-            const unsigned rowb = 2u * (unsigned)Cs;
-            const char* base = reinterpret_cast<const char*>(xs) + ((size_t)n_dma * DHW * Cs + c0) * 2;
+            // planes (c0 / 8) and (c0 / 8 + 1) of sample n_dma: a lane's piece is 16 bytes at 16 x its voxel index
+            const char* base = reinterpret_cast<const char*>(xs) + cl_index((size_t)n_dma, Cs, DHW, c0 >> 3, 0) * 2;
+            const size_t plane = DHW * 16;
             unsigned char* dst = lds + b * BUF + lw * (64 * 16);
 #pragma unroll
             for (int k = 0; k < NSLOT; ++k)
                 if (k < NSLOT - 1 || last_slot) {             // uniform
-                    const unsigned off = (unsigned)gv[k] * rowb;
+                    const unsigned off = (unsigned)gv[k] * 16u;
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
-                        __builtin_amdgcn_global_load_lds(CL_GLOBAL_PTR(base + off + 16 * h), CL_LDS_PTR(dst + (h * NVP + k * LTH) * 16), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(CL_GLOBAL_PTR(base + h * plane + off), CL_LDS_PTR(dst + (h * NVP + k * LTH) * 16), 16, 0, 0);
                 }
         };
         // scale / shift of chunk ct of the transform stream's tile (scalar loads, issued early: they share a counter with the
@@ -334,7 +288,7 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
             src_of(ct, xs, ss, Cs, c0);
             pending_tr = ss != nullptr;
             slope_tr = pending_tr ? a.slope : 1.f;
-            const unsigned taddr = (unsigned)(3 * BUF + WQ * 16 + G::SCR) + (unsigned)(((run_t & (CL_TABLE_SLOTS - 1)) * (Ctot / 2) + ct * 8) * 16);
+            const unsigned taddr = (unsigned)(3 * BUF + WQ * 16 + G::SCR) + (unsigned)(((kt & 1) * (Ctot / 2) + ct * 8) * 16);
 #define CL_TQ(i) asm volatile("ds_read_b128 %0, %1 offset:" #i "*16" : "=v"(tq[i]) : "v"(taddr) : "memory")
             CL_TQ(0); CL_TQ(1); CL_TQ(2); CL_TQ(3); CL_TQ(4); CL_TQ(5); CL_TQ(6); CL_TQ(7);
 #undef CL_TQ
@@ -398,7 +352,7 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS :: "memory");
         transform(0);
         CL_BARRIER();
-        int b_tr = 1, b_dma = 2, r_dma = 0;                  // buffers of chunk it+1 / it+2; chunk it+2 is use r_dma of its buffer
+        int b_tr = 1, b_dma = 2;                             // buffers of chunk it+1 / it+2
 #ifdef WMH_CL_DIAG
         unsigned s_issue = 0, s_wait = 0, s_tr = 0, s_b1 = 0, s_w = 0, s_b2 = 0;
 #endif
@@ -406,46 +360,31 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
             CL_STAMP(t0);
             if (advance(kt, ct)) setup_tr();
             load_ss();
-            // Chunk it+2 lands in the buffer chunk it-1 was consumed from.  If the consumers have let go of it, the DMA goes first and
-            // lands under the transform; if not, the transform (chunk it+1, which the consumers need next) goes first and the DMA
-            // follows when the buffer is free -- the staging side then has time to spare anyway.
-            const int done_target = 4 * r_dma;               // chunk it+2 is use r_dma of its buffer: that many uses must be over
-            const bool dma_first = CL_ABL(1) || (int)(cl_flag_read(cbase + CL_F_DONE + 4 * b_dma) - (unsigned)done_target) >= 0;     // uniform
-            if (dma_first) {
-                if (advance(kd, cd)) setup_dma();
-                if (!CL_ABL(1)) dma(b_dma);
-            }
+            if (advance(kd, cd)) setup_dma();
+            if (!CL_ABL(1)) dma(b_dma);
             CL_STAMP(t1);
-            // chunk it+1's DMA has landed: everything older than this iteration's DMAs (this wave has nothing but LDS-DMA in flight,
-            // which completes in issue order); a lane transforms exactly the pieces it fetched
+            // everything older than this iteration's DMAs has landed, i.e. chunk it+1's DMA (issued one iteration ago; this wave
+            // has nothing but LDS-DMA in flight, which completes in issue order); a lane transforms exactly the pieces it fetched
 #ifdef WMH_CL_DRAIN
             asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS :: "memory");
 #else
-            if (!dma_first || CL_ABL(1)) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS :: "memory");
-            else if (last_slot) asm volatile("s_waitcnt vmcnt(%8)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS : "n"(2 * NSLOT) : "memory");
-            else                asm volatile("s_waitcnt vmcnt(%8)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS : "n"(2 * NSLOT - 2) : "memory");
+            if (last_slot) asm volatile("s_waitcnt vmcnt(%8)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS : "n"(2 * NSLOT) : "memory");
+            else           asm volatile("s_waitcnt vmcnt(%8)\n\ts_waitcnt lgkmcnt(0)" : CL_TQ_OPS : "n"(2 * NSLOT - 2) : "memory");
 #endif
             CL_STAMP(t2);
             if (!CL_ABL(3)) transform(b_tr);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            cl_flag_add(cbase + CL_F_RW + 8 * b_tr);         // this wave's part of chunk it+1 is ready
             CL_STAMP(t3);
-            if (!dma_first) {
-                cl_flag_wait(cbase + CL_F_DONE + 4 * b_dma, done_target);
-                CL_STAMP(t4);
-                if (advance(kd, cd)) setup_dma();
-                dma(b_dma);
-                CL_STAMP(t5);
-                CL_STAMP_ADD(s_b1, t3, t4); CL_STAMP_ADD(s_w, t4, t5);
-#ifdef WMH_CL_DIAG
-                ++s_b2;
-#endif
-            }
-            CL_STAMP_ADD(s_issue, t0, t1); CL_STAMP_ADD(s_wait, t1, t2); CL_STAMP_ADD(s_tr, t2, t3);
+            CL_BARRIER();                                    // consumers are done with chunk `it`: its weights may go
+            CL_STAMP(t4);
+            CL_STAMP(t5);
+            CL_BARRIER();
+            CL_STAMP(t6);
+            CL_STAMP_ADD(s_issue, t0, t1); CL_STAMP_ADD(s_wait, t1, t2); CL_STAMP_ADD(s_tr, t2, t3); CL_STAMP_ADD(s_b1, t3, t4);
+            CL_STAMP_ADD(s_w, t4, t5); CL_STAMP_ADD(s_b2, t5, t6);
             b_tr = b_tr == 2 ? 0 : b_tr + 1;
-            if (b_dma == 2) { b_dma = 0; ++r_dma; } else ++b_dma;
+            b_dma = b_dma == 2 ? 0 : b_dma + 1;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the last iterations' DMAs target buffers nobody reads; they land before the LDS is given back)
 #ifdef WMH_CL_DIAG
         if (a.stamps && tid == 256) {
             unsigned long long* o = a.stamps + (size_t)blockIdx.x * 16;
@@ -464,23 +403,13 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         // the host zero-fills the record buffer, so samples a workgroup never touches read as empty records.
         // (bias and the shift live in a wave-private LDS scratch, [bias | shift][lane half][16 registers]: registers are short)
         float* scr = reinterpret_cast<float*>(lds + 3 * BUF + WQ * 16) + wave * 64;
-        // "this wave has every fragment of weight slice sl" / "... every operand of the activation buffer": LDS operations of a
-        // wave complete in order, so the add lands after the wave's reads
-        auto release_slice = [&](int sl) __attribute__((always_inline)) { cl_flag_add(cbase + CL_F_WDONE + 4 * sl); };
-        // Chunk i of this workgroup's chunk sequence is use r = i / 3 of buffer b = i % 3: it is normalised when READY[b] >= 7 (r + (b != 0))
-        // (chunk 0 is the prologue's, not counted), its weight slice sl is in LDS when WR >= 3 (i - 1) + sl + 1.  seen_*: what the last
-        // poll of this chunk's pair returned (the counters only grow).
-        int seen_ready = 0, seen_wr = 0, itc = 0, r_cur = 0;
-        unsigned long long pv = 0;
-        auto await = [&](int b, int ready, int wr) __attribute__((always_inline)) {
-            for (unsigned spin = 0; seen_ready - ready < 0 || seen_wr - wr < 0; ++spin) {
-                unsigned long long v;
-                asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cbase + CL_F_RW + 8 * b) : "memory");
-                seen_ready = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
-                seen_wr = __builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-                if (spin) __builtin_amdgcn_s_sleep(1);
-                if (spin > (1u << 24)) __builtin_trap();
-            }
+        const unsigned cnt_addr = (unsigned)(G::LDS + 2 * (a.C0 + a.C1) * 8);
+        // "this wave has every fragment of weight slice sl": one lane adds 1 to the slice's counter (LDS operations of a wave
+        // complete in order, so the add lands after the wave's reads of the slice)
+        auto release_slice = [&](int sl) __attribute__((always_inline)) {
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
+                         : "=&s"(saved) : "v"(cnt_addr + 4u * sl), "v"(1u) : "memory");
         };
         float m_sd[16], m_sq[16];
         int m_cnt = 0, m_n = -1, m_cob = 0;
@@ -505,11 +434,9 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         CL_BARRIER();
         int b_cur = 0;
 #if defined(WMH_CL_DIAG) && WMH_CL_DIAG == 2
-        unsigned c_mfma = 0, c_b1 = 0, c_b2 = 0;                       // (32-bit sums, the epilogue by difference: the register budget is tight)
+        unsigned c_mfma = 0, c_b1 = 0, c_b2 = 0;             // (32-bit sums; the epilogue by difference)
         CL_CSTAMP(c_start);
-#if defined(WMH_CL_DIAG) && WMH_CL_DIAG == 2
         const unsigned long long r_start = __builtin_amdgcn_s_memrealtime();
-#endif
 #endif
         for (int k = 0; k < ntiles_mine; ++k) {
             int g, tx, ty, tz, n0;
@@ -529,17 +456,6 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
             }
             for (int ch = 0; ch < nch; ++ch) {
                 const unsigned char* cur = bbase + b_cur * BUF;
-                CL_CSTAMP(v9);
-                const int ready_target = 7 * (r_cur + (b_cur != 0));
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv) :: "memory");
-                seen_ready = __builtin_amdgcn_readfirstlane((int)(unsigned)pv);             // (this buffer's pair, read ahead)
-                seen_wr = max(seen_wr, __builtin_amdgcn_readfirstlane((int)(unsigned)(pv >> 32)));
-#if defined(WMH_CL_DIAG) && WMH_CL_DIAG == 2
-                await(b_cur, ready_target, -(1 << 30));
-                CL_CSTAMP(v8);
-                CL_CSTAMP_ADD(c_b2, v9, v8);
-#endif
-                await(b_cur, ready_target, 3 * itc - 2);     // the chunk is normalised, weight slice 0 is in place
                 CL_CSTAMP(v0);
                 if (!CL_ABL(4)) {
                     // 18 row steps (kd, input row iy); a step's MFMAs are grouped by kw, and as soon as a group has been issued
@@ -566,27 +482,23 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
                                         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kr][kw], bv[kw], acc[m], 0, 0, 0);
                                 }
                                 const int nkd = iy + 1 < IY ? kd : kd + 1, niy = iy + 1 < IY ? iy + 1 : 0;      // next step
-                                if (iy == IY - 1 && kw == 0 && kd < 2) await(b_cur, ready_target, 3 * itc - 2 + kd + 1);         // weight slice kd+1 is in place
                                 if (!CL_ABL(7)) {
                                 if (nkd < 3) bv[kw] = *reinterpret_cast<const cl_bf16x8*>(cur + ((nkd * IY + niy) * IX + kw) * 16);
                                 if (iy + 1 <= 2) av[iy + 1][kw] = wl[(kd * 9 + (iy + 1) * 3 + kw) * 64];
                                 else if (iy == IY - 1 && kd < 2) av[0][kw] = wl[((kd + 1) * 9 + kw) * 64];
                                 } else if (iy + 1 <= 2) av[iy + 1][kw] = av[0][kw];
-                                if (iy == 1 && kw == 2) release_slice(kd);      // the slice's last fragment read has just been issued
-                                // the last operand reads of the chunk have been issued: the activation buffer may be refilled
-                                if (kd == 2 && iy == IY - 2 && kw == 2) {
-                                    cl_flag_add(cbase + CL_F_DONE + 4 * b_cur);
-                                    // the next chunk's counters, read under the last row step's MFMAs (a poll takes ~300 cycles to come back)
-                                    asm volatile("ds_read_b64 %0, %1" : "=v"(pv) : "v"(cbase + CL_F_RW + 8 * (b_cur == 2 ? 0 : b_cur + 1)) : "memory");
-                                }
+                                // all nine fragments of this kd were issued by row step 1 and have been consumed by now
+                                if (iy == CL_REL_IY && kw == 2 && kd < 2 && !CL_ABL(8)) release_slice(kd);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                 }
-                else { release_slice(0); release_slice(1); release_slice(2); cl_flag_add(cbase + CL_F_DONE + 4 * b_cur); pv = 0; }
                 CL_CSTAMP(v1);
-                CL_CSTAMP_ADD(c_mfma, v0, v1); CL_CSTAMP_ADD(c_b1, v9, v0);
-                if (b_cur == 2) { b_cur = 0; ++r_cur; } else ++b_cur;
-                ++itc;
+                CL_BARRIER();
+                CL_CSTAMP(v2);
+                CL_BARRIER();                                // the loaders swap the weight fragments in between
+                CL_CSTAMP(v3);
+                CL_CSTAMP_ADD(c_mfma, v0, v1); CL_CSTAMP_ADD(c_b1, v1, v2); CL_CSTAMP_ADD(c_b2, v2, v3);
+                b_cur = b_cur == 2 ? 0 : b_cur + 1;
             }
             __builtin_amdgcn_s_setprio(3);                    // the epilogue is vector work: not behind the loaders (priority 2)
             // ---- epilogue: this wave's z-slice, MT rows of 32 voxels x 32 output channels
@@ -611,24 +523,19 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
                         const cl_f32x2 sq = __builtin_elementwise_fma(d, d, cl_f32x2{m_sq[r], m_sq[r + 1]});
                         m_sd[r] = sd[0]; m_sd[r + 1] = sd[1]; m_sq[r] = sq[0]; m_sq[r + 1] = sq[1];
                     }
-                    unsigned short* yv = a.y + (((size_t)n0 * a.D + oz) * HW + (size_t)(oy0 + m) * a.W + ox) * a.Cout + cob;
-                    cl_store_mtile(acc[m], yv, kh);
+                    unsigned short* yv = a.y + cl_index((size_t)n0, a.Cout, DHW, cob >> 3, ((size_t)oz * a.H + (oy0 + m)) * a.W + ox);
+                    cl_store_mtile(acc[m], yv, kh, DHW * 8);
                 }
             __builtin_amdgcn_s_setprio(0);
         }
         flush();
 #if defined(WMH_CL_DIAG) && WMH_CL_DIAG == 2
-        if (a.stamps && tid == 0) {
-            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 16;
+        if (a.stamps && lane == 0) {                          // every consumer wave: [grid][4 waves][8] behind the staging waves' [grid][16]
+            unsigned long long* o = a.stamps + (size_t)gridDim.x * 16 + ((size_t)blockIdx.x * 4 + wave) * 8;
             CL_CSTAMP(c_end);
-            o[6] = (unsigned long long)total;
-            o[8] = c_mfma; o[9] = c_b1; o[10] = c_b2; o[11] = (unsigned)(c_end - c_start) - c_mfma - c_b1; o[12] = 0;
-            o[13] = c_end - c_start; o[14] = __builtin_amdgcn_s_memrealtime() - r_start;      // shader-clock ticks / 100 MHz ticks of the whole run
-        }
-        if (a.stamps && lane == 0) {                          // every consumer wave: [grid][4 waves][4] behind the [grid][16] block
-            unsigned long long* o = a.stamps + (size_t)gridDim.x * 16 + ((size_t)blockIdx.x * 4 + wave) * 4;
-            CL_CSTAMP(c_end);
-            o[0] = c_mfma; o[1] = c_b1; o[2] = c_b2; o[3] = (unsigned)(c_end - c_start) - c_mfma - c_b1;
+            o[0] = c_mfma; o[1] = c_b1; o[2] = c_b2; o[3] = (unsigned)(c_end - c_start) - c_mfma - c_b1 - c_b2;
+            o[4] = (unsigned long long)total;
+            o[5] = c_end - c_start; o[6] = __builtin_amdgcn_s_memrealtime() - r_start;   // shader-clock ticks / 100 MHz ticks of the whole run
         }
 #endif
     }
@@ -670,7 +577,7 @@ extern "C" int wmh_cl_conv3_fwd(const void* x0, const float* ss0, int C0, const 
         return wmh_fail(WMH_EINVAL, "cl_conv3_fwd: channels must be multiples of 16 (in) / 32 (out), rows multiples of 32 voxels");
     if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "cl_conv3_fwd: LeakyReLU slope must be in [0, 1]");
     const size_t dhw = (size_t)D * H * W;
-    if (dhw * (size_t)(C0 > C1 ? C0 : C1) * 2 >= ((size_t)1 << 32)) return wmh_fail(WMH_EINVAL, "cl_conv3_fwd: a sample exceeds 4 GB");
+    if (dhw * 16 >= ((size_t)1 << 32)) return wmh_fail(WMH_EINVAL, "cl_conv3_fwd: an 8-channel plane exceeds 4 GB");
     if ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(y)) & 15)
         return wmh_fail(WMH_EINVAL, "cl_conv3_fwd: tensors must be 16-byte aligned");
     ClConvArgs a;
@@ -703,7 +610,7 @@ extern "C" int wmh_cl_conv3_fwd(const void* x0, const float* ss0, int C0, const 
     hipStream_t st = (hipStream_t)stream;
     if (partials != nullptr && hipMemsetAsync(partials, 0, (size_t)N * Cout * a.npart * 16, st) != hipSuccess)
         return wmh_fail(WMH_ELAUNCH, "cl_conv3_fwd: clearing the moment records failed");
-    const int lds_bytes = ClGeo44::LDS + CL_TABLE_SLOTS * (C0 + C1) * 8 + CL_F_BYTES;     // + scale/shift tables + hand-over counters
+    const int lds_bytes = ClGeo44::LDS + 2 * (C0 + C1) * 8 + 16;           // + the weight-slice counters
     if (lds_bytes > 160 * 1024) return wmh_fail(WMH_EINVAL, "cl_conv3_fwd: too many input channels for the LDS scale/shift tables");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cl_conv3_kernel<ClGeo44>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL((cl_conv3_kernel<ClGeo44>), dim3(grid), dim3(768), lds_bytes, st, a, (int)T);
@@ -777,23 +684,23 @@ __global__ __launch_bounds__(256, GW == 4 ? 2 : 3) void cl_conv3s2_kernel(const 
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i][r] = b;
     }
-    const unsigned rowb = 2u * (unsigned)a.Cin;
-    const char* xbase = reinterpret_cast<const char*>(a.x) + (size_t)n * DHW * rowb;
+    const char* xbase = reinterpret_cast<const char*>(a.x) + cl_index((size_t)n, a.Cin, DHW, 0, 0) * 2;
+    const size_t plane = DHW * 16;
     const unsigned char* bbase = lds + (kh * NVP + 2 * j) * 16;
     static __device__ const float ident2s[2] = {1.f, 0.f};
     const bool has_ss = a.ss != nullptr;
     const float slope = has_ss ? a.slope : 1.f;
     for (int ch = 0; ch < a.nchunks; ++ch) {
         if (ch > 0) CL_BARRIER();                                        // the previous chunk's operand reads are done
-        const char* src = xbase + 32 * ch;
+        const char* src = xbase + (size_t)(2 * ch) * plane;
         unsigned char* dst = lds + wave * (64 * 16);
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k)
             if (k < NSLOT - 1 || wave < 2) {                             // uniform
-                const unsigned off = (unsigned)gv[k] * rowb;
+                const unsigned off = (unsigned)gv[k] * 16u;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    __builtin_amdgcn_global_load_lds(CL_GLOBAL_PTR(src + off + 16 * h), CL_LDS_PTR(dst + (h * NVP + k * 256) * 16), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(CL_GLOBAL_PTR(src + h * plane + off), CL_LDS_PTR(dst + (h * NVP + k * 256) * 16), 16, 0, 0);
             }
         // A operands straight from global memory (the layer's whole weight image is a few hundred KB and every workgroup
         // reads it: L2 hits): with 27 MFMAs per chunk their latency is cheap, and without a 27 KB weight buffer three
@@ -859,7 +766,8 @@ __global__ __launch_bounds__(256, GW == 4 ? 2 : 3) void cl_conv3s2_kernel(const 
     for (int i = 0; i < MT; ++i)
         if ((vmask >> i) & 1u) {
             const int oz = 2 * tz + ((m0 + i) >> 1), oy = 2 * ty + ((m0 + i) & 1);
-            cl_store_mtile(acc[i], a.y + ((((size_t)n * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + cob, kh);
+            cl_store_mtile(acc[i], a.y + cl_index((size_t)n, a.Cout, (size_t)a.Do * a.Ho * a.Wo, cob >> 3, ((size_t)oz * a.Ho + oy) * a.Wo + ox), kh,
+                           (size_t)a.Do * a.Ho * a.Wo * 8);
         }
 }
 
@@ -873,7 +781,7 @@ extern "C" int wmh_cl_conv3s2_fwd(const void* x, const float* ss, int Cin, const
     if (Cin < 16 || Cin % 16 || Cout % 32 || W % 64)
         return wmh_fail(WMH_EINVAL, "cl_conv3s2_fwd: Cin % 16, Cout % 32 and input rows that are multiples of 64 voxels");
     if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "cl_conv3s2_fwd: LeakyReLU slope must be in [0, 1]");
-    if ((size_t)D * H * W * Cin * 2 >= ((size_t)1 << 32)) return wmh_fail(WMH_EINVAL, "cl_conv3s2_fwd: a sample exceeds 4 GB");
+    if ((size_t)D * H * W * 16 >= ((size_t)1 << 32)) return wmh_fail(WMH_EINVAL, "cl_conv3s2_fwd: an 8-channel plane exceeds 4 GB");
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wf)) & 15)
         return wmh_fail(WMH_EINVAL, "cl_conv3s2_fwd: tensors must be 16-byte aligned");
     ClConvS2Args a;

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void cl_from_ncdhw_kernel(const float* x, uint
         cl_u32x4 w;
 #pragma unroll
         for (int p = 0; p < 4; ++p) w[p] = cl_pack2(xp[(size_t)(2 * p) * S], xp[(size_t)(2 * p + 1) * S]);
-        *reinterpret_cast<cl_u32x4*>(y + ((size_t)n * S + v) * C + 8 * c8) = w;
+        *reinterpret_cast<cl_u32x4*>(y + cl_index(n, C, S, c8, v)) = w;
     }
 }
 __global__ __launch_bounds__(256) void cl_to_ncdhw_kernel(const uint16_t* x, float* y, int C, size_t S, size_t total) {
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void cl_to_ncdhw_kernel(const uint16_t* x, flo
         size_t r = i / S;
         const int c8 = (int)(r % C8);
         const size_t n = r / C8;
-        const cl_u32x4 u = *reinterpret_cast<const cl_u32x4*>(x + ((size_t)n * S + v) * C + 8 * c8);
+        const cl_u32x4 u = *reinterpret_cast<const cl_u32x4*>(x + cl_index(n, C, S, c8, v));
         float* yp = y + ((size_t)n * C + 8 * c8) * S + v;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void cl_conv3_first_kernel(const ClFirstArgs a
 #pragma unroll
     for (int m = 0; m < TY; ++m)
         if ((vmask >> m) & 1u)
-            cl_store_mtile<true>(acc[m], a.y + (((size_t)n * a.D + oz) * HW + (size_t)(oy0 + m) * a.W + ox) * a.Cout + cob, kh);
+            cl_store_mtile<true>(acc[m], a.y + cl_index(n, a.Cout, (size_t)a.D * HW, cob >> 3, ((size_t)oz * a.H + (oy0 + m)) * a.W + ox), kh, (size_t)a.D * HW * 8);
 }
 // weight image of the first convolution: [G][2 k-steps][64 lanes][8] bf16; w = torch layout [Cout][1][27] fp32 (host)
 extern "C" size_t wmh_cl_conv3_first_packed_halfs(int Cout) { return (size_t)((Cout + 31) / 32) * 2 * 64 * 8; }
@@ -194,11 +194,12 @@ __global__ __launch_bounds__(256, 2) void cl_convT_kernel(const ClConvTArgs a) {
         const size_t v = (size_t)mt * 32 + j;                 // flattened (n, z, y, x); S % 32 == 0: a tile stays in one sample
         const size_t n = v / S;
         const int n_u = __builtin_amdgcn_readfirstlane((int)n);
-        size_t r = v - n * S;
-        const int x = (int)(r % a.W); r /= a.W;
-        const int y = (int)(r % a.H);
-        const int z = (int)(r / a.H);
-        const uint16_t* xv = a.x + v * a.Cin + 8 * kh;
+        const size_t r = v - n * S;
+        size_t rr = r;
+        const int x = (int)(rr % a.W); rr /= a.W;
+        const int y = (int)(rr % a.H);
+        const int z = (int)(rr / a.H);
+        const uint16_t* xv = a.x + cl_index(n, a.Cin, S, kh, r);           // + two planes per k-step
         const float* ssn = a.ss ? a.ss + (size_t)n_u * a.Cin * 2 + 16 * kh : nullptr;
         f32x16 acc[8];
 #pragma unroll
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void cl_convT_kernel(const ClConvTArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
         for (int s = 0; s < nks; ++s) {
-            const cl_u32x4 raw = *reinterpret_cast<const cl_u32x4*>(xv + 16 * s);
+            const cl_u32x4 raw = *reinterpret_cast<const cl_u32x4*>(xv + (size_t)(2 * s) * S * 8);
             cl_u32x4 bq = raw;
             if (ssn) {                                        // uniform
                 float sc[8], sh[8];
@@ -221,10 +222,10 @@ __global__ __launch_bounds__(256, 2) void cl_convT_kernel(const ClConvTArgs a) {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[(size_t)(s * 8 + t) * 64], bv, acc[t], 0, 0, 0);
         }
         const size_t H2 = 2 * (size_t)a.H, W2 = 2 * (size_t)a.W;
-        uint16_t* yb = a.y + ((((size_t)n * 2 * a.D + 2 * z) * H2 + 2 * y) * W2 + 2 * x) * a.Cout + g * 32;
+        uint16_t* yb = a.y + cl_index(n, a.Cout, 8 * S, g * 4, (((size_t)2 * z) * H2 + 2 * y) * W2 + 2 * x);
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-            cl_store_mtile(acc[t], yb + (((size_t)(t >> 2) * H2 + ((t >> 1) & 1)) * W2 + (t & 1)) * a.Cout, kh);
+            cl_store_mtile(acc[t], yb + (((size_t)(t >> 2) * H2 + ((t >> 1) & 1)) * W2 + (t & 1)) * 8, kh, 8 * S * 8);
     }
 }
 // weight image: [G][Cin/16][8 taps][64 lanes][8] bf16 from torch layout [Cin][Cout][2][2][2] fp32 (host)
@@ -288,10 +289,10 @@ __global__ __launch_bounds__(256) void cl_seghead_accum_kernel(const uint16_t* x
             const int f = pl.flip[b];
             const int s0 = (f & 4) ? P0 - 1 - p0 : p0, s1 = (f & 2) ? P1 - 1 - p1 : p1, s2 = (f & 1) ? P2 - 1 - p2 : p2;
             const size_t src = ((size_t)s0 * P1 + s1) * P2 + s2;
-            const cl_u32x4* xp = reinterpret_cast<const cl_u32x4*>(x + ((size_t)b * P + src) * C);
+            const cl_u32x4* xp = reinterpret_cast<const cl_u32x4*>(x + cl_index((size_t)b, C, P, 0, src));
             cl_u32x4 u[C / 8];
 #pragma unroll
-            for (int q = 0; q < C / 8; ++q) u[q] = __builtin_nontemporal_load(xp + q);      // read once
+            for (int q = 0; q < C / 8; ++q) u[q] = __builtin_nontemporal_load(xp + (size_t)q * P);      // read once (plane q)
             float lg[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) lg[k] = 0.f;

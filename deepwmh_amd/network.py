@@ -342,9 +342,9 @@ class UNetEngine:
                                                   _lib.ptr(ss), None, N, layer.cout, self._stream()), 'wmh_instnorm_finalize')
 
     def _cl_conv(self, key, layer, x0, ss0, x1=None, ss1=None):
-        """x0 (x1): CL16 tensors [N, D, H, W, C] (torch.bfloat16).  Stride 1 (one or two sources) or stride 2 (one source)."""
-        N, D, H, W, C0 = x0.shape
-        C1 = 0 if x1 is None else x1.shape[4]
+        """x0 (x1): CL16 tensors [N, C / 8, D, H, W, 8] (torch.bfloat16).  Stride 1 (one or two sources) or stride 2 (one source)."""
+        N, C0, D, H, W = self._cl_dims(x0)
+        C1 = 0 if x1 is None else self._cl_dims(x1)[1]
         assert C0 + C1 == layer.cin and layer.kz == 3
         lib = self.lib
         s = layer.stride
@@ -354,7 +354,7 @@ class UNetEngine:
         else:
             assert x1 is None and layer.sz == 2
             npart = _lib.check(lib.wmh_cl_conv3s2_num_partials(Do, Ho, Wo), 'wmh_cl_conv3s2_num_partials')
-        y = self._buf(key + '.ycl', (N, Do, Ho, Wo, layer.cout), torch.bfloat16)
+        y = self._buf(key + '.ycl', self._cl_shape(N, layer.cout, Do, Ho, Wo), torch.bfloat16)
         part = self._buf(key + '.part', (N, layer.cout, npart, 4))
         ss = self._buf(key + '.ss', (N, layer.cout, 2))
         wf = layer.packed_bf16(0)
@@ -379,16 +379,29 @@ class UNetEngine:
         self._finalize(layer, part, npart, ss, N)
         return y, ss
 
+    @staticmethod
+    def _cl_shape(N, C, D, H, W):
+        """torch shape of a CL16 tensor (cl_common.h): 8-channel planes, [n][c / 8][z][y][x][c % 8]"""
+        assert C % 8 == 0
+        return (N, C // 8, D, H, W, 8)
+
+    @staticmethod
+    def _cl_dims(t):
+        """(N, C, D, H, W) of a CL16 tensor"""
+        N, C8, D, H, W, e = t.shape
+        assert e == 8
+        return N, 8 * C8, D, H, W
+
     def _to_cl(self, key, x):
         """NCDHW fp32 -> CL16 (level boundary; raw values, the pending scale/shift stays valid)."""
         N, Cc, D, H, W = x.shape
-        y = self._buf(key + '.cl', (N, D, H, W, Cc), torch.bfloat16)
+        y = self._buf(key + '.cl', self._cl_shape(N, Cc, D, H, W), torch.bfloat16)
         _lib.check(self.lib.wmh_cl_from_ncdhw(_lib.ptr(x), _lib.ptr(y), N, Cc, D * H * W, self._stream()), 'wmh_cl_from_ncdhw')
         self._account(0.0, 6.0 * x.numel())
         return y
 
     def _from_cl(self, key, x):
-        N, D, H, W, Cc = x.shape
+        N, Cc, D, H, W = self._cl_dims(x)
         y = self._buf(key + '.nc', (N, Cc, D, H, W))
         _lib.check(self.lib.wmh_cl_to_ncdhw(_lib.ptr(x), _lib.ptr(y), N, Cc, D * H * W, self._stream()), 'wmh_cl_to_ncdhw')
         self._account(0.0, 6.0 * x.numel())
@@ -408,7 +421,7 @@ class UNetEngine:
             level = i // 2
             if i == 0:
                 npart = _lib.check(lib.wmh_cl_conv3_first_num_partials(D, H, W), 'wmh_cl_conv3_first_num_partials')
-                cur = self._buf('enc0.ycl', (N, D, H, W, layer.cout), torch.bfloat16)
+                cur = self._buf('enc0.ycl', self._cl_shape(N, layer.cout, D, H, W), torch.bfloat16)
                 part = self._buf('enc0.part', (N, layer.cout, npart, 4))
                 cur_ss = self._buf('enc0.ss', (N, layer.cout, 2))
                 _lib.check(lib.wmh_cl_conv3_first_fwd(_lib.ptr(x), _lib.ptr(self._cl_first_wf), _lib.ptr(layer.bias), _lib.ptr(cur),
@@ -430,8 +443,8 @@ class UNetEngine:
             skip, skip_ss = skips[-(u + 1)]
             if level < ncl:
                 if cur.dtype == torch.bfloat16:
-                    Nn, Dd, Hh, Ww, Cc = cur.shape
-                    up = self._buf('tu%d.ycl' % u, (Nn, 2 * Dd, 2 * Hh, 2 * Ww, st['cskip']), torch.bfloat16)
+                    Nn, Cc, Dd, Hh, Ww = self._cl_dims(cur)
+                    up = self._buf('tu%d.ycl' % u, self._cl_shape(Nn, st['cskip'], 2 * Dd, 2 * Hh, 2 * Ww), torch.bfloat16)
                     _lib.check(lib.wmh_cl_convt_fwd(_lib.ptr(cur), _lib.ptr(cur_ss), _lib.ptr(st['tu_wf_cl']), _lib.ptr(up), Nn, Cc,
                                                     st['cskip'], Dd, Hh, Ww, LRELU_SLOPE, self._stream()), 'wmh_cl_convt_fwd')
                     self._account(2.0 * Cc * st['cskip'] * 8 * Nn * Dd * Hh * Ww, 2.0 * cur.numel() + 2.0 * up.numel() + 2.0 * Cc * st['cskip'] * 8)

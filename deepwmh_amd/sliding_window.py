@@ -150,9 +150,9 @@ class SlidingWindowPredictor:
             if self.engine.acct is not None:          # the head reads the last feature map once (its output is in `agg`)
                 self.engine.acct['flop'] += 2.0 * K * seg_w.shape[1] * n * P[0] * P[1] * P[2]
                 self.engine.acct['bytes'] += y.element_size() * float(y[:n].numel())
-            if self.engine.ncl:                       # channels-last bf16 feature map [n, P0, P1, P2, C]
+            if self.engine.ncl:                       # CL16 bf16 feature map [n, C / 8, P0, P1, P2, 8]
                 _lib.check(lib.wmh_cl_seghead_softmax_accumulate(
-                    _lib.ptr(y), _lib.ptr(ss), _lib.ptr(seg_w), K, _lib.ptr(gauss), _lib.ptr(agg), y.shape[4],
+                    _lib.ptr(y), _lib.ptr(ss), _lib.ptr(seg_w), K, _lib.ptr(gauss), _lib.ptr(agg), 8 * y.shape[1],
                     P[0], P[1], P[2], A[0], A[1], A[2], _lib.iarr(origin), n, _lib.iarr(flips), LRELU_SLOPE, st),
                     'wmh_cl_seghead_softmax_accumulate')
                 return

@@ -279,6 +279,14 @@ int wmh_conv3d_k3_wgrad_bf16_supported(int Cin, int Cout, int N, int D, int H, i
 size_t wmh_conv3d_k3_wgrad_bf16_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
 int wmh_conv3d_k3_wgrad_bf16(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
                              float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
+/* Diagnostics: with a non-NULL buffer (device memory, 8 x 8 bytes per workgroup and zero-filled by the caller; 2 x grid records for
+ * the wave-specialised 16-bit kernels) the persistent convolution kernels launched afterwards add s_memtime cycle counts per workgroup:
+ * [0] the first consumer wave's MFMA phases, [1] its barrier waits, [2] its epilogues, [3] chunk iterations, [4..6] a loader wave's work /
+ * barrier wait / work beside an epilogue.  s_memtime counts shader-clock cycles, so [0]+[1]+[2] over the launch's duration is the clock the
+ * CUs actually ran at (bench.py: roofline.in_kernel; tools/f16x2_check.py).  NULL (the default) switches the stamps off.  Not stream
+ * ordered: set it, launch, synchronise, clear it. */
+void wmh_debug_set_conv_stamps(void* stamps);
+
 /* The same weight gradient in the f16x2 "pair" mode (fp32-grade training, the default of nnUNet_train): dy and the activated input
  * are each split into two fp16 numbers (hi toward zero, lo = the remainder: 21-22 significant bits) and kept as one dword per voxel;
  * two v_mfma_f32_32x32x16_f16 per 8 voxels and channel form dy_hi (x_hi + x_lo) + dy_lo (x_hi + x_lo) in fp32 accumulators.

@@ -26,12 +26,22 @@ def bf16_round(a):
 
 
 def to_cl(x):
-    """numpy [N,C,D,H,W] (values already bf16-representable or not: rounded) -> cuda bf16 tensor [N,D,H,W,C]."""
-    return torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 4, 1))).to(torch.bfloat16).cuda().contiguous()
+    """numpy [N,C,D,H,W] (values already bf16-representable or not: rounded) -> cuda bf16 tensor in the CL16 format of cl_common.h,
+    [N, C/8, D, H, W, 8]: planes of 8 channels, the 8 channels of a voxel contiguous."""
+    N, C, D, H, W = x.shape
+    assert C % 8 == 0
+    t = np.ascontiguousarray(x.reshape(N, C // 8, 8, D, H, W).transpose(0, 1, 3, 4, 5, 2))
+    return torch.from_numpy(t).to(torch.bfloat16).cuda().contiguous()
 
 
 def from_cl(t):
-    return t.float().cpu().numpy().transpose(0, 4, 1, 2, 3)
+    """CL16 tensor -> numpy [N,C,D,H,W] fp32.  A 5-D tensor [N, D, H, W, C] is taken as a buffer of that many elements handed to a
+    kernel as its output (the tests allocate them that way): the memory is [N, C/8, D, H, W, 8]."""
+    if t.dim() == 5:
+        N, D, H, W, C = t.shape
+        t = t.contiguous().reshape(N, C // 8, D, H, W, 8)
+    N, C8, D, H, W, _ = t.shape
+    return np.ascontiguousarray(t.float().cpu().numpy().transpose(0, 1, 5, 2, 3, 4)).reshape(N, C8 * 8, D, H, W)
 
 
 def pending(xq, ss):

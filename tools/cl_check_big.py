@@ -31,8 +31,10 @@ wq = w.to(torch.bfloat16).float()
 z = x.float() * ss[:, :, 0][:, :, None, None, None] + ss[:, :, 1][:, :, None, None, None]
 xin = torch.maximum(z, z * 0.01).to(torch.bfloat16).float()
 ref = F.conv3d(xin, wq, bias, padding=1)
-x0 = x[:, :C0].permute(0, 2, 3, 4, 1).contiguous()
-x1 = x[:, C0:].permute(0, 2, 3, 4, 1).contiguous() if C1 else None
+# CL16 (cl_common.h): [N, C/8, D, H, W, 8]
+to_cl = lambda t: t.reshape(t.shape[0], t.shape[1] // 8, 8, *t.shape[2:]).permute(0, 1, 3, 4, 5, 2).contiguous()
+x0 = to_cl(x[:, :C0])
+x1 = to_cl(x[:, C0:]) if C1 else None
 ss0 = ss[:, :C0].contiguous()
 ss1 = ss[:, C0:].contiguous() if C1 else None
 wh = np.ascontiguousarray(w.cpu().numpy().reshape(Cout, Cin, 27))
@@ -40,12 +42,12 @@ wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_bf16(0, Cin, Cout), dtype=np.uint16
 lib.wmh_conv3d_k3_pack_weights_bf16(0, wh.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p))
 wfd = torch.from_numpy(wf.view(np.int16)).cuda()
 npart = lib.wmh_cl_conv3_num_partials(S, S, S)
-y = torch.full((N, S, S, S, Cout), float('nan'), dtype=torch.bfloat16, device='cuda')
+y = torch.full((N, Cout // 8, S, S, S, 8), float('nan'), dtype=torch.bfloat16, device='cuda')
 part = torch.empty(N, Cout, npart, 4, device='cuda')
 _lib.check(lib.wmh_cl_conv3_fwd(_lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wfd), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(part),
                                 N, S, S, S, Cout, 0.01, None), 'cl_conv3')
 torch.cuda.synchronize()
-got = y.float().permute(0, 4, 1, 2, 3)
+got = y.float().permute(0, 1, 5, 2, 3, 4).reshape(N, Cout, S, S, S)
 err = (got - ref).abs()
 tol = 2.0 ** -7 * ref.abs() + 2e-3 * float(ref.abs().max())
 bad = (err > tol) | ~torch.isfinite(got)

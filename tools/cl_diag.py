@@ -1,6 +1,8 @@
-"""Where a chunk iteration of cl_conv3_kernel spends its cycles: builds a diagnostic copy of the kernel (-DWMH_CL_DIAG:
-s_memtime stamps around the phases of both roles; the production library has none) and prints per-iteration averages
-over the workgroups.  Read the SHARES, not the run time.   python tools/cl_diag.py [S C0 C1 Cout]"""
+"""Where a chunk iteration of cl_conv3_kernel spends its cycles, and at which shader clock: builds two diagnostic copies of the
+kernel (-DWMH_CL_DIAG=1: s_memtime stamps around the phases of the staging waves, =2: of the four consumer waves plus the ratio
+s_memtime / s_memrealtime of the whole run = the clock the CUs actually ran at; the production library has no stamps) and prints
+per-iteration averages over the workgroups.  WMH_CL_ABL=m: timing-only ablations (compile-time, results are wrong): 1 no DMA,
+4 no transform, 8 no MFMAs, 16 no epilogue, 64 no operand reloads.      python tools/cl_diag.py [S C0 C1 Cout]"""
 import ctypes as C
 import os
 import subprocess
@@ -10,7 +12,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, 'deepwmh_amd', 'csrc')
-so = '/tmp/libcl_diag.so'
 ABL = int(os.environ.get('WMH_CL_ABL', '0'))                 # timing-only ablations: 1 no DMA, 4 no transform, 8 no MFMAs, 16 no epilogue, 64 no operand reloads
 ROLE = int(os.environ.get('WMH_CL_DIAG_ROLE', '0'))          # 1: stamps in the staging waves only, 2: in the consumer waves only, 0: both builds
 def build(role):
@@ -34,10 +35,11 @@ y = torch.empty(N, S, S, S, Cout, dtype=torch.bfloat16, device='cuda')
 npart = plib.wmh_cl_conv3_num_partials(S, S, S)
 part = torch.empty(N, Cout, npart, 4, device='cuda')
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-st = np.zeros((256, 16))
+GRID = 256
+print('%dx%d^3, %d+%d -> %d channels, WMH_CL_ABL=%d' % (N, S, C0, C1, Cout, ABL))
 for role in ((1, 2) if ROLE == 0 else (ROLE,)):
     lib = C.CDLL(build(role))
-    stamps = torch.zeros(256 * 32, dtype=torch.int64, device='cuda')
+    stamps = torch.zeros(GRID * 16 + GRID * 4 * 8, dtype=torch.int64, device='cuda')
     lib.wmh_cl_diag_stamps.argtypes = [C.c_void_p]
     lib.wmh_cl_conv3_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
@@ -52,22 +54,22 @@ for role in ((1, 2) if ROLE == 0 else (ROLE,)):
         torch.cuda.synchronize()
         assert rc == 0
     allst = stamps.cpu().numpy().astype(np.float64)
-    got = allst[:256 * 16].reshape(256, 16)
-    if role == 2: perwave = allst[256 * 16:].reshape(256, 4, 4)
-    cols = list(range(0, 8)) + [13, 14, 15] if role == 1 else list(range(8, 13)) + ([6] if ROLE == 2 else [])
-    if role == 2: print('  shader clock over the run (s_memtime / s_memrealtime at 100 MHz): %.0f MHz' % float((got[:, 13] / np.maximum(got[:, 14], 1)).mean() * 100))
-    st[:, cols] = got[:, cols]
-    print('build %d (stamps in the %s waves): %.3f ms' % (role, 'staging' if role == 1 else 'consumer', e0.elapsed_time(e1)))
-it = st[:, 6]
-ok = it > 0
-per = lambda col: float((st[ok, col] / it[ok]).mean())
-print('%dx%d^3, %d+%d -> %d channels, WMH_CL_ABL=%d: %d iterations per workgroup' % (N, S, C0, C1, Cout, ABL, int(it[ok].mean())))
-print('  staging : table + poll + DMA-first issue %8.0f | wait DMA(it+1) %8.0f | transform + flag %8.0f | wait for the buffer (transform-first) %8.0f | late DMA %8.0f | share of transform-first iterations %.2f | sum %8.0f'
-      % (per(0), per(1), per(2), per(3), per(4), per(5), sum(per(c) for c in range(5))))
-print('  consumer: MFMA phase (with slice polls) %8.0f | chunk-start poll %8.0f (of it for the activations %8.0f) | epilogue/iter %8.0f | tile prologue/iter %8.0f | sum %8.0f'
-      % (per(8), per(9), per(10), per(11), per(12), sum(per(c) for c in (8, 9, 11, 12))))
-print('  weights : wait for slice 0 / 1 / 2 to be released %8.0f %8.0f %8.0f | load wait + 3 x 9 KB into LDS + flags %8.0f' % (per(7), per(13), per(14), per(15)))
-if ROLE in (0, 2):
-    for w in range(4):
-        v = perwave[ok, w, :] / it[ok, None]
-        print('  consumer wave %d: MFMA phase %8.0f | chunk-start poll %8.0f (activations %8.0f) | epilogue + rest %8.0f' % (w, v[:, 0].mean(), v[:, 1].mean(), v[:, 2].mean(), v[:, 3].mean()))
+    ms = e0.elapsed_time(e1)
+    if role == 1:
+        st = allst[:GRID * 16].reshape(GRID, 16)
+        ok = st[:, 6] > 0
+        per = lambda col: float((st[ok, col] / st[ok, 6]).mean())
+        print('  build 1 (stamps in the staging waves), %.3f ms, %d chunk iterations per workgroup; shader-clock cycles per iteration:' % (ms, int(st[ok, 6].mean())))
+        print('    staging wave: issue table reads + DMA %6.0f | wait DMA(it+1) %6.0f | transform %6.0f | barrier 1 %6.0f | barrier 2 %6.0f | sum %6.0f'
+              % (per(0), per(1), per(2), per(3), per(4) + per(5), sum(per(c) for c in range(6))))
+    else:
+        pw = allst[GRID * 16:].reshape(GRID, 4, 8)
+        ok = pw[:, 0, 4] > 0
+        it = pw[ok, 0, 4]
+        mhz = float((pw[ok, :, 5] / np.maximum(pw[ok, :, 6], 1)).mean() * 100)
+        print('  build 2 (stamps in the consumer waves), %.3f ms; shader clock over the run (s_memtime / s_memrealtime at 100 MHz): %.0f MHz' % (ms, mhz))
+        print('    108 MFMAs per iteration = 3456 cycles of issue; at this clock the bf16 MFMA peak is %.0f TFLOP/s' % (2500.0 * mhz / 2400.0))
+        for w in range(4):
+            v = pw[ok, w, :4] / it[:, None]
+            print('    consumer wave %d: MFMA phase %6.0f | barrier 1 %6.0f | barrier 2 %6.0f | epilogue + tile prologue, per iteration %6.0f | sum %6.0f'
+                  % (w, v[:, 0].mean(), v[:, 1].mean(), v[:, 2].mean(), v[:, 3].mean(), v.sum(1).mean()))

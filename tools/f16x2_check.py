@@ -64,7 +64,8 @@ def run(N, S, C0, C1, Cout, check=True, reps=5):
     if os.environ.get('WMH_STAMPS'):
         stamps = torch.zeros((1 << 20) * 4, dtype=torch.int64, device='cuda')
         lib.wmh_debug_set_conv_stamps(C.c_void_p(stamps.data_ptr()))
-        x3(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); x3(); e1.record(); torch.cuda.synchronize()
         lib.wmh_debug_set_conv_stamps(None)
         raw = stamps.view(-1, 8).cpu().numpy()
         st = raw[raw[:, 3] > 0]
@@ -74,6 +75,12 @@ def run(N, S, C0, C1, Cout, check=True, reps=5):
         print('   x3 per chunk iteration of 8 channels (ticks): consumer mfma %.0f + barrier wait %.0f, epilogue %.0f per iteration; loader work %.0f + '
               'barrier wait %.0f; %d workgroups x %.0f iterations' % (st[:, 0].mean() / n, st[:, 1].mean() / n, st[:, 2].mean() / n, st[:, 4].mean() / n,
                                                                      st[:, 5].mean() / n, len(st), n))
+        # s_memtime counts shader-clock cycles: a consumer wave's phases add up to the workgroup's life time
+        cyc = float((st[:, 0] + st[:, 1] + st[:, 2]).mean())
+        ncu = torch.cuda.get_device_properties(0).multi_processor_count
+        issue = 4.0 * 2 * 27 * Cin * Cout * N * S ** 3 / 32768.0 / (4 * ncu) * 32          # four partial products per 16 channels; per SIMD
+        print('   stamped launch %.3f ms, %.0f cycles per workgroup: the CUs ran at %.0f MHz; MFMA issue alone is %.0f cycles = %.2f of them'
+              % (e0.elapsed_time(e1), cyc, cyc / e0.elapsed_time(e1) / 1e3, issue, issue / cyc))
 
 
 run(2, 64, 32, 0, 32)
