@@ -11,7 +11,8 @@
 //              16 B); voxels outside the volume become zeros there.  These waves issue LDS-DMA ONLY (see the weight wave).
 //   wave 11    weights.  The next chunk's 27 KB ride in its registers (ordinary loads ONLY: a counted s_waitcnt vmcnt over a mix
 //              of ordinary loads and LDS-DMA does not say which are still out) and go into the single LDS weight buffer in
-//              three kd-slices, two of them under the consumers' MFMAs (LDS counter), the last between the two barriers.
+//              three kd-slices under the consumers' MFMAs (an LDS counter per slice: a consumer wave counts itself out of a
+//              slice when it has issued its last fragment read of it); one workgroup barrier per chunk iteration.
 //   waves 0-3  consumers: one z-slice of the tile each (TY rows of 32 voxels).  LDS image is planar, [half][voxel] x 16 B
 //              (half = channels 0-7 / 8-15 of the chunk): consecutive lanes read consecutive 16-byte slots, conflict-free
 //              for every tap shift without a swizzle, and a DMA wave-instruction fills 64 consecutive voxels of one half.
@@ -41,7 +42,7 @@ struct ClConvArgs {
 // Diagnostic build (tools/cl_diag.py).  -DWMH_CL_DIAG=1: s_memtime stamps in the staging waves, =2: in the consumer waves -- both at
 // once, or run-time ablation switches, cost registers this kernel does not have (244 bytes of scratch, an epilogue 10x slower).
 // Timing-only ablations, compile-time (-DWMH_CL_ABL_MASK=m; results are wrong): bit 1 = skip the activation DMA, 3 the transform,
-// 4 the MFMAs, 5 the epilogue, 7 the operand reloads, 8 the sliced weight hand-over.
+// 4 the MFMAs, 5 the epilogue, 7 the operand reloads, 8 the sliced weight hand-over, 9 the stores, 10 the moments.
 #ifndef WMH_CL_ABL_MASK
 #define WMH_CL_ABL_MASK 0
 #endif
@@ -133,11 +134,19 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         // The buffer is handed over in three kd-slices: the consumers count themselves out of slices 0 and 1 on an LDS counter as
         // soon as their last fragment of the slice has arrived (half way through the slice's MFMAs), and this wave refills
         // those two under the remaining MFMAs; only the last 9 KB are written between the barriers, where everybody waits.
+// A/B switches of round 3 (same-box measurements, configs[2] bench): CL_WPRIO = priority of the weight wave (3: no change),
+// CL_REL_IY = row step of a kd at whose end a consumer wave counts itself out of the kd's weight slice (1: right behind the issue of
+// its last fragment read -- LDS operations of a wave complete in order; 2: one row step later), CL_ONE_BARRIER = the last slice is
+// handed over through its counter like the first two, and a chunk iteration has ONE workgroup barrier instead of two
+// (11.93 -> 12.07 volumes/s with CL_REL_IY 1).
 #ifndef CL_WPRIO
 #define CL_WPRIO 0
 #endif
 #ifndef CL_REL_IY
-#define CL_REL_IY 2
+#define CL_REL_IY 1
+#endif
+#ifndef CL_ONE_BARRIER
+#define CL_ONE_BARRIER 1
 #endif
         if (CL_WPRIO) __builtin_amdgcn_s_setprio(CL_WPRIO);
         cl_u32x4 wst[WIT];
@@ -171,20 +180,41 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
         issue_w();
         write_w();
         CL_BARRIER();
+#ifdef WMH_CL_DIAG
+        unsigned w_s0 = 0, w_w0 = 0, w_s1 = 0, w_w1 = 0, w_b1 = 0;
+#endif
         for (int it = 0; it < total; ++it) {
+            CL_STAMP(q0);
             if (kw_ * nch + cw + 1 < total && ++cw == nch) { cw = 0; ++kw_; locate_w(); }
             issue_w();                                       // chunk it+1 (the last iteration repeats the last chunk)
             if (!CL_ABL(8)) {
-                wait_slice(0, 4u * (unsigned)(it + 1)); write_slice(0);
-                wait_slice(1, 4u * (unsigned)(it + 1)); write_slice(1);
-                CL_BARRIER();                                // consumers are done with chunk `it`: the last slice may go
+                wait_slice(0, 4u * (unsigned)(it + 1));
+                CL_STAMP(q1);
+                write_slice(0);
+                asm volatile("" ::: "memory");
+                CL_STAMP(q2);
+                wait_slice(1, 4u * (unsigned)(it + 1));
+                CL_STAMP(q3);
+                write_slice(1);
+                asm volatile("" ::: "memory");
+                CL_STAMP(q4);
+                if (CL_ONE_BARRIER) wait_slice(2, 4u * (unsigned)(it + 1));
+                else CL_BARRIER();                           // consumers are done with chunk `it`: the last slice may go
+                CL_STAMP(q5);
+                CL_STAMP_ADD(w_s0, q0, q1); CL_STAMP_ADD(w_w0, q1, q2); CL_STAMP_ADD(w_s1, q2, q3); CL_STAMP_ADD(w_w1, q3, q4); CL_STAMP_ADD(w_b1, q4, q5);
                 write_slice(2);
             } else {
-                CL_BARRIER();
+                if (!CL_ONE_BARRIER) CL_BARRIER();
                 write_w();
             }
             CL_BARRIER();
         }
+#if defined(WMH_CL_DIAG) && WMH_CL_DIAG == 1
+        if (a.stamps && lane == 0) {
+            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 16;
+            o[8] = w_s0; o[9] = w_w0; o[10] = w_s1; o[11] = w_w1; o[12] = w_b1;
+        }
+#endif
     } else if (loader) {
         // ================================ staging waves ====================================================
         if (!CL_ABL(6)) __builtin_amdgcn_s_setprio(2);       // ahead of the MFMA-issuing consumer on the same SIMD
@@ -375,7 +405,7 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
             if (!CL_ABL(3)) transform(b_tr);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             CL_STAMP(t3);
-            CL_BARRIER();                                    // consumers are done with chunk `it`: its weights may go
+            if (!CL_ONE_BARRIER) CL_BARRIER();               // (two-barrier form: consumers are done with chunk `it`, its last weight slice may go)
             CL_STAMP(t4);
             CL_STAMP(t5);
             CL_BARRIER();
@@ -488,14 +518,14 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
                                 else if (iy == IY - 1 && kd < 2) av[0][kw] = wl[((kd + 1) * 9 + kw) * 64];
                                 } else if (iy + 1 <= 2) av[iy + 1][kw] = av[0][kw];
                                 // all nine fragments of this kd were issued by row step 1 and have been consumed by now
-                                if (iy == CL_REL_IY && kw == 2 && kd < 2 && !CL_ABL(8)) release_slice(kd);
+                                if (iy == CL_REL_IY && kw == 2 && (kd < 2 || CL_ONE_BARRIER) && !CL_ABL(8)) release_slice(kd);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                 }
                 CL_CSTAMP(v1);
-                CL_BARRIER();
+                if (!CL_ONE_BARRIER) CL_BARRIER();
                 CL_CSTAMP(v2);
-                CL_BARRIER();                                // the loaders swap the weight fragments in between
+                CL_BARRIER();                                // chunk it+1 is normalised, its weights are in place, nobody reads chunk it any more
                 CL_CSTAMP(v3);
                 CL_CSTAMP_ADD(c_mfma, v0, v1); CL_CSTAMP_ADD(c_b1, v1, v2); CL_CSTAMP_ADD(c_b2, v2, v3);
                 b_cur = b_cur == 2 ? 0 : b_cur + 1;
@@ -516,6 +546,7 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
             for (int m = 0; m < MT; ++m)
                 if (oz < a.D && oy0 + m < a.H && !CL_ABL(5)) {   // uniform
                     m_cnt += 32;
+                    if (!CL_ABL(10))
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {         // two registers per packed instruction
                         const cl_f32x2 d = cl_f32x2{acc[m][r], acc[m][r + 1]} - cl_f32x2{m_k[r], m_k[r + 1]};
@@ -524,7 +555,7 @@ __global__ __launch_bounds__(768, 3) void cl_conv3_kernel(const ClConvArgs a, co
                         m_sd[r] = sd[0]; m_sd[r + 1] = sd[1]; m_sq[r] = sq[0]; m_sq[r + 1] = sq[1];
                     }
                     unsigned short* yv = a.y + cl_index((size_t)n0, a.Cout, DHW, cob >> 3, ((size_t)oz * a.H + (oy0 + m)) * a.W + ox);
-                    cl_store_mtile(acc[m], yv, kh, DHW * 8);
+                    if (!CL_ABL(9) || a.slope < -1.f) cl_store_mtile(acc[m], yv, kh, DHW * 8);      // (ablation: a predicate that is never true)
                 }
             __builtin_amdgcn_s_setprio(0);
         }

@@ -62,6 +62,8 @@ for role in ((1, 2) if ROLE == 0 else (ROLE,)):
         print('  build 1 (stamps in the staging waves), %.3f ms, %d chunk iterations per workgroup; shader-clock cycles per iteration:' % (ms, int(st[ok, 6].mean())))
         print('    staging wave: issue table reads + DMA %6.0f | wait DMA(it+1) %6.0f | transform %6.0f | barrier 1 %6.0f | barrier 2 %6.0f | sum %6.0f'
               % (per(0), per(1), per(2), per(3), per(4) + per(5), sum(per(c) for c in range(6))))
+        print('    weight wave : loads issued .. slice 0 released %6.0f | slice 0 -> LDS (waits for its loads) %6.0f | .. slice 1 released %6.0f | slice 1 -> LDS %6.0f | '
+              'at barrier 1 after %6.0f, waits there %6.0f' % (per(8), per(9), per(10), per(11), per(8) + per(9) + per(10) + per(11), per(12)))
     else:
         pw = allst[GRID * 16:].reshape(GRID, 4, 8)
         ok = pw[:, 0, 4] > 0
