@@ -455,7 +455,9 @@ int wmh_component_filtering(const uint8_t* mask, uint8_t* out, uint8_t* scratch_
                             unsigned long long* best, int D, int H, int W, const int* do_filter3, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Channels-last bf16 tensors ("CL16": [n][z][y][x][c], c fastest, bf16 bit patterns, 16-byte aligned) -- the
+ * Channels-last bf16 tensors ("CL16": [n][c / 8][z][y][x][c % 8] -- planes of 8 channels, a voxel's 8 channels of a plane contiguous
+ * = one 16-byte piece; bf16 bit patterns, 16-byte aligned; C % 8 == 0; a plane must stay below 4 GB.  Rounds 1-2 kept all C channels of a
+ * voxel together; with planes a wave's 64 lanes, which work on consecutive voxels, read and write contiguous runs) -- the
  * storage='bf16' form of the bf16 inference configuration (BASELINE.json configs[2]: "bf16 forward, fused
  * InstanceNorm+LeakyReLU"; the reference reaches its reduced-precision forward through nnU-Net's autocast predict,
  * [nnU-Net neural_network.py::predict_3D(mixed_precision=True), not in tree], called at
@@ -479,17 +481,17 @@ int wmh_cl_conv3_num_partials(int D, int H, int W);
 int wmh_cl_conv3_fwd(const void* x0, const float* ss0, int C0, const void* x1, const float* ss1, int C1,
                      const uint16_t* wf, const float* bias, void* y, float* partials, int N, int D, int H, int W,
                      int Cout, float lrelu_slope, void* stream);
-/* Conv3d 3x3x3, stride 2, padding 1 (the first convolution of an encoder stage): x [N][D][H][W][Cin] ->
- * y [N][(D+1)/2][(H+1)/2][W/2][Cout]; W % 64 == 0.  wf: image of wmh_conv3d_k3_pack_weights_bf16(cfg 0, ...). */
+/* Conv3d 3x3x3, stride 2, padding 1 (the first convolution of an encoder stage): x CL16 of [N][Cin] channels x [D][H][W] ->
+ * y CL16 of [N][Cout] x [(D+1)/2][(H+1)/2][W/2]; W % 64 == 0.  wf: image of wmh_conv3d_k3_pack_weights_bf16(cfg 0, ...). */
 int wmh_cl_conv3s2_num_partials(int Do, int Ho, int Wo);
 int wmh_cl_conv3s2_fwd(const void* x, const float* ss, int Cin, const uint16_t* wf, const float* bias, void* y,
                        float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
-/* ConvTranspose3d kernel 2 stride 2 without bias: x [N][D][H][W][Cin] -> y [N][2D][2H][2W][Cout]; D*H*W % 32 == 0. */
+/* ConvTranspose3d kernel 2 stride 2 without bias: x CL16 [N][Cin] x [D][H][W] -> y CL16 [N][Cout] x [2D][2H][2W]; D*H*W % 32 == 0. */
 size_t wmh_cl_convt_packed_halfs(int Cin, int Cout);
 int wmh_cl_convt_pack_weights(const float* w /* [Cin][Cout][2][2][2] */, int Cin, int Cout, uint16_t* wf);
 int wmh_cl_convt_fwd(const void* x, const float* ss, const uint16_t* wf, void* y, int N, int Cin, int Cout, int D, int H,
                      int W, float lrelu_slope, void* stream);
-/* wmh_seghead_softmax_accumulate on a CL16 feature map x [n][P0][P1][P2][C] (C = 32, K = 2). */
+/* wmh_seghead_softmax_accumulate on a CL16 feature map x of [n][C] channels x [P0][P1][P2] (C = 32, K = 2). */
 int wmh_cl_seghead_softmax_accumulate(const void* x, const float* ss, const float* wseg, int K, const float* gauss,
                                       float* agg, int C, int P0, int P1, int P2, int A0, int A1, int A2,
                                       const int* origin, int n, const int* flips, float lrelu_slope, void* stream);
