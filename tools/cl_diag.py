@@ -60,10 +60,10 @@ for role in ((1, 2) if ROLE == 0 else (ROLE,)):
         ok = st[:, 6] > 0
         per = lambda col: float((st[ok, col] / st[ok, 6]).mean())
         print('  build 1 (stamps in the staging waves), %.3f ms, %d chunk iterations per workgroup; shader-clock cycles per iteration:' % (ms, int(st[ok, 6].mean())))
-        print('    staging wave: issue table reads + DMA %6.0f | wait DMA(it+1) %6.0f | transform %6.0f | barrier 1 %6.0f | barrier 2 %6.0f | sum %6.0f'
-              % (per(0), per(1), per(2), per(3), per(4) + per(5), sum(per(c) for c in range(6))))
+        print('    staging wave: issue table reads + DMA %6.0f | wait DMA(it+1) %6.0f | transform %6.0f | barrier wait %6.0f | sum %6.0f'
+              % (per(0), per(1), per(2), per(3) + per(4) + per(5), sum(per(c) for c in range(6))))
         print('    weight wave : loads issued .. slice 0 released %6.0f | slice 0 -> LDS (waits for its loads) %6.0f | .. slice 1 released %6.0f | slice 1 -> LDS %6.0f | '
-              'at barrier 1 after %6.0f, waits there %6.0f' % (per(8), per(9), per(10), per(11), per(8) + per(9) + per(10) + per(11), per(12)))
+              '.. slice 2 released %6.0f (then 9 KB -> LDS and the barrier)' % (per(8), per(9), per(10), per(11), per(12)))
     else:
         pw = allst[GRID * 16:].reshape(GRID, 4, 8)
         ok = pw[:, 0, 4] > 0
@@ -73,5 +73,5 @@ for role in ((1, 2) if ROLE == 0 else (ROLE,)):
         print('    108 MFMAs per iteration = 3456 cycles of issue; at this clock the bf16 MFMA peak is %.0f TFLOP/s' % (2500.0 * mhz / 2400.0))
         for w in range(4):
             v = pw[ok, w, :4] / it[:, None]
-            print('    consumer wave %d: MFMA phase %6.0f | barrier 1 %6.0f | barrier 2 %6.0f | epilogue + tile prologue, per iteration %6.0f | sum %6.0f'
-                  % (w, v[:, 0].mean(), v[:, 1].mean(), v[:, 2].mean(), v[:, 3].mean(), v.sum(1).mean()))
+            print('    consumer wave %d: MFMA phase %6.0f | barrier wait %6.0f | epilogue + tile prologue, per iteration %6.0f | sum %6.0f'
+                  % (w, v[:, 0].mean(), v[:, 1].mean() + v[:, 2].mean(), v[:, 3].mean(), v.sum(1).mean()))
