@@ -124,6 +124,49 @@ def test_convtranspose_data_gradient_on_the_strided_pair_kernels(lib, shape):
         assert lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(wd), Cs, Ci, 0, Cs, 1, P(wf), None) != 0
 
 
+def test_cycle_stamps_of_the_pair_kernel_leave_the_results_alone(lib):
+    """wmh_debug_set_conv_stamps: the persistent kernels add s_memtime cycle counts per workgroup to the caller's buffer (bench.py derives
+    the clock the CUs ran at from them); the convolution's output is bit-identical with and without, and clearing the hook stops the writes."""
+    from deepwmh_amd import _lib
+    P = _lib.ptr
+    N, C, S = 2, 32, 32
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(N, C, S, S, S, device='cuda', generator=g)
+    ss = torch.stack([1 + 0.3 * torch.randn(N, C, device='cuda', generator=g), 0.2 * torch.randn(N, C, device='cuda', generator=g)], -1).contiguous()
+    w = (torch.randn(C, C, 27, device='cuda', generator=g) / np.sqrt(27 * C)).contiguous()
+    cfg = lib.wmh_conv3d_k3_bf16_config(lib.wmh_conv3d_k3_config(C, C, S, S, S, 1), C, S)
+    assert cfg == 0 and lib.wmh_conv3d_k3_f16x2_supported(cfg)
+    wf = torch.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, C, C), dtype=torch.int16, device='cuda')
+    _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(w), C, C, 0, C, 0, P(wf), None), 'pack')
+    part = torch.empty(N, C, lib.wmh_conv3d_k3_num_partials_f16x2(cfg, N, S, S, S), 4, device='cuda')
+
+    def run():
+        y = torch.full((N, C, S, S, S), float('nan'), device='cuda')
+        _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(x), P(ss), C, None, None, 0, P(wf), None, P(y), P(part), None, N, S, S, S, C, 0.01, None), 'f16x2')
+        torch.cuda.synchronize()
+        return y
+    plain = run()
+    stamps = torch.zeros(4096 * 8, dtype=torch.int64, device='cuda')
+    lib.wmh_debug_set_conv_stamps(C_void(stamps))
+    try:
+        stamped = run()
+    finally:
+        lib.wmh_debug_set_conv_stamps(None)
+    assert torch.equal(plain, stamped)
+    st = stamps.view(-1, 8).cpu().numpy()
+    used = st[st[:, 3] > 0]
+    assert len(used) > 0 and (used[:, 0] > 0).all()                  # MFMA-phase cycles of every workgroup that had chunks to do
+    assert ((used[:, 0] + used[:, 1] + used[:, 2]) < 2e9).all()      # a 32^3 layer takes well under a second of cycles
+    stamps.zero_()
+    again = run()
+    assert torch.equal(plain, again) and int(stamps.abs().sum()) == 0
+
+
+def C_void(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def test_engine_f16x2_meets_the_fp32_gate(tiny_net, tiny_io):
     """Tiny net, tiled + mirrored prediction: the same bounds tests/test_gpu_network.py puts on the fp32 path."""
     from deepwmh_amd.network import UNetEngine
