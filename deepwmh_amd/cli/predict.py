@@ -193,7 +193,7 @@ def main(argv=None):
     if args.disable_mixed_precision:
         precision, storage = 'fp32', 'fp32'
     eng = UNetEngine(plan, sd, 'cuda:0', precision=precision, storage=storage)   # CUDA_VISIBLE_DEVICES already selected the GPU (predict.py:150)
-    pred = SlidingWindowPredictor(eng, plan.patch_size, args.step_size, True, not args.disable_tta, batch=8 if eng.ncl else 16)   # 16: two tiles' mirrored copies per forward
+    pred = SlidingWindowPredictor(eng, plan.patch_size, args.step_size, True, not args.disable_tta, batch=16)   # two tiles' mirrored copies per forward
 
     cases = list_cases(args.input_folder, args.selected_cases)[args.part_id::args.num_parts]
     os.makedirs(args.output_folder, exist_ok=True)

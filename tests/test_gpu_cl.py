@@ -390,8 +390,8 @@ def test_configs2_full_width_patch_against_the_fp32_path():
 
 def test_configs2_stress_eight_volumes_three_repetitions():
     """BASELINE.json configs[2] at the size its LDS-DMA ordering race showed at (garbage tiles "only at full size",
-    every small test green): 8 volumes of 160x192x160, each 8 tiles x 8 mirrors = 64 batch-8 forwards of the 31 M-parameter net on
-    channels-last bf16 tensors, three repetitions.  Every result finite, all three repetitions bit-equal, masks against the fp32
+    every small test green): 8 volumes of 160x192x160, each 8 tiles x 8 mirrors = 64 patches in forwards of 16 (two tiles' mirrored copies,
+    as bench.py and nnUNet_predict run it; rounds 2-3 ran it in forwards of 8) of the 31 M-parameter net on channels-last bf16 tensors, three repetitions.  Every result finite, all three repetitions bit-equal, masks against the fp32
     path."""
     from deepwmh_amd.network import UNetEngine
     from deepwmh_amd.plan import baseline_plan
@@ -402,7 +402,7 @@ def test_configs2_stress_eight_volumes_three_repetitions():
     vols = [torch.from_numpy(synthetic_flair((160, 192, 160), seed=v)).cuda() for v in range(8)]
     eng = UNetEngine(plan, sd, 'cuda:0', precision='bf16', storage='bf16')
     assert eng.ncl == 3
-    pred = SlidingWindowPredictor(eng, do_mirroring=True, batch=8)
+    pred = SlidingWindowPredictor(eng, do_mirroring=True, batch=16)      # what bench.py and nnUNet_predict use: two tiles' mirrored copies per forward
     first = None
     for rep in range(3):
         outs = []

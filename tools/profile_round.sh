@@ -18,8 +18,8 @@ for p in fp32 f16x2 bf16; do
 done
 for mode in f16x2 fp32 bf16_storage; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    # batch = what bench.py's predictor puts into one forward in that mode (16 patches, channels-last: 8)
-    b=16; [ $mode = bf16_storage ] && b=8
+    # batch = what bench.py's predictor puts into one forward (16 patches: two tiles' mirrored copies)
+    b=16
     WMH_BATCH=$b WMH_PMC_MODE=$mode rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${mode}_$c -o p -- python3 tools/pmc_traffic.py > $out/pmc_${mode}_$c.log 2>&1
   done
 done
