@@ -183,14 +183,32 @@ struct ClConvTArgs {
     long long tiles;             // M-tiles of 32 voxels over N*D*H*W
     float slope;
 };
+// NKS = Cin / 16 (4: the plan's 64-channel level; 0 = any, loads inside the k loop).  With a compile-time NKS a tile's
+// NKS operand pieces (one per 8-channel plane pair and lane) are loaded together, and the NEXT tile's are issued before this tile's 16 stores
+// per lane, so that they do not queue behind them.
+template <int NKS>
 __global__ __launch_bounds__(256, 2) void cl_convT_kernel(const ClConvTArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.y;
-    const int nks = a.Cin / 16;
+    const int nks = NKS ? NKS : a.Cin / 16;
     const size_t S = (size_t)a.D * a.H * a.W;
     const cl_bf16x8* wp = reinterpret_cast<const cl_bf16x8*>(a.wf) + (size_t)g * nks * 8 * 64 + lane;
-    for (long long mt = (long long)blockIdx.x * 4 + wave; mt < a.tiles; mt += (long long)gridDim.x * 4) {
+    const long long step = (long long)gridDim.x * 4;
+    cl_u32x4 pre[NKS ? NKS : 1];
+    auto src_of = [&](long long mt) __attribute__((always_inline)) {
+        const size_t v = (size_t)mt * 32 + j, n = v / S;
+        return a.x + cl_index(n, a.Cin, S, kh, v - n * S);          // + two planes per k-step
+    };
+    long long mt = (long long)blockIdx.x * 4 + wave;
+    if constexpr (NKS > 0) {
+        if (mt < a.tiles) {
+            const uint16_t* xv = src_of(mt);
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) pre[s] = *reinterpret_cast<const cl_u32x4*>(xv + (size_t)(2 * s) * S * 8);
+        }
+    }
+    for (; mt < a.tiles; mt += step) {
         const size_t v = (size_t)mt * 32 + j;                 // flattened (n, z, y, x); S % 32 == 0: a tile stays in one sample
         const size_t n = v / S;
         const int n_u = __builtin_amdgcn_readfirstlane((int)n);
@@ -206,8 +224,7 @@ __global__ __launch_bounds__(256, 2) void cl_convT_kernel(const ClConvTArgs a) {
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-        for (int s = 0; s < nks; ++s) {
-            const cl_u32x4 raw = *reinterpret_cast<const cl_u32x4*>(xv + (size_t)(2 * s) * S * 8);
+        auto kstep = [&](int s, const cl_u32x4 raw) __attribute__((always_inline)) {
             cl_u32x4 bq = raw;
             if (ssn) {                                        // uniform
                 float sc[8], sh[8];
@@ -220,6 +237,17 @@ __global__ __launch_bounds__(256, 2) void cl_convT_kernel(const ClConvTArgs a) {
 #pragma unroll
             for (int t = 0; t < 8; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[(size_t)(s * 8 + t) * 64], bv, acc[t], 0, 0, 0);
+        };
+        if constexpr (NKS > 0) {
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) kstep(s, pre[s]);
+            if (mt + step < a.tiles) {                        // uniform per wave
+                const uint16_t* xn = src_of(mt + step);
+#pragma unroll
+                for (int s = 0; s < NKS; ++s) pre[s] = *reinterpret_cast<const cl_u32x4*>(xn + (size_t)(2 * s) * S * 8);
+            }
+        } else {
+            for (int s = 0; s < nks; ++s) kstep(s, *reinterpret_cast<const cl_u32x4*>(xv + (size_t)(2 * s) * S * 8));
         }
         const size_t H2 = 2 * (size_t)a.H, W2 = 2 * (size_t)a.W;
         uint16_t* yb = a.y + cl_index(n, a.Cout, 8 * S, g * 4, (((size_t)2 * z) * H2 + 2 * y) * W2 + 2 * x);
@@ -257,7 +285,10 @@ extern "C" int wmh_cl_convt_fwd(const void* x, const float* ss, const uint16_t* 
     a.tiles = (long long)(N * S / 32);
     a.slope = lrelu_slope;
     const unsigned gx = cl_blocks((size_t)a.tiles, 4, 4096);
-    hipLaunchKernelGGL(cl_convT_kernel, dim3(gx, a.G), dim3(256), 0, (hipStream_t)stream, a);
+    // (measured, batch 8: 64 -> 32 channels at 64^3 -> 128^3 0.49 -> 0.36 ms with the prefetch; 128 -> 64 at 32^3 -> 64^3 0.14 -> 0.29 ms with
+    // eight pieces held per lane, so that level keeps its loads inside the k loop)
+    if (Cin == 64) hipLaunchKernelGGL(cl_convT_kernel<4>, dim3(gx, a.G), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(cl_convT_kernel<0>, dim3(gx, a.G), dim3(256), 0, (hipStream_t)stream, a);
     return wmh_check_launch("cl_convT_kernel");
 }
 
