@@ -31,7 +31,9 @@ sys.path.insert(0, ROOT)
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (dense peaks)
 # f16x2: a product is four bf16 matrix instructions (both operands split into two bf16 numbers), so the mode's ceiling in
 # ALGORITHMIC flops is a quarter of the bf16 peak
-PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'f16x2': 625.0}
+# f16x2: 16-bit MFMA peak x 3/10 -- the pair kernels of the stride-1 layers issue 10 v_mfma_f32_32x32x16_f16 per three taps and 16 channels
+# (three of the four partial products; rounds 2-3 until r03x: all four = 12 instructions, peak / 4 = 625)
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'f16x2': 750.0}
 NOMINAL_SCLK_MHZ = 2400            # the clock the guide's peaks are quoted at
 HBM_PEAK_GBS = 8000.0
 FWD_GFLOP_PER_PATCH = 954.46     # BASELINE.md section 2 (the engine's own count of what it queued is reported next to it)
@@ -39,8 +41,8 @@ AGG_GBYTES_PER_VOLUME = 0.46     # aggregation read-modify-write + volume in / l
 KERNEL_NAME = {
     'fp32': 'conv3d_k3_ws_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM, wave-specialised)',
     'bf16': 'conv3d_k3_bf16_ws_kernel<cfg0> (v_mfma_f32_32x32x16_bf16 implicit GEMM, wave-specialised)',
-    'f16x2': 'conv3d_k3_bf16_ws_kernel<cfg0, PAIR> (fp32 tensors; operands split into fp16 pairs, 4 x v_mfma_f32_32x32x16_f16 per '
-              '16 channels and tap, fp32 accumulate; peak = 16-bit MFMA peak / 4)',
+    'f16x2': 'conv3d_k3_bf16_ws_kernel<cfg0, PAIR> (fp32 tensors; operands split into fp16 pairs, three of the four partial products: 10 x '
+              'v_mfma_f32_32x32x16_f16 per 16 channels and three taps, fp32 accumulate; peak = 16-bit MFMA peak x 3 / 10)',
     'bf16_storage': 'cl_conv3_kernel<ClGeo<4,4>> (channels-last bf16 tensors, v_mfma_f32_32x32x16_bf16, LDS-DMA staging, every stride-1 launch)',
 }
 
@@ -325,7 +327,7 @@ def in_kernel_clock_f16x2(device, batch):
     cycles = float((st[:, 0] + st[:, 1] + st[:, 2]).mean())
     mhz = cycles / ms / 1e3
     flop = 2.0 * 27 * Cin * Cout * N * S ** 3
-    issue = 4.0 * flop / 32768.0 / (4 * ncu) * 32.0             # four partial products; 32 cycles per v_mfma_f32_32x32x16_f16, per SIMD
+    issue = (10.0 / 3.0) * flop / 32768.0 / (4 * ncu) * 32.0    # 10 MFMAs per three taps and 16 channels; 32 cycles per v_mfma_f32_32x32x16_f16, per SIMD
     tflops = flop / ms / 1e9
     return dict(layer='32 -> 32 channels, %d x 128^3 (one stamped launch after the timed region)' % N, launch_ms=round(ms, 3), achieved=round(tflops, 1),
                 sclk_mhz=round(mhz), cycles_per_workgroup=round(cycles), mfma_issue_cycles=round(issue), mfma_issue_share=round(issue / cycles, 3),
@@ -333,7 +335,7 @@ def in_kernel_clock_f16x2(device, batch):
                             epilogue=round(float(st[:, 2].mean() / cycles), 3)),
                 frac_at_in_kernel_clock=round(tflops / (PEAK_TFLOPS['f16x2'] * mhz / NOMINAL_SCLK_MHZ), 3),
                 note='s_memtime counts shader-clock cycles: the consumer wave\'s phases over the launch duration = the clock the CUs ran at; '
-                     'mfma_issue_share = cycles in which the matrix pipe can be issuing (4 x 27 x channels/16 MFMAs of 32 cycles per voxel tile) / all cycles')
+                     'mfma_issue_share = cycles in which the matrix pipe can be issuing (10/3 x 27 x channels/16 MFMAs of 32 cycles per voxel tile) / all cycles')
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -383,7 +385,8 @@ def workload_string(args, tta, forwards, world):
                 '%d patch forwards per volume' % (shp, mir, forwards))
     if args.precision == 'f16x2':
         return ('configs[1]: one %s FLAIR volume per GPU, 128^3 patches, step 0.5, fp32 tensors and accumulation, 3x3x3 products '
-                'formed from fp16 pairs (21-22 significant bits per operand; all other layers exact fp32), Gaussian aggregation, %s; '
+                'formed from fp16 pairs (21-22 significant bits per operand; the stride-1 kernels leave out the lo x lo partial product, 2^-22 of a product; '
+                'all other layers exact fp32), Gaussian aggregation, %s; '
                 '%d patch forwards per volume' % (shp, mir, forwards))
     return ('configs[2]: bf16 forward (bf16 matrix-core operands, fp32 accumulate, %s activation tensors, fused '
             'InstanceNorm+LeakyReLU), batch of %d synthetic %s volumes per step per GPU, 128^3 patches, step 0.5, Gaussian '
@@ -484,7 +487,7 @@ def measure_training_mode(plan, sd, device, precision, iters, warmup):
                 loss_first_to_last=[round(losses[0], 6), round(losses[-1], 6)], clock=cs.report(),
                 roofline=dict(bound='mfma', kernel='whole iteration (every launch of the step)', achieved=round(tflops, 2), peak=peak,
                               unit='TFLOP/s', frac=round(tflops / peak, 4), algorithmic_tflop_per_step=TRAIN_TFLOP_PER_ITER,
-                              note='fp32: v_mfma_f32_32x32x2_f32 peak; f16x2: 16-bit MFMA peak / 4 although its stride-2 layers run on the fp32 '
+                              note='fp32: v_mfma_f32_32x32x2_f32 peak; f16x2: 16-bit MFMA peak x 3/10 (the instruction count of the stride-1 forward / data-gradient kernels; its weight-gradient, strided and transposed kernels form all four partial products, 4 MFMAs per 16 channels and tap) although its stride-2 weight gradients run on the fp32 '
                                    'instruction; bf16: priced against the bf16 peak although the stride-2 layers, statistics and reductions '
                                    'of this mode stay fp32'))
     add_sustained(out['roofline'], out['clock'])

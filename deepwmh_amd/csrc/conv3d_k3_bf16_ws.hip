@@ -69,7 +69,11 @@ __device__ __forceinline__ float ld_uniform(const float* p) {
 // sum_k A B = w_hi (x_hi + x_lo), then w_lo (x_hi + x_lo).  (The other way round -- one A, two B -- costs an LDS read per
 // MFMA, and with one 32-channel output tile per wave that is exactly the LDS bandwidth: 4.3 instead of 3.x ms per layer.)
 // 4 MFMAs per 16 channels and tap instead of 1 -- still 4x fewer cycles than the fp32 instruction -- with fp32 accumulation,
-// fp32 tensors and the fp32 epilogue.
+// fp32 tensors and the fp32 epilogue.  Since the end of round 3 (WMH_PAIR3, the default) the fourth partial product, w_lo x_lo --
+// 2^-22 of a product, below the split's own truncation -- is left out and the three w_lo x_hi terms of a (kd, kr) take two
+// MFMAs instead of three: 10 MFMAs per three taps and 16 channels (see the consumer loop); a layer's error against float64 is
+// unchanged to two digits (tools/f16x2_check.py: 3.5e-7 / 6.8e-7 relative L2 on the 32- / 128-channel test layers, the exact-fp32
+// kernel's 5.3e-7 / 1.07e-6).
 template <class C, bool IN16 = false, bool OUT16 = false, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArgs a, const int T /*tiles*/) {
     constexpr int S = C::S, MT = C::MT, NT = C::NT, CKB = PAIR ? 8 : 16;
@@ -381,6 +385,97 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 // (kd, kw) group: their weight fragments are read together (9 exposed LDS latencies per chunk instead of 27: the
                 // compiler reads a tap's fragments right in front of its first MFMA), and an input row is read once for the up to
                 // three (kr, output row) pairs that use it.
+#ifndef WMH_PAIR3
+#define WMH_PAIR3 1
+#endif
+#ifndef WMH_PAIR3_ROWSHARE
+#define WMH_PAIR3_ROWSHARE 0
+#endif
+                if constexpr (PAIR && WMH_PAIR3) {
+                // THREE of the four partial products (w_lo x_lo, 2^-22 of a product, is not formed): per (kd, kr) and output row the
+                // three taps' [w_hi | w_hi] [x_hi | x_lo] as before, then w_lo x_hi of the taps kw = 0, 1 in ONE MFMA -- A = [w_lo(kw 0) |
+                // w_lo(kw 1)], B = [x_hi(voxel + 0) | x_hi(voxel + 1)]: both are the existing LDS images read with a different address in
+                // the upper lane half -- and w_lo x_hi of kw = 2 with A = [w_lo | 0] against the B operand already in registers.
+                // 5 MFMAs where the four-product form issues 6, from 4 operand reads per (kr, output row) where it has 1 per tap.
+                int bP[MT];                                                                                  // hi piece of voxel + kh
+#pragma unroll
+                for (int m = 0; m < MT; ++m) bP[m] = kh ? ((badr[1][m] & ~16) | (16 * ((((dx + 1) >> 3) & 1)))) : badr[0][m];
+                const bf16x8* wlp = wl + 32 + kh * (NT * 64);                                                // lo piece of tap + kh
+                const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                bf16x8 aH[2][3], aP[2], aS[2], bb[2][4];          // NT == 1: two sets of A fragments / B operands (the step pipeline below)
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    if constexpr (NT == 1) {
+                        // one step per (kr, output row): the next step's four B operands (and, at the end of a kr, the next (kd, kr)'s five
+                        // A fragments) are read before this step's five MFMAs are issued; sched_barrier keeps it that way (left alone the
+                        // compiler hoists a whole kr's operand reads: 684 bytes of scratch)
+                        auto loadA = [&](int t0, bf16x8 (&ah)[3], bf16x8& alp, bf16x8& als) __attribute__((always_inline)) {
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) ah[kw] = wl[(t0 + kw) * 64];
+                            alp = wlp[t0 * 64];
+                            const bf16x8 l2 = wl[(t0 + 2) * 64 + 32];
+                            als = kh ? zero8 : l2;
+                        };
+                        auto loadB = [&](int kd_, int kr_, int m_, bf16x8 (&b)[4]) __attribute__((always_inline)) {
+                            const int off = (kd_ * C::ZS + kr_ * C::YS) * 32;
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) b[kw] = *reinterpret_cast<const bf16x8*>(cur + badr[kw][m_] + off);
+                            b[3] = *reinterpret_cast<const bf16x8*>(cur + bP[m_] + off);
+                        };
+                        if (kd == 0) { loadA(0, aH[0], aP[0], aS[0]); loadB(0, 0, 0, bb[0]); }
+#pragma unroll
+                        for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                const int q = (kd * 3 + kr) * MT + m;             // step; A set = (kd*3+kr) & 1, B set = q & 1
+                                const int as = (kd * 3 + kr) & 1, bs = q & 1;
+                                if (m + 1 < MT) loadB(kd, kr, m + 1, bb[bs ^ 1]);
+                                else if (kd * 3 + kr < 8) {
+                                    const int nk = kd * 3 + kr + 1;
+                                    loadA(nk * 3, aH[as ^ 1], aP[as ^ 1], aS[as ^ 1]);
+                                    loadB(nk / 3, nk % 3, 0, bb[bs ^ 1]);
+                                }
+#pragma unroll
+                                for (int pr = 0; pr < 5; ++pr) {
+                                    const bf16x8 aa = pr < 3 ? aH[as][pr] : (pr == 3 ? aP[as] : aS[as]);
+                                    const bf16x8 bv = pr < 3 ? bb[bs][pr] : (pr == 3 ? bb[bs][3] : bb[bs][2]);
+                                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aa), __builtin_bit_cast(f16x8, bv), acc[0][m], 0, 0, 0);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                    } else {
+#pragma unroll
+                        for (int kr = 0; kr < 3; ++kr) {
+                            const int t0 = kd * 9 + kr * 3;
+                            bf16x8 ah[3][NT], alp[NT], als[NT];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                                for (int kw = 0; kw < 3; ++kw) ah[kw][nt] = wl[((t0 + kw) * NT + nt) * 64];
+                                alp[nt] = wlp[(t0 * NT + nt) * 64];
+                                const bf16x8 l2 = wl[((t0 + 2) * NT + nt) * 64 + 32];
+                                als[nt] = kh ? zero8 : l2;
+                            }
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                const int off = (kd * C::ZS + kr * C::YS) * 32;
+                                bf16x8 b[3];
+#pragma unroll
+                                for (int kw = 0; kw < 3; ++kw) b[kw] = *reinterpret_cast<const bf16x8*>(cur + badr[kw][m] + off);
+                                const bf16x8 bp = *reinterpret_cast<const bf16x8*>(cur + bP[m] + off);
+#pragma unroll
+                                for (int pr = 0; pr < 5; ++pr)
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt) {
+                                        const bf16x8 aa = pr < 3 ? ah[pr][nt] : (pr == 3 ? alp[nt] : als[nt]);
+                                        const bf16x8 bb = pr < 3 ? b[pr] : (pr == 3 ? bp : b[2]);
+                                        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aa), __builtin_bit_cast(f16x8, bb), acc[nt][m], 0, 0, 0);
+                                    }
+                            }
+                        }
+                    }
+                }
+                } else
 #pragma unroll
                 for (int grp = 0; grp < 9; ++grp) {
                     const int kw = grp % 3;

@@ -105,9 +105,10 @@ int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, c
                            int C1, const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D,
                            int H, int W, int Cout, float lrelu_slope, void* stream);
 /* "f16x2": fp32-grade products on the 16-bit matrix instruction.  Every operand is split into two FP16 numbers
- * (x = x_hi + x_lo: 21-22 significant bits together; round 2 used bf16 pairs, 16 bits) and all four partial products are
- * accumulated in fp32: 4 v_mfma_f32_32x32x16_f16 per 16 input channels and tap instead of 1, still a quarter of the fp32
- * instruction's cycles.  Measured against float64, a layer's error is below the exact-fp32 kernel's (tools/f16x2_check.py).
+ * (x = x_hi + x_lo: 21-22 significant bits together; round 2 used bf16 pairs, 16 bits) and the partial products are
+ * accumulated in fp32: 4 v_mfma_f32_32x32x16_f16 per 16 input channels and tap instead of 1 -- in the wave-specialised kernels of
+ * configurations 0 / 2 / 21 ten per three taps, w_lo x_lo (2^-22 of a product) being left out -- still a quarter of the fp32
+ * instruction's cycles or less.  Measured against float64, a layer's error is below the exact-fp32 kernel's (tools/f16x2_check.py).
  * fp32 NCDHW tensors in and out, configurations 0 / 2 / 21 (stride 1, rows of >= 16 voxels), 1 (stride 2, output rows of 32 voxels:
  * its own wave-specialised kernel; one source, no split-K workspace) and 3 / 4 / 5; geometry and
  * epilogue of wmh_conv3d_k3_fwd_bf16, moments records: wmh_conv3d_k3_num_partials_f16x2.  wf: wmh_conv3d_k3_pack_weights_f16x2
