@@ -185,7 +185,7 @@ class UNetEngine:
         use_bf16 = (self.precision == 'bf16' and layer.kz == 3 and layer.sz == s and (C1 == 0 or C0 % 16 == 0)
                     and bool(self.lib.wmh_conv3d_k3_bf16_supported(cfg)) and (plain or (cfg == 0 and s == 1)))
         # 'f16x2': the 3x3x3 convolutions that have a 16-bit-operand kernel (stride 1: rows of >= 8 voxels; stride 2: output rows of 8 or 16)
-        # form their products from fp16 pairs (x = hi + lo, 21-22 significant bits per operand, all four partial products, fp32
+        # form their products from fp16 pairs (x = hi + lo, 21-22 significant bits per operand; the stride-1 kernels form three of the four partial products, lo x lo -- 2^-22 of a product -- being left out; fp32
         # accumulation): results at the exact-fp32 kernel's error level at 2-2.7x its speed.  Everything else is the exact-fp32 path.
         cfg_x = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
         use_x3 = (self.precision == 'f16x2' and layer.kz == 3 and layer.sz == s and (C1 == 0 or C0 % 8 == 0)
