@@ -31,9 +31,10 @@ sys.path.insert(0, ROOT)
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (dense peaks)
 # f16x2: a product is four bf16 matrix instructions (both operands split into two bf16 numbers), so the mode's ceiling in
 # ALGORITHMIC flops is a quarter of the bf16 peak
-# f16x2: 16-bit MFMA peak x 3/10 -- the pair kernels of the stride-1 layers issue 10 v_mfma_f32_32x32x16_f16 per three taps and 16 channels
-# (three of the four partial products; rounds 2-3 until r03x: all four = 12 instructions, peak / 4 = 625)
-PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'f16x2': 750.0}
+# f16x2: 16-bit MFMA peak / 3 -- the pair kernels of the stride-1 layers form three of the four partial products, i.e. three MFMAs' worth of
+# k slots per tap and 16 channels (they ISSUE 10 v_mfma_f32_32x32x16_f16 per three taps: one of them is half empty, which counts against the
+# kernel, not against the ceiling).  Rounds 2-3 until r03x: all four products = 4 instructions per tap and 16 channels, peak / 4 = 625.
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'f16x2': 2500.0 / 3.0}
 NOMINAL_SCLK_MHZ = 2400            # the clock the guide's peaks are quoted at
 HBM_PEAK_GBS = 8000.0
 FWD_GFLOP_PER_PATCH = 954.46     # BASELINE.md section 2 (the engine's own count of what it queued is reported next to it)
@@ -42,7 +43,7 @@ KERNEL_NAME = {
     'fp32': 'conv3d_k3_ws_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM, wave-specialised)',
     'bf16': 'conv3d_k3_bf16_ws_kernel<cfg0> (v_mfma_f32_32x32x16_bf16 implicit GEMM, wave-specialised)',
     'f16x2': 'conv3d_k3_bf16_ws_kernel<cfg0, PAIR> (fp32 tensors; operands split into fp16 pairs, three of the four partial products: 10 x '
-              'v_mfma_f32_32x32x16_f16 per 16 channels and three taps, fp32 accumulate; peak = 16-bit MFMA peak x 3 / 10)',
+              'v_mfma_f32_32x32x16_f16 per 16 channels and three taps, fp32 accumulate; peak = 16-bit MFMA peak / 3: three products)',
     'bf16_storage': 'cl_conv3_kernel<ClGeo<4,4>> (channels-last bf16 tensors, v_mfma_f32_32x32x16_bf16, LDS-DMA staging, every stride-1 launch)',
 }
 
@@ -274,7 +275,7 @@ def add_sustained(roofline, clock):
     if clock and roofline and roofline.get('bound') == 'mfma' and clock['sclk_mhz_median'] > 0:
         k = min(1.0, clock['sclk_mhz_median'] / NOMINAL_SCLK_MHZ)
         roofline['frac_at_sustained_clock'] = round(roofline['frac'] / k, 4)
-        if roofline.get('peak') in (PEAK_TFLOPS['bf16'], PEAK_TFLOPS['f16x2']):
+        if roofline.get('peak') in (PEAK_TFLOPS['bf16'], round(PEAK_TFLOPS['f16x2'], 1)):
             # measured on this part (tools/micro/mfma_clock.hip, profiles/r03q_clock_mfma.txt): what a kernel of nothing but MFMAs reaches
             roofline['pure_mfma_stream'] = ('v_mfma_f32_32x32x16_f16 back to back on register operands holds 1735 MHz = 0.68 of the nominal '
                                             'peak (bf16: 2025 MHz = 0.80; v_mfma_f32_32x32x2_f32: 2396 MHz = 0.98)')
@@ -365,7 +366,7 @@ def roofline_block(timings, precision, storage, dt):
         pass
     r = dict(bound=bound, kernel=KERNEL_NAME[mode_key(precision, storage)])
     if bound == 'mfma':
-        r.update(achieved=round(tflops, 3), peak=peak_t, unit='TFLOP/s', frac=round(tflops / peak_t, 4))
+        r.update(achieved=round(tflops, 3), peak=round(peak_t, 1), unit='TFLOP/s', frac=round(tflops / peak_t, 4))
     else:
         r.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
     r.update(traffic=traffic, traffic_measured=traffic_note, launches=len(timings), avg_launch_ms=round(tot_ms / nl, 4),
@@ -485,9 +486,9 @@ def measure_training_mode(plan, sd, device, precision, iters, warmup):
                                                         '(forward, data and weight gradients), fp32 master weights / statistics / optimizer'),
                 steps=iters, warmup=warmup, ms_per_step=round(1e3 * dt / iters, 3), value=round(2 * iters / dt, 3), unit='patches/s',
                 loss_first_to_last=[round(losses[0], 6), round(losses[-1], 6)], clock=cs.report(),
-                roofline=dict(bound='mfma', kernel='whole iteration (every launch of the step)', achieved=round(tflops, 2), peak=peak,
+                roofline=dict(bound='mfma', kernel='whole iteration (every launch of the step)', achieved=round(tflops, 2), peak=round(peak, 1),
                               unit='TFLOP/s', frac=round(tflops / peak, 4), algorithmic_tflop_per_step=TRAIN_TFLOP_PER_ITER,
-                              note='fp32: v_mfma_f32_32x32x2_f32 peak; f16x2: 16-bit MFMA peak x 3/10 (the instruction count of the stride-1 forward / data-gradient kernels; its weight-gradient, strided and transposed kernels form all four partial products, 4 MFMAs per 16 channels and tap) although its stride-2 weight gradients run on the fp32 '
+                              note='fp32: v_mfma_f32_32x32x2_f32 peak; f16x2: 16-bit MFMA peak / 3 (three partial products: the stride-1 forward / data-gradient kernels; its weight-gradient, strided and transposed kernels form all four partial products, 4 MFMAs per 16 channels and tap) although its stride-2 weight gradients run on the fp32 '
                                    'instruction; bf16: priced against the bf16 peak although the stride-2 layers, statistics and reductions '
                                    'of this mode stay fp32'))
     add_sustained(out['roofline'], out['clock'])
