@@ -275,7 +275,7 @@ def add_sustained(roofline, clock):
     if clock and roofline and roofline.get('bound') == 'mfma' and clock['sclk_mhz_median'] > 0:
         k = min(1.0, clock['sclk_mhz_median'] / NOMINAL_SCLK_MHZ)
         roofline['frac_at_sustained_clock'] = round(roofline['frac'] / k, 4)
-        if roofline.get('peak') in (PEAK_TFLOPS['bf16'], round(PEAK_TFLOPS['f16x2'], 1)):
+        if any(abs(float(roofline.get('peak') or 0.0) - pk) < 0.1 for pk in (PEAK_TFLOPS['bf16'], PEAK_TFLOPS['f16x2'])):
             # measured on this part (tools/micro/mfma_clock.hip, profiles/r03q_clock_mfma.txt): what a kernel of nothing but MFMAs reaches
             roofline['pure_mfma_stream'] = ('v_mfma_f32_32x32x16_f16 back to back on register operands holds 1735 MHz = 0.68 of the nominal '
                                             'peak (bf16: 2025 MHz = 0.80; v_mfma_f32_32x32x2_f32: 2396 MHz = 0.98)')
