@@ -402,7 +402,21 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 for (int m = 0; m < MT; ++m) bP[m] = kh ? ((badr[1][m] & ~16) | (16 * ((((dx + 1) >> 3) & 1)))) : badr[0][m];
                 const bf16x8* wlp = wl + 32 + kh * (NT * 64);                                                // lo piece of tap + kh
                 const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-                bf16x8 aH[2][3], aP[2], aS[2], bb[2][4];          // NT == 1: two sets of A fragments / B operands (the step pipeline below)
+#ifndef WMH_PAIR3_KW2
+#define WMH_PAIR3_KW2 1
+#endif
+                // (WMH_PAIR3_KW2) the w_lo x_hi terms of the taps (kr 0, kw 2) and (kr 1, kw 2) of an output row share ONE MFMA as well:
+                // A = [w_lo(kr 0, kw 2) | w_lo(kr 1, kw 2)], B = [x_hi(row, voxel + 2) | x_hi(row + 1, voxel + 2)], issued with kr = 1;
+                // only (kr 2, kw 2) keeps the half-empty [w_lo | 0] form: 14 MFMAs per (kd, output row) instead of 15 (13.5 would be all
+                // slots used).  In the explicitly pipelined NT = 1 instance: MFMA phase 13.0 k -> 12.4-12.6 k cycles per chunk; in the
+                // compiler-scheduled two-tile instances (256 VGPRs already) 13.0 k -> 13.3 k cycles -- and the bench still a little faster
+                // with it (same-box A/B: 4.881 without the pairing, 4.963 with it in the NT = 1 instance only, 4.988 in all: KW2N).
+                constexpr bool KW2N = true;
+                int bQ[MT];                                                                                  // hi piece of voxel + 2 in row + kh
+#pragma unroll
+                for (int m = 0; m < MT; ++m) bQ[m] = ((badr[2][m] & ~16) | (16 * ((((dx + 2) >> 3) & 1)))) + (kh ? C::YS * 32 : 0);
+                const bf16x8* wlq = wl + 32 + kh * (3 * NT * 64);                                            // lo piece of tap + 3 kh (next kr)
+                bf16x8 aH[2][3], aP[2], aS[2], bb[2][5];          // NT == 1: two sets of A fragments / B operands (the step pipeline below)
 #pragma unroll
                 for (int kd = 0; kd < 3; ++kd) {
                     if constexpr (NT == 1) {
@@ -410,17 +424,22 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                         // A fragments) are read before this step's five MFMAs are issued; sched_barrier keeps it that way (left alone the
                         // compiler hoists a whole kr's operand reads: 684 bytes of scratch)
                         auto loadA = [&](int t0, bf16x8 (&ah)[3], bf16x8& alp, bf16x8& als) __attribute__((always_inline)) {
+                            const int kr_ = (t0 / 3) % 3;
 #pragma unroll
                             for (int kw = 0; kw < 3; ++kw) ah[kw] = wl[(t0 + kw) * 64];
                             alp = wlp[t0 * 64];
-                            const bf16x8 l2 = wl[(t0 + 2) * 64 + 32];
-                            als = kh ? zero8 : l2;
+                            if (WMH_PAIR3_KW2 && kr_ == 1) als = wlq[(t0 - 3 + 2) * 64];       // [w_lo(kr 0, kw 2) | w_lo(kr 1, kw 2)]
+                            else if (!WMH_PAIR3_KW2 || kr_ == 2) {
+                                const bf16x8 l2 = wl[(t0 + 2) * 64 + 32];
+                                als = kh ? zero8 : l2;
+                            }
                         };
-                        auto loadB = [&](int kd_, int kr_, int m_, bf16x8 (&b)[4]) __attribute__((always_inline)) {
+                        auto loadB = [&](int kd_, int kr_, int m_, bf16x8 (&b)[5]) __attribute__((always_inline)) {
                             const int off = (kd_ * C::ZS + kr_ * C::YS) * 32;
 #pragma unroll
                             for (int kw = 0; kw < 3; ++kw) b[kw] = *reinterpret_cast<const bf16x8*>(cur + badr[kw][m_] + off);
                             b[3] = *reinterpret_cast<const bf16x8*>(cur + bP[m_] + off);
+                            if (WMH_PAIR3_KW2 && kr_ == 1) b[4] = *reinterpret_cast<const bf16x8*>(cur + bQ[m_] + kd_ * C::ZS * 32);
                         };
                         if (kd == 0) { loadA(0, aH[0], aP[0], aS[0]); loadB(0, 0, 0, bb[0]); }
 #pragma unroll
@@ -437,8 +456,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                                 }
 #pragma unroll
                                 for (int pr = 0; pr < 5; ++pr) {
+                                    if (WMH_PAIR3_KW2 && kr == 0 && pr == 4) continue;             // (kr 0, kw 2): with kr 1
                                     const bf16x8 aa = pr < 3 ? aH[as][pr] : (pr == 3 ? aP[as] : aS[as]);
-                                    const bf16x8 bv = pr < 3 ? bb[bs][pr] : (pr == 3 ? bb[bs][3] : bb[bs][2]);
+                                    const bf16x8 bv = pr < 3 ? bb[bs][pr] : (pr == 3 ? bb[bs][3] : ((WMH_PAIR3_KW2 && kr == 1) ? bb[bs][4] : bb[bs][2]));
                                     acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aa), __builtin_bit_cast(f16x8, bv), acc[0][m], 0, 0, 0);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
@@ -453,8 +473,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 #pragma unroll
                                 for (int kw = 0; kw < 3; ++kw) ah[kw][nt] = wl[((t0 + kw) * NT + nt) * 64];
                                 alp[nt] = wlp[(t0 * NT + nt) * 64];
-                                const bf16x8 l2 = wl[((t0 + 2) * NT + nt) * 64 + 32];
-                                als[nt] = kh ? zero8 : l2;
+                                if (KW2N && kr == 1) als[nt] = wlq[((t0 - 3 + 2) * NT + nt) * 64];
+                                else if (!KW2N || kr == 2) {
+                                    const bf16x8 l2 = wl[((t0 + 2) * NT + nt) * 64 + 32];
+                                    als[nt] = kh ? zero8 : l2;
+                                }
                             }
 #pragma unroll
                             for (int m = 0; m < MT; ++m) {
@@ -463,12 +486,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 #pragma unroll
                                 for (int kw = 0; kw < 3; ++kw) b[kw] = *reinterpret_cast<const bf16x8*>(cur + badr[kw][m] + off);
                                 const bf16x8 bp = *reinterpret_cast<const bf16x8*>(cur + bP[m] + off);
+                                bf16x8 bq = b[2];
+                                if (KW2N && kr == 1) bq = *reinterpret_cast<const bf16x8*>(cur + bQ[m] + kd * C::ZS * 32);
 #pragma unroll
                                 for (int pr = 0; pr < 5; ++pr)
 #pragma unroll
                                     for (int nt = 0; nt < NT; ++nt) {
+                                        if (KW2N && kr == 0 && pr == 4) continue;                  // (kr 0, kw 2): with kr 1
                                         const bf16x8 aa = pr < 3 ? ah[pr][nt] : (pr == 3 ? alp[nt] : als[nt]);
-                                        const bf16x8 bb = pr < 3 ? b[pr] : (pr == 3 ? bp : b[2]);
+                                        const bf16x8 bb = pr < 3 ? b[pr] : (pr == 3 ? bp : bq);
                                         acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aa), __builtin_bit_cast(f16x8, bb), acc[nt][m], 0, 0, 0);
                                     }
                             }
