@@ -32,8 +32,8 @@ sys.path.insert(0, ROOT)
 # f16x2: a product is four bf16 matrix instructions (both operands split into two bf16 numbers), so the mode's ceiling in
 # ALGORITHMIC flops is a quarter of the bf16 peak
 # f16x2: 16-bit MFMA peak / 3 -- the pair kernels of the stride-1 layers form three of the four partial products, i.e. three MFMAs' worth of
-# k slots per tap and 16 channels (they ISSUE 28 v_mfma_f32_32x32x16_f16 per nine taps where 27 fully used ones would do: one is half empty, which
-# counts against the kernel, not against the ceiling).  Rounds 2-3 until r03x: all four products = 4 instructions per tap and 16 channels, peak / 4 = 625.
+# k slots per tap and 16 channels (they ISSUE 82 v_mfma_f32_32x32x16_f16 per 27 taps and 16 channels where 81 fully used ones would do: one per 8 channels is half empty,
+# which counts against the kernel, not against the ceiling).  Rounds 2-3 until r03x: all four products = 4 instructions per tap and 16 channels, peak / 4 = 625.
 PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'f16x2': 2500.0 / 3.0}
 NOMINAL_SCLK_MHZ = 2400            # the clock the guide's peaks are quoted at
 HBM_PEAK_GBS = 8000.0
@@ -42,8 +42,8 @@ AGG_GBYTES_PER_VOLUME = 0.46     # aggregation read-modify-write + volume in / l
 KERNEL_NAME = {
     'fp32': 'conv3d_k3_ws_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM, wave-specialised)',
     'bf16': 'conv3d_k3_bf16_ws_kernel<cfg0> (v_mfma_f32_32x32x16_bf16 implicit GEMM, wave-specialised)',
-    'f16x2': 'conv3d_k3_bf16_ws_kernel<cfg0, PAIR> (fp32 tensors; operands split into fp16 pairs, three of the four partial products: 28 x '
-              'v_mfma_f32_32x32x16_f16 per 16 channels and nine taps, fp32 accumulate; peak = 16-bit MFMA peak / 3: three products)',
+    'f16x2': 'conv3d_k3_bf16_ws_kernel<cfg0, PAIR> (fp32 tensors; operands split into fp16 pairs, three of the four partial products: 82 x '
+              'v_mfma_f32_32x32x16_f16 per 16 channels and 27 taps, fp32 accumulate; peak = 16-bit MFMA peak / 3: three products)',
     'bf16_storage': 'cl_conv3_kernel<ClGeo<4,4>> (channels-last bf16 tensors, v_mfma_f32_32x32x16_bf16, LDS-DMA staging, every stride-1 launch)',
 }
 
@@ -328,7 +328,7 @@ def in_kernel_clock_f16x2(device, batch):
     cycles = float((st[:, 0] + st[:, 1] + st[:, 2]).mean())
     mhz = cycles / ms / 1e3
     flop = 2.0 * 27 * Cin * Cout * N * S ** 3
-    issue = (28.0 / 9.0) * flop / 32768.0 / (4 * ncu) * 32.0    # 28 MFMAs per nine taps and 16 channels; 32 cycles per v_mfma_f32_32x32x16_f16, per SIMD
+    issue = (82.0 / 27.0) * flop / 32768.0 / (4 * ncu) * 32.0   # 82 MFMAs per 27 taps and 16 channels; 32 cycles per v_mfma_f32_32x32x16_f16, per SIMD
     tflops = flop / ms / 1e9
     return dict(layer='32 -> 32 channels, %d x 128^3 (one stamped launch after the timed region)' % N, launch_ms=round(ms, 3), achieved=round(tflops, 1),
                 sclk_mhz=round(mhz), cycles_per_workgroup=round(cycles), mfma_issue_cycles=round(issue), mfma_issue_share=round(issue / cycles, 3),
@@ -336,7 +336,7 @@ def in_kernel_clock_f16x2(device, batch):
                             epilogue=round(float(st[:, 2].mean() / cycles), 3)),
                 frac_at_in_kernel_clock=round(tflops / (PEAK_TFLOPS['f16x2'] * mhz / NOMINAL_SCLK_MHZ), 3),
                 note='s_memtime counts shader-clock cycles: the consumer wave\'s phases over the launch duration = the clock the CUs ran at; '
-                     'mfma_issue_share = cycles in which the matrix pipe can be issuing (28/9 x 27 x channels/16 MFMAs of 32 cycles per voxel tile) / all cycles')
+                     'mfma_issue_share = cycles in which the matrix pipe can be issuing (82 x channels/16 MFMAs of 32 cycles per voxel tile) / all cycles')
 
 
 # ------------------------------------------------------------------------------------------------------------

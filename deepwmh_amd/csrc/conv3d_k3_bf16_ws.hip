@@ -416,6 +416,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 #pragma unroll
                 for (int m = 0; m < MT; ++m) bQ[m] = ((badr[2][m] & ~16) | (16 * ((((dx + 2) >> 3) & 1)))) + (kh ? C::YS * 32 : 0);
                 const bf16x8* wlq = wl + 32 + kh * (3 * NT * 64);                                            // lo piece of tap + 3 kh (next kr)
+                // ... and (kd 0, kr 2, kw 2) with (kd 1, kr 2, kw 2), issued with kd = 1: the upper lane half reads one slice (ZS) deeper;
+                // (kd 2, kr 2, kw 2) alone keeps the half-empty form: 41 MFMAs per output row and chunk (40.5 = every slot used)
+                int bR[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) bR[m] = ((badr[2][m] & ~16) | (16 * ((((dx + 2) >> 3) & 1)))) + 2 * C::YS * 32 + (kh ? C::ZS * 32 : 0);
+                const bf16x8* wlr = wl + 32 + kh * (9 * NT * 64);                                            // lo piece of tap + 9 kh (next kd)
                 bf16x8 aH[2][3], aP[2], aS[2], bb[2][5];          // NT == 1: two sets of A fragments / B operands (the step pipeline below)
 #pragma unroll
                 for (int kd = 0; kd < 3; ++kd) {
@@ -428,8 +434,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 #pragma unroll
                             for (int kw = 0; kw < 3; ++kw) ah[kw] = wl[(t0 + kw) * 64];
                             alp = wlp[t0 * 64];
+                            const int kd_ = t0 / 9;
                             if (WMH_PAIR3_KW2 && kr_ == 1) als = wlq[(t0 - 3 + 2) * 64];       // [w_lo(kr 0, kw 2) | w_lo(kr 1, kw 2)]
-                            else if (!WMH_PAIR3_KW2 || kr_ == 2) {
+                            else if (WMH_PAIR3_KW2 && kr_ == 2 && kd_ == 1) als = wlr[(6 + 2) * 64];     // [w_lo(kd 0, kr 2, kw 2) | w_lo(kd 1, ...)]
+                            else if (!WMH_PAIR3_KW2 || (kr_ == 2 && kd_ == 2)) {
                                 const bf16x8 l2 = wl[(t0 + 2) * 64 + 32];
                                 als = kh ? zero8 : l2;
                             }
@@ -440,6 +448,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                             for (int kw = 0; kw < 3; ++kw) b[kw] = *reinterpret_cast<const bf16x8*>(cur + badr[kw][m_] + off);
                             b[3] = *reinterpret_cast<const bf16x8*>(cur + bP[m_] + off);
                             if (WMH_PAIR3_KW2 && kr_ == 1) b[4] = *reinterpret_cast<const bf16x8*>(cur + bQ[m_] + kd_ * C::ZS * 32);
+                            if (WMH_PAIR3_KW2 && kr_ == 2 && kd_ == 1) b[4] = *reinterpret_cast<const bf16x8*>(cur + bR[m_]);
                         };
                         if (kd == 0) { loadA(0, aH[0], aP[0], aS[0]); loadB(0, 0, 0, bb[0]); }
 #pragma unroll
@@ -456,9 +465,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                                 }
 #pragma unroll
                                 for (int pr = 0; pr < 5; ++pr) {
-                                    if (WMH_PAIR3_KW2 && kr == 0 && pr == 4) continue;             // (kr 0, kw 2): with kr 1
+                                    if (WMH_PAIR3_KW2 && pr == 4 && (kr == 0 || (kr == 2 && kd == 0))) continue;   // issued with kr 1 / with kd 1
                                     const bf16x8 aa = pr < 3 ? aH[as][pr] : (pr == 3 ? aP[as] : aS[as]);
-                                    const bf16x8 bv = pr < 3 ? bb[bs][pr] : (pr == 3 ? bb[bs][3] : ((WMH_PAIR3_KW2 && kr == 1) ? bb[bs][4] : bb[bs][2]));
+                                    const bf16x8 bv = pr < 3 ? bb[bs][pr] : (pr == 3 ? bb[bs][3] : ((WMH_PAIR3_KW2 && (kr == 1 || (kr == 2 && kd == 1))) ? bb[bs][4] : bb[bs][2]));
                                     acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aa), __builtin_bit_cast(f16x8, bv), acc[0][m], 0, 0, 0);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
@@ -474,7 +483,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                                 for (int kw = 0; kw < 3; ++kw) ah[kw][nt] = wl[((t0 + kw) * NT + nt) * 64];
                                 alp[nt] = wlp[(t0 * NT + nt) * 64];
                                 if (KW2N && kr == 1) als[nt] = wlq[((t0 - 3 + 2) * NT + nt) * 64];
-                                else if (!KW2N || kr == 2) {
+                                else if (KW2N && kr == 2 && kd == 1) als[nt] = wlr[((6 + 2) * NT + nt) * 64];
+                                else if (!KW2N || (kr == 2 && kd == 2)) {
                                     const bf16x8 l2 = wl[((t0 + 2) * NT + nt) * 64 + 32];
                                     als[nt] = kh ? zero8 : l2;
                                 }
@@ -488,11 +498,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                                 const bf16x8 bp = *reinterpret_cast<const bf16x8*>(cur + bP[m] + off);
                                 bf16x8 bq = b[2];
                                 if (KW2N && kr == 1) bq = *reinterpret_cast<const bf16x8*>(cur + bQ[m] + kd * C::ZS * 32);
+                                if (KW2N && kr == 2 && kd == 1) bq = *reinterpret_cast<const bf16x8*>(cur + bR[m]);
 #pragma unroll
                                 for (int pr = 0; pr < 5; ++pr)
 #pragma unroll
                                     for (int nt = 0; nt < NT; ++nt) {
-                                        if (KW2N && kr == 0 && pr == 4) continue;                  // (kr 0, kw 2): with kr 1
+                                        if (KW2N && pr == 4 && (kr == 0 || (kr == 2 && kd == 0))) continue;   // issued with kr 1 / with kd 1
                                         const bf16x8 aa = pr < 3 ? ah[pr][nt] : (pr == 3 ? alp[nt] : als[nt]);
                                         const bf16x8 bb = pr < 3 ? b[pr] : (pr == 3 ? bp : bq);
                                         acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aa), __builtin_bit_cast(f16x8, bb), acc[nt][m], 0, 0, 0);

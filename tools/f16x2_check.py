@@ -78,7 +78,7 @@ def run(N, S, C0, C1, Cout, check=True, reps=5):
         # s_memtime counts shader-clock cycles: a consumer wave's phases add up to the workgroup's life time
         cyc = float((st[:, 0] + st[:, 1] + st[:, 2]).mean())
         ncu = torch.cuda.get_device_properties(0).multi_processor_count
-        issue = (28.0 / 9.0) * 2 * 27 * Cin * Cout * N * S ** 3 / 32768.0 / (4 * ncu) * 32   # 28 MFMAs per nine taps and 16 channels; per SIMD
+        issue = (82.0 / 27.0) * 2 * 27 * Cin * Cout * N * S ** 3 / 32768.0 / (4 * ncu) * 32   # 82 MFMAs per 27 taps and 16 channels; per SIMD
         print('   stamped launch %.3f ms, %.0f cycles per workgroup: the CUs ran at %.0f MHz; MFMA issue alone is %.0f cycles = %.2f of them'
               % (e0.elapsed_time(e1), cyc, cyc / e0.elapsed_time(e1) / 1e3, issue, issue / cyc))
 
