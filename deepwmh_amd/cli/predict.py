@@ -52,10 +52,29 @@ def build_parser():
     return ap
 
 
-def count_gpus_without_runtime(topology='/sys/class/kfd/kfd/topology/nodes'):
-    """Number of GPUs from the KFD topology in sysfs (nodes with simd_count > 0; CPU nodes have 0), narrowed by a
-    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES list when one is set.  torch.cuda.device_count() can fall back to
-    hipGetDeviceCount, which initialises the HIP runtime -- the fan-out parent must not (it only starts children)."""
+def _env_id_list(var):
+    vis = os.environ.get(var)
+    if vis is None or vis.strip() == '':
+        return None
+    return [v.strip() for v in vis.split(',') if v.strip()]
+
+
+def count_gpus_without_runtime(topology='/sys/class/kfd/kfd/topology/nodes', probe_cmd=None):
+    """Number of GPUs a child of this process would see, found WITHOUT initialising the HIP runtime here (the fan-out parent only
+    starts children).  First choice: a short-lived child that asks the runtime itself (`torch.cuda.device_count()`), which sees what
+    the container's cgroup and ROCR_VISIBLE_DEVICES leave visible -- with HIP_/CUDA_VISIBLE_DEVICES removed, exactly as fan_out's
+    children run (the reference sets CUDA_VISIBLE_DEVICES to ONE id, predict.py:150-152; MI355WMH_GPUS replaces it).  If that child
+    cannot run: the KFD topology in sysfs (nodes with simd_count > 0; CPU nodes have 0) narrowed by ROCR_VISIBLE_DEVICES."""
+    cmd = probe_cmd if probe_cmd is not None else [sys.executable, '-c', 'import torch; print(torch.cuda.device_count())']
+    if cmd:
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ('HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')}
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env).stdout.decode().split()
+            n = int(out[-1])
+            if n > 0:
+                return n
+        except Exception:
+            pass
     n = 0
     try:
         nodes = sorted(os.listdir(topology), key=lambda v: int(v) if v.isdigit() else 0)
@@ -69,12 +88,12 @@ def count_gpus_without_runtime(topology='/sys/class/kfd/kfd/topology/nodes'):
             continue
         if int(props.get('simd_count', '0')) > 0:
             n += 1
-    for var in ('HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
-        vis = os.environ.get(var)
-        if vis is not None and vis.strip() != '':
-            n = min(n, len([v for v in vis.split(',') if v.strip()]))
+    ids = _env_id_list('ROCR_VISIBLE_DEVICES')
+    if ids is not None:
+        n = min(n, len(ids))
     if n < 1:
-        raise RuntimeError('MI355WMH_GPUS=all: no GPU in %s; list the ids explicitly (e.g. MI355WMH_GPUS=0-7)' % topology)
+        raise RuntimeError('MI355WMH_GPUS=all: no GPU visible (runtime probe failed, %s empty); list the ids explicitly '
+                           '(e.g. MI355WMH_GPUS=0-7)' % topology)
     return n
 
 
@@ -128,9 +147,11 @@ def fan_out(argv, gpus, ncases, child_cmd=None, poll_s=0.05):
     for r in range(n):
         env = dict(os.environ)
         env.pop('MI355WMH_GPUS', None)                          # the children are plain single-GPU runs
-        env['CUDA_VISIBLE_DEVICES'] = str(gpus[r])              # the reference's own convention (predict.py:150-152)
+        # the reference's own convention (predict.py:150-152): one id in CUDA_VISIBLE_DEVICES.  The reference itself hands this command
+        # CUDA_VISIBLE_DEVICES=<one id>, which MI355WMH_GPUS exists to widen: its ids replace that variable (and HIP_VISIBLE_DEVICES);
+        # ROCR_VISIBLE_DEVICES, the layer below HIP, is inherited, so the ids count within what the container was given
+        env['CUDA_VISIBLE_DEVICES'] = str(gpus[r])
         env.pop('HIP_VISIBLE_DEVICES', None)
-        env.pop('ROCR_VISIBLE_DEVICES', None)
         env['PYTHONPATH'] = root + (os.pathsep + env['PYTHONPATH'] if env.get('PYTHONPATH') else '')
         cmd = list(child_cmd) + list(argv) + ['--part_id', str(r), '--num_parts', str(n)]
         procs.append((r, gpus[r], subprocess.Popen(cmd, env=env)))
@@ -145,8 +166,8 @@ def fan_out(argv, gpus, ncases, child_cmd=None, poll_s=0.05):
             live.remove(item)
             if rc != 0 and rc_final == 0:
                 rc_final = rc if rc > 0 else 1
-                print('deepwmh_amd nnUNet_predict: part %d on GPU %d exited with code %d; stopping the other parts'
-                      % (r, g, rc), file=sys.stderr, flush=True)
+                print('deepwmh_amd nnUNet_predict: part %d on GPU %d exited with code %d (its cases, indices %s of the sorted case '
+                      'list, are not predicted); stopping the other parts' % (r, g, rc, list(range(ncases))[r::n]), file=sys.stderr, flush=True)
                 for _, _, q in live:
                     q.terminate()
         if live:

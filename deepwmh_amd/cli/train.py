@@ -103,6 +103,8 @@ def main(argv=None):
         if mom is not None:
             tr.mom.copy_(torch.as_tensor(np.asarray(mom)).to(tr.mom.device))
             tr.first_step = False
+        if info['checkpoint'].get('deepwmh_amd_loss_scale') and tr.loss_scale != 1.0:
+            tr.loss_scale = float(info['checkpoint']['deepwmh_amd_loss_scale'])
         best = info['checkpoint'].get('deepwmh_amd_best')
         ma_resume = info['checkpoint'].get('deepwmh_amd_ma')
         if rank == 0:
@@ -120,7 +122,7 @@ def main(argv=None):
         if rank != 0:
             return
         # the SGD momentum (as large as the weights) only where training can continue from: model_latest
-        extra = dict(deepwmh_amd_best=best, deepwmh_amd_ma=ma)
+        extra = dict(deepwmh_amd_best=best, deepwmh_amd_ma=ma, deepwmh_amd_loss_scale=float(tr.loss_scale))
         if name == 'model_latest':
             extra['deepwmh_amd_momentum'] = tr.momentum_state()
         ck.save_checkpoint(folder, tr.state_dict(), plans, args.fold, name, epoch=epoch, extra=extra)
@@ -134,6 +136,7 @@ def main(argv=None):
             tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool, plan.pool_op_kernel_sizes)
             losses.append(tr.run_iteration(x, tg, lr).clone())           # stays on the device: no per-iteration sync
         losses = [float(v) for v in torch.stack(losses).cpu()]
+        skipped_before, losses = getattr(tr, '_skipped_reported', 0), [v for v in losses if np.isfinite(v)] or [float('nan')]
         vl = []
         for _ in range(nval):
             data, seg = vloader.next_batch()
@@ -145,6 +148,9 @@ def main(argv=None):
         if rank == 0:
             print('epoch %d/%d: lr %.6f train loss %.4f val loss %.4f (%.1f s)'
                   % (epoch + 1, args.epochs, lr, float(np.mean(losses)), v, time.time() - t0), flush=True)
+            if tr.skipped_steps != skipped_before:      # GradScaler semantics: the device skipped updates whose gradient norm was not finite
+                print('  %d optimizer step(s) skipped (non-finite gradients); loss scale now %g' % (tr.skipped_steps - skipped_before, tr.loss_scale), flush=True)
+        tr._skipped_reported = tr.skipped_steps
         if best is None or ma > best:
             best = ma
             save('model_best', epoch + 1)

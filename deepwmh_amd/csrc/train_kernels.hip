@@ -451,15 +451,18 @@ __global__ __launch_bounds__(256) void sqnorm_partials_kernel(const float* g, si
     const double t = block_sum_256(a, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
-// out[0] = total norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))
+// out[0] = total norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)).  A non-finite norm (an overflow somewhere in a
+// loss-scaled fp16-pair backward pass) is reported as it is with coefficient 0: sgd_nesterov_kernel then skips the whole update,
+// as torch.cuda.amp.GradScaler.step does in nnU-Net's own fp16 run_iteration [nnU-Net, not in tree].
 __global__ void clip_coef_kernel(const double* part, int nblk, float max_norm, float* out) {
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int b = 0; b < nblk; ++b) s += part[b];
         const double norm = sqrt(s);
         const double coef = max_norm / (norm + 1e-6);
+        const bool finite = norm <= 1.7e308;               // false for inf and NaN
         out[0] = (float)norm;
-        out[1] = (float)(coef < 1.0 ? coef : 1.0);
+        out[1] = finite ? (float)(coef < 1.0 ? coef : 1.0) : 0.f;
     }
 }
 extern "C" int wmh_grad_clip_coef(const float* grads, size_t n, float max_norm, float* out2, double* workspace, void* stream) {
@@ -473,6 +476,8 @@ extern "C" int wmh_grad_clip_coef(const float* grads, size_t n, float max_norm, 
 __global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* p, const float* g, float* m, size_t n, float lr, float mom,
                                                            float wd, const float* clip, int first) {
     const float cs = clip ? clip[1] : 1.f;
+    // non-finite gradient norm: parameters and momentum stay as they are (one inf / NaN gradient would poison both for good)
+    if (clip && !(fabsf(clip[0]) <= 3.4028234e38f)) return;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float pv = p[i];
         float gv = g[i] * cs;

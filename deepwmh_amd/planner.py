@@ -117,6 +117,11 @@ def plan_stage(current_spacing, original_spacing, original_shape, num_cases, nmo
             log('WARNING: upstream\'s plan (patch %s, poolings %s) is outside the HIP kernels\' repertoire; re-planned with the in-plane '
                 'axes pooled together: patch %s, poolings %s' % ([int(v) for v in first['patch_size']], first['pool_op_kernel_sizes'],
                                                                 [int(v) for v in st['patch_size']], st['pool_op_kernel_sizes']))
+        # recorded IN the plans (and so in every checkpoint's plans): models of this stage are not interchangeable with upstream's
+        st['deviates_from_upstream'] = dict(reason='in-plane axes pooled together (HIP kernels implement [2,2,2] / [1,2,2] poolings)',
+                                            upstream_pool_op_kernel_sizes=[[int(v) for v in p] for p in first['pool_op_kernel_sizes']],
+                                            upstream_patch_size=[int(v) for v in first['patch_size']],
+                                            upstream_batch_size=int(first['batch_size']))
         return st
     raise ValueError('no plan with [2,2,2] / [1,2,2] poolings for spacing %s, median shape %s (upstream plans %s)'
                      % (np.asarray(current_spacing).tolist(), np.asarray(first['median_patient_size_in_voxels']).tolist(),

@@ -57,7 +57,13 @@ class UNetTrainer:
         # this mode the backward pass runs on the loss scaled by 2^16 -- the static form of the GradScaler nnU-Net's own fp16 AMP
         # training uses -- and loss and gradient arena are scaled back (exactly: a power of two) at the end of backward().  Without it
         # the full-size gradients were 7 % off (tools/grad_compare.py); the forward pass (O(1) activations) needs nothing.
+        # The scale is dynamic like GradScaler's (init 2^16, x0.5 after a step whose gradient norm was not finite, x2 after 2000 clean
+        # steps, never above 2^16 -- the value the full-size gradients were validated at): the device skips such a step on its own
+        # (wmh_grad_clip_coef reports the norm, wmh_sgd_nesterov_step leaves parameters and momentum alone), the host learns of it one
+        # iteration later from a pinned copy of the norm (no synchronisation on the step's own stream work).
         self.loss_scale = 65536.0 if self.x3 else 1.0
+        self.max_loss_scale, self.min_loss_scale, self.growth_interval = self.loss_scale, 1.0, 2000
+        self.skipped_steps, self._clean_steps, self._norm_event = 0, 0, None
         plan.check_supported()
         self.plan, self.device = plan, torch.device(device)
         if self.device.type != 'cuda':
@@ -108,6 +114,7 @@ class UNetTrainer:
         self.first_step = True
         self._bufs, self._packed, self._version = {}, {}, 0
         self.clip_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._norm_host = torch.zeros(2, dtype=torch.float32).pin_memory()
         self.loss_acc = torch.zeros(1, dtype=torch.float64, device=dev)
         self.ws_d = torch.empty(max(self.lib.wmh_dice_ce_loss_workspace_doubles(), 1024), dtype=torch.float64, device=dev)
 
@@ -460,6 +467,7 @@ class UNetTrainer:
         if self._avg is None or self._avg.group is not group:
             self._avg = OverlappedGradientAverager(self.grads, self.grad_ranges, group, min_elems=2 * 1024 * 1024)   # >= 8 MB per message
         self._avg.begin()
+        self._update_loss_scale()
         lib, st, tape = self.lib, self._st(), self.tape
         nd = len(self.dec)
         self.loss_acc.zero_()
@@ -531,6 +539,23 @@ class UNetTrainer:
         return self.loss_acc
 
     # ---- optimizer -----------------------------------------------------------------------------------------------
+    def _update_loss_scale(self):
+        """Looks at the gradient norm of the PREVIOUS optimizer step (copied to pinned memory behind it): a non-finite one means the
+        device skipped that update; halve the scale for the iterations to come.  Called before a backward pass picks the scale."""
+        if self._norm_event is None:
+            return
+        self._norm_event.synchronize()                       # long done: a whole forward pass has been queued since
+        self._norm_event = None
+        if bool(np.isfinite(self._norm_host[0].item())):
+            self._clean_steps += 1
+            if self._clean_steps >= self.growth_interval and self.loss_scale < self.max_loss_scale:
+                self.loss_scale, self._clean_steps = min(self.max_loss_scale, self.loss_scale * 2.0), 0
+        else:
+            self.skipped_steps += 1
+            self._clean_steps = 0
+            if self.loss_scale != 1.0:
+                self.loss_scale = max(self.min_loss_scale, self.loss_scale * 0.5)
+
     def optimizer_step(self, lr):
         st = self._st()
         _lib.check(self.lib.wmh_grad_clip_coef(_lib.ptr(self.grads), self.nparams, self.clip, _lib.ptr(self.clip_out), _lib.ptr(self.ws_d),
@@ -538,8 +563,11 @@ class UNetTrainer:
         _lib.check(self.lib.wmh_sgd_nesterov_step(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.mom), self.nparams, lr,
                                                   self.momentum, self.weight_decay, _lib.ptr(self.clip_out), 1 if self.first_step else 0,
                                                   st), 'wmh_sgd_nesterov_step')
-        self.first_step = False
+        self.first_step = False                              # (a skipped first step leaves the zero momentum: same arithmetic either way)
         self._version += 1                                   # packed weight images are stale
+        self._norm_host.copy_(self.clip_out, non_blocking=True)
+        self._norm_event = torch.cuda.Event()
+        self._norm_event.record(torch.cuda.current_stream())
 
     def allreduce_grads(self, group=None):
         """The exchange without overlap, for gradients that were not produced by backward(): one bucketed RCCL all-reduce

@@ -349,9 +349,11 @@ int wmh_convtranspose3d_wgrad(const float* x, const float* ss, const float* dY, 
                               int N, int Cin, int Cout, int D, int H, int W, int kt, float slope, void* stream);
 int wmh_convtranspose3d_k2s2_wgrad(const float* x, const float* ss, const float* dY, float* dW, float* workspace,
                                    int N, int Cin, int Cout, int D, int H, int W, float slope, void* stream);
-/* out2[0] = ||grads||_2, out2[1] = min(1, max_norm/(norm+1e-6)); workspace = 1024 doubles. */
+/* out2[0] = ||grads||_2, out2[1] = min(1, max_norm/(norm+1e-6)); workspace = 1024 doubles.  A non-finite norm (overflow in a
+   loss-scaled backward pass) is reported in out2[0] with out2[1] = 0. */
 int wmh_grad_clip_coef(const float* grads, size_t n, float max_norm, float* out2, double* workspace, void* stream);
-/* torch.optim.SGD(momentum, nesterov=True, weight_decay) on a flat arena; clip = out2 of wmh_grad_clip_coef or NULL. */
+/* torch.optim.SGD(momentum, nesterov=True, weight_decay) on a flat arena; clip = out2 of wmh_grad_clip_coef or NULL.  When
+   clip[0] is not finite the step is skipped: parameters and momentum are left untouched (GradScaler.step semantics). */
 int wmh_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, size_t n, float lr, float momentum,
                           float weight_decay, const float* clip, int first_step, void* stream);
 

@@ -411,3 +411,32 @@ def test_f16x2_gradients_at_full_size_against_the_fp32_step():
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     print('f16x2 vs fp32 gradients at full size: relative L2 %.3g, cosine %.9f' % (rel, cos))
     assert bool(torch.isfinite(a).all()) and rel <= 3e-3 and cos >= 0.99999
+
+
+def test_f16x2_overflowing_backward_skips_the_step_and_lowers_the_scale(tiny_net, tiny_io):
+    """the fp16-pair backward kernels go non-finite once a loss-scaled dy leaves fp16's range.  A step whose gradient norm
+    is not finite must leave parameters and momentum untouched (GradScaler.step in nnU-Net's fp16 run_iteration) and halve the scale
+    for the iterations after it; with the scale back in range training continues."""
+    from deepwmh_amd.trainer import UNetTrainer, downsample_targets
+    plan, _net, sd = tiny_net
+    vol = tiny_io['volume'][0]
+    data = np.stack([vol[4:36, 8:40, 4:36], vol[8:40, 0:32, 2:34][::-1].copy()])[:, None].astype(np.float32)
+    labels = np.stack([(tiny_io['seg_tta'][4:36, 8:40, 4:36] > 0)] * 2).astype(np.uint8)
+    xd = torch.from_numpy(data).cuda()
+    td = downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
+    tr = UNetTrainer(plan, sd, 'cuda:0', precision='f16x2')
+    tr.run_iteration(xd, td, 1e-2)                          # one ordinary step: momentum is no longer zero
+    torch.cuda.synchronize()
+    p0, m0 = tr.params.clone(), tr.mom.clone()
+    tr.loss_scale = tr.max_loss_scale = 2.0 ** 60           # dy * 2^60 is far outside fp16: the pair kernels produce inf / NaN
+    tr.run_iteration(xd, td, 1e-2)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(tr.clip_out[0])), 'the scaled backward pass was expected to overflow'
+    assert torch.equal(tr.params, p0) and torch.equal(tr.mom, m0), 'a non-finite step must not touch parameters or momentum'
+    tr.run_iteration(xd, td, 1e-2)                          # the host has seen the norm by now: scale halved, this step overflows too
+    assert tr.skipped_steps >= 1 and tr.loss_scale == 2.0 ** 59
+    tr.loss_scale = 65536.0
+    tr.run_iteration(xd, td, 1e-2)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(tr.clip_out[0])) and bool(torch.isfinite(tr.params).all())
+    assert not torch.equal(tr.params, p0), 'with the scale back in range the optimizer steps again'

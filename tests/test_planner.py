@@ -80,6 +80,10 @@ def test_every_emitted_plan_is_one_the_hip_path_runs():
     _, _, _, st = planner.plan_3d_fullres([(1.2, 1.0, 1.2)] * 20, [(120, 150, 118)] * 20, 1, 2, log=msgs.append)
     assert list(st['patch_size']) == [128, 160, 112] and st['pool_op_kernel_sizes'] == [[2, 2, 2]] * 4
     assert any('re-planned' in m for m in msgs)
+    # the deviation is recorded in the plans entry itself, not only logged
+    assert st['deviates_from_upstream']['upstream_pool_op_kernel_sizes'][-1] == [2, 2, 1]
+    _, _, _, st = planner.plan_3d_fullres([(1, 1, 1)] * 20, [(160, 192, 160)] * 20, 1, 2)
+    assert 'deviates_from_upstream' not in st               # an upstream-identical plan carries no flag
 
 
 def test_unplannable_dataset_fails_before_preprocessing():

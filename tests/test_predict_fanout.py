@@ -18,7 +18,7 @@ STUB = textwrap.dedent('''
     log = os.environ['STUB_LOG']
     with open(os.path.join(log, 'part%d.json' % part), 'w') as f:
         json.dump(dict(argv=a, gpu=os.environ.get('CUDA_VISIBLE_DEVICES'), fan=os.environ.get('MI355WMH_GPUS'), parts=parts,
-                       hip=os.environ.get('HIP_VISIBLE_DEVICES')), f)
+                       hip=os.environ.get('HIP_VISIBLE_DEVICES'), rocr=os.environ.get('ROCR_VISIBLE_DEVICES')), f)
     if os.environ.get('STUB_FAIL_PART') == str(part):
         sys.exit(7)
     if os.environ.get('STUB_FAIL_PART') is not None:
@@ -39,6 +39,26 @@ def test_gpu_list_forms():
             cli.parse_gpu_list(bad)
 
 
+def test_counting_gpus_for_all(tmp_path, monkeypatch):
+    """MI355WMH_GPUS=all: the runtime is asked in a short-lived child (never in the fan-out parent); without one, sysfs narrowed by
+    ROCR_VISIBLE_DEVICES (that variable used to be ignored).  CUDA_VISIBLE_DEVICES -- which the reference sets to one id
+    (predict.py:150-152) -- does not narrow 'all'."""
+    topo = tmp_path / 'nodes'
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024, 1024]):          # two CPU nodes, four GPUs
+        (topo / str(i)).mkdir(parents=True)
+        (topo / str(i) / 'properties').write_text('cpu_cores_count 8\nsimd_count %d\n' % simd)
+    monkeypatch.setenv('CUDA_VISIBLE_DEVICES', '0')
+    monkeypatch.delenv('ROCR_VISIBLE_DEVICES', raising=False)
+    assert cli.count_gpus_without_runtime(str(topo), probe_cmd=[]) == 4
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '1,3')
+    assert cli.count_gpus_without_runtime(str(topo), probe_cmd=[]) == 2
+    probe = tmp_path / 'probe.py'
+    probe.write_text('import os\nassert "CUDA_VISIBLE_DEVICES" not in os.environ\nprint("noise")\nprint(3)\n')
+    assert cli.count_gpus_without_runtime(str(topo), probe_cmd=[sys.executable, str(probe)]) == 3
+    probe.write_text('import sys\nsys.exit(1)\n')                   # probe fails: sysfs
+    assert cli.count_gpus_without_runtime(str(topo), probe_cmd=[sys.executable, str(probe)]) == 2
+
+
 def _stub(tmp_path, monkeypatch):
     stub = tmp_path / 'stub_child.py'
     stub.write_text(STUB)
@@ -47,6 +67,7 @@ def _stub(tmp_path, monkeypatch):
     monkeypatch.setenv('STUB_LOG', str(log))
     monkeypatch.setenv('MI355WMH_GPUS', '0-7')
     monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0')
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '0,1,2,3,4,5,6,7')
     return [sys.executable, str(stub)], log
 
 
@@ -58,6 +79,7 @@ def test_one_child_per_gpu_with_part_ids(tmp_path, monkeypatch):
     recs = [json.load(open(log / ('part%d.json' % r))) for r in range(4)]
     assert [r['gpu'] for r in recs] == ['4', '5', '6', '7']            # the reference's own single-id convention
     assert all(r['parts'] == 4 and r['fan'] is None and r['hip'] is None for r in recs)     # children do not fan out again
+    assert all(r['rocr'] == '0,1,2,3,4,5,6,7' for r in recs)            # the layer below HIP is inherited: ids count within it
     assert all(r['argv'][:len(argv)] == argv for r in recs)             # the reference's flags reach every child untouched
 
 
