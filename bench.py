@@ -28,23 +28,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (dense peaks)
-# f16x2: a product is four bf16 matrix instructions (both operands split into two bf16 numbers), so the mode's ceiling in
-# ALGORITHMIC flops is a quarter of the bf16 peak
-# f16x2: 16-bit MFMA peak / 3 -- the pair kernels of the stride-1 layers form three of the four partial products, i.e. three MFMAs' worth of
-# k slots per tap and 16 channels (they ISSUE 82 v_mfma_f32_32x32x16_f16 per 27 taps and 16 channels where 81 fully used ones would do: one per 8 channels is half empty,
-# which counts against the kernel, not against the ceiling).  Rounds 2-3 until r03x: all four products = 4 instructions per tap and 16 channels, peak / 4 = 625.
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (dense peaks).  f16x2: the stride-1 pair kernels form three of the four
+# partial products of the fp16 hi/lo split, i.e. three 16-bit MFMAs' worth of k slots per tap and 16 channels: ceiling = 16-bit peak / 3
+# (until r03x all four products were formed and the ceiling was peak / 4 = 625: `peak_basis` says which one a line uses).
 PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'f16x2': 2500.0 / 3.0}
+PEAK_BASIS = {'fp32': 'v_mfma_f32_32x32x2_f32 dense peak', 'bf16': '16-bit MFMA dense peak', 'f16x2': '16-bit MFMA dense peak / 3 (three partial products)'}
 NOMINAL_SCLK_MHZ = 2400            # the clock the guide's peaks are quoted at
 HBM_PEAK_GBS = 8000.0
 FWD_GFLOP_PER_PATCH = 954.46     # BASELINE.md section 2 (the engine's own count of what it queued is reported next to it)
 AGG_GBYTES_PER_VOLUME = 0.46     # aggregation read-modify-write + volume in / label map out
 KERNEL_NAME = {
-    'fp32': 'conv3d_k3_ws_kernel<cfg0> (v_mfma_f32_32x32x2_f32 implicit GEMM, wave-specialised)',
-    'bf16': 'conv3d_k3_bf16_ws_kernel<cfg0> (v_mfma_f32_32x32x16_bf16 implicit GEMM, wave-specialised)',
-    'f16x2': 'conv3d_k3_bf16_ws_kernel<cfg0, PAIR> (fp32 tensors; operands split into fp16 pairs, three of the four partial products: 82 x '
-              'v_mfma_f32_32x32x16_f16 per 16 channels and 27 taps, fp32 accumulate; peak = 16-bit MFMA peak / 3: three products)',
-    'bf16_storage': 'cl_conv3_kernel<ClGeo<4,4>> (channels-last bf16 tensors, v_mfma_f32_32x32x16_bf16, LDS-DMA staging, every stride-1 launch)',
+    'fp32': 'conv3d_k3_ws_kernel<cfg0>',
+    'bf16': 'conv3d_k3_bf16_ws_kernel<cfg0>',
+    'f16x2': 'conv3d_k3_bf16_ws_kernel<cfg0, PAIR>',
+    'bf16_storage': 'cl_conv3_kernel (every stride-1 launch)',
 }
 
 
@@ -84,6 +81,9 @@ def parse_args(argv=None):
     ap.add_argument('--also', choices=['auto', 'off'], default='auto',
                     help='auto (N=1, fp32 headline only): after the headline, measure configs[2] (channels-last bf16, 8 volumes per '
                          'step), the f16x2 mode and one training iteration (fp32, bf16) and report them in an "also" object')
+    ap.add_argument('--detail-file', default='auto',
+                    help='where the FULL record goes (every mode with its clock samples, phases, parity objects, sample descriptions); the one '
+                         'printed line carries the numbers only.  auto: gpurun_out/bench_detail.json when gpurun_out/ exists, else nowhere')
     ap.add_argument('--dry-run', action='store_true',
                     help='launch plumbing only (CPU test of --gpus N): gloo process group, no kernels, value null')
     args = ap.parse_args(argv)
@@ -172,17 +172,13 @@ def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits, extra_no
             osw.mirror_and_predict = orig
         t_est = t_full + (mirrors - 1) * fwd_s[0]
         out = dict(value=1.0 / t_est, unit='volumes/s', cores=cores, kind='port',
-                   sample='whole %dx%dx%d volume WITHOUT mirroring, timed end to end after one warm-up patch forward: %.1f s '
-                          '(%d patch forwards %.1f s + padding/aggregation/argmax %.1f s) = %.4f volumes/s timed; '
-                          'the mirrored workload is 8x the forwards -> %.1f s per volume (that factor is the only '
-                          'extrapolation); torch-CPU fp32 oracle on %d threads'
-                          % (vol.shape[1], vol.shape[2], vol.shape[3], t_full, npatch, fwd_s[0], t_full - fwd_s[0],
-                             1.0 / t_full, t_est, cores),
+                   sample='whole volume WITHOUT mirroring timed end to end (%.1f s: %d forwards %.1f s + aggregation %.1f s); value = 1 / (that with the '
+                          'forwards x %d for mirroring)' % (t_full, npatch, fwd_s[0], t_full - fwd_s[0], mirrors),
                    timed_no_mirroring=dict(value=1.0 / t_full, seconds=round(t_full, 2), forward_seconds=round(fwd_s[0], 2)))
         margin = np.abs(prob_o[1] - prob_o[0])
 
         def versus_oracle(seg_g, prob_g):
-            return dict(sample='whole volume, 8 tiles, Gaussian aggregation, no mirroring: HIP path vs oracle',
+            return dict(sample='whole volume, no mirroring, vs the CPU oracle',
                         max_abs_softmax_err=float(np.abs(prob_g - prob_o).max()),
                         argmax_mismatches=int(((seg_g != seg_o) & (margin > 2e-4)).sum()),
                         argmax_mismatches_any_margin=int((seg_g != seg_o).sum()),
@@ -199,8 +195,7 @@ def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits, extra_no
             what = 'one %dx%dx%d sub-patch forward (1/8 patch), scaled x8' % (P[0] // 2, P[1] // 2, P[2] // 2)
         est = npatch * mirrors * t / frac
         out = dict(value=1.0 / est, unit='volumes/s', cores=cores, kind='port',
-                   sample='%s, %.1f s, torch-CPU fp32 oracle on %d threads; forward only (aggregation excluded), '
-                          'extrapolated to %d forwards' % (what, t, cores, npatch * mirrors))
+                   sample='%s, %.1f s, forward only, extrapolated to %d forwards' % (what, t, npatch * mirrors))
     if parity is None and ref_patch is not None and gpu_patch_logits is not None:
         margin = np.abs(ref_patch[:, 1] - ref_patch[:, 0])
         parity = dict(sample='first patch, no mirroring',
@@ -266,8 +261,7 @@ class ClockSampler:
             return None
         med = lambda v: sorted(v)[len(v) // 2]
         return dict(sclk_mhz_median=round(med(self.f)), sclk_mhz_min=round(min(self.f)), sclk_mhz_nominal=NOMINAL_SCLK_MHZ,
-                    socket_power_w_median=round(med(self.w)) if self.w else None, samples=len(self.f),
-                    source='hwmon freq1_input / power1_input of the device, every 50 ms over the timed region')
+                    socket_power_w_median=round(med(self.w)) if self.w else None, samples=len(self.f))
 
 
 def add_sustained(roofline, clock):
@@ -275,12 +269,6 @@ def add_sustained(roofline, clock):
     if clock and roofline and roofline.get('bound') == 'mfma' and clock['sclk_mhz_median'] > 0:
         k = min(1.0, clock['sclk_mhz_median'] / NOMINAL_SCLK_MHZ)
         roofline['frac_at_sustained_clock'] = round(roofline['frac'] / k, 4)
-        if any(abs(float(roofline.get('peak') or 0.0) - pk) < 0.1 for pk in (PEAK_TFLOPS['bf16'], PEAK_TFLOPS['f16x2'])):
-            # measured on this part (tools/micro/mfma_clock.hip, profiles/r03q_clock_mfma.txt): what a kernel of nothing but MFMAs reaches
-            roofline['pure_mfma_stream'] = ('v_mfma_f32_32x32x16_f16 back to back on register operands holds 1735 MHz = 0.68 of the nominal '
-                                            'peak (bf16: 2025 MHz = 0.80; v_mfma_f32_32x32x2_f32: 2396 MHz = 0.98)')
-        roofline['sustained_clock_note'] = ('peak x %d / %d MHz: the shader clock the power management held during the timed region '
-                                            '(median); frac itself is priced against the nominal peak' % (clock['sclk_mhz_median'], NOMINAL_SCLK_MHZ))
 
 
 def in_kernel_clock_f16x2(device, batch):
@@ -292,7 +280,7 @@ def in_kernel_clock_f16x2(device, batch):
     import ctypes as C
     import torch
     from deepwmh_amd import _lib
-    lib, P = _lib.load(), _lib.ptr
+    lib, P = _lib.load_diag(), _lib.ptr          # the product library's kernels hold no stamp code (csrc/wmh_common.h)
     N, S, Cin, Cout = int(batch), 128, 32, 32
     cfg = lib.wmh_conv3d_k3_bf16_config(lib.wmh_conv3d_k3_config(Cin, Cout, S, S, S, 1), Cout, S)
     if not lib.wmh_conv3d_k3_f16x2_supported(cfg):
@@ -334,9 +322,7 @@ def in_kernel_clock_f16x2(device, batch):
                 sclk_mhz=round(mhz), cycles_per_workgroup=round(cycles), mfma_issue_cycles=round(issue), mfma_issue_share=round(issue / cycles, 3),
                 phases=dict(mfma=round(float(st[:, 0].mean() / cycles), 3), barrier_wait=round(float(st[:, 1].mean() / cycles), 3),
                             epilogue=round(float(st[:, 2].mean() / cycles), 3)),
-                frac_at_in_kernel_clock=round(tflops / (PEAK_TFLOPS['f16x2'] * mhz / NOMINAL_SCLK_MHZ), 3),
-                note='s_memtime counts shader-clock cycles: the consumer wave\'s phases over the launch duration = the clock the CUs ran at; '
-                     'mfma_issue_share = cycles in which the matrix pipe can be issuing (82 x channels/16 MFMAs of 32 cycles per voxel tile) / all cycles')
+                frac_at_in_kernel_clock=round(tflops / (PEAK_TFLOPS['f16x2'] * mhz / NOMINAL_SCLK_MHZ), 3))
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -366,7 +352,7 @@ def roofline_block(timings, precision, storage, dt):
         pass
     r = dict(bound=bound, kernel=KERNEL_NAME[mode_key(precision, storage)])
     if bound == 'mfma':
-        r.update(achieved=round(tflops, 3), peak=round(peak_t, 1), unit='TFLOP/s', frac=round(tflops / peak_t, 4))
+        r.update(achieved=round(tflops, 3), peak=round(peak_t, 1), peak_basis=PEAK_BASIS[precision], unit='TFLOP/s', frac=round(tflops / peak_t, 4))
     else:
         r.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
     r.update(traffic=traffic, traffic_measured=traffic_note, launches=len(timings), avg_launch_ms=round(tot_ms / nl, 4),
@@ -380,20 +366,14 @@ def roofline_block(timings, precision, storage, dt):
 
 def workload_string(args, tta, forwards, world):
     shp = '%dx%dx%d' % tuple(args.shape)
-    mir = 'mirroring (TTA x8) %s' % ('on' if tta else 'off')
+    mir = 'mirroring %s' % ('on' if tta else 'off')
     if args.precision == 'fp32':
-        return ('configs[1] on the exact-fp32 kernels: one %s FLAIR volume per GPU, 128^3 patches, step 0.5, fp32, Gaussian aggregation, %s; '
-                '%d patch forwards per volume' % (shp, mir, forwards))
+        return 'configs[1], exact-fp32 kernels: one %s volume per GPU, 128^3 patches, step 0.5, Gaussian aggregation, %s, %d forwards per volume' % (shp, mir, forwards)
     if args.precision == 'f16x2':
-        return ('configs[1]: one %s FLAIR volume per GPU, 128^3 patches, step 0.5, fp32 tensors and accumulation, 3x3x3 products '
-                'formed from fp16 pairs (21-22 significant bits per operand; the stride-1 kernels leave out the lo x lo partial product, 2^-22 of a product; '
-                'all other layers exact fp32), Gaussian aggregation, %s; '
-                '%d patch forwards per volume' % (shp, mir, forwards))
-    return ('configs[2]: bf16 forward (bf16 matrix-core operands, fp32 accumulate, %s activation tensors, fused '
-            'InstanceNorm+LeakyReLU), batch of %d synthetic %s volumes per step per GPU, 128^3 patches, step 0.5, Gaussian '
-            'aggregation, %s; %d patch forwards per volume'
+        return ('configs[1]: one %s volume per GPU, 128^3 patches, step 0.5, fp32 tensors and accumulation (3x3x3 products from fp16 hi+lo pairs), '
+                'Gaussian aggregation, %s, %d forwards per volume' % (shp, mir, forwards))
+    return ('configs[2]: bf16 forward (%s tensors), fused InstanceNorm+LeakyReLU, batch of %d %s volumes per step per GPU, %s, %d forwards per volume'
             % ('bf16' if args.storage == 'bf16' else 'fp32', args.volumes_per_step, shp, mir, forwards))
-
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -478,19 +458,13 @@ def measure_training_mode(plan, sd, device, precision, iters, warmup):
     peak = PEAK_TFLOPS[precision]
     losses = [float(v) for v in torch.stack(losses).cpu()]
     del tr
-    out = dict(workload='one nnUNetTrainerV2 iteration, batch 2 x 128^3, BASELINE plan (31.2 M parameters), deep supervision, Dice+CE, '
-                         'clip 12, SGD-Nesterov; %s' % ('fp32 throughout' if precision == 'fp32' else
-                                                        'forward, data-gradient and stride-1 weight-gradient convolutions from fp16 pairs (fp32 tensors '
-                                                        'and accumulation), strided weight gradients / statistics / optimizer exact fp32' if precision == 'f16x2' else
-                                                        'bf16 matrix-core operands for the stride-1 convolutions of the wide levels '
-                                                        '(forward, data and weight gradients), fp32 master weights / statistics / optimizer'),
-                steps=iters, warmup=warmup, ms_per_step=round(1e3 * dt / iters, 3), value=round(2 * iters / dt, 3), unit='patches/s',
-                loss_first_to_last=[round(losses[0], 6), round(losses[-1], 6)], clock=cs.report(),
-                roofline=dict(bound='mfma', kernel='whole iteration (every launch of the step)', achieved=round(tflops, 2), peak=round(peak, 1),
-                              unit='TFLOP/s', frac=round(tflops / peak, 4), algorithmic_tflop_per_step=TRAIN_TFLOP_PER_ITER,
-                              note='fp32: v_mfma_f32_32x32x2_f32 peak; f16x2: 16-bit MFMA peak / 3 (three partial products: the stride-1 forward / data-gradient kernels; its weight-gradient, strided and transposed kernels form all four partial products, 4 MFMAs per 16 channels and tap) although its stride-2 weight gradients run on the fp32 '
-                                   'instruction; bf16: priced against the bf16 peak although the stride-2 layers, statistics and reductions '
-                                   'of this mode stay fp32'))
+    out = dict(workload='one nnUNetTrainerV2 iteration (forward with deep supervision, Dice+CE, backward, clip, SGD-Nesterov), batch 2 x 128^3, BASELINE plan',
+               precision=precision, steps=iters, warmup=warmup, ms_per_step=round(1e3 * dt / iters, 3), value=round(2 * iters / dt, 3), unit='patches/s',
+               loss_first_to_last=[round(losses[0], 6), round(losses[-1], 6)], clock=cs.report(),
+               # whole iteration against the mode's forward ceiling: an upper bound for f16x2 / bf16, whose weight-gradient, strided and transposed
+               # kernels form four products or stay fp32
+               roofline=dict(bound='mfma', kernel='whole iteration', achieved=round(tflops, 2), peak=round(peak, 1), peak_basis=PEAK_BASIS[precision],
+                             unit='TFLOP/s', frac=round(tflops / peak, 4), algorithmic_tflop_per_step=TRAIN_TFLOP_PER_ITER))
     add_sustained(out['roofline'], out['clock'])
     return out
 
@@ -539,13 +513,92 @@ def training_parity_tiny():
                 rows.append(float((got - ref).abs().max()) / float(ref.abs().max()))
         rows.sort()
         gn = float(torch.cat([tr.g[n].double().cpu().reshape(-1) for n, _ in net.named_parameters()]).norm())
-        out[precision] = dict(sample='tiny net (tests/golden), batch 2 x 32^3, one iteration vs float64 torch autograd on the CPU; the fixture has a '
-                                     'pre-activation 1.8e-6 from a LeakyReLU kink in a 512-voxel channel: an evaluation that rounds it to the other side '
-                                     'is ~5 % off on the parameters behind it (tests/test_gpu_trainer.py), the cosine is the robust figure',
-                              loss=l, oracle_loss=float(loss.detach()), gradient_rel_l2_err=(num / max(den, 1e-30)) ** 0.5,
+        out[precision] = dict(sample='tiny net, batch 2 x 32^3, one iteration vs float64 autograd', loss=l, oracle_loss=float(loss.detach()), gradient_rel_l2_err=(num / max(den, 1e-30)) ** 0.5,
                               gradient_cosine=dot / max(gn * den ** 0.5, 1e-30),
                               median_parameter_rel_max_err=rows[len(rows) // 2], worst_parameter_rel_max_err=rows[-1])
     return out
+
+def compact_line(res):
+    """The ONE printed line.  The driver keeps the last 2000 characters of stdout, so: the contract's keys, numbers only (prose lives in
+    DESIGN.md, the full record in --detail-file), and LAST a `summary` that holds every mode's headline figure."""
+    def pick(d, *keys):
+        return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+    r = res.get('roofline') or {}
+    also = res.get('also') or {}
+    line = pick(res, 'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling')
+    line['vs_baseline'] = res.get('vs_baseline')
+    line.update(pick(res, 'dtype', 'data'))
+    line['config'] = pick(res.get('config', {}), 'workload', 'tta', 'patch', 'step', 'batch', 'volumes_per_step', 'weights', 'parallelism')
+    rl = pick(r, 'bound', 'kernel', 'achieved', 'peak', 'peak_basis', 'unit', 'frac')
+    rl['traffic'] = r.get('traffic')
+    if r.get('traffic') is not None:
+        rl['traffic_source'] = 'separate rocprofv3 --pmc passes (profiles/pmc_traffic.json), not this run'
+    rl.update(pick(r, 'launches', 'avg_launch_ms', 'algorithmic_gflop_per_launch', 'algorithmic_gbytes_per_launch', 'share_of_step_time'))
+    ik = r.get('in_kernel')
+    if isinstance(ik, dict) and 'sclk_mhz' in ik:
+        rl['in_kernel'] = pick(ik, 'sclk_mhz', 'mfma_issue_share', 'phases')
+    line['roofline'] = rl
+    if res.get('cpu_baseline'):
+        line['cpu_baseline'] = pick(res['cpu_baseline'], 'value', 'unit', 'cores', 'kind', 'sample')
+    if res.get('clock'):
+        line['clock'] = pick(res['clock'], 'sclk_mhz_median', 'socket_power_w_median')
+    line.update(pick(res, 'end_to_end_tflops'))
+    if res.get('hbm_whole_path'):
+        line['hbm_whole_path_frac'] = res['hbm_whole_path'].get('frac')
+
+    rnd = lambda v, n=4: None if v is None else float(('%.' + str(n) + 'g') % v)
+    summary = {}
+    name = {'f16x2': 'configs1_f16x2', 'fp32': 'configs1_fp32_exact'}.get(res.get('precision'), 'configs2_bf16')
+    summary[name] = rnd(res.get('value'))
+    frac, pmax, mism, sclk = {name: r.get('frac')}, {}, {}, {name: (res.get('clock') or {}).get('sclk_mhz_median')}
+    if 'fp32_exact' in also:
+        summary['configs1_fp32_exact'] = rnd(also['fp32_exact'].get('value'))
+        frac['configs1_fp32_exact'] = also['fp32_exact']['roofline'].get('frac')
+        sclk['configs1_fp32_exact'] = (also['fp32_exact'].get('clock') or {}).get('sclk_mhz_median')
+        po = also['fp32_exact'].get('parity_vs_oracle')
+        if po:
+            pmax['fp32_exact_vs_oracle'] = rnd(po['max_abs_softmax_err'], 3)
+            mism['fp32_exact_vs_oracle'] = [po['argmax_mismatches'], po['argmax_mismatches_any_margin']]
+    if 'configs2_bf16_storage' in also:
+        c2 = also['configs2_bf16_storage']
+        summary['configs2_bf16'] = rnd(c2.get('value'))
+        frac['configs2_bf16'] = c2['roofline'].get('frac')
+        sclk['configs2_bf16'] = (c2.get('clock') or {}).get('sclk_mhz_median')
+        pf = c2.get('parity_vs_fp32_path')
+        if pf:
+            pmax['configs2_bf16_vs_fp32_path'] = rnd(pf['max_abs_softmax_diff'], 3)
+            summary['configs2_dice_vs_fp32_mask'] = rnd(pf['dice_vs_fp32_mask'], 6)
+    tm, tpar = {}, {}
+    for prec in ('fp32', 'f16x2', 'bf16'):
+        t = also.get('train_' + prec)
+        if t:
+            tm[prec] = rnd(t['ms_per_step'])
+            frac['train_' + prec] = t['roofline'].get('frac')
+            if t.get('parity'):
+                tpar[prec] = rnd(t['parity']['gradient_rel_l2_err'], 3)
+    if tm:
+        summary['train_ms'] = tm
+    if tpar:
+        summary['train_gradient_rel_l2_vs_float64_tiny_net'] = tpar
+    par = res.get('parity')
+    if par and 'max_abs_softmax_err' in par:
+        pmax[('f16x2' if res.get('precision') == 'f16x2' else res.get('precision', 'mode')) + '_vs_oracle'] = rnd(par['max_abs_softmax_err'], 3)
+        if 'argmax_mismatches_any_margin' in par:
+            mism[('f16x2' if res.get('precision') == 'f16x2' else res.get('precision', 'mode')) + '_vs_oracle'] = [par['argmax_mismatches'], par['argmax_mismatches_any_margin']]
+    pf = res.get('parity_vs_fp32_path')
+    if pf:
+        pmax[name + '_vs_fp32_path'] = rnd(pf['max_abs_softmax_diff'], 3)
+    if pmax:
+        summary['parity_max_abs'] = pmax
+    if mism:
+        summary['argmax_mismatches_outside_2e-4_margin_and_any'] = mism
+    summary['frac'] = {k: v for k, v in frac.items() if v is not None}
+    summary['sclk_mhz'] = {k: v for k, v in sclk.items() if v is not None}
+    if res.get('cpu_baseline'):
+        summary['cpu_volumes_per_s'] = rnd(res['cpu_baseline']['value'], 3)
+    line['summary'] = summary                      # last key: it must survive the driver's 2000-character tail
+    return line
+
 
 # ------------------------------------------------------------------------------------------------------------
 def run_rank(args):
@@ -655,10 +708,10 @@ def run_rank(args):
         vols_rank = args.steps * V                      # volumes this rank queued in the timed region
         gb_vol = acct['bytes'] / vols_rank / 1e9 + AGG_GBYTES_PER_VOLUME
         dtype = ('f32' if args.precision == 'fp32' else
-                 'f32 tensors and accumulate / products from fp16 pairs (two fp16 per operand, 21-22 significant bits)' if args.precision == 'f16x2' else
+                 'f32 (tensors, accumulation; 3x3x3 products from fp16 hi+lo pairs, 21-22 significant bits)' if args.precision == 'f16x2' else
                  'bf16 operands / f32 accumulate+storage' if args.storage == 'fp32' else
-                 'bf16 operands and activation tensors / f32 accumulate')
-        res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=nvol / dt,
+                 'bf16 operands and tensors / f32 accumulate')
+        res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', precision=args.precision, value=nvol / dt,
                    unit='volumes/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='strong' if by_patch else 'weak',
                    vs_baseline=None, dtype=dtype, data='synthetic',
@@ -695,7 +748,7 @@ def run_rank(args):
             # every other mode on the driver's record: short runs, same protocol, after the headline's timed region
             also = {}
             m, e32, vd32, vh32 = measure_inference_mode(plan, sd, device, 'fp32', 'fp32', 1, 3, 1, tta, args.shape, None)
-            m['workload'] = 'configs[1] on the exact-fp32 kernels (v_mfma_f32_32x32x2_f32), mirroring %s' % ('on' if tta else 'off')
+            m['workload'] = 'configs[1] on the exact-fp32 kernels, mirroring %s' % ('on' if tta else 'off')
             m['dtype'] = 'f32'
             also['fp32_exact'] = m
             p32 = SlidingWindowPredictor(e32, do_mirroring=tta, batch=8)
@@ -741,7 +794,16 @@ def run_rank(args):
             res['cpu_baseline'], res['parity'], px = cpu_baseline(plan, sd, vols_h[0].numpy(), tta, args.cpu_baseline, gpu_nt, lg, extra_nt)
             for k, v in px.items():
                 res['also'][k]['parity_vs_oracle'] = v
-        print(json.dumps(res), flush=True)
+        detail = args.detail_file
+        if detail == 'auto':
+            detail = os.path.join(ROOT, 'gpurun_out', 'bench_detail.json') if os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else None
+        if detail:
+            try:
+                with open(detail, 'w') as f:
+                    json.dump(res, f, indent=1)
+            except OSError:
+                pass
+        print(json.dumps(compact_line(res)), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0

@@ -5,6 +5,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('WMH_LIB_PATH', os.path.join(_HERE, 'lib', 'libdeepwmh_amd.so'))   # override: diagnostic builds
+# the same sources with -DWMH_DIAG (cycle stamps in the kernels, WMH_* variant switches from the environment): tools and a few tests only
+DIAG_LIB_PATH = os.path.join(_HERE, 'lib', 'libdeepwmh_amd_diag.so')
 
 _vp, _i, _f, _sz, _d = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_double
 _ip = C.POINTER(C.c_int)
@@ -80,6 +82,7 @@ SIGNATURES = {
     'wmh_conv3d_k3_wgrad_f16x2': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_wgrad_f16x2_stamp_count': (_sz, [_i, _i, _i, _i, _i, _i]),
     'wmh_debug_set_conv_stamps': (None, [_vp]),
+    'wmh_diag_build': (_i, []),
     'wmh_conv3d_k3_wgrad_f16x2_stamped': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     'wmh_convtranspose3d_packed_dwords_f16x2': (_sz, [_i, _i, _i]),
     'wmh_convtranspose3d_pack_weights_f16x2_device': (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -144,6 +147,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_diag = None
 
 
 class WMHError(RuntimeError):
@@ -170,6 +174,24 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def load_diag():
+    """The diagnostic library as a SECOND handle beside the product library (bench.py's in-kernel clock leg, tools/): same ABI."""
+    global _diag
+    if _diag is None:
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise ImportError('deepwmh_amd: %s not found (python deepwmh_amd/build.py builds it next to the product library)' % DIAG_LIB_PATH)
+        import torch  # noqa: F401
+        lib = C.CDLL(DIAG_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.wmh_diag_build() != 1:
+            raise ImportError('%s was not compiled with -DWMH_DIAG' % DIAG_LIB_PATH)
+        _diag = lib
+    return _diag
 
 
 def check(rc, what=''):

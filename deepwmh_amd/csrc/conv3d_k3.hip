@@ -172,7 +172,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
 
     // ---- prologue ---------------------------------------------------------------------------------
     unsigned long long t_begin = 0, t_loop = 0, t_epi = 0;
-    if (a.stamps) t_begin = __builtin_amdgcn_s_memtime();
+    if (WMH_STAMPS(a)) t_begin = __builtin_amdgcn_s_memtime();
     load_chunk(ch_lo);
 #pragma unroll
     for (int d = 0; d < APF; ++d) loadA(ch_lo * C::NTAPS + d, aring[d]);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
         }
         if (!(ABL & 16)) __syncthreads();     // next buffer fully written, this one fully read
     };
-    if (a.stamps) t_loop = __builtin_amdgcn_s_memtime();
+    if (WMH_STAMPS(a)) t_loop = __builtin_amdgcn_s_memtime();
     {
         int ch = ch_lo;
         for (; ch + 1 < ch_hi; ch += 2) {
@@ -239,11 +239,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv3d_k3_kernel(const ConvArgs
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
-    if (a.stamps) t_epi = __builtin_amdgcn_s_memtime();
+    if (WMH_STAMPS(a)) t_epi = __builtin_amdgcn_s_memtime();
     conv_epilogue<C, OUT16>(a, acc, g, ks, n0 + tn_w, wave, j, kh, dx, dy, dz, ts0, oz0, oy0, ox0, (tz * a.nty + ty) * a.ntx + tx);
-    if (a.stamps && tid == 0) {
+    if (WMH_STAMPS(a) && tid == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-        unsigned long long* o = a.stamps + (size_t)blockIdx.x * 4;
+        unsigned long long* o = WMH_STAMPS(a) + (size_t)blockIdx.x * 4;
         o[0] = t_loop - t_begin; o[1] = t_epi - t_loop; o[2] = t_end - t_epi; o[3] = (unsigned long long)(ch_hi - ch_lo);
     }
 }
@@ -403,13 +403,20 @@ static const CfgInfo& cfg_info(int cfg) {
 }
 unsigned long long* g_conv_stamps = nullptr;       // diagnostics: also read by the bf16 launcher
 // diagnostics: device buffer of 4 x uint64 per workgroup that the next conv launches fill (NULL = off)
+// (libdeepwmh_amd_diag.so only: the product library has no stamp code in its kernels, wmh_common.h)
 extern "C" void wmh_debug_set_conv_stamps(void* p) { g_conv_stamps = (unsigned long long*)p; }
-static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+extern "C" int wmh_diag_build(void) {
+#ifdef WMH_DIAG
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 template <class C>
 static int launch_conv(const ConvArgs& a, unsigned nblk, hipStream_t st) {
     static bool attr_set = false;
-    static const int lds_extra = env_int("WMH_LDS_EXTRA", 0);   // experiments: limit residency
+    static const int lds_extra = wmh_diag_env("WMH_LDS_EXTRA", 0);   // experiments: limit residency
     const int lds = C::LDS_FLOATS * 4 + lds_extra;
     if (!attr_set) {
         if (lds > 48 * 1024)
@@ -437,7 +444,7 @@ static int launch_variant(const ConvArgs& a0, hipStream_t st) {
 }
 template <int ABL>
 static int launch_abl(const ConvArgs& a, unsigned nblk, hipStream_t st) {
-    const int lds = Cfg0::LDS_FLOATS * 4 + env_int("WMH_LDS_EXTRA", 0);
+    const int lds = Cfg0::LDS_FLOATS * 4 + wmh_diag_env("WMH_LDS_EXTRA", 0);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_kernel<Cfg0, ABL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL((conv3d_k3_kernel<Cfg0, ABL>), dim3(nblk), dim3(Cfg0::THREADS), lds, st, a);
@@ -555,7 +562,7 @@ extern "C" int wmh_conv3d_k3_pack_weights_device(int cfg, const float* w, int Ci
 
 // split-K factor for a launch: only the small, under-filled layers split
 static int pick_ksplit(const CfgInfo& c, long long nblk, int nchunks) {
-    static const int force = env_int("WMH_KSPLIT", 0);
+    static const int force = wmh_diag_env("WMH_KSPLIT", 0);
     if (force > 0) return force < nchunks ? force : nchunks;
     if (nblk >= 512) return 1;
     int ks = (int)((1024 + nblk - 1) / nblk);
@@ -602,7 +609,7 @@ static int conv_fwd(int cfg, const float* x0, const float* ss0, int C0, const fl
     if ((size_t)a.Do * a.Ho * a.Wo * 4 * 32 >= ((size_t)1 << 32)) return wmh_fail(WMH_EINVAL, "conv3d_k3: 32 output channel planes must stay below 4 GB (epilogue lane offsets are 32-bit)");
     a.slope = lrelu_slope;
     a.G = cdiv(Cout, 32 * c.NT);
-    static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
+    static const int swz_env = wmh_diag_env("WMH_XCD_SWIZZLE", 1);
     a.xcd_swizzle = swz_env;
     a.stamps = g_conv_stamps;
     a.by = a.bz = 1;
@@ -615,7 +622,7 @@ static int conv_fwd(int cfg, const float* x0, const float* ss0, int C0, const fl
     hipStream_t st = (hipStream_t)stream;
     if (in16 || out16) a.KS = 1, nblk = tiles;               // bf16 tensors: no split-K slabs
     if (a.KS > 1) a.y = workspace;
-    static const int use_ws = env_int("WMH_WS", 1);   // wave-specialised persistent form: +4 % on the large layers
+    static const int use_ws = wmh_diag_env("WMH_WS", 1);   // wave-specialised persistent form: +4 % on the large layers
     int rc;
     // the wave-specialised form moves aligned 16-byte quads on 32-bit lane offsets and writes LeakyReLU as max(t, slope t)
     const bool ws_ok = (W % 4) == 0 && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && (!x1 || (reinterpret_cast<uintptr_t>(x1) & 15) == 0) &&
@@ -628,7 +635,7 @@ static int conv_fwd(int cfg, const float* x0, const float* ss0, int C0, const fl
         if (cfg != 1 || out16 || !ws_ok) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_st: bf16 sources are implemented for config 1 (W % 4 == 0, aligned) only");
         return wmh_launch_conv_ws_in16(cfg, a, st);
     }
-    static const int first_env = env_int("WMH_FIRST_TAPS", 1);      // 0: the general kernel for the one-channel first layer too (diagnostics)
+    static const int first_env = wmh_diag_env("WMH_FIRST_TAPS", 1);      // 0: the general kernel for the one-channel first layer too (diagnostics)
     const bool first = cfg == 8 && C0 == 1 && C1 == 0 && first_env;
     if (out16) {
         if (cfg != 8) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_st: a bf16 output is implemented for config 8 only");
@@ -645,9 +652,9 @@ static int conv_fwd(int cfg, const float* x0, const float* ss0, int C0, const fl
         return wmh_launch_conv_ws(cfg, a, st);
     }
 #ifdef WMH_DIAG_ABLATIONS
-    static const int abl = env_int("WMH_ABL", 0);
+    static const int abl = wmh_diag_env("WMH_ABL", 0);
     if (cfg == 0 && abl) return launch_cfg0_ablation(abl, a, (unsigned)nblk, st);
-    static const int var = env_int("WMH_VARIANT", 0);
+    static const int var = wmh_diag_env("WMH_VARIANT", 0);
     if (cfg == 0 && var == 1) return launch_variant<Cfg0v1>(a, st);
     if (cfg == 0 && var == 2) return launch_variant<Cfg0v2>(a, st);
     if (cfg == 0 && var == 3) return launch_variant<Cfg0v3>(a, st);

@@ -116,9 +116,9 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
     for (int d = 0; d < APF; ++d) loadA(ch_lo, d, aring[d]);
 
     const char* ldsb = reinterpret_cast<const char*>(ldsq);
-    unsigned long long t_stage = 0, t_mfma = 0, t_mark = 0;          // diagnostics (a.stamps != NULL only)
+    unsigned long long t_stage = 0, t_mfma = 0, t_mark = 0;          // diagnostics (WMH_STAMPS(a) != NULL only)
     for (int ch = ch_lo; ch < ch_hi; ++ch) {
-        if (a.stamps) t_mark = __builtin_amdgcn_s_memtime();
+        if (WMH_STAMPS(a)) t_mark = __builtin_amdgcn_s_memtime();
         // ---- stage 16 input channels of the halo tile -------------------------------------------------------
         const int cb = ch * CKB;
         const float* xs; const float* ss; int Cs, c0;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
             }
         }
         __syncthreads();
-        if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
+        if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
         // ---- 27 taps x MT x NT MFMAs -----------------------------------------------------------------------------
         // The B operands of step + 1 are read BEFORE the MFMAs of step are issued (sched_barrier pins them): a wave issues in order and
         // an MFMA holds the issue until the pipe takes it, so a read placed in front of its own use -- the compiler's schedule -- waits
@@ -235,9 +235,9 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
             for (int nt = 0; nt < NT; ++nt) aring[APF - 1][nt] = anew[nt];
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mfma += t - t_mark; }
+        if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mfma += t - t_mark; }
     }
-    if (a.stamps) t_mark = __builtin_amdgcn_s_memtime();
+    if (WMH_STAMPS(a)) t_mark = __builtin_amdgcn_s_memtime();
     if constexpr (PAIR) {                                   // undo the weights' 2^8 (exact; split-K slabs hold unscaled partial sums)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -245,8 +245,8 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
             for (int m = 0; m < MT; ++m) acc[nt][m] *= (1.f / WMH_PAIR_WSCALE);
     }
     if (!(abl & 2)) conv_epilogue<C>(a, acc, g, ks, n0, wave, j, kh, dx, dy, dz, ts0, oz0, oy0, ox0, (tz * a.nty + ty) * a.ntx + tx);
-    if (a.stamps && tid == 0) {
-        unsigned long long* o = a.stamps + (size_t)blockIdx.x * 4;
+    if (WMH_STAMPS(a) && tid == 0) {
+        unsigned long long* o = WMH_STAMPS(a) + (size_t)blockIdx.x * 4;
         o[0] = t_stage; o[1] = t_mfma; o[2] = __builtin_amdgcn_s_memtime() - t_mark; o[3] = (unsigned long long)(ch_hi - ch_lo);
     }
 }
@@ -255,14 +255,13 @@ __global__ __launch_bounds__(C::THREADS, (C::THREADS > 256 ? 4 : 2)) void conv3d
 extern unsigned long long* g_conv_stamps;
 int wmh_launch_conv_bf16_ws(int cfg, const ConvArgs& a, hipStream_t st, int in16, int out16);      // conv3d_k3_bf16_ws.hip
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> BCfg0;      // same tile geometry as the fp32 Cfg0 / Cfg2
 typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> BCfg2;
 // The kernel is bound by memory latency, not by the matrix cores: the same tiles cut into 8 waves of 4 (cfg 0) / 2 (cfg 2)
 // M-tiles halve the accumulator registers, so two workgroups = 16 waves fit a CU and twice as many loads are in flight.
 typedef ConvCfg<1, 32, 1, 4, 8, 1, 4, 1, 4, 6> BCfg0w;
 typedef ConvCfg<1, 16, 2, 2, 16, 1, 2, 2, 4, 6> BCfg2w;
-static int bf16_variant() { static const int v = env_int("WMH_BF16_WAVES8", 0); return v; }
+static int bf16_variant() { static const int v = wmh_diag_env("WMH_BF16_WAVES8", 0); return v; }
 
 static inline unsigned short f2bf(float f) {
     unsigned u; memcpy(&u, &f, 4);
@@ -299,8 +298,8 @@ static BGeo bf16_geo(int cfg, bool w8) {
 }
 // The configuration wmh_conv3d_k3_fwd_bf16 should be called with, given the one wmh_conv3d_config chose for the layer
 extern "C" int wmh_conv3d_k3_bf16_config(int cfg, int Cout, int W) {
-    static const int wide = env_int("WMH_BF16_WIDE", 1);
-    static const int use_ws = env_int("WMH_BF16_WS", 1);
+    static const int wide = wmh_diag_env("WMH_BF16_WIDE", 1);
+    static const int use_ws = wmh_diag_env("WMH_BF16_WS", 1);
     if (cfg == 0 && wide && use_ws && bf16_variant() == 0 && Cout % 64 == 0 && W % 4 == 0) return WMH_BF16_CFG_WIDE;
     return cfg;
 }
@@ -483,7 +482,7 @@ static int launch_bf16(const ConvArgs& a, unsigned nblk, hipStream_t st) {
 // grids are one workgroup per CU or less and every chunk iteration ends in a barrier, so nothing hides the staging latency;
 // with the channel reduction cut into slabs several workgroups share a CU.  Same rule as the fp32 path's pick_ksplit.
 static int bf16_ksplit(long long nblk, int nchunks) {
-    static const int force = env_int("WMH_KSPLIT", 0);
+    static const int force = wmh_diag_env("WMH_KSPLIT", 0);
     if (force > 0) return force < nchunks ? force : nchunks;
     if (nblk >= 512) return 1;
     int ks = (int)((1024 + nblk - 1) / nblk);
@@ -529,15 +528,15 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
     a.slope = lrelu_slope;
     a.G = cdiv(Cout, 32 * NT);
     a.KS = 1;
-    static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
-    static const int abl_env = env_int("WMH_BF16_ABL", 0);
+    static const int swz_env = wmh_diag_env("WMH_XCD_SWIZZLE", 1);
+    static const int abl_env = wmh_diag_env("WMH_BF16_ABL", 0);
     a.xcd_swizzle = (swz_env & 1) | (abl_env << 4);
     a.stamps = g_conv_stamps;
     a.by = a.bz = 1;
     const long long nblk = (long long)a.ntx * a.nty * a.ntz * N * a.G;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    static const int use_ws = env_int("WMH_BF16_WS", 1);
+    static const int use_ws = wmh_diag_env("WMH_BF16_WS", 1);
     // the wave-specialised form loads aligned 16-byte quads: rows must start 16-byte aligned
     const bool quad_ok = (W % 4) == 0 && (size_t)16 * D * H * W * 4 < ((size_t)1 << 32) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && (!x1 || (reinterpret_cast<uintptr_t>(x1) & 15) == 0);
     if (small) {
@@ -610,8 +609,8 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     a.slope = lrelu_slope;
     a.G = cdiv(Cout, 32 * NT);
     a.KS = 1;
-    static const int swz_env = env_int("WMH_XCD_SWIZZLE", 1);
-    static const int abl_x = env_int("WMH_BF16_ABL", 0);      // diagnostics (timing only): see the one-role kernel
+    static const int swz_env = wmh_diag_env("WMH_XCD_SWIZZLE", 1);
+    static const int abl_x = wmh_diag_env("WMH_BF16_ABL", 0);      // diagnostics (timing only): see the one-role kernel
     a.xcd_swizzle = (swz_env & 1) | (small ? abl_x << 4 : 0);
     a.stamps = g_conv_stamps;
     a.by = a.bz = 1;

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         // cout group pg of that tile.  Kept as counters: `q / nch`, `q % nch` and tile_of() per chunk were ~400 scalar
         // instructions of the ~1700 a loader wave issues per chunk -- and the loader's instruction count is what bounds it.
         int pq = 0, pk = 0, pc = 0, pg = 0;
-        unsigned long long t_issue = 0, t_conv = 0;      // diagnostics (a.stamps): loads issued / conversion + LDS writes
+        unsigned long long t_issue = 0, t_conv = 0;      // diagnostics (WMH_STAMPS(a)): loads issued / conversion + LDS writes
         auto group_of = [&](int k) __attribute__((always_inline)) {
             int g, tx, ty, tz, n0;
             tile_of(blockIdx.x + k * gridDim.x, g, tx, ty, tz, n0);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         auto step = [&](auto hc, int buf) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value, hn = h + RS - 1;
             unsigned long long ts0 = 0;
-            if (a.stamps) ts0 = __builtin_amdgcn_s_memtime();
+            if (WMH_STAMPS(a)) ts0 = __builtin_amdgcn_s_memtime();
             if constexpr (hn < NHS) {
                 issue(std::integral_constant<int, hn>{}, pc);
             } else {
@@ -296,9 +296,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 if constexpr (hn == NHS) { if (nc == 0) setup(blockIdx.x + nk * gridDim.x); }   // first half-slot of the next chunk: maybe a new tile
                 issue(std::integral_constant<int, hn - NHS>{}, nc);
             }
-            if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_issue += t - ts0; ts0 = t; }
+            if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_issue += t - ts0; ts0 = t; }
             convert(hc, buf);
-            if (a.stamps) t_conv += __builtin_amdgcn_s_memtime() - ts0;
+            if (WMH_STAMPS(a)) t_conv += __builtin_amdgcn_s_memtime() - ts0;
         };
         auto produce = [&](int buf) __attribute__((always_inline)) {                          // chunk (pk, pc)
             load_ss();                                        // before the next tile's setup(): n0_cur is still this chunk's
@@ -327,22 +327,22 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             write_w();
         }
         __syncthreads();
-        unsigned long long tw = 0, tb = 0, t0 = 0, twl = 0;  // diagnostics (a.stamps != NULL): work / barrier wait / work next to an epilogue
+        unsigned long long tw = 0, tb = 0, t0 = 0, twl = 0;  // diagnostics (WMH_STAMPS(a) != NULL): work / barrier wait / work next to an epilogue
         for (int it = 0; it < total; ++it) {
             advance();                                       // the chunk written during this iteration: it + 1 (the last iteration
                                                              // repeats the last chunk into the buffer nobody reads any more)
-            if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+            if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
             produce((it + 1) & 1);
-            if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; if (pc == (nch > 1 ? 1 : 0)) twl += t - t0; t0 = t; }
+            if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; if (pc == (nch > 1 ? 1 : 0)) twl += t - t0; t0 = t; }
             __syncthreads();                                 // consumers are done with chunk `it`: its weights may go
             write_w();
             __syncthreads();
-            if (a.stamps) tb += __builtin_amdgcn_s_memtime() - t0;
+            if (WMH_STAMPS(a)) tb += __builtin_amdgcn_s_memtime() - t0;
         }
-        if (a.stamps && tid == 256) {
-            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+        if (WMH_STAMPS(a) && tid == 256) {
+            unsigned long long* o = WMH_STAMPS(a) + (size_t)blockIdx.x * 8;
             o[4] = tw; o[5] = tb; o[6] = twl;
-            unsigned long long* o2 = a.stamps + (size_t)(gridDim.x + blockIdx.x) * 8;     // second record block
+            unsigned long long* o2 = WMH_STAMPS(a) + (size_t)(gridDim.x + blockIdx.x) * 8;     // second record block
             o2[0] = t_issue; o2[1] = t_conv;               // twl: iterations whose consumers start with the previous tile's epilogue
         }
     } else {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 }
             for (int ch = 0; ch < nch; ++ch, ++it) {
                 const char* cur = ldsb + (size_t)(it & 1) * CS * 32;
-                if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+                if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
                 // Taps are processed in the order (kd, kw, kr) -- wmh_tap_of(), the one-role kernel's order too -- three kr taps per
                 // (kd, kw) group: their weight fragments are read together (9 exposed LDS latencies per chunk instead of 27: the
                 // compiler reads a tap's fragments right in front of its first MFMA), and an input row is read once for the up to
@@ -548,12 +548,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                     }
                   }
                 }
-                if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
+                if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
                 __syncthreads();
                 __syncthreads();                             // the loaders swap the weight fragments in between
-                if (a.stamps) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; tb += d; if (ch == 0) tbl += d; }
+                if (WMH_STAMPS(a)) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; tb += d; if (ch == 0) tbl += d; }
             }
-            if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+            if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
             if constexpr (PAIR) {                               // undo the weights' 2^8 (exact)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -562,10 +562,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             }
             conv_epilogue<C, OUT16>(a, acc, g, 0, n0, wave, j, kh, dx, dy, dz, ts0, tz * C::TZ, ty * C::TY, tx * C::TX,
                              (tz * a.nty + ty) * a.ntx + tx);
-            if (a.stamps) te += __builtin_amdgcn_s_memtime() - t0;
+            if (WMH_STAMPS(a)) te += __builtin_amdgcn_s_memtime() - t0;
         }
-        if (a.stamps && tid == 0) {
-            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+        if (WMH_STAMPS(a) && tid == 0) {
+            unsigned long long* o = WMH_STAMPS(a) + (size_t)blockIdx.x * 8;
             o[0] = tm; o[1] = tb; o[2] = te; o[3] = (unsigned long long)total; o[7] = tbl;   // tbl: barrier wait of a tile's first chunk
         }
     }
@@ -593,7 +593,7 @@ static int launch_bf16_ws(const ConvArgs& a_in, hipStream_t st) {
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 bf16 (wave-specialised): too many tiles");
     const int grid = T < ncu ? (int)T : ncu;
     ConvArgs a = a_in;
-    static const int supertile = getenv("WMH_SUPERTILE") ? atoi(getenv("WMH_SUPERTILE")) : 1;
+    static const int supertile = wmh_diag_env("WMH_SUPERTILE", 1);
     if (supertile && (a.xcd_swizzle & 1)) wmh_pick_supertile(a, C::TY, C::TZ, grid / 8 > 0 ? grid / 8 : 1);
     hipLaunchKernelGGL((conv3d_k3_bf16_ws_kernel<C, IN16, OUT16, PAIR>), dim3(grid), dim3(512), lds, st, a, (int)T);
     return wmh_check_launch("conv3d_k3_bf16_ws_kernel");

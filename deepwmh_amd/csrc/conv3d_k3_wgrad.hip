@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
 struct WgradPlan { int TX, TY, TZ, IZ, IY, IX, ntx, nty, ntz, ntiles, NG, NCG, P, dys, xcs, lds_bytes; };
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static bool wgrad_old_form() {
-    static const bool v = getenv("WMH_WGRAD_OLD") != nullptr;      // diagnostic: the unpipelined kernel
+    static const bool v = wmh_diag_env_set("WMH_WGRAD_OLD");      // diagnostic: the unpipelined kernel
     return v;
 }
 static WgradPlan plan_wgrad(int Cin, int Cout, int N, int D, int H, int W, int S, int KZ = 3, int SZ = 0) {

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
     const size_t DHW = (size_t)a.D * HW;
 
     unsigned long long st_work = 0, st_wait = 0, st_t = 0;
-    const bool stamping = a.stamps != nullptr;
+    const bool stamping = WMH_STAMPS(a) != nullptr;
 
     if (wave < 4) {
         // ---------------------------------------------------------------- consumers: MFMAs only
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
                 }
             }
         }
-        if (stamping && lane == 0 && wave == 0) { a.stamps[blockIdx.x * 4 + 0] = st_work; a.stamps[blockIdx.x * 4 + 1] = st_wait; }
+        if (stamping && lane == 0 && wave == 0) { WMH_STAMPS(a)[blockIdx.x * 4 + 0] = st_work; WMH_STAMPS(a)[blockIdx.x * 4 + 1] = st_wait; }
         return;
     }
 
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
             if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_wait += t - st_t; st_t = t; }
         }
     }
-    if (stamping && lane == 0 && wave == 4) { a.stamps[blockIdx.x * 4 + 2] = st_work; a.stamps[blockIdx.x * 4 + 3] = st_wait; }
+    if (stamping && lane == 0 && wave == 4) { WMH_STAMPS(a)[blockIdx.x * 4 + 2] = st_work; WMH_STAMPS(a)[blockIdx.x * 4 + 3] = st_wait; }
 }
 
 __global__ __launch_bounds__(256) void wgrad_f16x2_reduce_kernel(const float* part, float* dW, size_t n, int P) {
@@ -414,10 +414,10 @@ static int wgrad_f16x2_impl(const float* x0, const float* ss0, int C0, const flo
     a.N = N; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.Cin = Cin;
     a.ntx = q.ntx; a.nty = q.nty; a.ntz = q.ntz; a.ntiles = q.ntiles; a.NG = q.NG; a.NCG = q.NCG; a.P = q.P;
     a.order = q.order; a.m = q.m; a.q = q.q; a.nk = q.nk; a.slope = lrelu_slope; a.stamps = stamps;
-    if (getenv("WMH_WGRAD_PLAIN_ORDER")) { a.order = 0; }      // diagnostic: x -> y -> z tile order
+    if (wmh_diag_env_set("WMH_WGRAD_PLAIN_ORDER")) { a.order = 0; }      // diagnostic: x -> y -> z tile order
     const unsigned nblk = (unsigned)(q.NG * q.NCG * q.P);
     hipStream_t st = (hipStream_t)stream;
-    static const bool four = getenv("WMH_WGRAD_LOADERS4") != nullptr;   // diagnostic: 4 loader waves instead of 8
+    static const bool four = wmh_diag_env_set("WMH_WGRAD_LOADERS4");   // diagnostic: 4 loader waves instead of 8
     const int rc = four ? (q.TX == 32 ? launch_wp<32, 4, 2, 4>(a, nblk, st) : launch_wp<16, 8, 2, 4>(a, nblk, st))
                         : (q.TX == 32 ? launch_wp<32, 4, 2, 8>(a, nblk, st) : launch_wp<16, 8, 2, 8>(a, nblk, st));
     if (rc != WMH_OK) return rc;
@@ -439,5 +439,8 @@ extern "C" size_t wmh_conv3d_k3_wgrad_f16x2_stamp_count(int Cin, int Cout, int N
 extern "C" int wmh_conv3d_k3_wgrad_f16x2_stamped(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
                                                  float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope,
                                                  unsigned long long* stamps, void* stream) {
+#ifndef WMH_DIAG
+    if (stamps) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2_stamped: cycle stamps exist in libdeepwmh_amd_diag.so only");
+#endif
     return wgrad_f16x2_impl(x0, ss0, C0, x1, ss1, C1, dy, dW, workspace, N, D, H, W, Cout, lrelu_slope, stamps, stream);
 }

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_ws_kernel(const ConvArgs a, 
     // compile-time constants and every branch on them folds away.
 #ifdef WMH_DIAG_ABLATIONS
     const int dbg_ = dbg;
-    unsigned long long* const stamps_ = a.stamps;
+    unsigned long long* const stamps_ = WMH_STAMPS(a);
 #else
     constexpr int dbg_ = 0;
     constexpr unsigned long long* stamps_ = nullptr;
@@ -306,10 +306,10 @@ static int launch_ws(const ConvArgs& a_in, hipStream_t st) {
     const int ncu = ws_num_cus();
     const int grid = T < ncu ? (int)T : ncu;
     ConvArgs a = a_in;
-    static const int supertile = getenv("WMH_SUPERTILE") ? atoi(getenv("WMH_SUPERTILE")) : 1;
+    static const int supertile = wmh_diag_env("WMH_SUPERTILE", 1);
     if (supertile && a.xcd_swizzle) wmh_pick_supertile(a, C::TY, C::TZ, grid / 8 > 0 ? grid / 8 : 1);
 #ifdef WMH_DIAG_ABLATIONS
-    static const int dbg = getenv("WMH_WS_DBG") ? atoi(getenv("WMH_WS_DBG")) : 0;
+    static const int dbg = wmh_diag_env("WMH_WS_DBG", 0);
 #else
     const int dbg = 0;
 #endif

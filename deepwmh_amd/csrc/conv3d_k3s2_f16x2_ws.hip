@@ -116,7 +116,7 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
                 }
             const int g_next = group_of(k + 1);
             for (int ch = 0; ch < nch; ++ch, ++q) {
-                if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+                if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
                 const char* cur = ldsb + (size_t)(q & 1) * SPP * 32;
                 // this chunk's fragments and the next one's (the next tile's first chunk behind the last; past the end: re-read, never used)
                 const char* wc = wbytes + ((size_t)g * nch + ch) * CHB;
@@ -160,18 +160,18 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
                     for (int nt = 0; nt < NT; ++nt) aring[APF - 1][nt] = anew[nt];
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
+                if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
                 __syncthreads();                                // this chunk is consumed, the next one is staged
-                if (a.stamps) tb += __builtin_amdgcn_s_memtime() - t0;
+                if (WMH_STAMPS(a)) tb += __builtin_amdgcn_s_memtime() - t0;
             }
-            if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+            if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt][0] *= (1.f / WMH_PAIR_WSCALE);      // undo the weights' 2^8 (exact)
             conv_epilogue<C>(a, acc, g, 0, n0, wave, j, kh, dx, 0, 0, ts0, tz * C::TZ, ty * C::TY, tx * C::TX, (tz * a.nty + ty) * a.ntx + tx);
-            if (a.stamps) te += __builtin_amdgcn_s_memtime() - t0;
+            if (WMH_STAMPS(a)) te += __builtin_amdgcn_s_memtime() - t0;
         }
-        if (a.stamps && tid == 0) {
-            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+        if (WMH_STAMPS(a) && tid == 0) {
+            unsigned long long* o = WMH_STAMPS(a) + (size_t)blockIdx.x * 8;
             o[0] = tm; o[1] = tb; o[2] = te; o[3] = (unsigned long long)total;
         }
         return;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
         for (int h = 0; h < 2; ++h) {                           // iteration q + h: the consumers are on chunk q + h (buffer h)
             const int qq = q + h;
             if (qq >= total) break;
-            if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+            if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
             // chunk qq + 2 is fetched into the set chunk qq came from, then chunk qq + 1 (fetched during the previous iteration, set
             // h ^ 1) is converted into the other buffer
             const bool cv = qq + 1 < total, is = qq + 2 < total;
@@ -291,13 +291,13 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
 #pragma unroll
                 for (int i = 0; i < NITL; ++i) convert(h ^ 1, h ^ 1, i);
             }
-            if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; t0 = t; }
+            if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; t0 = t; }
             __syncthreads();
-            if (a.stamps) tbw += __builtin_amdgcn_s_memtime() - t0;
+            if (WMH_STAMPS(a)) tbw += __builtin_amdgcn_s_memtime() - t0;
         }
     }
-    if (a.stamps && lane == 0 && wave == 4) {
-        unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+    if (WMH_STAMPS(a) && lane == 0 && wave == 4) {
+        unsigned long long* o = WMH_STAMPS(a) + (size_t)blockIdx.x * 8;
         o[4] = tw; o[5] = tbw;
     }
 }
@@ -321,7 +321,7 @@ int wmh_launch_conv_s2_f16x2_ws(const ConvArgs& a_in, hipStream_t st) {
         return wmh_fail(WMH_EINVAL, "conv3d_k3 stride 2 f16x2 (wave-specialised): a sample of the source must stay below 4 GB (32-bit buffer offsets)");
     const int grid = T < ncu ? (int)T : ncu;
     ConvArgs a = a_in;
-    static const int supertile = getenv("WMH_SUPERTILE") ? atoi(getenv("WMH_SUPERTILE")) : 1;
+    static const int supertile = wmh_diag_env("WMH_SUPERTILE", 1);
     if (supertile && (a.xcd_swizzle & 1)) wmh_pick_supertile(a, S2Cfg::TY, S2Cfg::TZ, grid / 8 > 0 ? grid / 8 : 1);
     hipLaunchKernelGGL(conv3d_k3s2_f16x2_ws_kernel, dim3(grid), dim3(768), lds, st, a, (int)T);
     return wmh_check_launch("conv3d_k3s2_f16x2_ws_kernel");

@@ -230,7 +230,7 @@ extern "C" int wmh_convtranspose3d_fwd_f16x2(const float* x, const float* ss, co
     constexpr int NT = 2, CKC = 32;
     // 64 voxels per workgroup, four workgroups per CU (measured: 0.78 / 0.22 / 0.09 ms for the three wide levels at batch 8 against
     // 0.82 / 0.26 / 0.10 with 128 voxels and two workgroups; WMH_CONVT_MT=4 selects the latter)
-    static const int MT = (getenv("WMH_CONVT_MT") && atoi(getenv("WMH_CONVT_MT")) == 4) ? 4 : 2;
+    static const int MT = wmh_diag_env("WMH_CONVT_MT", 2) == 4 ? 4 : 2;
     ConvTPArgs a;
     a.x = x; a.ss = ss; a.wf = static_cast<const unsigned*>(wf); a.y = y; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     a.nrg = ctp_cdiv((long long)Cout * 4 * kt, 256);
@@ -241,7 +241,7 @@ extern "C" int wmh_convtranspose3d_fwd_f16x2(const float* x, const float* ss, co
     const int lds = 2 * (CKC / 4) * MT * 32 * 16;
     // streaming stores: 0.82 -> 0.78 ms for the 2 GB output of the full-resolution level in isolation, nothing in the network (the
     // next convolution's loaders wait for HBM either way): off unless WMH_CONVT_NTS=1
-    static const bool nts = getenv("WMH_CONVT_NTS") && atoi(getenv("WMH_CONVT_NTS")) != 0;
+    static const bool nts = wmh_diag_env("WMH_CONVT_NTS", 0) != 0;
     if (kt == 2 && MT == 4 && nts) hipLaunchKernelGGL((convT_k2s2_f16x2_kernel<NT, 4, CKC, 2, true>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
     else if (kt == 2 && MT == 2 && nts) hipLaunchKernelGGL((convT_k2s2_f16x2_kernel<NT, 2, CKC, 2, true>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);
     else if (kt == 2 && MT == 2) hipLaunchKernelGGL((convT_k2s2_f16x2_kernel<NT, 2, CKC, 2>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, a);

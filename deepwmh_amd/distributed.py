@@ -49,10 +49,13 @@ class OverlappedGradientAverager:
     sends what is left, waits, checks that every parameter was sent exactly once, and divides by the world size.
     Reduction results do not depend on how the arena was cut (an element-wise sum over ranks)."""
 
-    def __init__(self, flat_grads, ranges, group=None, min_elems=1 << 20):
-        """ranges: {parameter name: (start, end)} element ranges in flat_grads (disjoint; may include alignment padding)."""
+    def __init__(self, flat_grads, ranges, group=None, min_elems=1 << 20, force_collective=False):
+        """ranges: {parameter name: (start, end)} element ranges in flat_grads (disjoint; may include alignment padding).
+        force_collective: issue the all-reduces at world size 1 too (a sum over one rank: the identity) -- the single-GPU rehearsal of
+        the multi-GPU run (tests/test_gpu_rccl.py): RCCL's kernels then run beside the persistent convolution kernels of the backward
+        pass exactly as they will on a node."""
         self.flat, self.ranges, self.group, self.min_elems = flat_grads, dict(ranges), group, int(min_elems)
-        self.active = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.active = dist.is_initialized() and (dist.get_world_size(group) > 1 or bool(force_collective))
         self.world = dist.get_world_size(group) if self.active else 1
         self.begin()
 
@@ -94,7 +97,7 @@ class OverlappedGradientAverager:
         assert self.sent == sum(hi - lo for lo, hi in self.ranges.values())
         for w in self.works:
             w.wait()
-        if self.active:
+        if self.active and self.world > 1:
             self.flat.div_(self.world)
         self.begin()
         return self.flat
@@ -109,9 +112,12 @@ class PatchShardedPredictor:
       zeros(shape) / accumulate(agg, tile, origin) / count_map(A, origins) / finalize(agg, cnt, pad_lo, V)
     """
 
-    def __init__(self, backend, group=None):
+    def __init__(self, backend, group=None, force_collective=False):
+        """force_collective: at world size 1 still go through the exchange step (all_gather_into_tensor over the one rank, asynchronous,
+        alternating buffers) instead of the serial shortcut: the single-GPU rehearsal of configs[3] (tests/test_gpu_rccl.py)."""
         self.b = backend
         self.group = group
+        self.force = bool(force_collective) and dist.is_initialized()
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
@@ -130,7 +136,8 @@ class PatchShardedPredictor:
         W, r = self.world, self.rank
         rounds = (len(origins) + W - 1) // W
         agg = self.b.zeros((K,) + A)
-        send, recv = self._exchange_buffers(W, K, P) if W > 1 else (None, None)
+        collective = W > 1 or self.force
+        send, recv = self._exchange_buffers(W, K, P) if collective else (None, None)
 
         def drain(item):                                     # round rd's tiles, in the fixed global patch order
             work, gathered, rd = item
@@ -144,7 +151,7 @@ class PatchShardedPredictor:
         pending = None
         for rd in range(rounds):
             idx = rd * W + r
-            if W > 1:
+            if collective:
                 # this round's forwards run while the previous round's all-gather is still on the wire; the exchange buffers
                 # alternate (round rd-2, the last user of this pair, was drained one iteration ago)
                 mine = send[rd & 1]

@@ -457,15 +457,17 @@ class UNetTrainer:
         if self._avg is not None:
             self._avg.ready(names)
 
-    def backward(self, targets, group=None):
+    def backward(self, targets, group=None, force_collective=False):
         """targets: list of uint8 device tensors [N, spatial] per scale (full resolution first).  Fills the
         gradient arena and returns the device scalar holding the loss.  Under torch.distributed the arena is averaged
         over the ranks on the way: each parameter group's all-reduce starts as soon as its gradient is complete and
         runs next to the rest of the backward pass (distributed.OverlappedGradientAverager; with one process it only
         checks that every parameter's gradient was produced exactly once)."""
         from .distributed import OverlappedGradientAverager
-        if self._avg is None or self._avg.group is not group:
-            self._avg = OverlappedGradientAverager(self.grads, self.grad_ranges, group, min_elems=2 * 1024 * 1024)   # >= 8 MB per message
+        if self._avg is None or self._avg.group is not group or getattr(self._avg, 'forced', False) != bool(force_collective):
+            self._avg = OverlappedGradientAverager(self.grads, self.grad_ranges, group, min_elems=2 * 1024 * 1024,   # >= 8 MB per message
+                                                   force_collective=force_collective)
+            self._avg.forced = bool(force_collective)
         self._avg.begin()
         self._update_loss_scale()
         lib, st, tape = self.lib, self._st(), self.tape

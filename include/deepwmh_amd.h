@@ -280,7 +280,10 @@ int wmh_conv3d_k3_wgrad_bf16_supported(int Cin, int Cout, int N, int D, int H, i
 size_t wmh_conv3d_k3_wgrad_bf16_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
 int wmh_conv3d_k3_wgrad_bf16(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
                              float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
-/* Diagnostics: with a non-NULL buffer (device memory, 8 x 8 bytes per workgroup and zero-filled by the caller; 2 x grid records for
+/* 1 in libdeepwmh_amd_diag.so (the same sources compiled with -DWMH_DIAG: s_memtime stamps in the persistent kernels, WMH_* environment
+ * switches that select kernel variants), 0 in libdeepwmh_amd.so, the product, which contains neither. */
+int wmh_diag_build(void);
+/* Diagnostics (effective in libdeepwmh_amd_diag.so only; the product's kernels hold no stamp code): with a non-NULL buffer (device memory, 8 x 8 bytes per workgroup and zero-filled by the caller; 2 x grid records for
  * the wave-specialised 16-bit kernels) the persistent convolution kernels launched afterwards add s_memtime cycle counts per workgroup:
  * [0] the first consumer wave's MFMA phases, [1] its barrier waits, [2] its epilogues, [3] chunk iterations, [4..6] a loader wave's work /
  * barrier wait / work beside an epilogue.  s_memtime counts shader-clock cycles, so [0]+[1]+[2] over the launch's duration is the clock the

@@ -65,7 +65,8 @@ def test_roofline_block_follows_the_mode(precision, storage):
     r = bench.roofline_block([(0, _Ev(0.0), _Ev(ms), flop, nbytes)] * 3, precision, storage, dt=1.0)
     assert 0 < r['frac'] <= 1.0 and 0 < r['mfma_frac'] <= 1.0 and 0 < r['hbm_frac'] <= 1.0
     assert r['peak'] in (bench.PEAK_TFLOPS[precision], bench.HBM_PEAK_GBS)
-    assert ('bf16' in r['kernel']) == (precision == 'bf16')
+    assert ('bf16' in r['kernel'] or 'cl_conv3' in r['kernel']) == (precision == 'bf16')
+    assert 'peak_basis' in r or r['bound'] == 'hbm'      # which ceiling the fraction is priced against
     if precision == 'fp32':
         assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - flop / 6.9e-3 / 157.3e12) < 1e-3
     if (precision, storage) == ('bf16', 'fp32'):
@@ -103,4 +104,45 @@ def test_clock_sampler_without_a_device(tmp_path):
     assert rep['sclk_mhz_median'] == 1870 and rep['socket_power_w_median'] == 1250 and rep['samples'] >= 1
     r = dict(bound='mfma', frac=0.5, peak=bench.PEAK_TFLOPS['f16x2'])
     bench.add_sustained(r, rep)
-    assert abs(r['frac_at_sustained_clock'] - 0.5 * 2400 / 1870) < 1e-3 and 'pure_mfma_stream' in r
+    assert abs(r['frac_at_sustained_clock'] - 0.5 * 2400 / 1870) < 1e-3
+
+
+def test_the_printed_line_ends_with_a_summary_that_fits_the_drivers_tail():
+    """the driver keeps the last 2000 characters of stdout; every mode's headline number must be inside them."""
+    import json
+    mode = lambda v, f, c: dict(value=v, roofline=dict(frac=f), clock=dict(sclk_mhz_median=c))
+    res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', precision='f16x2', value=4.8047795683388745, unit='volumes/s',
+               n_gpus=1, steps=20, warmup=5, ms_per_step=208.12609314889414, higher_is_better=True, scaling='weak', vs_baseline=None,
+               dtype='f32 (tensors, accumulation; 3x3x3 products from fp16 hi+lo pairs, 21-22 significant bits)', data='synthetic',
+               config=dict(workload=bench.workload_string(bench.parse_args([]), True, 64, 1), tta=True, patch=[128, 128, 128], step=0.5, batch=16,
+                           volumes_per_step=1, weights='random He-init (seed 0)', timed_region='long text that stays in the detail file ' * 5,
+                           parallelism='volumes sharded over ranks, no collective'),
+               roofline=dict(bound='mfma', kernel=bench.KERNEL_NAME['f16x2'], achieved=334.37, peak=833.3, peak_basis=bench.PEAK_BASIS['f16x2'],
+                             unit='TFLOP/s', frac=0.4012, traffic=12733424941, traffic_measured='prose ' * 30, launches=240, avg_launch_ms=7.3987,
+                             algorithmic_gflop_per_launch=2473.901, algorithmic_gbytes_per_launch=10.0217, share_of_step_time=0.4266,
+                             in_kernel=dict(sclk_mhz=1450, mfma_issue_share=0.65, phases=dict(mfma=0.77, barrier_wait=0.04, epilogue=0.19), layer='prose ' * 20)),
+               clock=dict(sclk_mhz_median=1811, socket_power_w_median=1284, samples=80), end_to_end_tflops=293.6, hbm_whole_path=dict(frac=0.15),
+               cpu_baseline=dict(value=0.00385619295185118, unit='volumes/s', cores=128, kind='port', sample='whole volume WITHOUT mirroring timed end to end '
+                                 '(32.7 s: 8 forwards 32.4 s + aggregation 0.3 s); value = 1 / (that with the forwards x 8 for mirroring)'),
+               parity=dict(max_abs_softmax_err=1.1146068572998047e-05, argmax_mismatches=0, argmax_mismatches_any_margin=2),
+               parity_vs_fp32_path=dict(max_abs_softmax_diff=3.8e-6, dice_vs_fp32_mask=1.0),
+               also=dict(fp32_exact=dict(mode(2.175, 0.882, 2393), parity_vs_oracle=dict(max_abs_softmax_err=1.4e-5, argmax_mismatches=0, argmax_mismatches_any_margin=1)),
+                         configs2_bf16_storage=dict(mode(12.97, 0.43, 1960), parity_vs_fp32_path=dict(max_abs_softmax_diff=0.0203, dice_vs_fp32_mask=0.998596)),
+                         train_fp32=dict(ms_per_step=59.006, roofline=dict(frac=0.617), parity=dict(gradient_rel_l2_err=1.1e-6)),
+                         train_f16x2=dict(ms_per_step=31.779, roofline=dict(frac=0.2163), parity=dict(gradient_rel_l2_err=1.2e-6)),
+                         train_bf16=dict(ms_per_step=26.809, roofline=dict(frac=0.0854), parity=dict(gradient_rel_l2_err=0.086))))
+    line = bench.compact_line(res)
+    text = json.dumps(line)
+    assert list(line)[-1] == 'summary'
+    tail = text[-(2000 - 120):]                            # the driver appends a short stderr line to the tail
+    start = tail.index('"summary"')
+    sm = json.loads(tail[start + len('"summary": '):-1])
+    assert sm['configs1_f16x2'] == 4.805 and sm['configs1_fp32_exact'] == 2.175 and sm['configs2_bf16'] == 12.97
+    assert sm['train_ms'] == {'fp32': 59.01, 'f16x2': 31.78, 'bf16': 26.81} and sm['frac']['configs1_f16x2'] == 0.4012
+    assert sm['parity_max_abs']['f16x2_vs_oracle'] == 1.11e-05 and sm['parity_max_abs']['fp32_exact_vs_oracle'] == 1.4e-05
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+                'roofline', 'cpu_baseline'):
+        assert key in line
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(line['roofline'])
+    assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(line['cpu_baseline'])
+    assert len(text) < 3200 and 'prose' not in text

@@ -170,3 +170,40 @@ def test_overlapped_gradient_averaging_single_process_is_a_checked_no_op():
     ov.ready(['a'])
     with pytest.raises(RuntimeError):
         ov.finish()
+
+
+def _forced_worker(rank, world, port, golden, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from deepwmh_amd.distributed import OverlappedGradientAverager
+    from deepwmh_amd.plan import tiny_plan
+    from oracle.generic_unet import unet_from_plan
+    plan = tiny_plan(patch=32, base=4, num_pool=3, max_feat=32)
+    sd = dict(np.load(os.path.join(golden, 'tiny_net_weights.npz')))
+    net = unet_from_plan(plan).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    io = np.load(os.path.join(golden, 'tiny_net_io.npz'))
+    vol = torch.from_numpy(io['volume'])
+    plain = PatchShardedPredictor(OracleTileBackend(net, plan.patch_size, False))
+    forced = PatchShardedPredictor(OracleTileBackend(net, plan.patch_size, False), force_collective=True)
+    assert not plain.force and forced.force
+    (s0, p0), (s1, p1) = plain.predict(vol), forced.predict(vol)
+    assert torch.equal(p0, p1) and torch.equal(s0, s1)
+    g = torch.arange(1500, dtype=torch.float32) + 1
+    ov = OverlappedGradientAverager(g.clone(), {'a': (0, 400), 'b': (400, 1500)}, None, min_elems=300, force_collective=True)
+    assert ov.active and ov.world == 1
+    ov.ready(['b']); ov.ready(['a'])
+    assert torch.equal(ov.finish(), g)                       # a sum over one rank, not divided
+    np.save(out, p1.numpy())
+    dist.destroy_process_group()
+
+
+def test_force_collective_at_world_size_one_gloo(golden_dir, tmp_path, tiny_io):
+    """the switch that makes the one-rank case go through all_gather_into_tensor / async all_reduce (the GPU test
+    tests/test_gpu_rccl.py runs it on a one-rank RCCL group); here on gloo: same bits as the serial shortcut and as the oracle."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'prob.npy')
+    mp.spawn(_forced_worker, args=(1, port, golden_dir, out), nprocs=1, join=True)
+    prob = np.load(out)
+    assert np.array_equal(prob, tiny_io['prob_notta']) or float(np.abs(prob - tiny_io['prob_notta']).max()) <= 2e-6

@@ -431,9 +431,12 @@ def test_seghead_softmax_mirror_accumulate_and_finalize(lib):
 
 
 def test_wave_specialised_form_is_bit_identical(tmp_path):
-    """The persistent loader/consumer form of the conv (WMH_WS=1: 32- and 16-wide rows, stride 1 and 2, given a tile per CU)
-    must reproduce the one-role kernel bit for bit (same arithmetic, same k order).  Split-K is pinned off for the
-    comparison (it changes the summation order); the switches are read once per process, hence subprocesses."""
+    """The persistent loader/consumer form of the conv (the product's choice for 32- and 16-wide rows, stride 1 and 2, given a tile per
+    CU) must reproduce the one-role kernel bit for bit (same arithmetic, same k order).  The one-role kernel for these shapes and the
+    split-K pin (split-K changes the summation order) are variant switches, which exist in the diagnostic library only
+    (csrc/wmh_common.h): product library without switches against libdeepwmh_amd_diag.so with WMH_WS=0, both with split-K pinned off
+    where the product would split -- hence WMH_KSPLIT=1 through the diagnostic library on both sides for the reference run, and the
+    product run compared on the cases it does not split."""
     import os
     import subprocess
     import sys
@@ -462,13 +465,19 @@ def test_wave_specialised_form_is_bit_identical(tmp_path):
         "    torch.cuda.synchronize(); res_y.append(y.cpu().numpy().ravel()); res_p.append(part.cpu().numpy().ravel()); res_p.append(np.array([cfg], np.float32))\n"
         "np.save(sys.argv[1], np.concatenate(res_y)); np.save(sys.argv[2], np.concatenate(res_p))\n") % root
     outs = []
-    for ws in ('0', '1'):
+    from deepwmh_amd import _lib
+    for ws in ('0', '1', 'product'):
         f1, f2 = str(tmp_path / ('y%s.npy' % ws)), str(tmp_path / ('p%s.npy' % ws))
-        r = subprocess.run([sys.executable, '-c', script, f1, f2], env=dict(os.environ, WMH_WS=ws, WMH_KSPLIT='1'), capture_output=True, text=True)
+        env = dict(os.environ) if ws == 'product' else dict(os.environ, WMH_LIB_PATH=_lib.DIAG_LIB_PATH, WMH_WS=ws, WMH_KSPLIT='1')
+        r = subprocess.run([sys.executable, '-c', script, f1, f2], env=env, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append((np.load(f1), np.load(f2)))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert float(np.abs(outs[0][0]).max()) > 0.1
+    # the product library (no switches: wave-specialised, its own split-K decision) gives the same OUTPUTS up to the summation order of
+    # the layers it splits, and the same bits on the ones it does not
+    assert outs[2][0].shape == outs[1][0].shape
+    assert float(np.abs(outs[2][0] - outs[1][0]).max()) <= 2e-5 * float(np.abs(outs[1][0]).max())
 
 
 BF16_SMALL_CASES = [(2, 32, 0, 64, 8, 8, 8, 1), (1, 48, 16, 32, 5, 9, 7, 1), (2, 32, 0, 64, 16, 16, 16, 2), (1, 16, 0, 32, 9, 13, 15, 2),
@@ -535,9 +544,10 @@ def test_conv3d_k3_bf16_small_rows_and_strided(lib, case):
 
 
 def test_bf16_wave_specialised_form_is_bit_identical(tmp_path):
-    """conv3d_k3_bf16_ws.hip (loader / consumer waves, persistent, default) against the one-role bf16 kernel (WMH_BF16_WS=0):
-    same arithmetic and k order, so outputs and InstanceNorm partials must agree bit for bit.  Two sources, channel tails,
-    ragged tiles, both tile geometries (32-wide rows and 16-wide rows); the switch is read once per process."""
+    """conv3d_k3_bf16_ws.hip (loader / consumer waves, persistent: what the product library runs) against the one-role bf16 kernel
+    (libdeepwmh_amd_diag.so with WMH_BF16_WS=0 -- variant switches exist in the diagnostic library only): same arithmetic and k order,
+    so outputs and InstanceNorm partials must agree bit for bit.  Two sources, channel tails, ragged tiles, both tile geometries
+    (32-wide rows and 16-wide rows)."""
     import os
     import subprocess
     import sys
@@ -564,9 +574,11 @@ def test_bf16_wave_specialised_form_is_bit_identical(tmp_path):
         "    torch.cuda.synchronize(); outs += [y.cpu().numpy().ravel(), part.cpu().numpy().ravel(), np.array([cfg], np.float32)]\n"
         "np.save(sys.argv[1], np.concatenate(outs))\n") % root
     res = []
+    from deepwmh_amd import _lib
     for ws in ('0', '1'):
         f1 = str(tmp_path / ('y%s.npy' % ws))
-        r = subprocess.run([sys.executable, '-c', script, f1], env=dict(os.environ, WMH_BF16_WS=ws), capture_output=True, text=True)
+        env = dict(os.environ, WMH_LIB_PATH=_lib.DIAG_LIB_PATH, WMH_BF16_WS='0') if ws == '0' else dict(os.environ)     # '1': the product library
+        r = subprocess.run([sys.executable, '-c', script, f1], env=env, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(np.load(f1))
     assert res[0].shape == res[1].shape and np.array_equal(res[0], res[1])

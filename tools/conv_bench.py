@@ -9,7 +9,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from deepwmh_amd import _lib  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.load_diag() if (os.environ.get('WMH_STAMPS') or os.environ.get('WMH_DIAG_LIB')) else _lib.load()   # stamps and variant switches: diagnostic library only
 B = int(os.environ.get('WMH_BATCH', '8'))
 REPS = int(os.environ.get('WMH_REPS', '5'))
 # name, C0, C1, Cout, D(in), stride

@@ -8,7 +8,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from deepwmh_amd import _lib  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.load_diag() if (os.environ.get('WMH_STAMPS') or os.environ.get('WMH_DIAG_LIB')) else _lib.load()   # stamps and variant switches: diagnostic library only
 P = _lib.ptr
 B = int(os.environ.get('WMH_BATCH', '8'))
 LAYERS = [('enc0.1', 32, 0, 32, 128), ('dec4.0', 32, 32, 32, 128), ('enc1.1', 64, 0, 64, 64), ('dec3.0', 64, 64, 64, 64),

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepwmh_amd import _lib  # noqa: E402
-lib = _lib.load()
+lib = _lib.load_diag() if (os.environ.get('WMH_STAMPS') or os.environ.get('WMH_DIAG_LIB')) else _lib.load()   # stamps and variant switches: diagnostic library only
 P = _lib.ptr
 
 

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from deepwmh_amd import _lib  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.load_diag() if (os.environ.get('WMH_STAMPS') or os.environ.get('WMH_DIAG_LIB') or os.environ.get('WMH_WGRAD_PLAIN_ORDER')) else _lib.load()   # stamps and variant switches: diagnostic library only
 P = _lib.ptr
 n = 256 * 1024 * 1024
 a = torch.randn(n, device='cuda')

@@ -42,7 +42,7 @@ def workspace(lib, mode, Cin, Cout, N, D, H, W):
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_diag() if (os.environ.get('WMH_STAMPS') or os.environ.get('WMH_DIAG_LIB')) else _lib.load()   # stamps: diagnostic library only
     dev = 'cuda'
     g = torch.Generator().manual_seed(5)
     # accuracy on a layer float64 autograd finishes quickly
