@@ -126,10 +126,13 @@ def test_convtranspose_data_gradient_on_the_strided_pair_kernels(lib, shape):
         assert lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(wd), Cs, Ci, 0, Cs, 1, P(wf), None) != 0
 
 
-def test_cycle_stamps_of_the_pair_kernel_leave_the_results_alone(lib):
-    """wmh_debug_set_conv_stamps: the persistent kernels add s_memtime cycle counts per workgroup to the caller's buffer (bench.py derives
-    the clock the CUs ran at from them); the convolution's output is bit-identical with and without, and clearing the hook stops the writes."""
+def test_cycle_stamps_exist_in_the_diagnostic_library_only_and_leave_the_results_alone(lib):
+    """wmh_debug_set_conv_stamps: in libdeepwmh_amd_diag.so (-DWMH_DIAG) the persistent kernels add s_memtime cycle counts per workgroup to
+    the caller's buffer (bench.py derives the clock the CUs ran at from them); the product library's kernels hold no stamp code, so the hook
+    does nothing there.  The convolution's output is bit-identical across the two libraries, with and without stamps."""
     from deepwmh_amd import _lib
+    dlib = _lib.load_diag()
+    assert lib.wmh_diag_build() == 0 and dlib.wmh_diag_build() == 1
     P = _lib.ptr
     N, C, S = 2, 32, 32
     g = torch.Generator(device='cuda').manual_seed(3)
@@ -142,25 +145,32 @@ def test_cycle_stamps_of_the_pair_kernel_leave_the_results_alone(lib):
     _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(w), C, C, 0, C, 0, P(wf), None), 'pack')
     part = torch.empty(N, C, lib.wmh_conv3d_k3_num_partials_f16x2(cfg, N, S, S, S), 4, device='cuda')
 
-    def run():
+    def run(which):
         y = torch.full((N, C, S, S, S), float('nan'), device='cuda')
-        _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(x), P(ss), C, None, None, 0, P(wf), None, P(y), P(part), None, N, S, S, S, C, 0.01, None), 'f16x2')
+        rc = which.wmh_conv3d_k3_fwd_f16x2(cfg, P(x), P(ss), C, None, None, 0, P(wf), None, P(y), P(part), None, N, S, S, S, C, 0.01, None)
+        assert rc == 0
         torch.cuda.synchronize()
         return y
-    plain = run()
+    plain = run(lib)
     stamps = torch.zeros(4096 * 8, dtype=torch.int64, device='cuda')
-    lib.wmh_debug_set_conv_stamps(C_void(stamps))
+    lib.wmh_debug_set_conv_stamps(C_void(stamps))                    # product library: no stamp code in the kernels
     try:
-        stamped = run()
+        assert torch.equal(plain, run(lib)) and int(stamps.abs().sum()) == 0
     finally:
         lib.wmh_debug_set_conv_stamps(None)
+    assert torch.equal(plain, run(dlib))                             # same arithmetic in the diagnostic build
+    dlib.wmh_debug_set_conv_stamps(C_void(stamps))
+    try:
+        stamped = run(dlib)
+    finally:
+        dlib.wmh_debug_set_conv_stamps(None)
     assert torch.equal(plain, stamped)
     st = stamps.view(-1, 8).cpu().numpy()
     used = st[st[:, 3] > 0]
     assert len(used) > 0 and (used[:, 0] > 0).all()                  # MFMA-phase cycles of every workgroup that had chunks to do
     assert ((used[:, 0] + used[:, 1] + used[:, 2]) < 2e9).all()      # a 32^3 layer takes well under a second of cycles
     stamps.zero_()
-    again = run()
+    again = run(dlib)
     assert torch.equal(plain, again) and int(stamps.abs().sum()) == 0
 
 
