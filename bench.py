@@ -795,7 +795,9 @@ def run_rank(args):
             for k, v in px.items():
                 res['also'][k]['parity_vs_oracle'] = v
         detail = args.detail_file
-        if detail == 'auto':
+        if detail in ('none', 'off', ''):
+            detail = None
+        elif detail == 'auto':
             detail = os.path.join(ROOT, 'gpurun_out', 'bench_detail.json') if os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else None
         if detail:
             try:

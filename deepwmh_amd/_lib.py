@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('WMH_LIB_PATH', os.path.join(_HERE, 'lib', 'libdeepwmh_amd.so'))   # override: diagnostic builds
 # the same sources with -DWMH_DIAG (cycle stamps in the kernels, WMH_* variant switches from the environment): tools and a few tests only
-DIAG_LIB_PATH = os.path.join(_HERE, 'lib', 'libdeepwmh_amd_diag.so')
+DIAG_LIB_PATH = os.environ.get('WMH_DIAG_LIB_PATH', os.path.join(_HERE, 'lib', 'libdeepwmh_amd_diag.so'))
 
 _vp, _i, _f, _sz, _d = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_double
 _ip = C.POINTER(C.c_int)

@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 #include "conv3d_common.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -46,6 +48,28 @@ __device__ __forceinline__ float ws_vmax(float a, float b) {
 __device__ __forceinline__ float ld_uniform(const float* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<unsigned long long>(p));
 }
+
+// ---- the pair kernel's MFMA sequence (three partial products), flattened ------------------------------------------------------------
+// Per 8-channel chunk a consumer wave issues, for every output row m of its MT rows, 41 A fragments' worth of MFMAs ("groups"):
+// per (kd, kr) the three taps' [w_hi | w_hi] against [x_hi | x_lo] (pr 0..2), [w_lo(kw 0) | w_lo(kw 1)] against [x_hi(v) | x_hi(v + 1)]
+// (pr 3), and one more (pr 4) that pairs the remaining w_lo x_hi terms of kw = 2 across kr (kr 1: taps (kr 0, kw 2) | (kr 1, kw 2)),
+// across kd (kd 1, kr 2: (kd 0, kr 2, kw 2) | (kd 1, kr 2, kw 2)) or stands alone half empty (kd 2, kr 2).
+struct P3Grp { int kd, kr, pr; };
+constexpr int P3_NG = 41;
+constexpr P3Grp p3_grp(int gi) {
+    int n = 0;
+    for (int kd = 0; kd < 3; ++kd)
+        for (int kr = 0; kr < 3; ++kr)
+            for (int pr = 0; pr < 5; ++pr) {
+                if (pr == 4 && (kr == 0 || (kr == 2 && kd == 0))) continue;
+                if (n == gi) return P3Grp{kd, kr, pr};
+                ++n;
+            }
+    return P3Grp{0, 0, 0};
+}
+static_assert(p3_grp(P3_NG - 1).kd == 2 && p3_grp(P3_NG - 1).kr == 2 && p3_grp(P3_NG - 1).pr == 4, "41 groups");
+template <int... I, class F>
+__device__ __forceinline__ void p3_static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
 #ifndef WMH_BF16_WS_RING16
 #define WMH_BF16_WS_RING16(NHS) ((NHS) % 3 == 0 ? 3 : 2)
@@ -422,6 +446,59 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 #pragma unroll
                 for (int m = 0; m < MT; ++m) bR[m] = ((badr[2][m] & ~16) | (16 * ((((dx + 2) >> 3) & 1)))) + 2 * C::YS * 32 + (kh ? C::ZS * 32 : 0);
                 const bf16x8* wlr = wl + 32 + kh * (9 * NT * 64);                                            // lo piece of tap + 9 kh (next kd)
+#ifndef WMH_P3_FLAT
+#define WMH_P3_FLAT 1
+#endif
+#if WMH_P3_FLAT
+                // One flat sequence of P3_NG x MT steps, group-major: a group's A fragment(s) serve MT consecutive steps (one per output
+                // row), every step has its own B operand.  A fragments are read one group (MT steps) ahead, B operands RING steps ahead
+                // into a register ring; a step = its NT MFMAs, then the ring load that reuses its slot.  sched_barrier pins that order
+                // (left alone the compiler hoists the reads of a whole (kd, kr): scratch).  Against the step pipeline this replaces
+                // (five A fragments and five B operands, both double buffered: 80 registers, operands read 5 MFMAs ahead) the operands
+                // hold (2 NT + RING) x 4 registers and are read RING x NT MFMAs ahead.
+                constexpr int RING = NT == 1 ? 8 : 5, NSTEP = P3_NG * MT;
+                bf16x8 ring[RING], aF[2][NT];
+                auto loadA = [&](auto gc, bf16x8 (&dst)[NT]) __attribute__((always_inline)) {
+                    constexpr P3Grp G = p3_grp(decltype(gc)::value);
+                    constexpr int t0 = G.kd * 9 + G.kr * 3;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr (G.pr < 3) dst[nt] = wl[((t0 + G.pr) * NT + nt) * 64];
+                        else if constexpr (G.pr == 3) dst[nt] = wlp[(t0 * NT + nt) * 64];
+                        else if constexpr (G.kr == 1) dst[nt] = wlq[((t0 - 3 + 2) * NT + nt) * 64];          // [w_lo(kr 0, kw 2) | w_lo(kr 1, kw 2)]
+                        else if constexpr (G.kd == 1) dst[nt] = wlr[((6 + 2) * NT + nt) * 64];               // [w_lo(kd 0, kr 2, kw 2) | w_lo(kd 1, kr 2, kw 2)]
+                        else dst[nt] = wl[((t0 + 2) * NT + nt) * 64 + 32];                                    // w_lo(2, 2, 2): the upper half is zeroed at use
+                    }
+                };
+                auto loadB = [&](auto sc) __attribute__((always_inline)) -> bf16x8 {
+                    constexpr int st = decltype(sc)::value, m = st % MT;
+                    constexpr P3Grp G = p3_grp(st / MT);
+                    constexpr int off = (G.kd * C::ZS + G.kr * C::YS) * 32;
+                    if constexpr (G.pr < 3) return *reinterpret_cast<const bf16x8*>(cur + badr[G.pr][m] + off);
+                    else if constexpr (G.pr == 3) return *reinterpret_cast<const bf16x8*>(cur + bP[m] + off);
+                    else if constexpr (G.kr == 1) return *reinterpret_cast<const bf16x8*>(cur + bQ[m] + G.kd * C::ZS * 32);
+                    else if constexpr (G.kd == 1) return *reinterpret_cast<const bf16x8*>(cur + bR[m]);
+                    else return *reinterpret_cast<const bf16x8*>(cur + badr[2][m] + off);                    // [x_hi | x_lo](voxel + 2) once more
+                };
+                loadA(std::integral_constant<int, 0>{}, aF[0]);
+                p3_static_for(std::make_integer_sequence<int, RING>{}, [&](auto ic) __attribute__((always_inline)) { ring[decltype(ic)::value] = loadB(ic); });
+                __builtin_amdgcn_sched_barrier(0);
+                p3_static_for(std::make_integer_sequence<int, NSTEP>{}, [&](auto sc) __attribute__((always_inline)) {
+                    constexpr int st = decltype(sc)::value, g = st / MT, m = st % MT;
+                    constexpr P3Grp G = p3_grp(g);
+                    if constexpr (m == 0 && g + 1 < P3_NG) loadA(std::integral_constant<int, g + 1>{}, aF[(g + 1) & 1]);
+                    if constexpr (m == 0 && G.pr == 4 && G.kr == 2 && G.kd == 2) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) aF[g & 1][nt] = kh ? zero8 : aF[g & 1][nt];                  // A = [w_lo | 0]
+                    }
+                    const bf16x8 bv = ring[st % RING];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aF[g & 1][nt]), __builtin_bit_cast(f16x8, bv), acc[nt][m], 0, 0, 0);
+                    if constexpr (st + RING < NSTEP) ring[st % RING] = loadB(std::integral_constant<int, st + RING>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+#else
                 bf16x8 aH[2][3], aP[2], aS[2], bb[2][5];          // NT == 1: two sets of A fragments / B operands (the step pipeline below)
 #pragma unroll
                 for (int kd = 0; kd < 3; ++kd) {
@@ -512,6 +589,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                         }
                     }
                 }
+#endif
                 } else
 #pragma unroll
                 for (int grp = 0; grp < 9; ++grp) {

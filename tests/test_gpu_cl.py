@@ -431,3 +431,26 @@ def test_configs2_stress_eight_volumes_three_repetitions():
     print('configs[2] stress: 3 x 8 volumes bit-equal and finite; vs the fp32 path on volumes 0, 3, 7: worst Dice %.5f, max |softmax diff| %.3g'
           % (worst_dice, worst_diff))
     assert worst_dice > 0.99 and worst_diff < 5e-2
+
+
+def test_configs2_full_volume_with_mirroring_against_the_oracle_fixtures():
+    """configs[2] (channels-last bf16 tensors, bf16 matrix-core operands) at full size against the ORACLE, not only
+    against the fp32 HIP path: the whole mirrored 160x192x160 volume on both 31 M-parameter fixture networks
+    (tests/golden/fullsize_tta.npz: He init + trained-like perturbation; fullsize_tta_he.npz: plain He init, probabilities hugging 0.5 --
+    the worst case for mask agreement).  bf16 operands carry 8 significant bits, so the bound is a Dice / |dp| bound, stated here:
+    Dice >= 0.995 against the oracle's mask, max |softmax - oracle| <= 4e-2 on the fixture's lattice and margin band, mean error <= 1e-3."""
+    import os
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.plan import baseline_plan
+    from oracle.generic_unet import state_dict_numpy, unet_from_plan
+    from test_gpu_network import _fullsize_fixture_check, _state_abs_sum
+    plan = baseline_plan()
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    torch.manual_seed(0)
+    net = unet_from_plan(plan).eval()
+    G = np.load(os.path.join(golden, 'fullsize_tta_he.npz'))
+    assert abs(_state_abs_sum(net) - float(G['state_abs_sum'])) <= 1e-7 * float(G['state_abs_sum']), 'not the weights the fixture was made with'
+    eng = UNetEngine(plan, state_dict_numpy(net), 'cuda:0', precision='bf16', storage='bf16')
+    assert eng.ncl == 3
+    err, mism, mean_err, dice = _fullsize_fixture_check('fullsize_tta_he.npz', 'He-init', [('configs[2]', eng)])['configs[2]']
+    assert err <= 4e-2 and mean_err <= 1e-3 and dice >= 0.995, (err, mean_err, dice)
