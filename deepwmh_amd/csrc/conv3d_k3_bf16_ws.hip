@@ -54,6 +54,9 @@ __device__ __forceinline__ float ld_uniform(const float* p) {
 // per (kd, kr) the three taps' [w_hi | w_hi] against [x_hi | x_lo] (pr 0..2), [w_lo(kw 0) | w_lo(kw 1)] against [x_hi(v) | x_hi(v + 1)]
 // (pr 3), and one more (pr 4) that pairs the remaining w_lo x_hi terms of kw = 2 across kr (kr 1: taps (kr 0, kw 2) | (kr 1, kw 2)),
 // across kd (kd 1, kr 2: (kd 0, kr 2, kw 2) | (kd 1, kr 2, kw 2)) or stands alone half empty (kd 2, kr 2).
+#ifndef WMH_PAIR3
+#define WMH_PAIR3 1      /* 0: all four partial products, 108 MFMAs per 27 taps and 16 channels (the form until r03x) */
+#endif
 struct P3Grp { int kd, kr, pr; };
 constexpr int P3_NG = 41;
 constexpr P3Grp p3_grp(int gi) {
@@ -409,53 +412,35 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 // (kd, kw) group: their weight fragments are read together (9 exposed LDS latencies per chunk instead of 27: the
                 // compiler reads a tap's fragments right in front of its first MFMA), and an input row is read once for the up to
                 // three (kr, output row) pairs that use it.
-#ifndef WMH_PAIR3
-#define WMH_PAIR3 1
-#endif
-#ifndef WMH_PAIR3_ROWSHARE
-#define WMH_PAIR3_ROWSHARE 0
-#endif
                 if constexpr (PAIR && WMH_PAIR3) {
-                // THREE of the four partial products (w_lo x_lo, 2^-22 of a product, is not formed): per (kd, kr) and output row the
-                // three taps' [w_hi | w_hi] [x_hi | x_lo] as before, then w_lo x_hi of the taps kw = 0, 1 in ONE MFMA -- A = [w_lo(kw 0) |
-                // w_lo(kw 1)], B = [x_hi(voxel + 0) | x_hi(voxel + 1)]: both are the existing LDS images read with a different address in
-                // the upper lane half -- and w_lo x_hi of kw = 2 with A = [w_lo | 0] against the B operand already in registers.
-                // 5 MFMAs where the four-product form issues 6, from 4 operand reads per (kr, output row) where it has 1 per tap.
-                int bP[MT];                                                                                  // hi piece of voxel + kh
+                // THREE of the four partial products (w_lo x_lo, 2^-22 of a product, is not formed): the 41 groups of p3_grp().  Every operand
+                // is one of the existing LDS images read with a lane-half-dependent address: no second layout, packer or loader.
+                //   pr 0..2  A = [w_hi | w_hi](tap kw)                       B = [x_hi | x_lo](voxel + kw)
+                //   pr 3     A = [w_lo(kw 0) | w_lo(kw 1)]                   B = [x_hi(voxel) | x_hi(voxel + 1)]
+                //   pr 4     kr 1:        A = [w_lo(kr 0, kw 2) | w_lo(kr 1, kw 2)]            B = [x_hi(row, voxel + 2) | x_hi(row + 1, voxel + 2)]
+                //            kd 1, kr 2:  A = [w_lo(kd 0, kr 2, kw 2) | w_lo(kd 1, kr 2, kw 2)]  B: the upper lane half one slice (ZS) deeper
+                //            kd 2, kr 2:  A = [w_lo(2, 2, 2) | 0]                              B = [x_hi | x_lo](voxel + 2)   (half empty)
+                // 41 MFMAs per output row and 8-channel chunk where 40.5 would be every k slot used (the four-product form: 54).
+                int bP[MT], bQ[MT], bR[MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) bP[m] = kh ? ((badr[1][m] & ~16) | (16 * ((((dx + 1) >> 3) & 1)))) : badr[0][m];
+                for (int m = 0; m < MT; ++m) {
+                    bP[m] = kh ? ((badr[1][m] & ~16) | (16 * ((((dx + 1) >> 3) & 1)))) : badr[0][m];                               // hi piece of voxel + kh
+                    bQ[m] = ((badr[2][m] & ~16) | (16 * ((((dx + 2) >> 3) & 1)))) + (kh ? C::YS * 32 : 0);                          // hi piece of voxel + 2 in row + kh
+                    bR[m] = ((badr[2][m] & ~16) | (16 * ((((dx + 2) >> 3) & 1)))) + 2 * C::YS * 32 + (kh ? C::ZS * 32 : 0);         // ... in row + 2 of slice + kh
+                }
                 const bf16x8* wlp = wl + 32 + kh * (NT * 64);                                                // lo piece of tap + kh
-                const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#ifndef WMH_PAIR3_KW2
-#define WMH_PAIR3_KW2 1
-#endif
-                // (WMH_PAIR3_KW2) the w_lo x_hi terms of the taps (kr 0, kw 2) and (kr 1, kw 2) of an output row share ONE MFMA as well:
-                // A = [w_lo(kr 0, kw 2) | w_lo(kr 1, kw 2)], B = [x_hi(row, voxel + 2) | x_hi(row + 1, voxel + 2)], issued with kr = 1;
-                // only (kr 2, kw 2) keeps the half-empty [w_lo | 0] form: 14 MFMAs per (kd, output row) instead of 15 (13.5 would be all
-                // slots used).  In the explicitly pipelined NT = 1 instance: MFMA phase 13.0 k -> 12.4-12.6 k cycles per chunk; in the
-                // compiler-scheduled two-tile instances (256 VGPRs already) 13.0 k -> 13.3 k cycles -- and the bench still a little faster
-                // with it (same-box A/B: 4.881 without the pairing, 4.963 with it in the NT = 1 instance only, 4.988 in all: KW2N).
-                constexpr bool KW2N = true;
-                int bQ[MT];                                                                                  // hi piece of voxel + 2 in row + kh
-#pragma unroll
-                for (int m = 0; m < MT; ++m) bQ[m] = ((badr[2][m] & ~16) | (16 * ((((dx + 2) >> 3) & 1)))) + (kh ? C::YS * 32 : 0);
                 const bf16x8* wlq = wl + 32 + kh * (3 * NT * 64);                                            // lo piece of tap + 3 kh (next kr)
-                // ... and (kd 0, kr 2, kw 2) with (kd 1, kr 2, kw 2), issued with kd = 1: the upper lane half reads one slice (ZS) deeper;
-                // (kd 2, kr 2, kw 2) alone keeps the half-empty form: 41 MFMAs per output row and chunk (40.5 = every slot used)
-                int bR[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) bR[m] = ((badr[2][m] & ~16) | (16 * ((((dx + 2) >> 3) & 1)))) + 2 * C::YS * 32 + (kh ? C::ZS * 32 : 0);
                 const bf16x8* wlr = wl + 32 + kh * (9 * NT * 64);                                            // lo piece of tap + 9 kh (next kd)
-#ifndef WMH_P3_FLAT
-#define WMH_P3_FLAT 1
-#endif
-#if WMH_P3_FLAT
+                const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
                 // One flat sequence of P3_NG x MT steps, group-major: a group's A fragment(s) serve MT consecutive steps (one per output
                 // row), every step has its own B operand.  A fragments are read one group (MT steps) ahead, B operands RING steps ahead
                 // into a register ring; a step = its NT MFMAs, then the ring load that reuses its slot.  sched_barrier pins that order
-                // (left alone the compiler hoists the reads of a whole (kd, kr): scratch).  Against the step pipeline this replaces
-                // (five A fragments and five B operands, both double buffered: 80 registers, operands read 5 MFMAs ahead) the operands
-                // hold (2 NT + RING) x 4 registers and are read RING x NT MFMAs ahead.
+                // (left alone the compiler hoists the reads of a whole (kd, kr): scratch).  Round 3's step pipeline (a step = one (kr, output
+                // row): five A fragments and five B operands, both double buffered, 80 registers, operands read 5 MFMAs ahead) took 12.3 k
+                // cycles per chunk at 8 rows x 32 output channels, this one 11.6 k (328 MFMAs = 10.5 k of issue); the 64-channel tile 13.1 k
+                // -> 11.3 k.  What the faster issue buys in time is about half of that: the CUs run it at a lower clock (1578 -> 1519 MHz).
+                // An epilogue interleaved with the last chunk's MFMAs (profiles/r04g_interleaved_epilogue_ab.txt) saved another 4.6 % of the
+                // cycles and LOST time: clock 1440 -> 1310 MHz.  The kernel is where the part's power management lets it be.
                 constexpr int RING = NT == 1 ? 8 : 5, NSTEP = P3_NG * MT;
                 bf16x8 ring[RING], aF[2][NT];
                 auto loadA = [&](auto gc, bf16x8 (&dst)[NT]) __attribute__((always_inline)) {
@@ -498,98 +483,6 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                     if constexpr (st + RING < NSTEP) ring[st % RING] = loadB(std::integral_constant<int, st + RING>{});
                     __builtin_amdgcn_sched_barrier(0);
                 });
-#else
-                bf16x8 aH[2][3], aP[2], aS[2], bb[2][5];          // NT == 1: two sets of A fragments / B operands (the step pipeline below)
-#pragma unroll
-                for (int kd = 0; kd < 3; ++kd) {
-                    if constexpr (NT == 1) {
-                        // one step per (kr, output row): the next step's four B operands (and, at the end of a kr, the next (kd, kr)'s five
-                        // A fragments) are read before this step's five MFMAs are issued; sched_barrier keeps it that way (left alone the
-                        // compiler hoists a whole kr's operand reads: 684 bytes of scratch)
-                        auto loadA = [&](int t0, bf16x8 (&ah)[3], bf16x8& alp, bf16x8& als) __attribute__((always_inline)) {
-                            const int kr_ = (t0 / 3) % 3;
-#pragma unroll
-                            for (int kw = 0; kw < 3; ++kw) ah[kw] = wl[(t0 + kw) * 64];
-                            alp = wlp[t0 * 64];
-                            const int kd_ = t0 / 9;
-                            if (WMH_PAIR3_KW2 && kr_ == 1) als = wlq[(t0 - 3 + 2) * 64];       // [w_lo(kr 0, kw 2) | w_lo(kr 1, kw 2)]
-                            else if (WMH_PAIR3_KW2 && kr_ == 2 && kd_ == 1) als = wlr[(6 + 2) * 64];     // [w_lo(kd 0, kr 2, kw 2) | w_lo(kd 1, ...)]
-                            else if (!WMH_PAIR3_KW2 || (kr_ == 2 && kd_ == 2)) {
-                                const bf16x8 l2 = wl[(t0 + 2) * 64 + 32];
-                                als = kh ? zero8 : l2;
-                            }
-                        };
-                        auto loadB = [&](int kd_, int kr_, int m_, bf16x8 (&b)[5]) __attribute__((always_inline)) {
-                            const int off = (kd_ * C::ZS + kr_ * C::YS) * 32;
-#pragma unroll
-                            for (int kw = 0; kw < 3; ++kw) b[kw] = *reinterpret_cast<const bf16x8*>(cur + badr[kw][m_] + off);
-                            b[3] = *reinterpret_cast<const bf16x8*>(cur + bP[m_] + off);
-                            if (WMH_PAIR3_KW2 && kr_ == 1) b[4] = *reinterpret_cast<const bf16x8*>(cur + bQ[m_] + kd_ * C::ZS * 32);
-                            if (WMH_PAIR3_KW2 && kr_ == 2 && kd_ == 1) b[4] = *reinterpret_cast<const bf16x8*>(cur + bR[m_]);
-                        };
-                        if (kd == 0) { loadA(0, aH[0], aP[0], aS[0]); loadB(0, 0, 0, bb[0]); }
-#pragma unroll
-                        for (int kr = 0; kr < 3; ++kr)
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) {
-                                const int q = (kd * 3 + kr) * MT + m;             // step; A set = (kd*3+kr) & 1, B set = q & 1
-                                const int as = (kd * 3 + kr) & 1, bs = q & 1;
-                                if (m + 1 < MT) loadB(kd, kr, m + 1, bb[bs ^ 1]);
-                                else if (kd * 3 + kr < 8) {
-                                    const int nk = kd * 3 + kr + 1;
-                                    loadA(nk * 3, aH[as ^ 1], aP[as ^ 1], aS[as ^ 1]);
-                                    loadB(nk / 3, nk % 3, 0, bb[bs ^ 1]);
-                                }
-#pragma unroll
-                                for (int pr = 0; pr < 5; ++pr) {
-                                    if (WMH_PAIR3_KW2 && pr == 4 && (kr == 0 || (kr == 2 && kd == 0))) continue;   // issued with kr 1 / with kd 1
-                                    const bf16x8 aa = pr < 3 ? aH[as][pr] : (pr == 3 ? aP[as] : aS[as]);
-                                    const bf16x8 bv = pr < 3 ? bb[bs][pr] : (pr == 3 ? bb[bs][3] : ((WMH_PAIR3_KW2 && (kr == 1 || (kr == 2 && kd == 1))) ? bb[bs][4] : bb[bs][2]));
-                                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aa), __builtin_bit_cast(f16x8, bv), acc[0][m], 0, 0, 0);
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                    } else {
-#pragma unroll
-                        for (int kr = 0; kr < 3; ++kr) {
-                            const int t0 = kd * 9 + kr * 3;
-                            bf16x8 ah[3][NT], alp[NT], als[NT];
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                                for (int kw = 0; kw < 3; ++kw) ah[kw][nt] = wl[((t0 + kw) * NT + nt) * 64];
-                                alp[nt] = wlp[(t0 * NT + nt) * 64];
-                                if (KW2N && kr == 1) als[nt] = wlq[((t0 - 3 + 2) * NT + nt) * 64];
-                                else if (KW2N && kr == 2 && kd == 1) als[nt] = wlr[((6 + 2) * NT + nt) * 64];
-                                else if (!KW2N || (kr == 2 && kd == 2)) {
-                                    const bf16x8 l2 = wl[((t0 + 2) * NT + nt) * 64 + 32];
-                                    als[nt] = kh ? zero8 : l2;
-                                }
-                            }
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) {
-                                const int off = (kd * C::ZS + kr * C::YS) * 32;
-                                bf16x8 b[3];
-#pragma unroll
-                                for (int kw = 0; kw < 3; ++kw) b[kw] = *reinterpret_cast<const bf16x8*>(cur + badr[kw][m] + off);
-                                const bf16x8 bp = *reinterpret_cast<const bf16x8*>(cur + bP[m] + off);
-                                bf16x8 bq = b[2];
-                                if (KW2N && kr == 1) bq = *reinterpret_cast<const bf16x8*>(cur + bQ[m] + kd * C::ZS * 32);
-                                if (KW2N && kr == 2 && kd == 1) bq = *reinterpret_cast<const bf16x8*>(cur + bR[m]);
-#pragma unroll
-                                for (int pr = 0; pr < 5; ++pr)
-#pragma unroll
-                                    for (int nt = 0; nt < NT; ++nt) {
-                                        if (KW2N && pr == 4 && (kr == 0 || (kr == 2 && kd == 0))) continue;   // issued with kr 1 / with kd 1
-                                        const bf16x8 aa = pr < 3 ? ah[pr][nt] : (pr == 3 ? alp[nt] : als[nt]);
-                                        const bf16x8 bb = pr < 3 ? b[pr] : (pr == 3 ? bp : bq);
-                                        acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aa), __builtin_bit_cast(f16x8, bb), acc[nt][m], 0, 0, 0);
-                                    }
-                            }
-                        }
-                    }
-                }
-#endif
                 } else
 #pragma unroll
                 for (int grp = 0; grp < 9; ++grp) {
