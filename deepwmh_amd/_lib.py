@@ -34,6 +34,9 @@ SIGNATURES = {
     'wmh_conv3d_k3_packed_halfs_f16x2': (_sz, [_i, _i, _i]),
     'wmh_conv3d_k3_pack_weights_f16x2': (_i, [_i, _vp, _i, _i, _vp]),
     'wmh_conv3d_k3_pack_weights_f16x2_device': (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'wmh_conv3d_k3_pack_job_bytes': (_sz, []),
+    'wmh_conv3d_k3_pack_job_f16x2': (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'wmh_conv3d_k3_pack_weights_f16x2_batch': (_i, [_vp, _i, _vp]),
     'wmh_conv3d_k3_f16x2_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_fwd_f16x2': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_bf16_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i]),

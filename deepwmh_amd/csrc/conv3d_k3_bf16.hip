@@ -424,9 +424,17 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16_device(int cfg, const float* w, i
 // The f16x2 image on the device (training: weights change every step): modes as above, chunks of 8 input channels,
 // high parts on lanes 0-31 and low parts on lanes 32-63 of every fragment.
 // il: the interleaved image of the strided 32-row configuration (a lane holds 4 channels x (hi, lo); conv3d_k3s2_f16x2_ws.hip)
-__global__ __launch_bounds__(256) void pack_f16x2_kernel(const float* w, uint16_t* wf, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
-                                                           int NT, int NCH, size_t total, int il) {
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+struct PackJobF16x2 {                    // one weight image to (re)build: 64 bytes, plain data (the batch entry point takes an array of them)
+    const float* w; uint16_t* wf;
+    int Cin_total, Cout, ci_off, ci_cnt, mode, NT, NCH, il;
+    unsigned long long total, pad_;
+};
+static_assert(sizeof(PackJobF16x2) == 64, "PackJobF16x2 is part of the C ABI (wmh_conv3d_k3_pack_job_bytes)");
+__device__ __forceinline__ void pack_f16x2_body(const PackJobF16x2& J, size_t first, size_t stride) {
+    const float* w = J.w;
+    uint16_t* wf = J.wf;
+    const int Cin_total = J.Cin_total, Cout = J.Cout, ci_off = J.ci_off, ci_cnt = J.ci_cnt, mode = J.mode, NT = J.NT, NCH = J.NCH, il = J.il;
+    for (size_t idx = first; idx < J.total; idx += stride) {
         size_t r = idx;
         const int e = (int)(r % 8); r /= 8;
         const int lane = (int)(r % 64); r /= 64;
@@ -454,19 +462,44 @@ __global__ __launch_bounds__(256) void pack_f16x2_kernel(const float* w, uint16_
         wf[idx] = __builtin_bit_cast(uint16_t, out);
     }
 }
-extern "C" int wmh_conv3d_k3_pack_weights_f16x2_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
-                                                        uint16_t* wf, void* stream) {
+__global__ __launch_bounds__(256) void pack_f16x2_kernel(const PackJobF16x2 J) {
+    pack_f16x2_body(J, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+// every image of a training step in ONE launch: blockIdx.y = job (the step's 43 single launches were 0.6 ms of a 31 ms iteration)
+__global__ __launch_bounds__(256) void pack_f16x2_batch_kernel(const PackJobF16x2* jobs) {
+    const PackJobF16x2 J = jobs[blockIdx.y];
+    pack_f16x2_body(J, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+static int pack_job_f16x2(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode, uint16_t* wf, PackJobF16x2& J) {
     const int NT = bf16_nt(cfg);
     if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg) || !w || !wf || ci_off < 0 || ci_cnt < 1 || ci_off + ci_cnt > Cin_total || (mode != 0 && mode != 1 && mode != 2))
         return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: bad args or configuration without a f16x2 kernel");
     if (cfg == 1 && mode == 1) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: configuration 1 (stride 2) has no data-gradient image");
     if (mode == 2 && bf16_stride(cfg) != 2) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: mode 2 (transposed convolution's data gradient) is a stride-2 image");
     const int eCin = mode == 1 ? Cout : ci_cnt, eCout = mode == 1 ? ci_cnt : Cout;
-    const int NCH = cdiv(eCin, 8);
-    const size_t total = (size_t)cdiv(eCout, 32 * NT) * NCH * 27 * NT * 64 * 8;
-    unsigned nb = (unsigned)((total + 255) / 256); if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(pack_f16x2_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wf, Cin_total, Cout, ci_off, ci_cnt, mode, NT, NCH, total, cfg == 1 ? 1 : 0);
+    J.w = w; J.wf = wf; J.Cin_total = Cin_total; J.Cout = Cout; J.ci_off = ci_off; J.ci_cnt = ci_cnt; J.mode = mode; J.NT = NT;
+    J.NCH = cdiv(eCin, 8); J.il = cfg == 1 ? 1 : 0;
+    J.total = (unsigned long long)cdiv(eCout, 32 * NT) * J.NCH * 27 * NT * 64 * 8; J.pad_ = 0;
+    return WMH_OK;
+}
+extern "C" int wmh_conv3d_k3_pack_weights_f16x2_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
+                                                        uint16_t* wf, void* stream) {
+    PackJobF16x2 J;
+    const int rc = pack_job_f16x2(cfg, w, Cin_total, Cout, ci_off, ci_cnt, mode, wf, J);
+    if (rc != WMH_OK) return rc;
+    unsigned nb = (unsigned)((J.total + 255) / 256); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(pack_f16x2_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, J);
     return wmh_check_launch("pack_f16x2_kernel");
+}
+extern "C" size_t wmh_conv3d_k3_pack_job_bytes(void) { return sizeof(PackJobF16x2); }
+extern "C" int wmh_conv3d_k3_pack_job_f16x2(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode, uint16_t* wf, void* job_out) {
+    if (!job_out) return wmh_fail(WMH_EINVAL, "pack_job_f16x2: no job record");
+    return pack_job_f16x2(cfg, w, Cin_total, Cout, ci_off, ci_cnt, mode, wf, *static_cast<PackJobF16x2*>(job_out));
+}
+extern "C" int wmh_conv3d_k3_pack_weights_f16x2_batch(const void* jobs_device, int njobs, void* stream) {
+    if (!jobs_device || njobs < 1 || njobs > 65535) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_batch: bad args");
+    hipLaunchKernelGGL(pack_f16x2_batch_kernel, dim3(256, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, static_cast<const PackJobF16x2*>(jobs_device));
+    return wmh_check_launch("pack_f16x2_batch_kernel");
 }
 
 template <class C, int RIT, bool PAIR = false>

@@ -123,6 +123,13 @@ int wmh_conv3d_k3_pack_weights_f16x2(int cfg, const float* w, int Cin, int Cout,
  * 1 / 3 / 5): w is a ConvTranspose3d(k2, s2) weight [Cout][ci_cnt][2][2][2] whose data gradient is a stride-2 convolution of dY */
 int wmh_conv3d_k3_pack_weights_f16x2_device(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode,
                                              uint16_t* wf, void* stream);
+/* The same image builds as ONE launch (a training step rebuilds ~43 of them): wmh_conv3d_k3_pack_job_f16x2 validates one build exactly as
+ * wmh_conv3d_k3_pack_weights_f16x2_device does and writes its record (wmh_conv3d_k3_pack_job_bytes() bytes of plain data, host memory) into
+ * job_out; the caller copies an array of such records to the device once (the pointers inside are the w / wf it passed) and hands it to
+ * wmh_conv3d_k3_pack_weights_f16x2_batch whenever the weights have changed.  Results are bit-identical to the single launches. */
+size_t wmh_conv3d_k3_pack_job_bytes(void);
+int wmh_conv3d_k3_pack_job_f16x2(int cfg, const float* w, int Cin_total, int Cout, int ci_off, int ci_cnt, int mode, uint16_t* wf, void* job_out);
+int wmh_conv3d_k3_pack_weights_f16x2_batch(const void* jobs_device, int njobs, void* stream);
 /* Configurations 3 / 4 / 5 (rows of 16 / 8 voxels, stride 2 / 1 / 2; D, H, W = the INPUT extent) run the one-role kernel and
  * take split-K slab memory like wmh_conv3d_k3_fwd_bf16_splitk (workspace >= wmh_conv3d_k3_f16x2_workspace_floats floats, or NULL). */
 size_t wmh_conv3d_k3_f16x2_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout);

@@ -440,3 +440,40 @@ def test_f16x2_overflowing_backward_skips_the_step_and_lowers_the_scale(tiny_net
     torch.cuda.synchronize()
     assert bool(torch.isfinite(tr.clip_out[0])) and bool(torch.isfinite(tr.params).all())
     assert not torch.equal(tr.params, p0), 'with the scale back in range the optimizer steps again'
+
+
+def test_f16x2_weight_images_rebuilt_in_one_launch_equal_the_single_builds(tiny_net, tiny_io):
+    """From the second iteration on, UNetTrainer rebuilds every f16x2 weight image of a step with ONE launch
+    (wmh_conv3d_k3_pack_weights_f16x2_batch over a job table uploaded once) instead of ~43: same bits as the single builds, and two
+    iterations give the parameters of a trainer that never batches."""
+    from collections import OrderedDict
+    from deepwmh_amd.trainer import UNetTrainer, downsample_targets
+    plan, _net, sd = tiny_net
+    vol = tiny_io['volume'][0]
+    data = np.stack([vol[4:36, 8:40, 4:36], vol[8:40, 0:32, 2:34][::-1].copy()])[:, None].astype(np.float32)
+    labels = np.stack([(tiny_io['seg_tta'][4:36, 8:40, 4:36] > 0)] * 2).astype(np.uint8)
+    xd = torch.from_numpy(data).cuda()
+    td = downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
+    tr = UNetTrainer(plan, sd, 'cuda:0', precision='f16x2')
+    tr.run_iteration(xd, td, 1e-2)                          # single builds; the jobs are remembered
+    assert len(tr._x3_jobs) >= 10
+    # the images of the CURRENT parameters, built one launch each
+    singles = {}
+    for key, (cfg, w, cin, cout, ci_off, ci_cnt, mode, wf) in tr._x3_jobs.items():
+        ref = torch.empty_like(wf)
+        assert tr.lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, w.data_ptr(), cin, cout, ci_off, ci_cnt, mode, ref.data_ptr(), None) == 0
+        singles[key] = ref
+        wf.fill_(0x7e00)                                    # poison: the batch launch must rewrite every element
+    tr.repack_x3_batch()
+    torch.cuda.synchronize()
+    for key, args in tr._x3_jobs.items():
+        assert torch.equal(args[7], singles[key]), key
+    # two more iterations (batched) against a trainer whose job list is emptied before every forward (never batches)
+    tr2 = UNetTrainer(plan, sd, 'cuda:0', precision='f16x2')
+    tr2.run_iteration(xd, td, 1e-2)
+    for _ in range(2):
+        tr.run_iteration(xd, td, 1e-2)
+        tr2._x3_jobs = OrderedDict()
+        tr2.run_iteration(xd, td, 1e-2)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.params, tr2.params) and torch.equal(tr.mom, tr2.mom)
