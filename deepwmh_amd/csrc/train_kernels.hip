@@ -168,18 +168,50 @@ __device__ __forceinline__ float upstream(const BwdSrc& s, size_t nc_off, size_t
     if (s.dl) for (int k = 0; k < s.K; ++k) d = fmaf(s.wseg[k * C + c], s.dl[(n * s.K + k) * S + v], d);
     return d;
 }
-// grid (SPLIT, N*C): block (sp, nc) reduces the sp-th slice of the spatial range; partial sums per block
+// grid (SPLIT, N*C): block (sp, nc) reduces the sp-th slice of the spatial range; partial sums per block.
+// V4 (S % 4 == 0, checked by the launcher): a thread takes four consecutive voxels per step with 16-byte loads -- the dword form kept too
+// few bytes in flight per thread and left these two passes at 60-70 % of what the HBM delivers (4.0 ms of a 31 ms training iteration).
+template <bool V4>
 __global__ __launch_bounds__(256) void in_lrelu_bwd_reduce_kernel(const float* y, const float* ss, const float* mr,
                                                                   BwdSrc src, double* psums, int C, size_t S, float slope,
                                                                   int nq) {
     __shared__ double sh[4];
     const size_t nc = blockIdx.y, n = nc / C;
     const int c = (int)(nc % C);
-    const size_t chunk = (S + gridDim.x - 1) / gridDim.x;
-    const size_t v0 = (size_t)blockIdx.x * chunk, v1 = v0 + chunk < S ? v0 + chunk : S;
+    size_t chunk = (S + gridDim.x - 1) / gridDim.x;
+    if (V4) chunk = (chunk + 3) & ~(size_t)3;
+    const size_t v0 = (size_t)blockIdx.x * chunk < S ? (size_t)blockIdx.x * chunk : S, v1 = v0 + chunk < S ? v0 + chunk : S;
     const float sc = ss[2 * nc], shf = ss[2 * nc + 1], mean = mr[2 * nc], rstd = mr[2 * nc + 1];
     const float* yp = y + nc * S;
     double a0 = 0.0, a1 = 0.0, ak[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (V4) {
+        float wk[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < src.K && src.dl; ++k) wk[k] = src.wseg[k * C + c];
+        for (size_t v = v0 + 4 * (size_t)threadIdx.x; v < v1; v += 1024) {
+            const float4 y4 = *reinterpret_cast<const float4*>(yp + v);
+            float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src.g1) { const float4 t = *reinterpret_cast<const float4*>(src.g1 + nc * S + v); d4.x += t.x; d4.y += t.y; d4.z += t.z; d4.w += t.w; }
+            if (src.g2) { const float4 t = *reinterpret_cast<const float4*>(src.g2 + nc * S + v); d4.x += t.x; d4.y += t.y; d4.z += t.z; d4.w += t.w; }
+            float4 l4[4];
+            if (src.dl)
+                for (int k = 0; k < src.K; ++k) {
+                    l4[k] = *reinterpret_cast<const float4*>(src.dl + (n * src.K + k) * S + v);
+                    d4.x = fmaf(wk[k], l4[k].x, d4.x); d4.y = fmaf(wk[k], l4[k].y, d4.y); d4.z = fmaf(wk[k], l4[k].z, d4.z); d4.w = fmaf(wk[k], l4[k].w, d4.w);
+                }
+            const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, dA[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = fmaf(yv[e], sc, shf);
+                const float dz = z > 0.f ? dA[e] : dA[e] * slope;
+                const float xh = (yv[e] - mean) * rstd;
+                a0 += dz; a1 += (double)dz * xh;
+                if (src.dl) {
+                    const float act = z > 0.f ? z : z * slope;
+                    for (int k = 0; k < src.K; ++k) ak[k] += (double)act * (e == 0 ? l4[k].x : e == 1 ? l4[k].y : e == 2 ? l4[k].z : l4[k].w);
+                }
+            }
+        }
+    } else {
     for (size_t v = v0 + threadIdx.x; v < v1; v += 256) {
         const float yv = yp[v];
         const float z = fmaf(yv, sc, shf);
@@ -191,6 +223,7 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_reduce_kernel(const float* y
             const float act = z > 0.f ? z : z * slope;
             for (int k = 0; k < src.K; ++k) ak[k] += (double)act * src.dl[(n * src.K + k) * S + v];
         }
+    }
     }
     double* out = psums + (nc * gridDim.x + blockIdx.x) * nq;
     double t = block_sum_256(a0, sh); if (threadIdx.x == 0) out[0] = t;
@@ -207,6 +240,7 @@ __global__ void in_lrelu_bwd_combine_kernel(const double* psums, double* sums, i
     sums[(size_t)nc * nq + q] = s;
 }
 // dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); each block also leaves sum(dy) of its slice (conv bias gradient)
+template <bool V4>
 __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const float* y, const float* ss, const float* mr,
                                                                  const float* gamma, BwdSrc src, const double* sums,
                                                                  float* dy, double* dysum, int C, size_t S, float slope,
@@ -220,6 +254,32 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const float* y,
     const float* yp = y + nc * S;
     float* op = dy + nc * S;
     double acc = 0.0;
+    if constexpr (V4) {
+        float wk[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < src.K && src.dl; ++k) wk[k] = src.wseg[k * C + c];
+        for (size_t v = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; v < S; v += (size_t)gridDim.x * 1024) {
+            const float4 y4 = *reinterpret_cast<const float4*>(yp + v);
+            float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src.g1) { const float4 t = *reinterpret_cast<const float4*>(src.g1 + nc * S + v); d4.x += t.x; d4.y += t.y; d4.z += t.z; d4.w += t.w; }
+            if (src.g2) { const float4 t = *reinterpret_cast<const float4*>(src.g2 + nc * S + v); d4.x += t.x; d4.y += t.y; d4.z += t.z; d4.w += t.w; }
+            if (src.dl)
+                for (int k = 0; k < src.K; ++k) {
+                    const float4 l = *reinterpret_cast<const float4*>(src.dl + (n * src.K + k) * S + v);
+                    d4.x = fmaf(wk[k], l.x, d4.x); d4.y = fmaf(wk[k], l.y, d4.y); d4.z = fmaf(wk[k], l.z, d4.z); d4.w = fmaf(wk[k], l.w, d4.w);
+                }
+            const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, dA[4] = {d4.x, d4.y, d4.z, d4.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = fmaf(yv[e], sc, shf);
+                const float dz = z > 0.f ? dA[e] : dA[e] * slope;
+                const float xh = (yv[e] - mean) * rstd;
+                o[e] = gr * (dz - m1 - xh * m2);
+                acc += o[e];
+            }
+            *reinterpret_cast<float4*>(op + v) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
     for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < S; v += (size_t)gridDim.x * 256) {
         const float yv = yp[v];
         const float z = fmaf(yv, sc, shf);
@@ -229,6 +289,7 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const float* y,
         const float o = gr * (dz - m1 - xh * m2);
         op[v] = o;
         acc += o;
+    }
     }
     const double t = block_sum_256(acc, sh);
     if (threadIdx.x == 0) dysum[nc * gridDim.x + blockIdx.x] = t;
@@ -277,11 +338,15 @@ extern "C" int wmh_in_lrelu_bwd(const float* y, const float* ss, const float* me
     double* psums = scratch + (size_t)NC * nq;
     double* dysum = psums + (size_t)NC * nq * split;
     const int nused = 2 + src.K;
-    hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel, dim3(split, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, src, psums, C,
+    // 16-byte form: four voxels per thread and step (every tensor is a whole number of 16-byte pieces per channel)
+    const bool v4 = S % 4 == 0 && ((uintptr_t)y | (uintptr_t)dy | (uintptr_t)g1 | (uintptr_t)g2 | (uintptr_t)dlogits) % 16 == 0;
+    if (v4) hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel<true>, dim3(split, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, src, psums, C, S, slope, nq);
+    else hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel<false>, dim3(split, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, src, psums, C,
                        S, slope, nq);
     hipLaunchKernelGGL(in_lrelu_bwd_combine_kernel, dim3((NC * nused + 63) / 64), dim3(64), 0, st, psums, sums, NC, (int)split,
                        nq, nused);
-    hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel, dim3(gx, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, gamma, src, sums,
+    if (v4) hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel<true>, dim3(gx, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, gamma, src, sums, dy, dysum, C, S, slope, nq);
+    else hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel<false>, dim3(gx, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, gamma, src, sums,
                        dy, dysum, C, S, slope, nq);
     hipLaunchKernelGGL(in_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sums, dysum, (int)gx, N, C, nq, src.K, dgamma,
                        dbeta, dlogits ? dwseg : nullptr, dbias);
