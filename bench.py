@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (dense peaks).  f16x2: the stride-1 pair kernels form three of the four
 # partial products of the fp16 hi/lo split, i.e. three 16-bit MFMAs' worth of k slots per tap and 16 channels: ceiling = 16-bit peak / 3
-# (DESIGN.md 3.3d; until r03x all four products were formed and the ceiling was peak / 4 = 625: `peak_basis` says which one a line uses).
+# (DESIGN.md 3.2; until r03x all four products were formed and the ceiling was peak / 4 = 625: `peak_basis` says which one a line uses).
 PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'f16x2': 2500.0 / 3.0}
 PEAK_BASIS = {'fp32': 'v_mfma_f32_32x32x2_f32 dense peak', 'bf16': '16-bit MFMA dense peak', 'f16x2': '16-bit MFMA dense peak / 3 (three partial products)'}
 NOMINAL_SCLK_MHZ = 2400            # the clock the guide's peaks are quoted at
@@ -205,7 +205,7 @@ def cpu_baseline(plan, sd, vol, tta, mode, gpu_notta, gpu_patch_logits, extra_no
 
 
 # ------------------------------------------------------------------------------------------------------------
-# shader clock and socket power over a timed region (the 16-bit MFMA modes run below the nominal clock: DESIGN.md 3.3e)
+# shader clock and socket power over a timed region (the 16-bit MFMA modes run below the nominal clock: DESIGN.md 3.2)
 # ------------------------------------------------------------------------------------------------------------
 class ClockSampler:
     """Reads the device's hwmon `freq1_input` (shader clock, Hz) and `power1_input` (socket power, uW) every 50 ms from a thread
@@ -462,7 +462,7 @@ def measure_training_mode(plan, sd, device, precision, iters, warmup):
                precision=precision, steps=iters, warmup=warmup, ms_per_step=round(1e3 * dt / iters, 3), value=round(2 * iters / dt, 3), unit='patches/s',
                loss_first_to_last=[round(losses[0], 6), round(losses[-1], 6)], clock=cs.report(),
                # whole iteration against the mode's forward ceiling: an upper bound for f16x2 / bf16, whose weight-gradient, strided and transposed
-               # kernels form four products or stay fp32 (DESIGN.md 3.4)
+               # kernels form four products or stay fp32 (DESIGN.md 3.6)
                roofline=dict(bound='mfma', kernel='whole iteration', achieved=round(tflops, 2), peak=round(peak, 1), peak_basis=PEAK_BASIS[precision],
                              unit='TFLOP/s', frac=round(tflops / peak, 4), algorithmic_tflop_per_step=TRAIN_TFLOP_PER_ITER))
     add_sustained(out['roofline'], out['clock'])

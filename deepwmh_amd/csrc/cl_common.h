@@ -10,7 +10,7 @@
 // lanes of a wave work on consecutive voxels, so a wave-instruction of the LDS-DMA or of the epilogue's stores then covers one
 // contiguous run of 16-byte pieces (a halo row of 34 voxels = 544 bytes, 5 cache lines) instead of one piece out of every voxel's
 // 2C bytes (64 cache lines per instruction at C >= 64): the texture addresser takes a cache line per cycle, and at 42 DMA
-// instructions per 16-channel chunk that was 2.7 k of the chunk's ~6 k cycles on the staging waves (DESIGN.md 3.3c).
+// instructions per 16-channel chunk that was 2.7 k of the chunk's ~6 k cycles on the staging waves (DESIGN.md 3.6).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -19,7 +19,7 @@
 //              An input row is read once per kd and feeds the up to three output rows that use it (54 + 27 LDS reads for 108
 //              MFMAs per chunk).  Epilogue: 16-byte stores (cl_store_mtile), fp32 InstanceNorm moments kept as running sums
 //              per (workgroup, sample) and flushed once per sample.
-// DESIGN.md 3.3c has the measurements (what bounds it, the ablations, the vmcnt finding).
+// DESIGN.md 3.4 has the measurements (what bounds it, the ablations, the vmcnt finding).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -1,5 +1,5 @@
 // conv3d_k3_wgrad_f16x2.hip -- weight gradient of the 3x3x3 convolution (pad 1, stride 1) in the f16x2 "pair" mode: fp32-grade
-// results from the 16-bit matrix instruction (conv3d_common.h, DESIGN.md section 3.3d).
+// results from the 16-bit matrix instruction (conv3d_common.h, DESIGN.md section 3.2).
 //
 //   dW[co][ci][tap] = sum_{n, o} dy[n, co, o] * x'[n, ci, o + tap - 1]
 //

@@ -1,5 +1,5 @@
 // conv3d_k3s2_dgrad_f16x2.hip -- data gradient of the stride-2 3x3x3 convolution (pad 1) in gather form, in the f16x2 "pair" mode
-// (fp32 tensors and accumulation, products from fp16 pairs: conv3d_common.h, DESIGN.md section 3.3d).
+// (fp32 tensors and accumulation, products from fp16 pairs: conv3d_common.h, DESIGN.md section 3.2).
 //
 //   dx[n, ci, i] = sum_{co} sum_{t : (i + 1 - t) even} dy[n, co, (i + 1 - t) / 2] * W[co, ci, t]        per axis
 //

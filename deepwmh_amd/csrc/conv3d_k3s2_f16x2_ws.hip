@@ -4,7 +4,7 @@
 // The one-role kernel that served these layers (conv3d_k3_bf16.hip, BCfg1) spends half its time staging: a 2 x 2 x 32 output tile reads
 // a 5 x 5 x 65 input box -- 12.7 staged voxels per output voxel -- and each of its four waves issues the 673 instructions of a chunk's
 // staging in order before it turns to the MFMAs (timing-only ablations: 0.85 of 1.74 ms for 32 -> 64 at 8 x 128^3 is the staging alone,
-// DESIGN.md section 3.3d).  Here the roles are split inside one workgroup of 12 waves per CU:
+// DESIGN.md section 3.2).  Here the roles are split inside one workgroup of 12 waves per CU:
 //   waves 0-3   consumers: wave w owns output row w of the tile (32 voxels) x 64 output channels; per tap one B operand from LDS (read
 //               one tap ahead of its MFMAs) and two weight fragments straight from L2 (a ring four taps deep, one 16-byte load per lane and
 //               fragment), four v_mfma_f32_32x32x16_f16; then the shared epilogue (conv3d_common.h: bias, fp32 InstanceNorm moments, stores);
@@ -14,9 +14,12 @@
 // Operands are one dword per (voxel | output channel, input channel), (hi | lo << 16), as in the pair weight gradient and the pair
 // transposed convolution: a k-slot pair holds a channel's (hi, lo), A as stored gives hi hi + lo lo and A rotated by 16 bits
 // (v_alignbit_b32, which overlaps with the MFMAs) gives the cross terms.
-// LDS: two activation buffers of 51 KB; the weights stay out of it (a chunk's 64-channel fragments are 55 KB: with them only one
-// activation buffer would fit).  One workgroup barrier per chunk; the loaders run ahead across tile boundaries, so the consumers'
-// epilogue overlaps with the staging of the next tile's first chunks.
+// LDS: two activation buffers of 51 KB; the weights stay out of it.  (Round 4 built the other form -- one 54 KB weight buffer in LDS, the
+// loaders carrying the next chunk's fragments in registers and dropping them in between two barriers, the consumers reading both operands
+// through register rings -- 144 registers, no spills, bit-identical, and NOT faster: 1.79 against 1.78 ms for 32 -> 64 from 8 x 128^3,
+// 0.68 against 0.66 ms for 64 -> 128 from 8 x 64^3, same box.  The L2 path of the fragments is not what bounds this kernel.)  One workgroup
+// barrier per chunk; the loaders run ahead across tile boundaries, so the consumers' epilogue overlaps with the staging of the next tile's
+// first chunks.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -181,16 +184,22 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
     const int lt = tid - 256;
     const unsigned cstride = 4u * (unsigned)DHW;                // bytes between channel planes (host checks the range)
     // slot i of this thread = voxel e = lt + 512 i of the 65 x 5 x 5 input box: where its two 16-byte pieces go (tile-invariant) ...
-    unsigned lhi[NITL], llo[NITL];
+    unsigned lhi[NITL];                                        // (the second piece sits at lhi ^ 16)
 #pragma unroll
     for (int i = 0; i < NITL; ++i) {
         const int e = lt + i * LTH;
         const int ew = e < C::SP ? e : SPP - 1;
         const int key = e < C::SP ? (((e % C::IX) >> 3) & 1) : 0;
-        lhi[i] = (unsigned)((ew * 2 + (0 ^ key)) * 16); llo[i] = (unsigned)((ew * 2 + (1 ^ key)) * 16);
+        lhi[i] = (unsigned)((ew * 2 + (0 ^ key)) * 16);
     }
     // ... and, per tile, where it comes from (byte offset in a channel plane) and whether it lies in the volume
-    unsigned voff[NITL], vkeep[NITL]; int s_n0 = 0;
+    unsigned exyz[NITL];                                        // x | y << 8 | z << 16 of the slot's voxel in the input box
+#pragma unroll
+    for (int i = 0; i < NITL; ++i) {
+        const int e = lt + i * LTH;
+        exyz[i] = (unsigned)(e % C::IX) | ((unsigned)((e / C::IX) % C::IY) << 8) | ((unsigned)(e / (C::IX * C::IY)) << 16);
+    }
+    unsigned voff[NITL], vbits = 0; int s_n0 = 0;               // vbits: bit i = slot i lies in the volume
     auto setup = [&](int v) __attribute__((always_inline)) {
         int g, tx, ty, tz, n0;
         tile_of(v, g, tx, ty, tz, n0);
@@ -200,15 +209,20 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
 #pragma unroll
         for (int i = 0; i < NITL; ++i) {
             const int e = lt + i * LTH;
-            const int x = e % C::IX, y = (e / C::IX) % C::IY, z = e / (C::IX * C::IY);
+            // the slot's position in the box, unpacked from ONE register per slot behind an opaque copy: left visible, the loop-invariant
+            // divisions of all four slots were hoisted out of the chunk loop into twelve registers -- the spills that followed made every
+            // iteration reload them with a scratch load that waits for the whole prefetch
+            unsigned pk = exyz[i];
+            asm volatile("" : "+v"(pk));
+            const int x = (int)(pk & 0xFFu), y = (int)((pk >> 8) & 0xFFu), z = (int)(pk >> 16);
             const int gx = ix0 + x, gy = iy0 + y, gz = iz0 + z;
             const bool ok = (e < C::SP) & ((unsigned)gx < (unsigned)a.W) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gz < (unsigned)a.D);
-            vkeep[i] = ok ? 0xFFFFFFFFu : 0u;
-            voff[i] = (4u * (unsigned)(gz * HW + gy * a.W + gx)) & vkeep[i];
+            vbits = i == 0 ? (ok ? 1u : 0u) : (vbits | (ok ? (1u << i) : 0u));
+            voff[i] = ok ? 4u * (unsigned)(gz * HW + gy * a.W + gx) : 0u;
         }
     };
     // two register sets: the chunk fetched during iteration q is converted during iteration q + 1
-    float xr[2][NITL][8]; unsigned keep[2][NITL]; int set_n0[2] = {0, 0}, set_ch[2] = {0, 0};
+    float xr[2][NITL][8]; unsigned kbits[2] = {0, 0}; int set_n0[2] = {0, 0}, set_ch[2] = {0, 0};
     int pk = 0, pc = 0;                                         // (tile counter, chunk) of the NEXT issue
     // issue(set, i): voxel slot i of the next chunk (8 channel loads); i == NITL - 1 also moves the cursor on.  convert(set, buf, i): slot i.
     // (The loaders' loads, not their conversions, are what slows the consumers down -- 4.3 k -> 6.5 k cycles of MFMA phase per chunk with
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
             const unsigned soff = (unsigned)min(c0 + c, a.C0 - 1) * cstride;          // channels past the end re-read the last one (scaled to zero)
             xr[set][i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff[i], (int)soff, 0));
         }
-        keep[set][i] = vkeep[i];
+        if (i == 0) kbits[set] = vbits;
         if (i == NITL - 1) {
             set_n0[set] = s_n0; set_ch[set] = pc;
             if (++pc == nch) { pc = 0; ++pk; if (pk < ntiles_mine) setup(blockIdx.x + pk * gridDim.x); }
@@ -250,14 +264,15 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
     auto convert = [&](int set, int buf, int i) __attribute__((always_inline)) {
         char* dst = reinterpret_cast<char*>(ldsq) + (size_t)buf * SPP * 32;
         unsigned w[8];
+        const unsigned keep = 0u - ((kbits[set] >> i) & 1u);   // all ones inside the volume
 #pragma unroll
         for (int c = 0; c < 8; ++c) {                           // one dword per channel: (hi | lo << 16)
             float t = fmaf(xr[set][i][c], scv[c], shv[c]);
             t = fmaxf(t, t * slope_eff);
-            w[c] = s2_split(t) & keep[set][i];
+            w[c] = s2_split(t) & keep;
         }
         *reinterpret_cast<uint4*>(dst + lhi[i]) = make_uint4(w[0], w[1], w[2], w[3]);
-        *reinterpret_cast<uint4*>(dst + llo[i]) = make_uint4(w[4], w[5], w[6], w[7]);
+        *reinterpret_cast<uint4*>(dst + (lhi[i] ^ 16u)) = make_uint4(w[4], w[5], w[6], w[7]);
     };
     unsigned long long tw = 0, tbw = 0, t0 = 0;
     if (total > 0) {
@@ -283,13 +298,17 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
             // h ^ 1) is converted into the other buffer
             const bool cv = qq + 1 < total, is = qq + 2 < total;
             if (cv) load_ss(h ^ 1);
+            // (sched_barrier: one slot's conversion at a time.  Without these fences the whole iteration is one basic block -- it was not
+            //  while cycle stamps were compiled in -- and the scheduler interleaves all four slots' conversions: 60 registers spilled, and
+            //  every scratch reload waits for the whole prefetch; the kernel ran 1.6x slower)
             if (is) {
 #pragma unroll
                 for (int i = 0; i < NITL; ++i) issue(h, i);
             }
+            __builtin_amdgcn_sched_barrier(0);
             if (cv) {
 #pragma unroll
-                for (int i = 0; i < NITL; ++i) convert(h ^ 1, h ^ 1, i);
+                for (int i = 0; i < NITL; ++i) { convert(h ^ 1, h ^ 1, i); __builtin_amdgcn_sched_barrier(0); }
             }
             if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; t0 = t; }
             __syncthreads();

@@ -1,5 +1,5 @@
 // convT_k2s2_f16x2.hip -- ConvTranspose3d(kernel (kt,2,2), stride (kt,2,2), bias=False) in the f16x2 "pair" mode: fp32 tensors and
-// accumulation, every product formed from fp16 pairs (conv3d_common.h, DESIGN.md section 3.3d).
+// accumulation, every product formed from fp16 pairs (conv3d_common.h, DESIGN.md section 3.2).
 //
 //   out[n, co, kt d + i, 2h + j, 2w + k] = sum_ci x'[n, ci, d, h, w] * W[ci, co, i, j, k]
 //

@@ -51,7 +51,7 @@ class UNetTrainer:
         self.precision = precision
         self.bf16_forward = self.bf16_dgrad = self.bf16_wgrad = precision == 'bf16'      # diagnostic switches (tools/diag_bf16_train.py)
         # 'f16x2': forward and stride-1 data-gradient convolutions with rows of >= 16 voxels form their products from fp16 pairs
-        # (network.py, DESIGN.md 3.3d: fp32-grade, 2-2.7x the fp32 instruction's speed); weight gradients and everything else fp32
+        # (network.py, DESIGN.md 3.2: fp32-grade, 2-2.7x the fp32 instruction's speed); weight gradients and everything else fp32
         self.x3 = precision == 'f16x2'
         # fp16's exponent range: the data gradients (dLoss/dy ~ 1e-8 .. 1e-2 at 2 x 128^3 voxels) sit below fp16's normal range, so in
         # this mode the backward pass runs on the loss scaled by 2^16 -- the static form of the GradScaler nnU-Net's own fp16 AMP

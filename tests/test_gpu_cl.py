@@ -389,7 +389,7 @@ def test_configs2_full_width_patch_against_the_fp32_path():
 
 
 def test_configs2_stress_eight_volumes_three_repetitions():
-    """BASELINE.json configs[2] at the size its LDS-DMA ordering race showed at (DESIGN 3.3c: garbage tiles "only at full size",
+    """BASELINE.json configs[2] at the size its LDS-DMA ordering race showed at (DESIGN 3.4: garbage tiles "only at full size",
     every small test green): 8 volumes of 160x192x160, each 8 tiles x 8 mirrors = 64 patches in forwards of 16 (two tiles' mirrored copies,
     as bench.py and nnUNet_predict run it; rounds 2-3 ran it in forwards of 8) of the 31 M-parameter net on channels-last bf16 tensors, three repetitions.  Every result finite, all three repetitions bit-equal, masks against the fp32
     path."""

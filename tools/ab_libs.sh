@@ -14,5 +14,5 @@ for r in 1 2; do
   WMH_LIB_PATH=$A WMH_DIAG_LIB_PATH=$AD python3 bench.py --also off --cpu-baseline off --steps 4 --detail-file none > $out/bench_A_$r.json 2> $out/bench_A_$r.err
   WMH_LIB_PATH=$B WMH_DIAG_LIB_PATH=$BD python3 bench.py --also off --cpu-baseline off --steps 4 --detail-file none > $out/bench_B_$r.json 2> $out/bench_B_$r.err
 done
-grep -h "8x128\|8x64\|8x32" $out/check_A_2.txt | sed 's/^/A /'; grep -h "8x128\|8x64\|8x32" $out/check_B_2.txt | sed 's/^/B /'
+grep -h "8x128\|8x64\|8x32\|stride 2" $out/check_A_2.txt | sed 's/^/A /'; grep -h "8x128\|8x64\|8x32\|stride 2" $out/check_B_2.txt | sed 's/^/B /'
 for f in $out/bench_*.json; do echo $f; python3 -c "import json,sys; d=json.load(open('$f')); print(d['value'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['roofline'].get('in_kernel'))"; done

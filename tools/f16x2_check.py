@@ -83,6 +83,40 @@ def run(N, S, C0, C1, Cout, check=True, reps=5):
               % (e0.elapsed_time(e1), cyc, cyc / e0.elapsed_time(e1) / 1e3, issue, issue / cyc))
 
 
+def run_s2(N, S, Cin, Cout, reps=5):
+    """The strided layers with 32-voxel output rows (configuration 1, conv3d_k3s2_f16x2_ws.hip): time, and error against float64 at N <= 2."""
+    g = torch.Generator(device='cuda').manual_seed(1)
+    x0 = torch.randn(N, Cin, S, S, S, device='cuda', generator=g)
+    ss0 = torch.stack([1 + 0.3 * torch.randn(N, Cin, device='cuda', generator=g), 0.2 * torch.randn(N, Cin, device='cuda', generator=g)], -1).contiguous()
+    w = (torch.randn(Cout, Cin, 27, device='cuda', generator=g) / (27 * Cin) ** 0.5).contiguous()
+    bias = torch.randn(Cout, device='cuda', generator=g) * 0.1
+    cfg = lib.wmh_conv3d_k3_bf16_config(lib.wmh_conv3d_k3_config(Cin, Cout, S, S, S, 2), Cout, S // 2)
+    assert cfg == 1 and lib.wmh_conv3d_k3_f16x2_supported(cfg), cfg
+    wf = torch.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cin, Cout), dtype=torch.int16, device='cuda')
+    _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(w), Cin, Cout, 0, Cin, 0, P(wf), None), 'pack')
+    So = S // 2
+    y = torch.empty(N, Cout, So, So, So, device='cuda')
+    part = torch.empty(N, Cout, lib.wmh_conv3d_k3_num_partials_f16x2(cfg, N, So, So, So), 4, device='cuda')
+
+    def x3():
+        _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(x0), P(ss0), Cin, None, None, 0, P(wf), P(bias), P(y), P(part), None, N, S, S, S, Cout, 0.01, None), 'x3 s2')
+    x3(); torch.cuda.synchronize()
+    msg = '%dx%d^3 %d->%d stride 2 cfg %d:' % (N, S, Cin, Cout, cfg)
+    if N <= 2:
+        act = torch.nn.functional.leaky_relu(x0.double() * ss0[..., 0, None, None, None].double() + ss0[..., 1, None, None, None].double(), 0.01)
+        ref = torch.nn.functional.conv3d(act, w.double().view(Cout, Cin, 3, 3, 3), bias.double(), padding=1, stride=2)
+        msg += '  rel L2 vs float64 %.3g' % float((y.double() - ref).norm() / ref.norm())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        x3()
+    e1.record(); torch.cuda.synchronize()
+    print(msg + '  x3 %.3f ms' % (e0.elapsed_time(e1) / reps), flush=True)
+
+
+run_s2(2, 64, 32, 64)
+run_s2(8, 128, 32, 64)
+run_s2(8, 64, 64, 128)
 run(2, 64, 32, 0, 32)
 run(1, 64, 32, 32, 32)
 run(2, 32, 128, 0, 128)

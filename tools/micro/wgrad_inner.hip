@@ -121,7 +121,7 @@ static void run(int nblk, unsigned long long* out, float* sink) {
     hipMemcpy(h, out, nblk * 8, hipMemcpyDeviceToHost);
     double s = 0; for (int i = 0; i < nblk; ++i) s += h[i];
     const double nm = (MODE >= 4) ? 64.0 * iters : 1024.0 * iters;
-    // s_memtime ticks at 100 MHz; convert to core clocks at 2.385 GHz
+    // s_memtime ticks at 100 MHz; convert to core clocks at 2.385 GHz (s_memtime in fact counts shader cycles: DESIGN.md 4)
     printf("mode %d  blocks %4d  %.1f clk per MFMA per wave (x%d waves/SIMD -> %.1f clk per MFMA per SIMD)\n", MODE, nblk,
            s / nblk / nm * 23.85, nblk / 256, s / nblk / nm * 23.85 / (nblk / 256));
 }
