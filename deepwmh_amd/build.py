@@ -1,5 +1,11 @@
-"""Build libdeepwmh_amd.so (hipcc, gfx950 only) in-tree so it travels with the source snapshot."""
+"""Build libdeepwmh_amd.so (hipcc, gfx950 only) in-tree so it travels with the source snapshot.
+
+Every translation unit is compiled with -Rpass-analysis=kernel-resource-usage; the remarks (registers, scratch, LDS per kernel) are kept next
+to the object and collected into lib/<library>.resources.json, which tests/test_build_resources.py reads: a hot kernel that starts spilling
+-- as the strided pair kernel did when round 4 compiled its cycle stamps out (1.6x slower, nothing else changed) -- fails the CPU suite."""
+import json
 import os
+import re
 import subprocess
 import sys
 
@@ -10,7 +16,7 @@ LIB = os.path.join(LIBDIR, 'libdeepwmh_amd.so')
 DIAG_LIB = os.path.join(LIBDIR, 'libdeepwmh_amd_diag.so')      # -DWMH_DIAG: cycle stamps + WMH_* variant switches (csrc/wmh_common.h)
 SOURCES = ['conv3d_k3.hip', 'conv3d_k3_ws.hip', 'conv3d_k3_bf16.hip', 'conv3d_k3_bf16_ws.hip', 'conv3d_k3s2_f16x2_ws.hip', 'conv3d_k3_wgrad.hip', 'conv3d_k3_wgrad_bf16.hip', 'conv3d_k3_wgrad_f16x2.hip', 'conv3d_k3s2_dgrad.hip', 'conv3d_k3s2_dgrad_f16x2.hip', 'convT_k2s2.hip', 'convT_k2s2_f16x2.hip', 'convT_k2s2_wgrad.hip', 'train_kernels.hip', 'volume_ops.hip', 'resample.hip', 'stage1_kernels.hip', 'wmh_kernels.hip', 'cl_conv3.hip', 'cl_misc.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-result']
+FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-result', '-Rpass-analysis=kernel-resource-usage']
 
 
 def _newer(a, b):
@@ -45,12 +51,41 @@ def _build_one(LIB, objname, extra_flags, force, verbose):
             cmd = jobs.pop(0)
             if verbose:
                 print(' '.join(cmd), flush=True)
-            running.append((cmd, subprocess.Popen(cmd)))
+            running.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
         cmd, proc = running.pop(0)
-        if proc.wait() != 0:
+        _, err = proc.communicate()
+        remarks = [l for l in err.splitlines() if 'kernel-resource-usage' in l]
+        rest = [l for l in err.splitlines() if 'kernel-resource-usage' not in l]
+        if rest and (verbose or proc.returncode != 0):
+            print('\n'.join(rest), file=sys.stderr, flush=True)
+        if proc.returncode != 0:
             for _, other in running:
                 other.kill()
             raise subprocess.CalledProcessError(proc.returncode, cmd)
+        with open(cmd[-1][:-2] + '.res', 'w') as f:         # <object>.res: the unit's resource remarks
+            f.write('\n'.join(remarks) + '\n')
+    res = {}
+    for o in objs:
+        unit, cur = os.path.basename(o)[:-2], None
+        try:
+            lines = open(o[:-2] + '.res').read().splitlines()
+        except OSError:
+            continue
+        for l in lines:
+            m = re.search(r'remark:\s+(.*?)\s*\[-Rpass', l)
+            if not m:
+                continue
+            t = m.group(1)
+            if t.startswith('Function Name:'):
+                cur = res.setdefault(t.split(':', 1)[1].strip(), dict(unit=unit))
+            elif cur is not None and ':' in t:
+                k, v = t.split(':', 1)
+                key = {'VGPRs': 'vgprs', 'AGPRs': 'agprs', 'TotalSGPRs': 'sgprs', 'ScratchSize [bytes/lane]': 'scratch_bytes_per_lane',
+                       'LDS Size [bytes/block]': 'static_lds_bytes', 'Occupancy [waves/SIMD]': 'waves_per_simd'}.get(k.strip())
+                if key:
+                    cur[key] = int(v.strip())
+    with open(LIB[:-3] + '.resources.json', 'w') as f:
+        json.dump(res, f, indent=0, sort_keys=True)
     if relink:
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
