@@ -25,6 +25,13 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* ticks, 
                 const f4 v = {(float)g, (float)lane, 1.f, 2.f};
                 *reinterpret_cast<f4*>(base + (size_t)((j & 3) + 8 * g + 4 * kh) * plane + r * 32 + 4 * (j >> 2)) = v;
             }
+        } else if (MODE == 3) {   // transposed accumulator (lane -> channel j, registers -> voxels): 4 dwordx4 stores, lane -> (channel j, voxels 8 g + 4 kh ..):
+                                  // 32 channel planes x 32 contiguous bytes per instruction
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f4 v = {(float)g, (float)lane, 1.f, 2.f};
+                *reinterpret_cast<f4*>(base + (size_t)j * plane + r * 32 + 8 * g + 4 * kh) = v;
+            }
         } else {                  // 4 dwordx4 stores: lane -> (channel (j>>3) [+4 kh], voxels 4 (j&7) ..): 8 consecutive lanes = one 128-byte line
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -44,16 +51,17 @@ int main(int argc, char** argv) {
     const size_t plane = (size_t)256 * 4 * iters * 32;          // floats per channel plane
     float* out; unsigned long long* ticks;
     hipMalloc(&out, plane * 32 * sizeof(float)); hipMalloc(&ticks, 1024 * 8);
-    const char* names[3] = {"global_store_dword  (2 x 128 B segments per instruction)", "global_store_dwordx4 (lanes of a quad on 4 channels)",
-                            "global_store_dwordx4 (8 lanes = one 128 B line)"};
+    const char* names[4] = {"global_store_dword  (2 x 128 B segments per instruction)", "global_store_dwordx4 (lanes of a quad on 4 channels)",
+                            "global_store_dwordx4 (8 lanes = one 128 B line)", "global_store_dwordx4 (lane = channel: 32 planes x 32 B)"};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         float ms = 0;
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, out, ticks, iters, plane);
             if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, out, ticks, iters, plane);
             if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, out, ticks, iters, plane);
+            if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), 0, 0, out, ticks, iters, plane);
             hipEventRecord(e1); hipDeviceSynchronize();
             hipEventElapsedTime(&ms, e0, e1);
         }
