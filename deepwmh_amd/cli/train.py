@@ -111,6 +111,8 @@ def main(argv=None):
             print('continuing from %s (epoch %d)' % (latest, start_epoch), flush=True)
     else:
         tr = UNetTrainer(plan, he_init_state_dict(plan, seed=args.seed, trained_like=False), device, precision=precision)
+    if rank == 0:
+        print('deepwmh_amd nnUNet_train: precision %s, %d rank(s)' % (precision, world), flush=True)
     if world > 1:                                       # identical start on every rank
         dist.broadcast(tr.params, 0); dist.broadcast(tr.mom, 0)
     loader = PrefetchLoader(PatchLoader(stage_dir, train_cases, plan.patch_size, bs, seed=args.seed + 1000 * rank + start_epoch))

@@ -53,6 +53,7 @@ class UNetTrainer:
         # 'f16x2': forward and stride-1 data-gradient convolutions with rows of >= 16 voxels form their products from fp16 pairs
         # (network.py, DESIGN.md 3.2: fp32-grade, 2-2.7x the fp32 instruction's speed); weight gradients and everything else fp32
         self.x3 = precision == 'f16x2'
+        self.x3_s2_dgrad = self.x3_tu_dgrad = True         # diagnostic attributes (tools/grad_compare.py): False = those data gradients on the exact-fp32 kernels
         # fp16's exponent range: the data gradients (dLoss/dy ~ 1e-8 .. 1e-2 at 2 x 128^3 voxels) sit below fp16's normal range, so in
         # this mode the backward pass runs on the loss scaled by 2^16 -- the static form of the GradScaler nnU-Net's own fp16 AMP
         # training uses -- and loss and gradient arena are scaled back (exactly: a power of two) at the end of backward().  Without it
@@ -432,7 +433,7 @@ class UNetTrainer:
                     + ([wseg_name] if (wseg_name and dl is not None) else []))
         if not need_dx:
             return None
-        if conv.stride == 2 and conv.iso and self.x3 and os.environ.get('WMH_TRAIN_S2_DGRAD', 'f16x2') != 'fp32':   # gather form on fp16 pairs (dy is loss-scaled into fp16's range; the switch: diagnostics)
+        if conv.stride == 2 and conv.iso and self.x3 and self.x3_s2_dgrad:   # gather form on fp16 pairs (dy is loss-scaled into fp16's range)
             assert C1 == 0
             key = ('dgrad.s2.x3', conv.name)
             hit = self._packed.get(key)
@@ -540,7 +541,7 @@ class UNetTrainer:
             self._ready([tu])
             # (1,2,2): the window embedded in a (1,3,3) one, stride (1,2,2)
             cfg = _lib.check(lib.wmh_conv3d_config(cskip, Cin, kt * D, 2 * H, 2 * W, 3 if kt == 2 else 1, kt, 2), 'config')
-            cfg_x3 = lib.wmh_conv3d_k3_bf16_config(cfg, Cin, 2 * W) if (self.x3 and kt == 2 and os.environ.get('WMH_TRAIN_TU_DGRAD') != 'fp32') else -1
+            cfg_x3 = lib.wmh_conv3d_k3_bf16_config(cfg, Cin, 2 * W) if (self.x3 and kt == 2 and self.x3_tu_dgrad) else -1
             if cfg_x3 in (1, 3, 5) and bool(lib.wmh_conv3d_k3_f16x2_supported(cfg_x3)):     # the strided pair kernels on the embedded image
                 key = ('tu.dgrad.x3', u, cfg_x3)
                 hit = self._packed.get(key)
