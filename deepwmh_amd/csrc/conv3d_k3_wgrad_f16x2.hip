@@ -5,17 +5,17 @@
 //
 // Voxels are the K dimension of v_mfma_f32_32x32x16_f16, one D tile [co 32][tap 32 (27 used)] per input channel.  Both operands are
 // split into two fp16 numbers (hi rounded toward zero, lo = the remainder rounded to nearest: 21-22 significant bits) and kept in LDS
-// as ONE DWORD PER VOXEL, (hi | lo << 16).  The 16 k-slots of an instruction carry 8 voxels x (hi, lo) of x' on the B side and
-// 8 voxels x (hi, lo) -- then, the dwords rotated by 16 bits, (lo, hi) -- of dy on the A side:
-//      sum_k A B = sum_v dy_hi(v) x_hi(v) + dy_lo(v) x_lo(v),     sum_k A' B = sum_v dy_lo(v) x_hi(v) + dy_hi(v) x_lo(v)
-// i.e. all four products from 2 instructions per 8 voxels and channel: a quarter of the fp32 instruction's cycles.  What makes it work where round 2's
-// attempt (three shifted 2-byte copies of every halo row, 2-byte LDS stores) did not: with a dword per voxel a tap's shift along x is a
-// whole number of dwords, so a lane's B operand -- 4 consecutive voxels starting at its tap's kx -- is two ds_read2_b32 from ONE copy
-// of the halo tile, written with plain 4-byte stores; and the second A operand is one v_alignbit_b32 per dword in registers.
+// as ONE DWORD PER VOXEL, (hi | lo << 16).  The 16 k-slots of an instruction carry 8 voxels x (hi, lo) of x' on the B side against
+// 8 voxels x (hi, hi) of dy on the A side (hi hi + hi lo), and every third instruction 16 voxels' dy_lo against their x_hi (the operands
+// repacked in registers, one v_perm_b32 per dword): three of the four partial products -- dy_lo x_lo, 2^-22 of a product, is not
+// formed, as in the forward kernel -- from 3 instructions per 16 voxels and channel (round 4; all four took 4).  What makes the layout
+// work where round 2's attempt (three shifted 2-byte copies of every halo row, 2-byte LDS stores) did not: with a dword per voxel a
+// tap's shift along x is a whole number of dwords, so a lane's B operand -- 4 consecutive voxels starting at its tap's kx -- is two
+// ds_read2_b32 from ONE copy of the halo tile, written with plain 4-byte stores.
 //
 // Wave-specialised workgroup of 8 waves covering 32 co x 16 ci: consumer wave w (0..3) owns ci = 4w..4w+3 -- four accumulators
-// that SHARE every dy fragment (5 LDS operand reads per 8 MFMAs; one channel at a time would need 8 and is LDS-bound) -- loader waves
-// 4..7 stage.  The unit of hand-over is one z slice of a TX x TY x TZ tile (TY * TX = 128 voxels, 16 steps of 8 MFMAs per consumer):
+// that SHARE every dy fragment (10 LDS operand reads per 12 MFMAs; one channel at a time would need 16 and is LDS-bound) -- loader waves
+// 4..7 stage.  The unit of hand-over is one z slice of a TX x TY x TZ tile (TY * TX = 128 voxels, 8 step pairs of 12 MFMAs per consumer):
 // dy slices are double-buffered per unit, the 16 channels' halo tiles per tile; while the consumers work on unit u the loaders convert
 // and write what they fetched during unit u - 1 (dy of unit u + 1, half of the next tile's channels) and issue the loads for the unit
 // after; one workgroup barrier per unit.  A workgroup walks tiles z-fastest and the workgroups of one XCD hold neighbouring (x, y)
@@ -144,43 +144,52 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
                         asm("" : "+v"(o));
                         bc[c] = (wp_lds_cp)(uintptr_t)o;
                     }
-                    // Software pipeline over the unit's 16 steps: the operand reads of step st + 1 are issued in two groups, each in
-                    // front of four MFMAs of step st (sched_barrier pins the groups).  A wave issues in order and an MFMA holds the
-                    // issue until the pipe takes it, so reads placed after a step's eight MFMAs -- the compiler's own schedule --
-                    // start 224 cycles late and the next step waits out the LDS latency with the matrix pipe empty (45 instead of
-                    // 32 cycles per MFMA).
-                    constexpr int NST = TY * (TX / 8);
-                    wp_u32x4 a4[2], b[2][4];
+                    // Three of the four partial products (dy_lo x_lo, 2^-22 of a product, is not formed -- as in the forward kernel),
+                    // two steps of 8 voxels at a time.  With a = the dy dwords and b = the x' dwords of the pair's first and second step:
+                    //      (dy_hi | dy_hi)(a0) . (x_hi | x_lo)(b0)      hi hi + hi lo of step 0
+                    //      (dy_hi | dy_hi)(a1) . (x_hi | x_lo)(b1)      the same of step 1
+                    //      (dy_lo(a0) | dy_lo(a1)) . (x_hi(b0) | x_hi(b1))   lo hi of both steps
+                    // 3 instructions per 16 voxels and channel instead of 4; the repacked operands are one v_perm_b32 per dword
+                    // (12 per pair on the A side, shared by the four channels; 4 per channel on the B side), which fit in the
+                    // MFMAs' issue gaps.  A channel's three MFMAs run back to back on its accumulator (no interleaving needed for
+                    // this instruction) and its operands of the NEXT pair are read right behind them, nine MFMAs before their use.
+                    constexpr int NST = TY * (TX / 8), NP = NST / 2;
+                    static_assert(NST % 2 == 0, "steps are taken in pairs");
+                    wp_u32x4 a4[2][2], b[2][4];
                     auto fetch_a = [&](int st, int set) __attribute__((always_inline)) {
-                        a4[set] = *reinterpret_cast<const wp_u32x4*>(ap + ((st / (TX / 8)) * TX + 8 * (st % (TX / 8))) * 4);
+                        a4[set][st & 1] = *reinterpret_cast<const wp_u32x4*>(ap + ((st / (TX / 8)) * TX + 8 * (st % (TX / 8))) * 4);
                     };
-                    auto fetch_b = [&](int st, int set, int c) __attribute__((always_inline)) {
+                    auto fetch_b = [&](int st, int c) __attribute__((always_inline)) {
                         const auto* q = reinterpret_cast<const __attribute__((address_space(3))) unsigned*>(bc[c] + (st / (TX / 8)) * RS + 32 * (st % (TX / 8)));
-                        b[set][c] = wp_u32x4{q[0], q[1], q[2], q[3]};                  // dword alignment: two ds_read2_b32
+                        b[st & 1][c] = wp_u32x4{q[0], q[1], q[2], q[3]};               // dword alignment: two ds_read2_b32
                     };
-                    fetch_a(0, 0);
+                    fetch_a(0, 0); fetch_a(1, 0);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) fetch_b(0, 0, c);
+                    for (int c = 0; c < 4; ++c) { fetch_b(0, c); fetch_b(1, c); }
 #pragma unroll
-                    for (int st = 0; st < NST; ++st) {
-                        const int cur = st & 1, nxt = cur ^ 1;
-                        // A = 4 voxels x (dy_hi, dy_lo) as stored; A' = the same dwords rotated by 16 bits: (dy_lo, dy_hi).
-                        // With B = 4 voxels x (x_hi, x_lo):  A B = hi hi + lo lo,  A' B = lo hi + hi lo  -- all four products
-                        wp_u32x4 ar;
+                    for (int j = 0; j < NP; ++j) {
+                        const int cur = j & 1, nxt = cur ^ 1;
+                        wp_u32x4 ah0, ah1, al;
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) ar[d] = __builtin_amdgcn_alignbit(a4[cur][d], a4[cur][d], 16);
-                        if (st + 1 < NST) { fetch_a(st + 1, nxt); fetch_b(st + 1, nxt, 0); fetch_b(st + 1, nxt, 1); }
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int d = 0; d < 4; ++d) {
+                            ah0[d] = __builtin_amdgcn_perm(a4[cur][0][d], a4[cur][0][d], 0x01000100u);     // (hi | hi)
+                            ah1[d] = __builtin_amdgcn_perm(a4[cur][1][d], a4[cur][1][d], 0x01000100u);
+                            al[d] = __builtin_amdgcn_perm(a4[cur][1][d], a4[cur][0][d], 0x07060302u);      // (lo of step 0 | lo of step 1)
+                        }
+                        if (j + 1 < NP) { fetch_a(2 * j + 2, nxt); fetch_a(2 * j + 3, nxt); }
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wp_f16x8, a4[cur]), __builtin_bit_cast(wp_f16x8, b[cur][c]), acc[c], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (st + 1 < NST) { fetch_b(st + 1, nxt, 2); fetch_b(st + 1, nxt, 3); }
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int c = 0; c < 4; ++c) {
+                            wp_u32x4 bh;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wp_f16x8, ar), __builtin_bit_cast(wp_f16x8, b[cur][c]), acc[c], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                            for (int d = 0; d < 4; ++d) bh[d] = __builtin_amdgcn_perm(b[1][c][d], b[0][c][d], 0x05040100u);   // (x_hi of step 0 | of step 1)
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wp_f16x8, ah0), __builtin_bit_cast(wp_f16x8, b[0][c]), acc[c], 0, 0, 0);
+                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wp_f16x8, ah1), __builtin_bit_cast(wp_f16x8, b[1][c]), acc[c], 0, 0, 0);
+                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wp_f16x8, al), __builtin_bit_cast(wp_f16x8, bh), acc[c], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (j + 1 < NP) { fetch_b(2 * j + 2, c); fetch_b(2 * j + 3, c); }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
                 if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_work += t - st_t; st_t = t; }
