@@ -67,11 +67,14 @@ template <int K>
 __global__ void loss_finalize_kernel(const double* part, int nblk, double M, float smooth, double weight, double* coef,
                                      double* loss_out) {
     __shared__ double tot[3 * K + 1];
-    const int q = threadIdx.x;
-    if (q < 3 * K + 1) {
+    // one wave; per quantity a fixed-order tree: lane l sums blocks l, l + 64, ..., then the lanes pairwise (a single lane walking
+    // all 1024 partial records -- dependent loads -- took 53 us, five times per iteration)
+#pragma unroll
+    for (int q = 0; q < 3 * K + 1; ++q) {
         double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += part[(size_t)b * (3 * K + 1) + q];     // fixed order
-        tot[q] = s;
+        for (int b = threadIdx.x; b < nblk; b += 64) s += part[(size_t)b * (3 * K + 1) + q];
+        for (int m = 1; m < 64; m <<= 1) s += shfl_xor_d(s, m);
+        if (threadIdx.x == 0) tot[q] = s;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -297,14 +300,18 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const float* y,
 // dgamma[c] = sum_n sums[n,c,1], dbeta[c] = sum_n sums[n,c,0], dwseg[k][c] = sum_n sums[n,c,2+k], dbias[c] = sum dysum
 __global__ void in_param_grads_kernel(const double* sums, const double* dysum, int gx, int N, int C, int nq, int K,
                                       float* dgamma, float* dbeta, float* dwseg, float* dbias) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
-    double g = 0.0, b = 0.0, w[4] = {0.0, 0.0, 0.0, 0.0}, db = 0.0;
+    // one wave per channel: the N * gx slice sums of dy as a fixed-order tree (lane l takes entries l, l + 64, ...), the N row sums
+    // serially on lane 0
+    const int c = blockIdx.x;
+    double db = 0.0;
+    for (int idx = threadIdx.x; idx < N * gx; idx += 64) db += dysum[((size_t)(idx / gx) * C + c) * gx + idx % gx];
+    for (int m = 1; m < 64; m <<= 1) db += shfl_xor_d(db, m);
+    if (threadIdx.x != 0) return;
+    double g = 0.0, b = 0.0, w[4] = {0.0, 0.0, 0.0, 0.0};
     for (int n = 0; n < N; ++n) {
         const double* s = sums + ((size_t)n * C + c) * nq;
         b += s[0]; g += s[1];
         for (int k = 0; k < K; ++k) w[k] += s[2 + k];
-        for (int i = 0; i < gx; ++i) db += dysum[((size_t)n * C + c) * gx + i];
     }
     if (dgamma) dgamma[c] = (float)g;
     if (dbeta) dbeta[c] = (float)b;
@@ -348,7 +355,7 @@ extern "C" int wmh_in_lrelu_bwd(const float* y, const float* ss, const float* me
     if (v4) hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel<true>, dim3(gx, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, gamma, src, sums, dy, dysum, C, S, slope, nq);
     else hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel<false>, dim3(gx, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, gamma, src, sums,
                        dy, dysum, C, S, slope, nq);
-    hipLaunchKernelGGL(in_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sums, dysum, (int)gx, N, C, nq, src.K, dgamma,
+    hipLaunchKernelGGL(in_param_grads_kernel, dim3(C), dim3(64), 0, st, sums, dysum, (int)gx, N, C, nq, src.K, dgamma,
                        dbeta, dlogits ? dwseg : nullptr, dbias);
     return wmh_check_launch("in_lrelu_bwd kernels");
 }
@@ -520,9 +527,10 @@ __global__ __launch_bounds__(256) void sqnorm_partials_kernel(const float* g, si
 // loss-scaled fp16-pair backward pass) is reported as it is with coefficient 0: sgd_nesterov_kernel then skips the whole update,
 // as torch.cuda.amp.GradScaler.step does in nnU-Net's own fp16 run_iteration [nnU-Net, not in tree].
 __global__ void clip_coef_kernel(const double* part, int nblk, float max_norm, float* out) {
+    double s = 0.0;                                        // one wave, fixed-order tree (as loss_finalize_kernel)
+    for (int b = threadIdx.x; b < nblk; b += 64) s += part[b];
+    for (int m = 1; m < 64; m <<= 1) s += shfl_xor_d(s, m);
     if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += part[b];
         const double norm = sqrt(s);
         const double coef = max_norm / (norm + 1e-6);
         const bool finite = norm <= 1.7e308;               // false for inf and NaN
