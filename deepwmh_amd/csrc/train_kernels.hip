@@ -233,26 +233,32 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_reduce_kernel(const float* y
     t = block_sum_256(a1, sh);        if (threadIdx.x == 0) out[1] = t;
     for (int k = 0; k < src.K && src.dl; ++k) { t = block_sum_256(ak[k], sh); if (threadIdx.x == 0) out[2 + k] = t; }
 }
-// sums[nc][q] = sum over slices (fixed order)
-__global__ void in_lrelu_bwd_combine_kernel(const double* psums, double* sums, int NC, int split, int nq, int nused) {
-    const int idx = blockIdx.x * 64 + threadIdx.x;
-    if (idx >= NC * nused) return;
-    const int nc = idx / nused, q = idx % nused;
-    double s = 0.0;
-    for (int sp = 0; sp < split; ++sp) s += psums[((size_t)nc * split + sp) * nq + q];
-    sums[(size_t)nc * nq + q] = s;
-}
 // dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); each block also leaves sum(dy) of its slice (conv bias gradient)
 template <bool V4>
 __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const float* y, const float* ss, const float* mr,
-                                                                 const float* gamma, BwdSrc src, const double* sums,
-                                                                 float* dy, double* dysum, int C, size_t S, float slope,
+                                                                 const float* gamma, BwdSrc src, const double* psums, int split,
+                                                                 double* sums, float* dy, double* dysum, int C, size_t S, float slope,
                                                                  int nq) {
     __shared__ double sh[4];
     const size_t nc = blockIdx.y, n = nc / C;
     const int c = (int)(nc % C);
     const float sc = ss[2 * nc], shf = ss[2 * nc + 1], mean = mr[2 * nc], rstd = mr[2 * nc + 1];
-    const float m1 = (float)(sums[nc * nq] / (double)S), m2 = (float)(sums[nc * nq + 1] / (double)S);
+    // the row's sums from the reduce pass's slices (split <= 256): every block of the row forms the same fixed-order tree; block 0
+    // also forms the head's sums and leaves all of them for in_param_grads_kernel (this was a launch of its own: 22 per step)
+    double tot0 = 0.0, tot1 = 0.0;
+    {
+        const int nused = 2 + (src.dl ? src.K : 0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (q >= nused || (q >= 2 && blockIdx.x != 0)) break;     // uniform
+            const double part = (int)threadIdx.x < split ? psums[(nc * split + threadIdx.x) * nq + q] : 0.0;
+            const double t = block_sum_256(part, sh);
+            if (q == 0) tot0 = t;
+            if (q == 1) tot1 = t;
+            if (blockIdx.x == 0 && threadIdx.x == 0) sums[nc * nq + q] = t;
+        }
+    }
+    const float m1 = (float)(tot0 / (double)S), m2 = (float)(tot1 / (double)S);
     const float gr = (gamma ? gamma[c] : 1.f) * rstd;
     const float* yp = y + nc * S;
     float* op = dy + nc * S;
@@ -344,17 +350,14 @@ extern "C" int wmh_in_lrelu_bwd(const float* y, const float* ss, const float* me
     double* sums = scratch;
     double* psums = scratch + (size_t)NC * nq;
     double* dysum = psums + (size_t)NC * nq * split;
-    const int nused = 2 + src.K;
     // 16-byte form: four voxels per thread and step (every tensor is a whole number of 16-byte pieces per channel)
     const bool v4 = S % 4 == 0 && ((uintptr_t)y | (uintptr_t)dy | (uintptr_t)g1 | (uintptr_t)g2 | (uintptr_t)dlogits) % 16 == 0;
     if (v4) hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel<true>, dim3(split, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, src, psums, C, S, slope, nq);
     else hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel<false>, dim3(split, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, src, psums, C,
                        S, slope, nq);
-    hipLaunchKernelGGL(in_lrelu_bwd_combine_kernel, dim3((NC * nused + 63) / 64), dim3(64), 0, st, psums, sums, NC, (int)split,
-                       nq, nused);
-    if (v4) hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel<true>, dim3(gx, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, gamma, src, sums, dy, dysum, C, S, slope, nq);
-    else hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel<false>, dim3(gx, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, gamma, src, sums,
-                       dy, dysum, C, S, slope, nq);
+    if (v4) hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel<true>, dim3(gx, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, gamma, src, psums, (int)split, sums, dy, dysum, C, S, slope, nq);
+    else hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel<false>, dim3(gx, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, gamma, src, psums, (int)split,
+                       sums, dy, dysum, C, S, slope, nq);
     hipLaunchKernelGGL(in_param_grads_kernel, dim3(C), dim3(64), 0, st, sums, dysum, (int)gx, N, C, nq, src.K, dgamma,
                        dbeta, dlogits ? dwseg : nullptr, dbias);
     return wmh_check_launch("in_lrelu_bwd kernels");
