@@ -461,8 +461,8 @@ def measure_training_mode(plan, sd, device, precision, iters, warmup):
     out = dict(workload='one nnUNetTrainerV2 iteration (forward with deep supervision, Dice+CE, backward, clip, SGD-Nesterov), batch 2 x 128^3, BASELINE plan',
                precision=precision, steps=iters, warmup=warmup, ms_per_step=round(1e3 * dt / iters, 3), value=round(2 * iters / dt, 3), unit='patches/s',
                loss_first_to_last=[round(losses[0], 6), round(losses[-1], 6)], clock=cs.report(),
-               # whole iteration against the mode's forward ceiling: an upper bound for f16x2 / bf16, whose weight-gradient, strided and transposed
-               # kernels form four products or stay fp32
+               # whole iteration against the mode's forward ceiling: an upper bound for f16x2 / bf16, whose strided and transposed kernels form
+               # four products or stay fp32
                roofline=dict(bound='mfma', kernel='whole iteration', achieved=round(tflops, 2), peak=round(peak, 1), peak_basis=PEAK_BASIS[precision],
                              unit='TFLOP/s', frac=round(tflops / peak, 4), algorithmic_tflop_per_step=TRAIN_TFLOP_PER_ITER))
     add_sustained(out['roofline'], out['clock'])

@@ -1,6 +1,6 @@
 """`precision='f16x2'`: the 3x3x3 convolutions form their products from FP16 pairs (x = hi + lo, 21-22 significant bits per
 operand, the partial products on v_mfma_f32_32x32x16_f16 -- all four in the one-role, strided and transposed kernels, three in the
-wave-specialised stride-1 kernels since the end of round 3: w_lo x_lo, 2^-22 of a product, is left out --, fp32 accumulate, weights
+wave-specialised stride-1 kernels (end of round 3) and in the pair weight gradient (round 4): lo x lo, 2^-22 of a product, is left out --, fp32 accumulate, weights
 scaled by 2^8 before the split).  Round 2
 used bf16 pairs (16 bits: 3.4e-6 per layer, 6.1e-5 on the full-size softmax); with fp16 pairs a layer's error against float64 is
 at or below the exact-fp32 kernel's.  The gate: softmax within 5e-5 of the oracle (the fp32 path's own bar is 1e-4), identical
