@@ -1,3 +1,5 @@
+# Same-box A/B of the pair weight gradient: an earlier build of the library (ab_old/libA.so + ab_old/libA_diag.so, copied from
+# deepwmh_amd/lib/ before rebuilding; ab_old/ is git-ignored) against the current one.  Usage (on the GPU box): bash tools/ab_wgrad.sh
 mkdir -p gpurun_out/r04m
 python -m pytest tests/test_gpu_train_kernels.py -x -q -m gpu -k "wgrad" 2>&1 | tail -4
 for r in 1 2; do
