@@ -457,11 +457,54 @@ __global__ __launch_bounds__(256) void seghead_logits_kernel(const float* x, con
         for (int k = 0; k < K; ++k) out[((size_t)b * K + k) * P + p] = lg[k];
     }
 }
+// The same per voxel (identical operation order: bit-identical logits), four consecutive voxels per thread with 16-byte loads and
+// stores, eight channels' loads in flight (P % 4 == 0, 16-byte aligned x and out).  The one-voxel form read the training step's
+// five deep-supervision heads at ~1 TB/s: 0.7 ms of a 28 ms iteration.
+template <int K>
+__global__ __launch_bounds__(256) void seghead_logits4_kernel(const float* x, const float* ss, const float* wseg,
+                                                              float* out, int C, size_t P, float slope) {
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * C * P;
+    const float* ssb = ss ? ss + (size_t)b * C * 2 : nullptr;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < P / 4; q += (size_t)gridDim.x * 256) {
+        float lg[K][4];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lg[k][i] = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            const f4v v4 = *reinterpret_cast<const f4v*>(xb + (size_t)c * P + 4 * q);
+            float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            if (ssb) {
+                const float sc = ssb[2 * c], sh = ssb[2 * c + 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = wmh_lrelu(fmaf(v[i], sc, sh), slope);
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float wk = wseg[k * C + c];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lg[k][i] = fmaf(v[i], wk, lg[k][i]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) *reinterpret_cast<f4v*>(out + ((size_t)b * K + k) * P + 4 * q) = f4v{lg[k][0], lg[k][1], lg[k][2], lg[k][3]};
+    }
+}
 static int seghead_logits(const float* x, const float* ss, const float* wseg, int K, float* out, int n, int C,
                           size_t spatial, float lrelu_slope, int in16, void* stream) {
     if (!x || !wseg || !out || n < 1 || C < 1 || spatial < 1) return wmh_fail(WMH_EINVAL, "seghead_logits: bad args");
     unsigned gx = cdivu(spatial, 256); if (gx > 65535) gx = 65535;
     hipStream_t st = (hipStream_t)stream;
+    if (!in16 && spatial % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && K >= 2 && K <= 4) {
+        unsigned g4 = cdivu(spatial / 4, 256); if (g4 > 65535) g4 = 65535;
+        if (K == 2) hipLaunchKernelGGL((seghead_logits4_kernel<2>), dim3(g4, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+        else if (K == 3) hipLaunchKernelGGL((seghead_logits4_kernel<3>), dim3(g4, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+        else hipLaunchKernelGGL((seghead_logits4_kernel<4>), dim3(g4, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+        return wmh_check_launch("seghead_logits4_kernel");
+    }
     switch (K) {
         case 2: if (in16) hipLaunchKernelGGL((seghead_logits_kernel<2, true>), dim3(gx, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
                 else hipLaunchKernelGGL((seghead_logits_kernel<2>), dim3(gx, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
