@@ -40,7 +40,8 @@ def _build_one(LIB, objname, extra_flags, force, verbose):
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
-        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+        # (an object without its .res file -- the resource remarks -- is recompiled: the JSON below is rebuilt from those files)
+        if force or _newer(s, o) or any(_newer(d, o) for d in deps) or not os.path.exists(o[:-2] + '.res'):
             jobs.append([HIPCC] + FLAGS + extra_flags + ['-c', s, '-o', o])
             relink = True
         objs.append(o)

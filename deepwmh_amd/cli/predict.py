@@ -59,22 +59,27 @@ def _env_id_list(var):
     return [v.strip() for v in vis.split(',') if v.strip()]
 
 
-def count_gpus_without_runtime(topology='/sys/class/kfd/kfd/topology/nodes', probe_cmd=None):
+def count_gpus_without_runtime(topology='/sys/class/kfd/kfd/topology/nodes', probe_cmd=None, probe_timeout=120):
     """Number of GPUs a child of this process would see, found WITHOUT initialising the HIP runtime here (the fan-out parent only
-    starts children).  First choice: a short-lived child that asks the runtime itself (`torch.cuda.device_count()`), which sees what
-    the container's cgroup and ROCR_VISIBLE_DEVICES leave visible -- with HIP_/CUDA_VISIBLE_DEVICES removed, exactly as fan_out's
-    children run (the reference sets CUDA_VISIBLE_DEVICES to ONE id, predict.py:150-152; MI355WMH_GPUS replaces it).  If that child
-    cannot run: the KFD topology in sysfs (nodes with simd_count > 0; CPU nodes have 0) narrowed by ROCR_VISIBLE_DEVICES."""
+    starts children).  A short-lived child asks the runtime itself (`torch.cuda.device_count()`), which sees what the container's
+    cgroup and ROCR_VISIBLE_DEVICES leave visible -- with HIP_/CUDA_VISIBLE_DEVICES removed, exactly as fan_out's children run (the
+    reference sets CUDA_VISIBLE_DEVICES to ONE id, predict.py:150-152; MI355WMH_GPUS replaces it).  Only if that child cannot be
+    started or does not answer within `probe_timeout` seconds: the KFD topology in sysfs (nodes with simd_count > 0; CPU nodes have 0)
+    narrowed by ROCR_VISIBLE_DEVICES -- which counts every GPU of the HOST, so it is accepted only when it cannot overcount: on a host
+    whose device files (/dev/dri/renderD*) are as many as the topology's GPUs.  Otherwise: fail and ask for explicit ids."""
     cmd = probe_cmd if probe_cmd is not None else [sys.executable, '-c', 'import torch; print(torch.cuda.device_count())']
+    why = 'no probe command'
     if cmd:
         try:
             env = {k: v for k, v in os.environ.items() if k not in ('HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')}
-            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env).stdout.decode().split()
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=probe_timeout, env=env).stdout.decode().split()
             n = int(out[-1])
             if n > 0:
+                print('deepwmh_amd nnUNet_predict: MI355WMH_GPUS=all -> %d GPU(s) (counted by the HIP runtime in a child process)' % n, flush=True)
                 return n
-        except Exception:
-            pass
+            why = 'the runtime probe saw no GPU'
+        except Exception as e:
+            why = 'the runtime probe failed (%s)' % type(e).__name__
     n = 0
     try:
         nodes = sorted(os.listdir(topology), key=lambda v: int(v) if v.isdigit() else 0)
@@ -91,9 +96,18 @@ def count_gpus_without_runtime(topology='/sys/class/kfd/kfd/topology/nodes', pro
     ids = _env_id_list('ROCR_VISIBLE_DEVICES')
     if ids is not None:
         n = min(n, len(ids))
+    elif topology == '/sys/class/kfd/kfd/topology/nodes':       # a restricted container exposes fewer render nodes than the host has GPUs
+        try:
+            nrender = len([f for f in os.listdir('/dev/dri') if f.startswith('renderD')])
+        except OSError:
+            nrender = 0
+        if nrender < n:
+            raise RuntimeError('MI355WMH_GPUS=all: %s, and sysfs lists %d GPU(s) of the host while %d device file(s) are visible here; '
+                               'list the ids explicitly (e.g. MI355WMH_GPUS=0-7)' % (why, n, nrender))
     if n < 1:
-        raise RuntimeError('MI355WMH_GPUS=all: no GPU visible (runtime probe failed, %s empty); list the ids explicitly '
-                           '(e.g. MI355WMH_GPUS=0-7)' % topology)
+        raise RuntimeError('MI355WMH_GPUS=all: no GPU visible (%s, %s empty); list the ids explicitly '
+                           '(e.g. MI355WMH_GPUS=0-7)' % (why, topology))
+    print('deepwmh_amd nnUNet_predict: MI355WMH_GPUS=all -> %d GPU(s) (%s; counted from %s)' % (n, why, topology), flush=True)
     return n
 
 

@@ -103,8 +103,16 @@ def main(argv=None):
         if mom is not None:
             tr.mom.copy_(torch.as_tensor(np.asarray(mom)).to(tr.mom.device))
             tr.first_step = False
-        if info['checkpoint'].get('deepwmh_amd_loss_scale') and tr.loss_scale != 1.0:
-            tr.loss_scale = float(info['checkpoint']['deepwmh_amd_loss_scale'])
+        # the loss scale belongs to the precision it was found in: a checkpoint of an fp32 / bf16 run stores 1.0, and continuing it with
+        # the f16x2 backward at scale 1 would run fp16-pair gradients in the regime trainer.py documents as 7 % off
+        saved_scale, saved_prec = info['checkpoint'].get('deepwmh_amd_loss_scale'), info['checkpoint'].get('deepwmh_amd_precision')
+        if saved_scale and tr.loss_scale != 1.0 and saved_prec == precision:
+            tr.loss_scale = float(saved_scale)
+            if rank == 0:
+                print('loss scale %g restored from the checkpoint (%s)' % (tr.loss_scale, precision), flush=True)
+        elif saved_scale and rank == 0 and tr.loss_scale != 1.0:
+            print('checkpoint was written by a %s run: its loss scale %g is not restored, starting at %g'
+                  % (saved_prec or 'pre-round-5', float(saved_scale), tr.loss_scale), flush=True)
         best = info['checkpoint'].get('deepwmh_amd_best')
         ma_resume = info['checkpoint'].get('deepwmh_amd_ma')
         if rank == 0:
@@ -124,7 +132,7 @@ def main(argv=None):
         if rank != 0:
             return
         # the SGD momentum (as large as the weights) only where training can continue from: model_latest
-        extra = dict(deepwmh_amd_best=best, deepwmh_amd_ma=ma, deepwmh_amd_loss_scale=float(tr.loss_scale))
+        extra = dict(deepwmh_amd_best=best, deepwmh_amd_ma=ma, deepwmh_amd_loss_scale=float(tr.loss_scale), deepwmh_amd_precision=precision)
         if name == 'model_latest':
             extra['deepwmh_amd_momentum'] = tr.momentum_state()
         ck.save_checkpoint(folder, tr.state_dict(), plans, args.fold, name, epoch=epoch, extra=extra)

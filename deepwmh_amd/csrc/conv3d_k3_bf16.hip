@@ -616,6 +616,7 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
         return wmh_launch_conv_bf16_ws(cfg, a, st, 0, 0);
     }
     if (use_ws && abl_env == 0 && !w8 && quad_ok) return wmh_launch_conv_bf16_ws(cfg, a, st, 0, 0);
+#ifdef WMH_DIAG        // the 8-wave one-role variants (WMH_BF16_WAVES8) spill 300-416 bytes per lane: diagnostic library only
     if (bf16_variant() == 2) {
         if (cfg == 0) return launch_bf16<BCfg0w, 1>(a, (unsigned)nblk, st);
         return launch_bf16<BCfg2w, 1>(a, (unsigned)nblk, st);
@@ -624,6 +625,7 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
         if (cfg == 0) return launch_bf16<BCfg0w, 2>(a, (unsigned)nblk, st);
         return launch_bf16<BCfg2w, 2>(a, (unsigned)nblk, st);
     }
+#endif
     if (cfg == 0) return launch_bf16<BCfg0, 4>(a, (unsigned)nblk, st);
     return launch_bf16<BCfg2, 3>(a, (unsigned)nblk, st);
 }

@@ -114,7 +114,7 @@ class UNetTrainer:
         self.load_state_dict(state_dict)
         self.first_step = True
         self._bufs, self._packed, self._version = {}, {}, 0
-        self._x3_jobs, self._x3_table, self._x3_batched_version = OrderedDict(), None, -1
+        self._x3_jobs, self._x3_table, self._x3_batched_version, self._x3_used = OrderedDict(), None, -1, {}
         self.clip_out = torch.zeros(2, dtype=torch.float32, device=dev)
         self._norm_host = torch.zeros(2, dtype=torch.float32).pin_memory()
         self.loss_acc = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -177,6 +177,7 @@ class UNetTrainer:
     def _pack_x3(self, conv, cfg, mode, ci_off, ci_cnt):
         key = (conv.name, cfg, mode, ci_off, ci_cnt, 'x3')
         hit = self._packed.get(key)
+        self._x3_used[key] = self._version                   # (repack_x3_batch drops the images nobody asked for during the last step)
         if hit is not None and hit[0] == self._version:
             return hit[1]
         ecin, ecout = (ci_cnt, conv.cout) if mode == 0 else (conv.cout, ci_cnt)
@@ -193,14 +194,24 @@ class UNetTrainer:
         _lib.check(self.lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, _lib.ptr(w), cin, cout, ci_off, ci_cnt, mode, _lib.ptr(wf), self._st()),
                    'wmh_conv3d_k3_pack_weights_f16x2_device')
         self._packed[key] = (self._version, wf)
-        if key not in self._x3_jobs:
+        job = self._x3_jobs.get(key)
+        if job is None or job[7] is not wf or job[1] is not w:      # a new image, or one whose buffers were replaced
             self._x3_jobs[key] = args
-            self._x3_table = None                            # a new image: the device table is rebuilt before its next use
+            self._x3_table = None                            # the device table is rebuilt before its next use
 
     def repack_x3_batch(self):
         """All f16x2 weight images this trainer has built so far, rebuilt from the current parameters in one launch (the parameters and the
         image buffers live at fixed addresses, so the job table is uploaded once).  A training step rebuilt 43 images one launch each:
         0.6 ms of a 31 ms iteration.  Bit-identical to the single builds (tests/test_gpu_trainer.py)."""
+        # images not requested while the previous parameter version was current (another batch / patch shape, a diagnostic switch
+        # flipped) are neither rebuilt nor kept alive by their job
+        stale = [k for k in self._x3_jobs if self._x3_used.get(k, -1) < self._version - 1]
+        for k in stale:
+            del self._x3_jobs[k]
+            self._x3_used.pop(k, None)
+            self._packed.pop(k, None)
+        if stale:
+            self._x3_table = None
         if not self._x3_jobs:
             return
         if self._x3_table is None:

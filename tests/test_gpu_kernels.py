@@ -474,10 +474,10 @@ def test_wave_specialised_form_is_bit_identical(tmp_path):
         outs.append((np.load(f1), np.load(f2)))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert float(np.abs(outs[0][0]).max()) > 0.1
-    # the product library (no switches: wave-specialised, its own split-K decision) gives the same OUTPUTS up to the summation order of
-    # the layers it splits, and the same bits on the ones it does not
+    # the product library is a separate compilation of the same sources (no switches: wave-specialised; no slab memory is passed here, so
+    # it cannot split K -- conv3d_k3.hip: "no slab memory given: run unsplit"): same bits, outputs and moment records
     assert outs[2][0].shape == outs[1][0].shape
-    assert float(np.abs(outs[2][0] - outs[1][0]).max()) <= 2e-5 * float(np.abs(outs[1][0]).max())
+    assert np.array_equal(outs[2][0], outs[1][0]) and np.array_equal(outs[2][1], outs[1][1])
 
 
 BF16_SMALL_CASES = [(2, 32, 0, 64, 8, 8, 8, 1), (1, 48, 16, 32, 5, 9, 7, 1), (2, 32, 0, 64, 16, 16, 16, 2), (1, 16, 0, 32, 9, 13, 15, 2),

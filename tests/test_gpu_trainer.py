@@ -477,3 +477,15 @@ def test_f16x2_weight_images_rebuilt_in_one_launch_equal_the_single_builds(tiny_
         tr2.run_iteration(xd, td, 1e-2)
     torch.cuda.synchronize()
     assert torch.equal(tr.params, tr2.params) and torch.equal(tr.mom, tr2.mom)
+    # an image nobody asks for any more (another patch shape, a diagnostic switch flipped back) leaves the job table after one step
+    used = set(tr._x3_jobs)
+    conv = tr.enc[1]
+    extra_cfg = next(c for c in (0, 2, 4) if (conv.name, c, 0, 0, conv.cin, 'x3') not in used)
+    tr._pack_x3(conv, extra_cfg, 0, 0, conv.cin)
+    assert len(tr._x3_jobs) == len(used) + 1
+    tr.run_iteration(xd, td, 1e-2)                          # rebuilt once more (it was requested under the previous parameters) ...
+    tr.run_iteration(xd, td, 1e-2)                          # ... and dropped here
+    assert set(tr._x3_jobs) == used
+    tr2.run_iteration(xd, td, 1e-2); tr2.run_iteration(xd, td, 1e-2)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.params, tr2.params)

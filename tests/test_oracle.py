@@ -131,3 +131,32 @@ def test_plan_from_nnunet_plans_dict():
     bad = tiny_plan(); bad.conv_kernel_sizes = [[3, 1, 3]] + [[3, 3, 3]] * 3
     with pytest.raises(NotImplementedError):
         bad.check_supported()
+
+
+def test_trained_tiny_fixture_is_what_the_oracle_computes(tiny_net, tiny_io, golden_dir):
+    """tests/golden/tiny_net_trained20.npz (the "trained-like" variant, 20 oracle SGD steps): the oracle's training step
+    reproduces the stored loss sequence and parameters, and the oracle's tiled predictor the stored probabilities of the trained net."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden_trained_tiny', os.path.join(golden_dir, 'make_golden_trained_tiny.py'))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    G = np.load(os.path.join(golden_dir, 'tiny_net_trained20.npz'))
+    plan, _, sd0 = tiny_net
+    vol = tiny_io['volume'][0]
+    lab = (vol > float(G['threshold'])).astype(np.uint8)
+    assert int(lab.sum()) == int(G['label_voxels']) and np.array_equal(mk.schedule(), G['schedule'])
+    net, losses = mk.train_oracle(plan, sd0, vol, lab, G['schedule'])
+    # (torch's CPU kernels sum in an order that depends on the thread count: tolerance, not bits)
+    np.testing.assert_allclose(losses, G['losses'], rtol=0, atol=2e-4)
+    assert losses[-1] < 0.25 * losses[0]                                  # it has learnt something
+    for k, v in net.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), G['w.' + k], rtol=0, atol=2e-4, err_msg=k)
+    # the stored weights through the predictor
+    net2 = unet_from_plan(plan).eval()
+    net2.load_state_dict({k[2:]: torch.from_numpy(G[k]) for k in G.files if k.startswith('w.')}, strict=True)
+    seg, prob = osw.predict_3d_tiled(net2, tiny_io['volume'], plan.patch_size, 0.5, False, True)
+    assert float(np.abs(prob[1] - G['prob1_notta']).max()) <= 2e-5
+    sure = np.abs(2.0 * G['prob1_notta'] - 1.0) > 2e-4
+    assert np.array_equal(seg[sure], G['seg_notta'][sure])
+    # most voxels are decided after 20 steps (median |p - 0.5| 0.30), unlike the random-init fixtures whose probabilities hug 0.5
+    assert float((np.abs(G['prob1_tta'] - 0.5) > 0.25).mean()) > 0.5
