@@ -81,6 +81,9 @@ def parse_args(argv=None):
     ap.add_argument('--also', choices=['auto', 'off'], default='auto',
                     help='auto (N=1, fp32 headline only): after the headline, measure configs[2] (channels-last bf16, 8 volumes per '
                          'step), the f16x2 mode and one training iteration (fp32, bf16) and report them in an "also" object')
+    ap.add_argument('--cli', choices=['auto', 'off'], default='auto',
+                    help='auto (with --also auto): after everything else, run bin/nnUNet_predict (with mirroring; with --disable_tta --save_softmax) '
+                         'and bin/nnUNet_train as child processes on BASELINE-sized cases and report their rates in `cli` / `summary.cli`')
     ap.add_argument('--detail-file', default='auto',
                     help='where the FULL record goes (every mode with its clock samples, phases, parity objects, sample descriptions); the one '
                          'printed line carries the numbers only.  auto: gpurun_out/bench_detail.json when gpurun_out/ exists, else nowhere')
@@ -434,6 +437,34 @@ def measure_inference_mode(plan, sd, device, precision, storage, V, steps, warmu
     return out, eng, vol_d, vols_h
 
 
+def measure_no_mirroring_rate(plan, sd, device, shape, steps=6):
+    """volumes/s of the hot path without mirroring (8 forwards per volume in one batch of 8; `--disable_tta`), same protocol as the headline:
+    the kernel-only figure the `--disable_tta --save_softmax` command is put next to."""
+    import torch
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    from deepwmh_amd.synthetic import synthetic_flair
+    eng = UNetEngine(plan, sd, device, precision='f16x2')
+    pred = SlidingWindowPredictor(eng, do_mirroring=False, batch=16)
+    vol_h = torch.from_numpy(synthetic_flair(tuple(shape), seed=0)).pin_memory()
+    seg_h = torch.empty(tuple(shape), dtype=torch.uint8).pin_memory()
+    vol_d = torch.empty((1,) + tuple(shape), dtype=torch.float32, device=device)
+
+    def step():
+        vol_d.copy_(vol_h, non_blocking=True)
+        seg_h.copy_(pred.predict_device(vol_d, return_prob=True)[0], non_blocking=True)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del eng, pred
+    torch.cuda.empty_cache()
+    return round(steps / dt, 3)
+
+
 def measure_training_mode(plan, sd, device, precision, iters, warmup):
     """One nnUNetTrainerV2 iteration (forward with deep supervision, Dice+CE, backward, clip, SGD-Nesterov) at batch 2 x 128^3,
     BASELINE plan, synthetic patches and labels resident in HBM."""
@@ -518,6 +549,96 @@ def training_parity_tiny():
                               median_parameter_rel_max_err=rows[len(rows) // 2], worst_parameter_rel_max_err=rows[-1])
     return out
 
+# ------------------------------------------------------------------------------------------------------------
+# the boundary DeepWMH sees: the three commands as fresh child processes
+# ------------------------------------------------------------------------------------------------------------
+def measure_cli(plan, sd, shape, n_mirror=12, n_softmax=24, train_batches=40):
+    """`bin/nnUNet_predict` and `bin/nnUNet_train` exactly as /root/reference/deepwmh/main/predict.py:153-156 and
+    deepwmh/pipeline/DCNN_multistage.py:292-309,331-344 run them -- child processes found on PATH, talking through folders of .nii.gz
+    files -- on BASELINE-sized synthetic cases: prediction with mirroring (DeepWMH_predict), prediction with `--disable_tta --save_softmax`
+    (the 5 x N Stage-II predictions), one epoch of `-b <train_batches>` iterations.  Children of this process (which has released its device
+    memory but keeps its context: they share the GPU with an idle parent); never an exec.  Rates are the commands' own report lines:
+    `cases/s` of the whole case loop (reads, preprocessing, GPU, export, compressed writes; model load excluded) and the rate once the first
+    case is through; the command's wall-clock is next to them."""
+    import re
+    import shutil
+    import tempfile
+    import torch
+    from deepwmh_amd import checkpoint as ck, nifti
+    from deepwmh_amd.synthetic import synthetic_flair
+    tmp = tempfile.mkdtemp(prefix='wmh_bench_cli_')
+    out = {}
+    try:
+        env = dict(os.environ, PATH=os.path.join(ROOT, 'bin') + os.pathsep + os.environ.get('PATH', ''), CUDA_VISIBLE_DEVICES=os.environ.get('CUDA_VISIBLE_DEVICES', '0'))
+        env.pop('MI355WMH_GPUS', None)
+        # -- a model folder in the layout DeepWMH installs, and input cases
+        res_dir, task = os.path.join(tmp, 'model'), 'Task002_FinalModel'
+        folder = ck.trainer_folder(res_dir, task)
+        ck.save_checkpoint(folder, {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()},
+                           ck.make_plans(plan, spacing=(1.0, 1.0, 1.0), use_mask_for_norm=True), 'all', 'model_best', epoch=1)
+        img = os.path.join(tmp, 'in')
+        os.makedirs(img)
+        ncase = max(n_mirror, n_softmax)
+        base = [synthetic_flair(tuple(shape), seed=100 + c)[0] for c in range(4)]
+        for c in range(ncase):                                  # (four distinct volumes, cycled: the files are what is timed, not their content)
+            v = base[c % 4]
+            nifti.write(os.path.join(img, 'case%02d_0000.nii.gz' % c), (v * 50 + 300 * (v != 0)).astype(np.float32), spacing=(1.0, 1.0, 1.0))
+        common = ('-i %s -o %%s -tr nnUNetTrainerV2 -m 3d_fullres -p nnUNetPlansv2.1 -t %s -f all -chk model_best --disable_post_processing '
+                  '--selected_cases %%s' % (img, task))
+
+        def run(cmd, extra_env=None):
+            t0 = time.time()
+            p = subprocess.run(cmd.split(), env=dict(env, **(extra_env or {})), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            return p.returncode, p.stdout, time.time() - t0
+
+        def predict_leg(n, flags, outdir):
+            cases = ' '.join('case%02d' % c for c in range(n))
+            rc, log, wall = run('nnUNet_predict ' + common % (os.path.join(tmp, outdir), cases) + flags, dict(RESULTS_FOLDER=res_dir))
+            m = re.search(r'(\d+) case\(s\) in ([0-9.]+) s \(([0-9.]+) cases/s(?:; first case done after ([0-9.]+) s, then ([0-9.]+) cases/s)?', log)
+            if rc != 0 or not m:
+                return dict(error='rc %d: %s' % (rc, log[-300:]))
+            gpu = [float(v) for v in re.findall(r'gpu ([0-9.]+) s', log)]
+            nfiles = len(os.listdir(os.path.join(tmp, outdir)))
+            return dict(cases=int(m.group(1)), cases_per_s=float(m.group(3)), first_case_s=float(m.group(4) or 0), cases_per_s_after_first=float(m.group(5) or 0),
+                        gpu_s_per_case_median=sorted(gpu)[len(gpu) // 2] if gpu else None, command_wall_s=round(wall, 2), files_written=nfiles)
+        out['predict_mirroring'] = predict_leg(n_mirror, '', 'out_tta')
+        out['predict_disable_tta_save_softmax'] = predict_leg(n_softmax, ' --disable_tta --save_softmax', 'out_softmax')
+        # -- training: raw dataset -> nnUNet_plan_and_preprocess -> one epoch of nnUNet_train
+        raw, pre, res2 = os.path.join(tmp, 'raw'), os.path.join(tmp, 'pre'), os.path.join(tmp, 'results')
+        root = os.path.join(raw, 'nnUNet_raw_data', 'Task001_LabelDenoising')
+        os.makedirs(os.path.join(root, 'imagesTr')); os.makedirs(os.path.join(root, 'labelsTr'))
+        training = []
+        for i in range(4):
+            v, name = base[i], 'case_%02d' % i
+            nifti.write(os.path.join(root, 'imagesTr', name + '_0000.nii.gz'), (v * 40 + 200 * (v != 0)).astype(np.float32), spacing=(1.0, 1.0, 1.0))
+            nifti.write(os.path.join(root, 'labelsTr', name + '.nii.gz'), (v > 1.6).astype(np.float32), spacing=(1.0, 1.0, 1.0))
+            training.append({'image': os.path.join(root, 'imagesTr', name + '.nii.gz'), 'label': os.path.join(root, 'labelsTr', name + '.nii.gz')})
+        with open(os.path.join(root, 'dataset.json'), 'w') as f:
+            json.dump({'name': '', 'description': '', 'reference': '', 'license': '', 'release': 'v1.0', 'tensorImageSize': '3D', 'modality': {'0': 'Modality_01'},
+                       'labels': {'0': 'background', '1': 'lesion'}, 'numTraining': 4, 'numTest': 0, 'training': training, 'test': []}, f)
+        tenv = dict(nnUNet_raw_data_base=raw, nnUNet_preprocessed=pre, RESULTS_FOLDER=res2)
+        rc, log, wall_pp = run('nnUNet_plan_and_preprocess -t 1 --verify_dataset_integrity', tenv)
+        if rc != 0:
+            out['train'] = dict(error='plan_and_preprocess rc %d: %s' % (rc, log[-300:]))
+        else:
+            rc, log, wall = run('nnUNet_train 3d_fullres nnUNetTrainerV2 1 all -e 2 -b %d --noval --save_every_epoch --disable_postprocessing_on_folds --val_batches 1' % train_batches, tenv)
+            ep = re.findall(r'epoch (\d+)/\d+: .*\(([0-9.]+) s: (\d+) iterations at ([0-9.]+) ms, validation ([0-9.]+) s\)', log)
+            if rc != 0 or len(ep) < 2:
+                out['train'] = dict(error='rc %d: %s' % (rc, log[-300:]))
+            else:
+                # epoch 2 = the steady state (epoch 1 carries buffer allocation and kernel loading); its wall-clock holds the iterations, the
+                # validation batch and whatever of the three checkpoint files' writing the background writer did not hide
+                e2 = ep[1]
+                out['train'] = dict(batches_per_epoch=int(e2[2]), ms_per_iteration_in_epoch=float(e2[3]), epoch_wall_s=float(e2[1]),
+                                    ms_per_iteration_all_in=round(1e3 * float(e2[1]) / int(e2[2]), 2), first_epoch_wall_s=float(ep[0][1]),
+                                    command_wall_s=round(wall, 2), plan_and_preprocess_wall_s=round(wall_pp, 2))
+    except Exception as e:                                      # the boundary leg must not take the headline down
+        out['error'] = '%s: %s' % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def compact_line(res):
     """The ONE printed line.  The driver keeps the last 2000 characters of stdout, so: the contract's keys, numbers only (prose lives in
     DESIGN.md, the full record in --detail-file), and LAST a `summary` that holds every mode's headline figure."""
@@ -596,6 +717,22 @@ def compact_line(res):
     summary['sclk_mhz'] = {k: v for k, v in sclk.items() if v is not None}
     if res.get('cpu_baseline'):
         summary['cpu_volumes_per_s'] = rnd(res['cpu_baseline']['value'], 3)
+    cli = res.get('cli')
+    if cli:
+        # the commands DeepWMH runs, as child processes: [cases/s of the whole case loop, cases/s after the first case, kernel-only volumes/s];
+        # training: [ms per iteration inside an epoch, epoch wall-clock / iterations (validation batch + checkpoint files included), kernel-only ms]
+        c, ko = {}, cli.get('kernel_only', {})
+        pm, ps, tr = cli.get('predict_mirroring', {}), cli.get('predict_disable_tta_save_softmax', {}), cli.get('train', {})
+        if 'cases_per_s' in pm:
+            c['predict_mirroring'] = [rnd(pm['cases_per_s']), rnd(pm['cases_per_s_after_first']), rnd(ko.get('mirroring_volumes_per_s'))]
+        if 'cases_per_s' in ps:
+            c['predict_disable_tta_save_softmax'] = [rnd(ps['cases_per_s']), rnd(ps['cases_per_s_after_first']), rnd(ko.get('no_mirroring_volumes_per_s'))]
+        if 'ms_per_iteration_all_in' in tr:
+            c['train_ms'] = [rnd(tr['ms_per_iteration_in_epoch']), rnd(tr['ms_per_iteration_all_in']), rnd(ko.get('train_ms_f16x2'))]
+        errs = [k for k, v in cli.items() if isinstance(v, dict) and 'error' in v] + (['cli'] if 'error' in cli else [])
+        if errs:
+            c['failed'] = errs
+        summary['cli'] = c
     line['summary'] = summary                      # last key: it must survive the driver's 2000-character tail
     return line
 
@@ -794,6 +931,17 @@ def run_rank(args):
             res['cpu_baseline'], res['parity'], px = cpu_baseline(plan, sd, vols_h[0].numpy(), tta, args.cpu_baseline, gpu_nt, lg, extra_nt)
             for k, v in px.items():
                 res['also'][k]['parity_vs_oracle'] = v
+        if also_on and args.cli != 'off':
+            # the boundary: the commands themselves, as children, after everything this process measures (its tensors are released first)
+            del pred
+            eng._bufs.clear()
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            nm_kernel = measure_no_mirroring_rate(plan, sd, device, args.shape)
+            res['cli'] = measure_cli(plan, sd, args.shape)
+            res['cli']['kernel_only'] = dict(mirroring_volumes_per_s=round(res['value'], 3), no_mirroring_volumes_per_s=nm_kernel,
+                                             train_ms_f16x2=res['also']['train_f16x2']['ms_per_step'])
         detail = args.detail_file
         if detail in ('none', 'off', ''):
             detail = None

@@ -261,12 +261,17 @@ def main(argv=None):
         if prob0 is not None:
             nifti.write(os.path.join(args.output_folder, case + '_0.nii.gz'), prob0, like=meta, dtype=np.float32)
 
-    nread = max(1, min(args.num_threads_preprocessing, 4))
+    # gunzip of one float32 case is ~0.2 s of one core and cannot be split, so the readers bound a --disable_tta run (0.03 s of GPU per case):
+    # as many as --num_threads_preprocessing allows (nnU-Net's default is 6)
+    nread = max(1, min(args.num_threads_preprocessing, 8))
     t_all = time.time()
+    t_case_done = []
     with ThreadPoolExecutor(nread) as readers, ThreadPoolExecutor(max(1, args.num_threads_nifti_save)) as writers:
         ahead = nread + 1
         loads = [readers.submit(load, c) for c, _ in todo[:ahead]]
         saves = []
+        if todo:
+            pred.warm_up()          # buffers + code objects while the first cases are being read (0.5 s that the first case used to carry)
         for i, (case, out) in enumerate(todo):
             t0 = time.time()
             vol, meta, t_load = loads[i].result()
@@ -281,13 +286,17 @@ def main(argv=None):
             seg_full, prob0 = export_prediction_device(seg_d, prob_d, props, args.save_softmax)     # synchronises
             t2 = time.time()
             saves.append(writers.submit(save, out, case, seg_full, prob0, meta))
+            t_case_done.append(time.time())
             print('  %s: shape %s%s, read %.2f s (waited %.2f s), gpu %.2f s'
                   % (case, tuple(data_d.shape[1:]), ' (resampled)' if resampled else '', t_load, t1 - t0, t2 - t1), flush=True)
         for f in saves:
             f.result()                                                       # re-raises a failed write
     if todo:
         dt = time.time() - t_all
-        print('  %d case(s) in %.2f s (%.2f cases/s)' % (len(todo), dt, len(todo) / dt), flush=True)
+        steady = ''
+        if len(todo) >= 4:          # rate once the pipeline is full: from the end of the first case's GPU work to the last file written
+            steady = '; first case done after %.2f s, then %.2f cases/s' % (t_case_done[0] - t_all, (len(todo) - 1) / max(1e-9, time.time() - t_case_done[0]))
+        print('  %d case(s) in %.2f s (%.2f cases/s%s)' % (len(todo), dt, len(todo) / dt, steady), flush=True)
     return 0
 
 

@@ -32,9 +32,6 @@ def build_parser():
                     help='exact-fp32 kernels throughout (also WMH_TRAIN_PRECISION=fp32).  The default is f16x2: fp32 tensors, statistics, '
                          'weight gradients and optimizer; forward and data-gradient products from fp16 pairs with a 2^16 loss scale -- '
                          'gradients at the fp32 step\'s level (nnU-Net itself defaults to fp16 AMP with a GradScaler)')
-    ap.add_argument('--bf16', action='store_true',
-                    help='mixed precision: bf16 operands in the forward/data-gradient/weight-gradient convolutions of the wide levels '
-                         '(extension; also WMH_TRAIN_PRECISION=bf16)')
     ap.add_argument('--val_batches', type=int, default=None)
     ap.add_argument('--seed', type=int, default=12345)
     return ap
@@ -89,8 +86,9 @@ def main(argv=None):
     precision = os.environ.get('WMH_TRAIN_PRECISION', 'f16x2')
     if args.fp32:
         precision = 'fp32'
-    elif args.bf16:
-        precision = 'bf16'
+    # (bf16 operands -- UNetTrainer(precision='bf16') -- are a library switch only, reachable here through WMH_TRAIN_PRECISION=bf16: its
+    #  gradients are 8.6 % off float64 autograd on the tiny net (bench.py, summary.train_gradient_rel_l2_vs_float64_tiny_net), so the
+    #  command DeepWMH runs 22 500 iterations with does not offer it as a flag)
     if precision not in ('fp32', 'f16x2', 'bf16'):
         sys.exit('nnUNet_train (deepwmh_amd): WMH_TRAIN_PRECISION must be fp32, f16x2 or bf16, got %r' % precision)
     start_epoch, best, ma_resume = 0, None, None
@@ -128,14 +126,30 @@ def main(argv=None):
     nval = args.val_batches if args.val_batches is not None else max(1, min(50, args.batches_per_epoch // 5))
     ma = ma_resume                                      # the smoothed criterion continues across `-c` (it decides model_best)
 
+    # Checkpoint files are written by ONE background thread, in order: an epoch of the reference's schedule (-b 150: 4.2 s here) ends with up
+    # to three files of 125-250 MB (model_best, model_ep_NNNN, model_latest with the momentum), 0.2-0.4 s each of pickling and file IO that the
+    # GPU would otherwise sit out.  The training thread only takes the host snapshot (one D2H copy per epoch, shared by the epoch's files).
+    from concurrent.futures import ThreadPoolExecutor
+    writer = ThreadPoolExecutor(1, thread_name_prefix='wmh_ckpt') if rank == 0 else None
+    pending, snap = [], dict(epoch=None)
+
+    def drain(keep=0):
+        while len(pending) > keep:
+            pending.pop(0).result()                          # re-raises a failed write
+
     def save(name, epoch):
         if rank != 0:
             return
+        if snap['epoch'] != epoch:                           # parameters (and momentum) as they are now; later files of this epoch reuse them
+            snap.update(epoch=epoch, sd=tr.state_dict(), mom=None)
         # the SGD momentum (as large as the weights) only where training can continue from: model_latest
         extra = dict(deepwmh_amd_best=best, deepwmh_amd_ma=ma, deepwmh_amd_loss_scale=float(tr.loss_scale), deepwmh_amd_precision=precision)
         if name == 'model_latest':
-            extra['deepwmh_amd_momentum'] = tr.momentum_state()
-        ck.save_checkpoint(folder, tr.state_dict(), plans, args.fold, name, epoch=epoch, extra=extra)
+            if snap['mom'] is None:
+                snap['mom'] = tr.momentum_state()
+            extra['deepwmh_amd_momentum'] = snap['mom']
+        drain(keep=3)                                        # bounded: at most one epoch's files in flight
+        pending.append(writer.submit(ck.save_checkpoint, folder, snap['sd'], plans, args.fold, name, epoch, extra))
 
     for epoch in range(start_epoch, args.epochs):
         lr = poly_lr(epoch, args.epochs, 1e-2, 0.9)
@@ -145,7 +159,8 @@ def main(argv=None):
             x = torch.from_numpy(data).to(device)
             tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool, plan.pool_op_kernel_sizes)
             losses.append(tr.run_iteration(x, tg, lr).clone())           # stays on the device: no per-iteration sync
-        losses = [float(v) for v in torch.stack(losses).cpu()]
+        losses = [float(v) for v in torch.stack(losses).cpu()]          # synchronises: the epoch's iterations are done
+        t_train = time.time() - t0
         skipped_before, losses = getattr(tr, '_skipped_reported', 0), [v for v in losses if np.isfinite(v)] or [float('nan')]
         vl = []
         for _ in range(nval):
@@ -156,8 +171,9 @@ def main(argv=None):
         v = float(np.mean(vl))
         ma = -v if ma is None else 0.9 * ma + 0.1 * (-v)           # moving-average criterion (higher is better)
         if rank == 0:
-            print('epoch %d/%d: lr %.6f train loss %.4f val loss %.4f (%.1f s)'
-                  % (epoch + 1, args.epochs, lr, float(np.mean(losses)), v, time.time() - t0), flush=True)
+            print('epoch %d/%d: lr %.6f train loss %.4f val loss %.4f (%.1f s: %d iterations at %.1f ms, validation %.2f s)'
+                  % (epoch + 1, args.epochs, lr, float(np.mean(losses)), v, time.time() - t0, args.batches_per_epoch,
+                     1e3 * t_train / max(1, args.batches_per_epoch), time.time() - t0 - t_train), flush=True)
             if tr.skipped_steps != skipped_before:      # GradScaler semantics: the device skipped updates whose gradient norm was not finite
                 print('  %d optimizer step(s) skipped (non-finite gradients); loss scale now %g' % (tr.skipped_steps - skipped_before, tr.loss_scale), flush=True)
         tr._skipped_reported = tr.skipped_steps
@@ -168,6 +184,9 @@ def main(argv=None):
             save('model_ep_%04d' % (epoch + 1), epoch + 1)
         save('model_latest', epoch + 1)                  # last: carries this epoch's `best`, so a `-c` run cannot overwrite a better model_best
     save('model_final_checkpoint', args.epochs)
+    drain()
+    if writer is not None:
+        writer.shutdown()
     loader.close()
     if world > 1:
         dist.destroy_process_group()

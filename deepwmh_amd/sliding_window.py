@@ -188,6 +188,17 @@ class SlidingWindowPredictor:
                    'wmh_finalize_argmax')
         return seg, prob
 
+    def warm_up(self, num_input_channels=None):
+        """One forward on zeros at the batch size predict_device will use: allocates the engine's activation buffers (29 GB at 16 patches of
+        the BASELINE plan) and makes the runtime load every kernel's code object -- half a second that `nnUNet_predict` otherwise spends inside its
+        first case.  Queued on the current stream; no host sync."""
+        Cc = int(num_input_channels or self.engine.plan.num_input_channels)
+        n = 8 * max(1, self.batch // 8) if self.do_mirroring else min(self.batch, 8)
+        x = self._scratch('patches', (n, Cc) + self.patch)
+        x.zero_()
+        self.engine.forward_features(x)
+        self.gaussian()
+
     def predict(self, volume, return_prob=True):
         """volume: numpy float32 [C,X,Y,Z] (preprocessed).  Returns numpy (seg, prob)."""
         vol = torch.from_numpy(np.ascontiguousarray(volume, dtype=np.float32)).to(self.device)

@@ -130,7 +130,11 @@ def test_the_printed_line_ends_with_a_summary_that_fits_the_drivers_tail():
                          configs2_bf16_storage=dict(mode(12.97, 0.43, 1960), parity_vs_fp32_path=dict(max_abs_softmax_diff=0.0203, dice_vs_fp32_mask=0.998596)),
                          train_fp32=dict(ms_per_step=59.006, roofline=dict(frac=0.617), parity=dict(gradient_rel_l2_err=1.1e-6)),
                          train_f16x2=dict(ms_per_step=31.779, roofline=dict(frac=0.2163), parity=dict(gradient_rel_l2_err=1.2e-6)),
-                         train_bf16=dict(ms_per_step=26.809, roofline=dict(frac=0.0854), parity=dict(gradient_rel_l2_err=0.086))))
+                         train_bf16=dict(ms_per_step=26.809, roofline=dict(frac=0.0854), parity=dict(gradient_rel_l2_err=0.086))),
+               cli=dict(predict_mirroring=dict(cases=12, cases_per_s=4.83219, first_case_s=0.31, cases_per_s_after_first=5.1234, command_wall_s=5.1, files_written=12),
+                        predict_disable_tta_save_softmax=dict(cases=24, cases_per_s=27.512, first_case_s=0.2, cases_per_s_after_first=31.04, command_wall_s=3.3, files_written=48),
+                        train=dict(batches_per_epoch=40, ms_per_iteration_in_epoch=28.91, epoch_wall_s=1.21, ms_per_iteration_all_in=30.25, command_wall_s=6.0),
+                        kernel_only=dict(mirroring_volumes_per_s=4.805, no_mirroring_volumes_per_s=38.2, train_ms_f16x2=31.779)))
     line = bench.compact_line(res)
     text = json.dumps(line)
     assert list(line)[-1] == 'summary'
@@ -140,9 +144,10 @@ def test_the_printed_line_ends_with_a_summary_that_fits_the_drivers_tail():
     assert sm['configs1_f16x2'] == 4.805 and sm['configs1_fp32_exact'] == 2.175 and sm['configs2_bf16'] == 12.97
     assert sm['train_ms'] == {'fp32': 59.01, 'f16x2': 31.78, 'bf16': 26.81} and sm['frac']['configs1_f16x2'] == 0.4012
     assert sm['parity_max_abs']['f16x2_vs_oracle'] == 1.11e-05 and sm['parity_max_abs']['fp32_exact_vs_oracle'] == 1.4e-05
+    assert sm['cli'] == {'predict_mirroring': [4.832, 5.123, 4.805], 'predict_disable_tta_save_softmax': [27.51, 31.04, 38.2], 'train_ms': [28.91, 30.25, 31.78]}
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
                 'roofline', 'cpu_baseline'):
         assert key in line
     assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(line['roofline'])
     assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(line['cpu_baseline'])
-    assert len(text) < 3200 and 'prose' not in text
+    assert len(text) < 3400 and 'prose' not in text

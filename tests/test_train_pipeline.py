@@ -137,7 +137,7 @@ def test_plan_train_continue_predict_through_the_executables(tmp_path):
         assert f in have, f
     assert os.path.isfile(os.path.join(os.path.dirname(fdir), 'plans.pkl'))
     assert 'precision f16x2' in p.stdout                             # the default mode; the switches that select the others:
-    for extra, envx, want in (('--fp32', {}, 'fp32'), ('', dict(WMH_TRAIN_PRECISION='bf16'), 'bf16'), ('--bf16', {}, 'bf16')):
+    for extra, envx, want in (('--fp32', {}, 'fp32'), ('', dict(WMH_TRAIN_PRECISION='bf16'), 'bf16')):      # (no --bf16 flag: library switch only)
         q = subprocess.run(shlex.split(train.replace('-e 2', '-e 1').replace('-b 3', '-b 1') + ' ' + extra), env=dict(env, RESULTS_FOLDER=str(tmp_path / ('res_' + want + extra[2:])), **envx),
                            capture_output=True, text=True)
         assert q.returncode == 0 and ('precision ' + want) in q.stdout, (extra, envx, q.stdout[-500:], q.stderr[-500:])

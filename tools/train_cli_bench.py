@@ -1,5 +1,5 @@
 """End-to-end iteration rate of the `nnUNet_train` drop-in (plan + preprocess a synthetic 160x192x160 dataset, then one
-epoch of B batches of 2 x 128^3 patches).  usage: python tools/train_cli_bench.py [batches] [--bf16]"""
+epoch of B batches of 2 x 128^3 patches).  usage: python tools/train_cli_bench.py [batches]"""
 import os
 import sys
 import tempfile
@@ -20,7 +20,7 @@ def main():
     os.environ.update(nnUNet_raw_data_base=raw, nnUNet_preprocessed=pre, RESULTS_FOLDER=res)
     t = time.time(); pp.main(['-t', '1', '--verify_dataset_integrity']); print('plan_and_preprocess: %.1f s' % (time.time() - t))
     argv = ['3d_fullres', 'nnUNetTrainerV2', '1', 'all', '-e', '1', '-b', str(nb), '--noval', '--val_batches', '1',
-            '--disable_postprocessing_on_folds'] + (['--bf16'] if '--bf16' in sys.argv else [])
+            '--disable_postprocessing_on_folds']
     t = time.time(); train.main(argv); dt = time.time() - t
     print('nnUNet_train: %d iterations (+1 validation batch, checkpoint writes, engine set-up) in %.1f s -> %.1f ms per iteration all-in'
           % (nb, dt, 1e3 * dt / nb))
