@@ -123,3 +123,81 @@ def save_checkpoint(folder, state_dict, plans, fold='all', checkpoint_name='mode
         init=init, name=TRAINER, **{'class': "<class 'nnunet.training.network_training.nnUNetTrainerV2.nnUNetTrainerV2'>"}, plans=plans), f))
     atomically(plans_file, lambda f: pickle.dump(plans, f))
     return model
+
+
+class CheckpointProcess:
+    """Checkpoint files written by a helper process (cli/_ckpt_writer.py: why a process and not a thread).  The trainer hands over raw
+    snapshots of its flat parameter / momentum arenas (one file write each, no pickling on the training side); jobs are executed in order;
+    `drain()` waits for everything submitted and raises if a write failed.  `plans` and the parameter layout are sent once."""
+
+    def __init__(self, param_order, offsets, plans, scratch_dir):
+        import json
+        import subprocess
+        import sys
+        import tempfile
+        self._json = json
+        shm = '/dev/shm'
+        self.dir = tempfile.mkdtemp(prefix='wmh_ckpt_', dir=shm if os.path.isdir(shm) and os.access(shm, os.W_OK) else scratch_dir)
+        plans_file = os.path.join(self.dir, 'plans.pkl')
+        with open(plans_file, 'wb') as f:
+            pickle.dump(plans, f)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='',
+                   PYTHONPATH=root + (os.pathsep + os.environ['PYTHONPATH'] if os.environ.get('PYTHONPATH') else ''))
+        self.proc = subprocess.Popen([sys.executable, '-m', 'deepwmh_amd.cli._ckpt_writer'], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                     env=env, text=True, bufsize=1)
+        self.pending = 0
+        self._send(dict(op='init', order=[[n, list(s)] for n, s in param_order], offsets=[int(v) for v in offsets], plans=plans_file))
+        self._snap, self._n = None, 0
+
+    def _send(self, job):
+        self.proc.stdin.write(self._json.dumps(job) + '\n')
+        self.proc.stdin.flush()
+        self.pending += 1
+
+    def snapshot(self, params_flat, momentum_flat=None):
+        """params_flat / momentum_flat: host float32 arrays (the whole arenas).  Files of the previous snapshot are dropped once the
+        jobs that use them have run (the drop is queued behind them)."""
+        if self._snap:
+            self._send(dict(op='drop', files=[f for f in self._snap if f]))
+        self._n += 1
+        pf = os.path.join(self.dir, 'params_%d.f32' % self._n)
+        params_flat.tofile(pf)
+        mf = None
+        if momentum_flat is not None:
+            mf = os.path.join(self.dir, 'momentum_%d.f32' % self._n)
+            momentum_flat.tofile(mf)
+        self._snap = (pf, mf)
+
+    def add_momentum(self, momentum_flat):
+        pf, mf = self._snap
+        if mf is None:
+            mf = os.path.join(self.dir, 'momentum_%d.f32' % self._n)
+            momentum_flat.tofile(mf)
+            self._snap = (pf, mf)
+
+    def save(self, folder, fold, name, epoch, extra, with_momentum=False):
+        pf, mf = self._snap
+        self._send(dict(op='save', params=pf, momentum=mf if with_momentum else None, folder=folder, fold=str(fold), name=name,
+                        epoch=int(epoch), extra=extra))
+
+    def drain(self, keep=0):
+        while self.pending > keep:
+            line = self.proc.stdout.readline()
+            if not line:
+                raise RuntimeError('checkpoint writer process ended unexpectedly (exit code %s)' % self.proc.poll())
+            self.pending -= 1
+            if not line.startswith('ok'):
+                raise RuntimeError('checkpoint writer: ' + line.strip())
+
+    def close(self):
+        import shutil
+        try:
+            self.drain()
+        finally:
+            try:
+                self.proc.stdin.close()
+                self.proc.wait(timeout=60)
+            except Exception:
+                self.proc.kill()
+            shutil.rmtree(self.dir, ignore_errors=True)

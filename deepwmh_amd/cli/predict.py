@@ -264,31 +264,60 @@ def main(argv=None):
     # gunzip of one float32 case is ~0.2 s of one core and cannot be split, so the readers bound a --disable_tta run (0.03 s of GPU per case):
     # as many as --num_threads_preprocessing allows (nnU-Net's default is 6)
     nread = max(1, min(args.num_threads_preprocessing, 8))
+    # Cases in flight: without mirroring a case is 25 ms of GPU work between two synchronising copies (the volume in, label map and
+    # probabilities out) and the host work around them -- a second case on a second stream, with its own activation buffers on the same
+    # weights, fills those gaps (the Stage-II predictions, DCNN_multistage.py:331-344: 5 x N cases with --disable_tta --save_softmax).
+    # With mirroring the GPU is busy 94 % of the time already and a second set of buffers (29 GB, half a second to allocate) does not pay.
+    ninflight = max(1, int(os.environ.get('WMH_PREDICT_INFLIGHT', '2' if args.disable_tta else '1')))
+    lanes = [(pred, torch.cuda.current_stream())]
+    for _ in range(1, min(ninflight, max(1, len(todo)))):
+        e2 = eng.clone()
+        lanes.append((SlidingWindowPredictor(e2, plan.patch_size, args.step_size, True, not args.disable_tta, batch=16), torch.cuda.Stream()))
+    import threading
+    lock = threading.Lock()
     t_all = time.time()
     t_case_done = []
-    with ThreadPoolExecutor(nread) as readers, ThreadPoolExecutor(max(1, args.num_threads_nifti_save)) as writers:
+    # the label map is small; the background probability (--save_softmax) is a float32 volume: its compression is spread over the gzip pool
+    # (nifti.gzip_members), so a few writer threads keep up with 40 cases a second
+    nwrite = max(1, args.num_threads_nifti_save, 4 if args.save_softmax else 1)
+    with ThreadPoolExecutor(nread) as readers, ThreadPoolExecutor(nwrite) as writers, ThreadPoolExecutor(len(lanes)) as gpu_lanes:
         ahead = nread + 1
         loads = [readers.submit(load, c) for c, _ in todo[:ahead]]
         saves = []
-        if todo:
-            pred.warm_up()          # buffers + code objects while the first cases are being read (0.5 s that the first case used to carry)
-        for i, (case, out) in enumerate(todo):
-            t0 = time.time()
-            vol, meta, t_load = loads[i].result()
-            loads[i] = None
-            if i + ahead < len(todo):
-                loads.append(readers.submit(load, todo[i + ahead][0]))
-            t1 = time.time()
-            # crop, (resample,) z-score, sliding window, (resample,) argmax, un-crop: all on the device
-            data_d, props = preprocess_case_device(vol, meta['spacing'], plans, stage, 'cuda:0')
-            resampled = tuple(data_d.shape[1:]) != tuple(props['shape_after_crop'])
-            seg_d, prob_d = pred.predict_device(data_d, return_prob=args.save_softmax or resampled)
-            seg_full, prob0 = export_prediction_device(seg_d, prob_d, props, args.save_softmax)     # synchronises
-            t2 = time.time()
-            saves.append(writers.submit(save, out, case, seg_full, prob0, meta))
-            t_case_done.append(time.time())
-            print('  %s: shape %s%s, read %.2f s (waited %.2f s), gpu %.2f s'
-                  % (case, tuple(data_d.shape[1:]), ' (resampled)' if resampled else '', t_load, t1 - t0, t2 - t1), flush=True)
+        nxt = [0]
+
+        def lane(k):
+            p_k, stream = lanes[k]
+            with torch.cuda.stream(stream):
+                p_k.warm_up()       # buffers + code objects while the first cases are being read (0.5 s that the first case used to carry)
+                while True:
+                    with lock:
+                        i = nxt[0]
+                        if i >= len(todo):
+                            return
+                        nxt[0] += 1
+                        fut = loads[i]
+                        loads[i] = None
+                        if i + ahead < len(todo):
+                            loads.append(readers.submit(load, todo[i + ahead][0]))
+                    case, out = todo[i]
+                    t0 = time.time()
+                    vol, meta, t_load = fut.result()
+                    t1 = time.time()
+                    # crop, (resample,) z-score, sliding window, (resample,) argmax, un-crop: all on the device
+                    data_d, props = preprocess_case_device(vol, meta['spacing'], plans, stage, 'cuda:0')
+                    resampled = tuple(data_d.shape[1:]) != tuple(props['shape_after_crop'])
+                    seg_d, prob_d = p_k.predict_device(data_d, return_prob=args.save_softmax or resampled)
+                    seg_full, prob0 = export_prediction_device(seg_d, prob_d, props, args.save_softmax)     # synchronises this lane's stream
+                    t2 = time.time()
+                    with lock:
+                        saves.append(writers.submit(save, out, case, seg_full, prob0, meta))
+                        t_case_done.append(time.time())
+                    print('  %s: shape %s%s, read %.2f s (waited %.2f s), gpu %.2f s'
+                          % (case, tuple(data_d.shape[1:]), ' (resampled)' if resampled else '', t_load, t1 - t0, t2 - t1), flush=True)
+
+        for f in [gpu_lanes.submit(lane, k) for k in range(len(lanes))]:
+            f.result()                                                       # re-raises a failed case
         for f in saves:
             f.result()                                                       # re-raises a failed write
     if todo:

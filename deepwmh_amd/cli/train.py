@@ -126,30 +126,29 @@ def main(argv=None):
     nval = args.val_batches if args.val_batches is not None else max(1, min(50, args.batches_per_epoch // 5))
     ma = ma_resume                                      # the smoothed criterion continues across `-c` (it decides model_best)
 
-    # Checkpoint files are written by ONE background thread, in order: an epoch of the reference's schedule (-b 150: 4.2 s here) ends with up
-    # to three files of 125-250 MB (model_best, model_ep_NNNN, model_latest with the momentum), 0.2-0.4 s each of pickling and file IO that the
-    # GPU would otherwise sit out.  The training thread only takes the host snapshot (one D2H copy per epoch, shared by the epoch's files).
-    from concurrent.futures import ThreadPoolExecutor
-    writer = ThreadPoolExecutor(1, thread_name_prefix='wmh_ckpt') if rank == 0 else None
-    pending, snap = [], dict(epoch=None)
-
-    def drain(keep=0):
-        while len(pending) > keep:
-            pending.pop(0).result()                          # re-raises a failed write
+    # Checkpoint files are written by a helper PROCESS, in order (cli/_ckpt_writer.py says why not a thread): the training process only takes
+    # the host snapshot -- one D2H copy of the flat parameter arena per epoch (and of the momentum where training can continue from), one raw
+    # file write each -- and goes on launching kernels.
+    writer = None
+    if rank == 0:
+        offs = [tr.grad_ranges[name][0] for name, _ in tr.param_order]
+        writer = ck.CheckpointProcess(tr.param_order, offs, plans, fdir)
+    snap = dict(epoch=None)
 
     def save(name, epoch):
         if rank != 0:
             return
-        if snap['epoch'] != epoch:                           # parameters (and momentum) as they are now; later files of this epoch reuse them
-            snap.update(epoch=epoch, sd=tr.state_dict(), mom=None)
-        # the SGD momentum (as large as the weights) only where training can continue from: model_latest
-        extra = dict(deepwmh_amd_best=best, deepwmh_amd_ma=ma, deepwmh_amd_loss_scale=float(tr.loss_scale), deepwmh_amd_precision=precision)
-        if name == 'model_latest':
-            if snap['mom'] is None:
-                snap['mom'] = tr.momentum_state()
-            extra['deepwmh_amd_momentum'] = snap['mom']
-        drain(keep=3)                                        # bounded: at most one epoch's files in flight
-        pending.append(writer.submit(ck.save_checkpoint, folder, snap['sd'], plans, args.fold, name, epoch, extra))
+        if snap['epoch'] != epoch:                           # parameters as they are now; later files of this epoch reuse the snapshot
+            writer.drain(keep=4)                             # bounded: at most one epoch's files in flight
+            snap['epoch'] = epoch
+            writer.snapshot(tr.params.detach().cpu().numpy())
+        # nnU-Net's checkpoint carries plain types; the json line does too (best / ma are floats or None)
+        extra = dict(deepwmh_amd_best=None if best is None else float(best), deepwmh_amd_ma=None if ma is None else float(ma),
+                     deepwmh_amd_loss_scale=float(tr.loss_scale), deepwmh_amd_precision=precision)
+        latest = name == 'model_latest'                      # the SGD momentum (as large as the weights) only where training can continue from
+        if latest:
+            writer.add_momentum(tr.mom.detach().cpu().numpy())
+        writer.save(folder, args.fold, name, epoch, extra, with_momentum=latest)
 
     for epoch in range(start_epoch, args.epochs):
         lr = poly_lr(epoch, args.epochs, 1e-2, 0.9)
@@ -184,9 +183,8 @@ def main(argv=None):
             save('model_ep_%04d' % (epoch + 1), epoch + 1)
         save('model_latest', epoch + 1)                  # last: carries this epoch's `best`, so a `-c` run cannot overwrite a better model_best
     save('model_final_checkpoint', args.epochs)
-    drain()
     if writer is not None:
-        writer.shutdown()
+        writer.close()                                       # waits for every file; a failed write fails the command
     loader.close()
     if world > 1:
         dist.destroy_process_group()

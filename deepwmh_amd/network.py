@@ -129,6 +129,14 @@ class UNetEngine:
         # every layer reads its input once and writes its output once, plus its weights.
         self.acct = None
 
+    def clone(self):
+        """A second engine on the same weights (packed images included) with activation buffers of its own: `nnUNet_predict` keeps two cases
+        in flight on two streams when a case is too short to hide the host work around it (--disable_tta)."""
+        import copy
+        c = copy.copy(self)
+        c._bufs, c.timed_cfgs, c.timings, c.acct = {}, set(), [], None
+        return c
+
     def _check_storage_supported(self):
         """storage='bf16' is served by specific kernel configurations (include/deepwmh_amd.h, the *_st calls): say so
         when the engine is built, not in the middle of a prediction."""

@@ -149,7 +149,7 @@ def gzip_members(payload, level=1):
     with _pool_lock:
         if _pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            _pool = ThreadPoolExecutor(max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))),
+            _pool = ThreadPoolExecutor(max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))),
                                        thread_name_prefix='wmh_gzip')
     parts = [view[i:i + _MEMBER_BYTES] for i in range(0, len(view), _MEMBER_BYTES)]
     return list(_pool.map(lambda b: _member(b, level), parts))

@@ -483,9 +483,13 @@ def test_f16x2_weight_images_rebuilt_in_one_launch_equal_the_single_builds(tiny_
     extra_cfg = next(c for c in (0, 2, 4) if (conv.name, c, 0, 0, conv.cin, 'x3') not in used)
     tr._pack_x3(conv, extra_cfg, 0, 0, conv.cin)
     assert len(tr._x3_jobs) == len(used) + 1
-    tr.run_iteration(xd, td, 1e-2)                          # rebuilt once more (it was requested under the previous parameters) ...
-    tr.run_iteration(xd, td, 1e-2)                          # ... and dropped here
+    tr.run_iteration(xd, td, 1e-2)                          # the request above counts as made during this step (same parameter version) ...
+    tr.run_iteration(xd, td, 1e-2)                          # ... so this step's batch still rebuilds it ...
+    assert len(tr._x3_jobs) == len(used) + 1
+    tr.run_iteration(xd, td, 1e-2)                          # ... and this one drops it: nobody asked for it during the previous step
     assert set(tr._x3_jobs) == used
-    tr2.run_iteration(xd, td, 1e-2); tr2.run_iteration(xd, td, 1e-2)
+    for _ in range(3):
+        tr2._x3_jobs = OrderedDict()
+        tr2.run_iteration(xd, td, 1e-2)
     torch.cuda.synchronize()
     assert torch.equal(tr.params, tr2.params)

@@ -111,3 +111,44 @@ def test_cli_accepts_the_reference_command_lines():
     with pytest.raises(SystemExit) as e:          # integrity check runs `nnUNet_predict -h` and expects exit 0
         p.parse_args(['-h'])
     assert e.value.code == 0
+
+
+def test_checkpoint_helper_process_writes_what_save_checkpoint_writes(tmp_path):
+    """`nnUNet_train` hands raw snapshots of its flat arenas to a helper process (cli/_ckpt_writer.py); the files it writes load back to the same
+    tensors, extras and momentum as a direct `save_checkpoint`, in submission order, and a failing job surfaces in drain()."""
+    import pytest
+    from deepwmh_amd import checkpoint as ck
+    from deepwmh_amd.plan import tiny_plan
+    plan = tiny_plan(patch=32, base=4, num_pool=3, max_feat=32)
+    plans = ck.make_plans(plan)
+    order = [('a.conv.weight', (4, 1, 3, 3, 3)), ('a.conv.bias', (4,)), ('tu.0.weight', (8, 4, 2, 2, 2))]
+    sizes = [int(np.prod(s)) for _, s in order]
+    offs = np.concatenate([[0], np.cumsum([(n + 3) // 4 * 4 for n in sizes])])
+    rng = np.random.default_rng(0)
+    flat, mom = rng.standard_normal(int(offs[-1])).astype(np.float32), rng.standard_normal(int(offs[-1])).astype(np.float32)
+    folder = ck.trainer_folder(str(tmp_path), 'Task001_X')
+    w = ck.CheckpointProcess(order, offs[:-1], plans, str(tmp_path))
+    w.snapshot(flat)
+    w.save(folder, 'all', 'model_best', 3, dict(deepwmh_amd_best=0.25, deepwmh_amd_ma=None, deepwmh_amd_loss_scale=65536.0, deepwmh_amd_precision='f16x2'))
+    w.add_momentum(mom)
+    w.save(folder, 'all', 'model_latest', 3, dict(deepwmh_amd_best=0.25), with_momentum=True)
+    flat2 = flat + 1
+    w.snapshot(flat2)                                   # the first snapshot's files are dropped behind the jobs that use them
+    w.save(folder, 'all', 'model_ep_0004', 4, {})
+    w.drain()
+    assert sorted(f for f in os.listdir(w.dir) if f.endswith('.f32')) == ['params_2.f32']
+    import torch
+    for name, src, epoch in (('model_best', flat, 3), ('model_latest', flat, 3), ('model_ep_0004', flat2, 4)):
+        c = torch.load(os.path.join(folder, 'all', name + '.model'), map_location='cpu', weights_only=False)
+        assert c['epoch'] == epoch
+        for (k, shape), o, n in zip(order, offs[:-1], sizes):
+            assert tuple(c['state_dict'][k].shape) == shape and np.array_equal(c['state_dict'][k].numpy().ravel(), src[o:o + n])
+        assert os.path.isfile(os.path.join(folder, 'all', name + '.model.pkl'))
+    c = torch.load(os.path.join(folder, 'all', 'model_latest.model'), map_location='cpu', weights_only=False)
+    assert np.array_equal(np.asarray(c['deepwmh_amd_momentum']), mom) and c['deepwmh_amd_best'] == 0.25
+    assert 'deepwmh_amd_momentum' not in torch.load(os.path.join(folder, 'all', 'model_best.model'), map_location='cpu', weights_only=False)
+    w.save('/proc/definitely/not/writable', 'all', 'model_best', 5, {})
+    with pytest.raises(RuntimeError):
+        w.drain()
+    w.close()
+    assert not os.path.exists(w.dir)
