@@ -39,6 +39,11 @@ SIGNATURES = {
     'wmh_conv3d_k3_pack_weights_f16x2_batch': (_i, [_vp, _i, _vp]),
     'wmh_conv3d_k3_f16x2_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_fwd_f16x2': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_conv3d_up_supported_f16x2': (_i, [_i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_up_packed_bytes_f16x2': (_sz, [_i, _i]),
+    'wmh_conv3d_up_num_partials_f16x2': (_i, [_i, _i, _i]),
+    'wmh_conv3d_up_pack_weights_f16x2': (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
+    'wmh_conv3d_up_fwd_f16x2': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'wmh_conv3d_k3_bf16_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_fwd_bf16_splitk': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_fwd_bf16': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),

@@ -21,6 +21,7 @@ struct ConvArgs {
     int by, bz;                     // supertile of the persistent kernels' tile order (wmh_tile_coords); 1, 1 = plain x -> y -> z order
     float slope;
     unsigned long long* stamps;     // diagnostics only (NULL in production): per-workgroup cycle counts
+    int accum;                      // conv3d_up_f16x2.hip only: y already holds bias + the skip half; add to it
 };
 
 // KZ: kernel extent along the first spatial axis (3, or 1 for nnU-Net's anisotropic [1,3,3] kernels); SZ: stride

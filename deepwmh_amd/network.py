@@ -61,6 +61,18 @@ class _ConvLayer:
             self._packed_bf16[key] = torch.from_numpy(wf.view(np.int16)).to(self.device)
         return self._packed_bf16[key]
 
+    def packed_f16x2_slice(self, cfg, ci_off, ci_cnt):
+        """The f16x2 image of the input-channel sub-range [ci_off, ci_off + ci_cnt) (a decoder stage's skip half), built on the device."""
+        key = ('x3', cfg, ci_off, ci_cnt)
+        if key not in self._packed_bf16:
+            wd = torch.from_numpy(self.w_host.reshape(self.cout, self.cin, -1)).to(self.device)
+            wf = torch.empty(self.lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, ci_cnt, self.cout), dtype=torch.int16, device=self.device)
+            _lib.check(self.lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, _lib.ptr(wd), self.cin, self.cout, ci_off, ci_cnt, 0, _lib.ptr(wf),
+                                                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'wmh_conv3d_k3_pack_weights_f16x2_device')
+            torch.cuda.current_stream().synchronize()          # wd goes out of scope
+            self._packed_bf16[key] = wf
+        return self._packed_bf16[key]
+
     def packed(self, cfg):
         if cfg not in self._packed:
             n = self.lib.wmh_conv3d_k3_packed_floats(cfg, self.cin, self.cout)
@@ -75,7 +87,7 @@ class _ConvLayer:
 class UNetEngine:
     """Holds the weights in HBM and runs the forward graph on a HIP stream."""
 
-    def __init__(self, plan: UNetPlan, state_dict, device='cuda:0', precision='fp32', storage='fp32'):
+    def __init__(self, plan: UNetPlan, state_dict, device='cuda:0', precision='fp32', storage='fp32', fuse_up=None):
         """precision 'fp32' (exact-fp32 matrix instruction everywhere) or 'bf16' (BASELINE.json config 3: the
         stride-1 convolutions of the >= 16-wide levels multiply bf16-rounded operands with fp32 accumulation;
         InstanceNorm statistics, heads and softmax stay fp32).  storage 'bf16' (with precision 'bf16' only) also
@@ -87,6 +99,10 @@ class UNetEngine:
             raise ValueError("storage must be 'fp32', or 'bf16' / 'bf16_ncdhw' together with precision='bf16'")
         self.precision = precision
         self.storage = storage
+        # f16x2: a decoder stage's transposed convolution is composed with the `up` half of the convolution behind it where the geometry allows
+        # (csrc/conv3d_up_f16x2.hip): no `up` tensor.  fuse_up=False (WMH_FUSE_UP=0) keeps the two-kernel form (A/B runs, tests).
+        import os
+        self.fuse_up = (os.environ.get('WMH_FUSE_UP', '1') != '0') if fuse_up is None else bool(fuse_up)
         plan.check_supported()
         self.plan = plan
         self.device = torch.device(device)
@@ -115,7 +131,7 @@ class UNetEngine:
                            'wmh_convtranspose3d_pack_weights_f16x2_device')
             convs = [_ConvLayer(self.lib, sd, c.name, c.cin, c.cout, 1, dev, c.kz, c.sz) for c in st['convs']]
             seg_w = torch.from_numpy(_np(sd[st['seg'] + '.weight']).reshape(plan.num_classes, cskip)).contiguous().to(dev)
-            self.dec.append(dict(tu_w=tu_w, tu_wf=tu_wf, tu_wf_x3=tu_wf_x3, kt=kt, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
+            self.dec.append(dict(tu_w=tu_w, tu_wf=tu_wf, tu_wf_x3=tu_wf_x3, tu_host=tu_host, kt=kt, cdown=cdown, cskip=cskip, convs=convs, seg_w=seg_w))
         if storage == 'bf16_ncdhw':
             self._check_storage_supported()
         self.ncl = 0                                   # resolution levels held as channels-last bf16 tensors
@@ -263,6 +279,63 @@ class UNetEngine:
         _lib.check(self.lib.wmh_instnorm_finalize(
             _lib.ptr(part), npart, _lib.ptr(layer.gamma), _lib.ptr(layer.beta), IN_EPS, _lib.ptr(ss), None,
             N, layer.cout, st), 'wmh_instnorm_finalize')
+        return y, ss
+
+    def _up_image(self, st):
+        """Composed weight image of a decoder stage (transposed convolution x the `up` input channels of its first convolution), built once."""
+        if 'up_wimg' not in st:
+            layer = st['convs'][0]
+            Cu, Cl = st['cskip'], st['cdown']              # tu: cdown -> cskip channels; cat((up, skip)): the first cskip inputs of the convolution
+            wimg = np.zeros(self.lib.wmh_conv3d_up_packed_bytes_f16x2(Cl, layer.cout), np.uint8)
+            w3 = np.ascontiguousarray(layer.w_host.reshape(layer.cout, layer.cin, 27))
+            wt = np.ascontiguousarray(st['tu_host'].reshape(Cl, Cu, 8))
+            _lib.check(self.lib.wmh_conv3d_up_pack_weights_f16x2(w3.ctypes.data_as(C.c_void_p), layer.cin, Cu, wt.ctypes.data_as(C.c_void_p), Cl,
+                                                                 layer.cout, wimg.ctypes.data_as(C.c_void_p)), 'wmh_conv3d_up_pack_weights_f16x2')
+            st['up_wimg'] = torch.from_numpy(wimg).to(self.device)
+        return st['up_wimg']
+
+    def _dec_first_fused(self, key, st, low, low_ss, skip, skip_ss):
+        """First convolution of a decoder stage WITHOUT the `up` tensor: the pair kernel on the skip channels (y = bias + conv(skip)), then the
+        composed transposed-convolution x convolution kernel adds the rest and takes the moments.  Returns (y, ss) or None where the
+        geometry is not served (then the caller runs the transposed convolution and the two-source convolution)."""
+        layer = st['convs'][0]
+        lib = self.lib
+        N, Cl, Dl, Hl, Wl = low.shape
+        D, H, W = 2 * Dl, 2 * Hl, 2 * Wl
+        Cs = skip.shape[1]
+        Cu = layer.cin - Cs
+        if (self.precision != 'f16x2' or not self.fuse_up or st['kt'] != 2 or layer.kz != 3 or layer.sz != 1 or Cu != st['cskip'] or W % 4 != 0
+                or tuple(skip.shape[2:]) != (D, H, W) or not lib.wmh_conv3d_up_supported_f16x2(Cl, Cu, layer.cout, D, H, W)):
+            return None
+        cfg = lib.wmh_conv3d_k3_bf16_config(_lib.check(lib.wmh_conv3d_config(Cs, layer.cout, D, H, W, 3, 1, 1), 'wmh_conv3d_config'), layer.cout, W)
+        if cfg not in (0, 2, 21) or not lib.wmh_conv3d_k3_f16x2_supported(cfg):
+            return None
+        wf = layer.packed_f16x2_slice(cfg, Cu, Cs)
+        wimg = self._up_image(st)
+        npart = _lib.check(lib.wmh_conv3d_up_num_partials_f16x2(D, H, W), 'wmh_conv3d_up_num_partials_f16x2')
+        y = self._buf(key + '.y', (N, layer.cout, D, H, W))
+        part = self._buf(key + '.part', (N, layer.cout, npart, 4))
+        ss = self._buf(key + '.ss', (N, layer.cout, 2))
+        st_ = self._stream()
+        timed = cfg in self.timed_cfgs
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, _lib.ptr(skip), _lib.ptr(skip_ss), Cs, None, None, 0, _lib.ptr(wf), _lib.ptr(layer.bias), _lib.ptr(y),
+                                               None, None, N, D, H, W, layer.cout, LRELU_SLOPE, st_), 'wmh_conv3d_k3_fwd_f16x2 (skip half)')
+        vox = N * D * H * W
+        if timed:
+            e1.record()
+            self.timings.append((cfg, e0, e1, 2.0 * Cs * layer.cout * 27 * vox, 4.0 * N * Cs * D * H * W + 4.0 * layer.cout * vox + 4.0 * layer.cout * Cs * 27))
+        _lib.check(lib.wmh_conv3d_up_fwd_f16x2(_lib.ptr(low), _lib.ptr(low_ss), Cl, _lib.ptr(wimg), _lib.ptr(y), _lib.ptr(part), N, D, H, W, layer.cout,
+                                               LRELU_SLOPE, 1, st_), 'wmh_conv3d_up_fwd_f16x2')
+        if self.acct is not None:
+            # the reference's work for this stage (BASELINE.md 2): transposed convolution + 27-tap convolution over all input channels;
+            # bytes: both sources once, the output once, the weights (no `up` tensor: it is not part of what this path moves)
+            self.acct['flop'] += 2.0 * Cl * Cu * N * Dl * Hl * Wl * 8 + 2.0 * layer.cin * layer.cout * 27 * vox
+            self.acct['bytes'] += 4.0 * low.numel() + 4.0 * skip.numel() + 4.0 * layer.cout * vox + 4.0 * (layer.cout * layer.cin * 27 + Cl * Cu * 8)
+        _lib.check(lib.wmh_instnorm_finalize(_lib.ptr(part), npart, _lib.ptr(layer.gamma), _lib.ptr(layer.beta), IN_EPS, _lib.ptr(ss), None,
+                                             N, layer.cout, st_), 'wmh_instnorm_finalize')
         return y, ss
 
     def _convT(self, key, w, wf, x, ss, cout, kt=2, out16=False, wf_x3=None):
@@ -487,9 +560,13 @@ class UNetEngine:
         outs = []
         for u, st in enumerate(self.dec):
             o16 = st16 and u == len(self.dec) - 1
-            up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt'], out16=o16, wf_x3=st['tu_wf_x3'])
             skip, skip_ss = skips[-(u + 1)]
-            cur, cur_ss = self._conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss, out16=o16)
+            fused = None if o16 else self._dec_first_fused('dec%d.0' % u, st, cur, cur_ss, skip, skip_ss)
+            if fused is not None:
+                cur, cur_ss = fused
+            else:
+                up = self._convT('tu%d' % u, st['tu_w'], st['tu_wf'], cur, cur_ss, st['cskip'], st['kt'], out16=o16, wf_x3=st['tu_wf_x3'])
+                cur, cur_ss = self._conv('dec%d.0' % u, st['convs'][0], up, None, skip, skip_ss, out16=o16)
             cur, cur_ss = self._conv('dec%d.1' % u, st['convs'][1], cur, cur_ss, out16=o16)
             if deep_supervision or u == len(self.dec) - 1:
                 outs.append((cur, cur_ss, st['seg_w']))

@@ -136,6 +136,23 @@ size_t wmh_conv3d_k3_f16x2_workspace_floats(int cfg, int Cin, int N, int D, int 
 int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
                              const uint16_t* wf, const float* bias, float* y, float* partials, float* workspace,
                              int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
+/* A decoder stage's transposed convolution composed with the `up` half of the 3x3x3 convolution behind it (f16x2 mode, inference;
+ * csrc/conv3d_up_f16x2.hip).  nnU-Net [Generic_UNet.forward, not in tree; reached through /root/reference/deepwmh/main/predict.py:153-156]
+ * computes up = tu(x_low), y = conv(cat(up, skip)); with nothing non-linear in between, conv(tu(.)) is a convolution of the low-resolution
+ * tensor with 2 x 2 x 2 taps whose weights depend on the parity class of the output voxel.  Calling sequence for such a stage:
+ *   1. wmh_conv3d_k3_fwd_f16x2 on the skip channels alone (weight image of the channel sub-range [Cup, Cin_total), partials NULL):
+ *      y = bias + conv(skip);
+ *   2. wmh_conv3d_up_fwd_f16x2(x_low, ss_low, ..., accumulate = 1): y += conv(tu(act(x_low))), InstanceNorm moment records of the sum
+ *      in `partials` ([N][Cout][wmh_conv3d_up_num_partials_f16x2(D, H, W)][4], as wmh_instnorm_finalize reads them).
+ * (D, H, W) is the OUTPUT (high-resolution) extent: whole 4 x 8 x 32 tiles, Cout a multiple of 32 (wmh_conv3d_up_supported_f16x2).
+ * The weight image is built on the host in double precision from the two layers' weights: w3 [Cout][Cin_total][27] whose input channels
+ * [0, Cup) are the transposed convolution's outputs (torch.cat((up, skip), 1)), wt = ConvTranspose3d(k2, s2) weight [Clow][Cup][2][2][2]. */
+int wmh_conv3d_up_supported_f16x2(int Clow, int Cup, int Cout, int D, int H, int W);
+size_t wmh_conv3d_up_packed_bytes_f16x2(int Clow, int Cout);
+int wmh_conv3d_up_num_partials_f16x2(int D, int H, int W);
+int wmh_conv3d_up_pack_weights_f16x2(const float* w3, int Cin_total, int Cup, const float* wt, int Clow, int Cout, void* wimg);
+int wmh_conv3d_up_fwd_f16x2(const float* xlow, const float* sslow, int Clow, const void* wimg, float* y, float* partials,
+                             int N, int D, int H, int W, int Cout, float lrelu_slope, int accumulate, void* stream);
 /* The same with split-K for the small-row configurations (rows of 16 / 8 voxels: the 16^3 / 8^3 levels): the channel reduction
  * is cut into slabs in `workspace` (>= wmh_conv3d_k3_bf16_workspace_floats floats; 0 = this launch does not split) and summed in
  * fixed order with the bias; the moments then come as one record per (n, c).  workspace NULL = wmh_conv3d_k3_fwd_bf16. */

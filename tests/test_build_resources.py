@@ -21,7 +21,7 @@ ALLOWED = {
                                                # aligned quads); 52 / 76 bytes.  Their 8-wave variants (300-416 bytes) exist in the diagnostic library only
 }
 HOT = ['conv3d_k3_bf16_ws_kernel', 'conv3d_k3s2_f16x2_ws_kernel', 'conv3d_k3_ws_kernel', 'conv3d_k3_wgrad_f16x2_kernel', '15cl_conv3_kernel',
-       'convT_k2s2_f16x2_kernel', 'conv3d_k3s2_dgrad_f16x2_kernel', 'seghead_softmax_accum', 'conv3d_first_kernel']
+       'convT_k2s2_f16x2_kernel', 'conv3d_k3s2_dgrad_f16x2_kernel', 'seghead_softmax_accum', 'conv3d_first_kernel', 'conv3d_up_f16x2_kernel']
 
 
 @pytest.fixture(scope='module')
