@@ -17,10 +17,13 @@
 // The skip half of the layer runs first as the ordinary pair kernel (conv3d_k3_bf16_ws.hip) on the skip channels alone and leaves
 // y = bias + conv(skip); this kernel adds its part, takes the InstanceNorm moments of the sum and stores it.
 //
-// One persistent 512-thread workgroup per CU, tile = 4 x 8 x 32 output voxels x 32 output channels:
+// One persistent 512-thread workgroup per CU.  A workgroup's tile is the voxels of ONE z parity pz of an 8 x 8 x 32 region (4 x 8 x 32 = 1024
+// voxels) x 32 output channels: it needs the weights of four of the eight parity classes only -- 32 KB per 8-channel chunk instead of 64 KB for
+// the same 96 MFMAs per wave, and the weight stream through the CU's one vector-memory path is what bounds this kernel (with compact 4 x 8 x 32
+// tiles the loaders took 5.5 k cycles per chunk against the consumers' 3.6 k, 2.7 k of them issuing the chunk's 24 KB per wave).
 //   waves 0-3  consumers.  All 32 voxels of an MFMA's B operand must share their weights, so an M-tile is 32 voxels of ONE parity class:
-//              wave w owns (pz, py) = (w >> 1, w & 1) and both px; M-tile m = 2 mt + px with mt -> (z, y-pair) and lanes -> 16 x positions x 2
-//              rows.  Per 8-channel chunk and class: 8 taps [w_hi | w_hi] x [x_hi | x_lo] and 4 MFMAs that pair the w_lo x_hi terms of two taps
+//              wave w owns py = w & 1, the z half h = w >> 1 and both px; M-tile m = 2 mt + px with mt -> (z, y-pair) and lanes -> 16 x positions
+//              x 2 rows.  Per 8-channel chunk and class: 8 taps [w_hi | w_hi] x [x_hi | x_lo] and 4 MFMAs that pair the w_lo x_hi terms of two taps
 //              (dz = 0 | 1) -- three of the four partial products, 12 MFMAs per M-tile (the 3x3x3 pair kernel: 41).  B operands from the LDS image
 //              of the low-resolution halo tile (4 x 6 x 18 voxels), A fragments from the chunk's 64 KB weight image in LDS (double
 //              buffered).  (First version: fragments straight from L2 through an 8-deep register ring -- every wave has its own two classes, 96 KB
@@ -45,12 +48,12 @@ typedef float up_f32x2 __attribute__((ext_vector_type(2)));
 typedef float up_f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int UTZ = 4, UTY = 8, UTX = 32;                    // output tile (voxels)
-constexpr int LIZ = UTZ / 2 + 2, LIY = UTY / 2 + 2, LIX = UTX / 2 + 2;      // low-resolution halo tile: 4 x 6 x 18
+constexpr int UTZ = 4, UTY = 8, UTX = 32;                    // output tile (voxels): the 4 z planes of one parity of an 8-plane region
+constexpr int LIZ = UTZ + 1, LIY = UTY / 2 + 2, LIX = UTX / 2 + 2;          // low-resolution halo tile: 5 x 6 x 18 (planes L + d - 1 + pz, L = 0..3, d = 0..1)
 constexpr int LYS = 20, LZS = LIY * LYS, LVOX = LIZ * LZS;   // row stride padded to 20 voxels: two rows apart = 1280 B = 0 mod 256 (LDS banks)
-constexpr int LQPR = (UTX / 2 + 8) / 4, LNQ = LIZ * LIY * LQPR;            // 6 aligned quads per halo row, 144 per chunk
+constexpr int LQPR = (UTX / 2 + 8) / 4, LNQ = LIZ * LIY * LQPR;            // 6 aligned quads per halo row, 180 per chunk
 constexpr int UP_RING = 8;                                   // B-operand ring (MFMAs ahead)
-constexpr int UP_W_OFF = 32768, UP_W_BYTES = 65536;          // two weight buffers behind the two activation buffers: [8 classes][8 taps][hi 32 | lo 32 pieces] x 16 B
+constexpr int UP_W_OFF = 40960, UP_W_BYTES = 32768;          // two weight buffers behind the two activation buffers: [4 classes py, px][8 taps][hi 32 | lo 32 pieces] x 16 B
 constexpr int UP_WIT = UP_W_BYTES / 16 / 256;                // 16-byte pieces per loader thread and chunk
 constexpr int UP_FRAG_BYTES = 8 * 1024;                      // image per (cout group, chunk, class): 8 taps x (32 hi + 32 lo pieces) x 16 B
 
@@ -81,6 +84,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
     int ntiles_mine = 0;
     for (int v = blockIdx.x; v < T; v += gridDim.x) ++ntiles_mine;
     const int total = ntiles_mine * nch;
+    // (Staggering every other workgroup by half a tile, so that one half's epilogues -- 256 KB of y traffic per tile and workgroup -- fall into the
+    //  other half's MFMA phases, changed nothing: epilogue 18.9 k cycles per tile either way.)
 
     if (wave >= 4) {
         // ================================================ loaders =================================================================
@@ -88,19 +93,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
         const int lt = tid - 256;
         const int row = lt / LQPR, q = lt - row * LQPR;            // this thread's quad of the halo tile (lt < LNQ)
         const bool mine = lt < LNQ;
-        int q_off = 0; unsigned q_ok = 0; int n0_cur = 0, g_cur = 0;
+        int q_off = 0; unsigned q_ok = 0; int n0_cur = 0, g_cur = 0, pz_cur = 0;
         auto setup = [&](int v) __attribute__((always_inline)) {
             int g, tx, ty, tz, n0;
             tile_of(v, g, tx, ty, tz, n0);
             n0_cur = __builtin_amdgcn_readfirstlane(n0); g_cur = __builtin_amdgcn_readfirstlane(g);
             tx = __builtin_amdgcn_readfirstlane(tx); ty = __builtin_amdgcn_readfirstlane(ty); tz = __builtin_amdgcn_readfirstlane(tz);
-            const int gx = tx * (UTX / 2) - 4 + 4 * q, gy = ty * (UTY / 2) - 1 + row % LIY, gz = tz * (UTZ / 2) - 1 + row / LIY;
+            pz_cur = tz & 1;                                       // tile tz = (region tz >> 1, z parity tz & 1)
+            const int gx = tx * (UTX / 2) - 4 + 4 * q, gy = ty * (UTY / 2) - 1 + row % LIY, gz = (tz >> 1) * UTZ - 1 + pz_cur + row / LIY;
             const bool ok = mine && gx >= 0 && gx < Wl && gy >= 0 && gy < Hl && gz >= 0 && gz < Dl;
             q_off = ok ? gz * HWl + gy * Wl + gx : 0;
             q_ok = ok ? 1u : 0u;
         };
         const unsigned pstride = 4u * (unsigned)DHWl;
-        up_f32x4 v[3][8]; unsigned okv[3] = {0, 0, 0}; int set_n0[3] = {0, 0, 0}, set_c[3] = {0, 0, 0}, set_g[3] = {0, 0, 0};
+        up_f32x4 v[3][8]; unsigned okv[3] = {0, 0, 0}; int set_n0[3] = {0, 0, 0}, set_c[3] = {0, 0, 0}, set_g[3] = {0, 0, 0}, set_pz[3] = {0, 0, 0};
         typedef unsigned up_u32x4 __attribute__((ext_vector_type(4)));
         up_u32x4 wst[UP_WIT];                                        // the weight image of the chunk being converted, on its way to LDS
         int pk = 0, pc = 0, pq = 0;                                  // (tile counter, chunk) of the NEXT issue; pq: its linear index (clamped)
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
             const unsigned qo = 4u * (unsigned)q_off;
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[s][c] = *reinterpret_cast<const up_f32x4*>(base + (qo + (unsigned)min(c, cmax) * pstride));
-            okv[s] = q_ok; set_n0[s] = n0_cur; set_c[s] = pc; set_g[s] = g_cur;
+            okv[s] = q_ok; set_n0[s] = n0_cur; set_c[s] = pc; set_g[s] = g_cur; set_pz[s] = pz_cur;
             // advance the cursor (past the last chunk it stays there: the ring re-reads the last chunk, branch-free loads for exact vmcnt)
             if (pq + 1 < total) {
                 ++pq;
@@ -172,11 +178,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
         constexpr auto S1 = std::integral_constant<int, 1>{};
         constexpr auto S2 = std::integral_constant<int, 2>{};
         const int abl = a.KS;                                         // diagnostics (timing only): 2 = weights loaded at the start only
-        auto w_issue = [&](auto sc) __attribute__((always_inline)) {   // the 64 KB weight image of the chunk in activation set s
+        auto w_issue = [&](auto sc) __attribute__((always_inline)) {   // the weight image (the four classes of the tile's pz) of the chunk in activation set s
             constexpr int s = decltype(sc)::value;
             if (abl == 2 && pq > 3) return;
-            const int g = __builtin_amdgcn_readfirstlane(set_g[s]), c = __builtin_amdgcn_readfirstlane(set_c[s]);
-            const up_u32x4* src = reinterpret_cast<const up_u32x4*>(reinterpret_cast<const char*>(a.wf) + ((size_t)g * nch + c) * UP_W_BYTES) + lt;
+            const int g = __builtin_amdgcn_readfirstlane(set_g[s]), c = __builtin_amdgcn_readfirstlane(set_c[s]), z1 = __builtin_amdgcn_readfirstlane(set_pz[s]);
+            const up_u32x4* src = reinterpret_cast<const up_u32x4*>(reinterpret_cast<const char*>(a.wf) + (((size_t)g * nch + c) * 2 + z1) * UP_W_BYTES) + lt;
 #pragma unroll
             for (int e = 0; e < UP_WIT; ++e) wst[e] = src[e * 256];
         };
@@ -235,15 +241,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
     // ================================================== consumers =================================================================
     const int j = lane & 31, kh = lane >> 5;
     const int i = j & 15, yy = j >> 4;
-    const int pz = wave >> 1, py = wave & 1;
+    const int zh = wave >> 1, py = wave & 1;                      // this wave's z half (zc = 2 zh + (mt >> 1)) and y parity
     // B operand addresses (bytes inside a buffer), per mt = (zc, yh) and x shift s = px + dx (0 .. 2):
-    //   bA: the lane half's piece (hi for kh 0, lo for kh 1) of voxel (zc + pz, yh + 2 yy + py, i + s) -- [x_hi | x_lo]
+    //   bA: the lane half's piece (hi for kh 0, lo for kh 1) of halo voxel (zc, yh + 2 yy + py, i + s) -- [x_hi | x_lo]  (the tile's pz is in the halo's origin)
     //   bP: the hi piece of that voxel for kh 0 and of the voxel one slice deeper (dz + 1) for kh 1   -- [x_hi(dz 0) | x_hi(dz 1)]
     int bA[4][3], bP[4][3];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        const int zc = mt >> 1, yh = mt & 1;
-        const int eb = ((zc + pz) * LIY + (yh + 2 * yy + py)) * LYS + i;
+        const int zc = 2 * zh + (mt >> 1), yh = mt & 1;
+        const int eb = (zc * LIY + (yh + 2 * yy + py)) * LYS + i;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const int key = ((i + s) >> 3) & 1;
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
         const int px = f / 12, ff = f % 12;
         return px * UP_FRAG_BYTES + (ff < 8 ? ff * 1024 + offH : (ff - 8) * 1024 + offL);
     };
-    const int cls0 = UP_W_OFF + (pz * 4 + py * 2) * UP_FRAG_BYTES;   // this wave's first class (px 0) inside a weight buffer
+    const int cls0 = UP_W_OFF + (py * 2) * UP_FRAG_BYTES;            // this wave's first class (px 0) among the buffer's four (py, px)
     __syncthreads();                                             // chunk 0 is staged
     int it = 0;
     unsigned long long tm = 0, tb = 0, te = 0, t0 = 0;           // diagnostics (WMH_STAMPS): MFMA phases / barrier waits / epilogues
@@ -314,44 +320,44 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
         const int cob = g * 32;
         float* const ych = a.y + ((size_t)n0 * a.Cout + cob) * DHW;
         const unsigned plane = 4u * (unsigned)DHW;
-        const int oz0 = tz * UTZ + pz, oy0 = ty * UTY + py + 4 * yy, ox0 = tx * UTX + 2 * i;
+        const int oz0 = (tz >> 1) * (2 * UTZ) + (tz & 1) + 4 * zh, oy0 = ty * UTY + py + 4 * yy, ox0 = tx * UTX + 2 * i;   // z = 8 region + pz + 2 zc
         char* const ychb = reinterpret_cast<char*>(ych);
-        // pass 1: acc <- acc / 2^8 (+ y)
+        // acc <- acc / 2^8 (+ y), stored at once (the two px classes of (mt, r) are the even and odd x of one row); with ACCUM the old values of
+        // row group mt + 2 are requested while group mt is added and stored: two groups (64 registers) in flight instead of four exposed round trips
+        auto lane_off = [&](int mt) __attribute__((always_inline)) {
+            return (unsigned)(4 * kh) * plane + 4u * (unsigned)((oz0 + 2 * (mt >> 1)) * HW + (oy0 + 2 * (mt & 1)) * a.W + ox0);
+        };
+        up_f32x2 old[2][16];
+        auto request = [&](auto mc) __attribute__((always_inline)) {
+            constexpr int mt = decltype(mc)::value;
+            if constexpr (ACCUM && mt < 4) {
+                const unsigned loff = lane_off(mt);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int zc = mt >> 1, yh = mt & 1;
-            if constexpr (ACCUM) {
-                // row r of the lane's half = channel plane (r & 3) + 8 (r >> 2) (+ 4 kh, in the lane offset): a uniform base per row and ONE
-                // lane offset per mt, so that sixteen loads in flight cost their 32 data registers and nothing else
-                const unsigned loff = (unsigned)(4 * kh) * plane + 4u * (unsigned)((oz0 + 2 * zc) * HW + (oy0 + 2 * yh) * a.W + ox0);
-                up_f32x2 old[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const char* rb = ychb + (size_t)((r & 3) + 8 * (r >> 2)) * plane;
-                    old[r] = *reinterpret_cast<const up_f32x2*>(rb + loff);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc[2 * mt][r] = fmaf(acc[2 * mt][r], 1.f / WMH_PAIR_WSCALE, old[r][0]);
-                    acc[2 * mt + 1][r] = fmaf(acc[2 * mt + 1][r], 1.f / WMH_PAIR_WSCALE, old[r][1]);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[2 * mt][r] *= (1.f / WMH_PAIR_WSCALE); acc[2 * mt + 1][r] *= (1.f / WMH_PAIR_WSCALE); }
+                for (int r = 0; r < 16; ++r)                       // row r = channel plane (r & 3) + 8 (r >> 2) (+ 4 kh in the lane offset): uniform bases
+                    old[mt & 1][r] = *reinterpret_cast<const up_f32x2*>(ychb + (size_t)((r & 3) + 8 * (r >> 2)) * plane + loff);
             }
-            __builtin_amdgcn_sched_barrier(0);                     // one row group at a time: hoisting all four groups' loads spills
-        }
-        // pass 2: stores (the two px classes of (mt, r) are the even and odd x of one row)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int zc = mt >> 1, yh = mt & 1;
-            unsigned off = (unsigned)(4 * kh) * plane + 4u * (unsigned)((oz0 + 2 * zc) * HW + (oy0 + 2 * yh) * a.W + ox0);
+        };
+        request(std::integral_constant<int, 0>{});
+        request(std::integral_constant<int, 1>{});
+        up_static_for(std::make_integer_sequence<int, 4>{}, [&](auto mc) __attribute__((always_inline)) {
+            constexpr int mt = decltype(mc)::value;
+            const unsigned loff = lane_off(mt);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                *reinterpret_cast<up_f32x2*>(ychb + off) = up_f32x2{acc[2 * mt][r], acc[2 * mt + 1][r]};
-                off += (r & 3) == 3 ? 5u * plane : plane;
+                float v0, v1;
+                if constexpr (ACCUM) {
+                    v0 = fmaf(acc[2 * mt][r], 1.f / WMH_PAIR_WSCALE, old[mt & 1][r][0]);
+                    v1 = fmaf(acc[2 * mt + 1][r], 1.f / WMH_PAIR_WSCALE, old[mt & 1][r][1]);
+                } else {
+                    v0 = acc[2 * mt][r] * (1.f / WMH_PAIR_WSCALE); v1 = acc[2 * mt + 1][r] * (1.f / WMH_PAIR_WSCALE);
+                }
+                acc[2 * mt][r] = v0; acc[2 * mt + 1][r] = v1;
+                *reinterpret_cast<up_f32x2*>(ychb + (size_t)((r & 3) + 8 * (r >> 2)) * plane + loff) = up_f32x2{v0, v1};
             }
-        }
+            __builtin_amdgcn_sched_barrier(0);
+            request(std::integral_constant<int, mt + 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
         if (a.part != nullptr) {
             // one-pass moments about a per-row shift K (conv3d_common.h::conv_epilogue, all 8 x 32 voxels of the wave valid)
             float vals[32], kshift[16];
@@ -370,6 +376,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
                 }
                 vals[2 * r] = sd; vals[2 * r + 1] = sq;
             }
+            // (DPP row adds instead of the recursive halving -- no permutes, no selects, the last lane writing all 16 records -- measured no faster
+            //  here and made an unrelated instance of the shared epilogue spill: not kept)
             halve_step<16>(vals, j); halve_step<8>(vals, j); halve_step<4>(vals, j); halve_step<2>(vals, j); halve_step<1>(vals, j);
             const float mine_v = vals[0];
             const float other = __shfl_xor(mine_v, 1);
@@ -400,8 +408,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
 extern unsigned long long* g_conv_stamps;      // conv3d_k3.hip (diagnostics)
 // ---- host side -----------------------------------------------------------------------------------------------------------------------
 extern "C" int wmh_conv3d_up_supported_f16x2(int Clow, int Cup, int Cout, int D, int H, int W) {
-    // output tile 4 x 8 x 32 (whole tiles only), 32 output channels per group, quads along the low-resolution rows
-    return (Clow >= 1 && Cup >= 1 && Cout >= 1 && (Cout % 32) == 0 && D > 0 && H > 0 && W > 0 && (D % UTZ) == 0 && (H % UTY) == 0 && (W % UTX) == 0 &&
+    // whole 8 x 8 x 32 output regions, 32 output channels per group, quads along the low-resolution rows
+    return (Clow >= 1 && Cup >= 1 && Cout >= 1 && (Cout % 32) == 0 && D > 0 && H > 0 && W > 0 && (D % (2 * UTZ)) == 0 && (H % UTY) == 0 && (W % UTX) == 0 &&
             (size_t)32 * D * H * W * 4 < ((size_t)1 << 32) && (size_t)Clow * (D / 2) * (H / 2) * (W / 2) * 4 < ((size_t)1 << 32)) ? 1 : 0;
 }
 extern "C" size_t wmh_conv3d_up_packed_bytes_f16x2(int Clow, int Cout) {
@@ -476,7 +484,7 @@ extern "C" int wmh_conv3d_up_pack_weights_f16x2(const float* w3, int Cin_total, 
 extern "C" int wmh_conv3d_up_fwd_f16x2(const float* xlow, const float* sslow, int Clow, const void* wimg, float* y, float* part,
                                         int N, int D, int H, int W, int Cout, float lrelu_slope, int accumulate, void* stream) {
     if (!xlow || !wimg || !y || N < 1) return wmh_fail(WMH_EINVAL, "conv3d_up_fwd_f16x2: null/empty argument");
-    if (!wmh_conv3d_up_supported_f16x2(Clow, 1, Cout, D, H, W)) return wmh_fail(WMH_EINVAL, "conv3d_up_fwd_f16x2: needs whole 4 x 8 x 32 output tiles and Cout % 32 == 0");
+    if (!wmh_conv3d_up_supported_f16x2(Clow, 1, Cout, D, H, W)) return wmh_fail(WMH_EINVAL, "conv3d_up_fwd_f16x2: needs whole 8 x 8 x 32 output regions and Cout % 32 == 0");
     if ((reinterpret_cast<uintptr_t>(xlow) & 15) != 0 || (reinterpret_cast<uintptr_t>(y) & 7) != 0 || ((W / 2) % 4) != 0)
         return wmh_fail(WMH_EINVAL, "conv3d_up_fwd_f16x2: 16-byte aligned source rows");
     if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_up_fwd_f16x2: LeakyReLU slope must be in [0, 1]");

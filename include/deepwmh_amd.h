@@ -144,7 +144,7 @@ int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss0, int C0, 
  *      y = bias + conv(skip);
  *   2. wmh_conv3d_up_fwd_f16x2(x_low, ss_low, ..., accumulate = 1): y += conv(tu(act(x_low))), InstanceNorm moment records of the sum
  *      in `partials` ([N][Cout][wmh_conv3d_up_num_partials_f16x2(D, H, W)][4], as wmh_instnorm_finalize reads them).
- * (D, H, W) is the OUTPUT (high-resolution) extent: whole 4 x 8 x 32 tiles, Cout a multiple of 32 (wmh_conv3d_up_supported_f16x2).
+ * (D, H, W) is the OUTPUT (high-resolution) extent: whole 8 x 8 x 32 regions, Cout a multiple of 32 (wmh_conv3d_up_supported_f16x2).
  * The weight image is built on the host in double precision from the two layers' weights: w3 [Cout][Cin_total][27] whose input channels
  * [0, Cup) are the transposed convolution's outputs (torch.cat((up, skip), 1)), wt = ConvTranspose3d(k2, s2) weight [Clow][Cup][2][2][2]. */
 int wmh_conv3d_up_supported_f16x2(int Clow, int Cup, int Cout, int D, int H, int W);
