@@ -372,17 +372,6 @@ extern "C" int wmh_conv3d_k3_pack_weights_f16x2(int cfg, const float* w, int Cin
                             if (!(v > -65000.f && v < 65000.f)) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2: a weight is not finite or exceeds +-253 (fp16 pair range)");
                             const uint16_t hi = f2h(v);
                             wf[(((((size_t)g * NCH + ch) * 27 + tap) * NT + nt) * 64 + lane) * 8 + e] = (lane >> 5) ? f2h(v - h2f(hi)) : hi;
-                            if (cfg == 1) {
-                                // the strided 32-row configuration (conv3d_k3s2_f16x2_ws.hip): a lane holds 4 channels x (hi, lo) -- channel
-                                // 4 (lane >> 5) + (e >> 1) of the chunk, half e & 1; hi = the value cut to 11 significant bits
-                                const int ci2 = ch * 8 + 4 * (lane >> 5) + (e >> 1);
-                                float v2 = 0.f;
-                                if (co < Cout && ci2 < Cin) v2 = w[((size_t)co * Cin + ci2) * 27 + tap] * WMH_PAIR_WSCALE;
-                                if (!(v2 > -65000.f && v2 < 65000.f)) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2: a weight is not finite or exceeds +-253 (fp16 pair range)");
-                                unsigned u; memcpy(&u, &v2, 4); u &= 0xFFFFE000u;
-                                float h; memcpy(&h, &u, 4);
-                                wf[(((((size_t)g * NCH + ch) * 27 + tap) * NT + nt) * 64 + lane) * 8 + e] = (e & 1) ? f2h(v2 - h) : f2h(h);
-                            }
                         }
     return WMH_OK;
 }
@@ -499,7 +488,7 @@ static int pack_job_f16x2(int cfg, const float* w, int Cin_total, int Cout, int 
     if (mode == 2 && bf16_stride(cfg) != 2) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: mode 2 (transposed convolution's data gradient) is a stride-2 image");
     const int eCin = mode == 1 ? Cout : ci_cnt, eCout = mode == 1 ? ci_cnt : Cout;
     J.w = w; J.wf = wf; J.Cin_total = Cin_total; J.Cout = Cout; J.ci_off = ci_off; J.ci_cnt = ci_cnt; J.mode = mode; J.NT = NT;
-    J.NCH = cdiv(eCin, 8); J.il = cfg == 1 ? 1 : 0;
+    J.NCH = cdiv(eCin, 8); J.il = 0;      // (il: the interleaved (hi | lo << 16) image of the round-3/4 strided kernel; since round 5 configuration 1 takes the common image)
     J.total = (unsigned long long)cdiv(eCout, 32 * NT) * J.NCH * 27 * NT * 64 * 8; J.pad_ = 0;
     return WMH_OK;
 }
@@ -650,8 +639,8 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: LeakyReLU slope must be in [0, 1]");
     if (C1 > 0 && (C0 % 8) != 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: C0 must be a multiple of 8 with two sources");
     if (cfg == 1 && C1 > 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: the strided 32-row configuration takes one source");
-    const bool small = cfg == 1 || cfg == 3 || cfg == 4 || cfg == 5;           // the one-role kernel
-    if (!small && ((W % 4) != 0 || (size_t)16 * D * H * W * 4 >= ((size_t)1 << 32) || (reinterpret_cast<uintptr_t>(x0) & 15) != 0 ||
+    const bool small = cfg == 1 || cfg == 3 || cfg == 4 || cfg == 5;           // the one-role kernel (3, 4, 5) / the strided wave-specialised one (1)
+    if ((!small || cfg == 1) && ((W % 4) != 0 || (size_t)16 * D * H * W * 4 >= ((size_t)1 << 32) || (reinterpret_cast<uintptr_t>(x0) & 15) != 0 ||
                    (x1 && (reinterpret_cast<uintptr_t>(x1) & 15) != 0)))
         return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: needs W % 4 == 0 and 16-byte aligned sources");
     ConvArgs a;

@@ -1,60 +1,100 @@
 // conv3d_k3s2_f16x2_ws.hip -- the 3x3x3 convolution with stride 2 and output rows of 32 voxels (configuration 1: the first convolution of
-// the 64^3 and 32^3 stages) in the f16x2 "pair" mode, wave-specialised and persistent.
+// the 64^3 and 32^3 stages) in the f16x2 "pair" mode, wave-specialised and persistent.  Round 5: rebuilt on both sides at once.
 //
-// The one-role kernel that served these layers (conv3d_k3_bf16.hip, BCfg1) spends half its time staging: a 2 x 2 x 32 output tile reads
-// a 5 x 5 x 65 input box -- 12.7 staged voxels per output voxel -- and each of its four waves issues the 673 instructions of a chunk's
-// staging in order before it turns to the MFMAs (timing-only ablations: 0.85 of 1.74 ms for 32 -> 64 at 8 x 128^3 is the staging alone,
-// DESIGN.md section 3.2).  Here the roles are split inside one workgroup of 12 waves per CU:
-//   waves 0-3   consumers: wave w owns output row w of the tile (32 voxels) x 64 output channels; per tap one B operand from LDS (read
-//               one tap ahead of its MFMAs) and two weight fragments straight from L2 (a ring four taps deep, one 16-byte load per lane and
-//               fragment), four v_mfma_f32_32x32x16_f16; then the shared epilogue (conv3d_common.h: bias, fp32 InstanceNorm moments, stores);
-//   waves 4-11  loaders: eight waves (two per SIMD beside the consumer) stage the next 8-channel chunk of the input box: buffer loads two
-//               chunks ahead into alternating register sets, the producer's InstanceNorm + LeakyReLU, the fp16 split, two 16-byte LDS
-//               writes per voxel.
-// Operands are one dword per (voxel | output channel, input channel), (hi | lo << 16), as in the pair weight gradient and the pair
-// transposed convolution: a k-slot pair holds a channel's (hi, lo), A as stored gives hi hi + lo lo and A rotated by 16 bits
-// (v_alignbit_b32, which overlaps with the MFMAs) gives the cross terms.
-// LDS: two activation buffers of 51 KB; the weights stay out of it.  (Round 4 built the other form -- one 54 KB weight buffer in LDS, the
-// loaders carrying the next chunk's fragments in registers and dropping them in between two barriers, the consumers reading both operands
-// through register rings -- 144 registers, no spills, bit-identical, and NOT faster: 1.79 against 1.78 ms for 32 -> 64 from 8 x 128^3,
-// 0.68 against 0.66 ms for 64 -> 128 from 8 x 64^3, same box.  The L2 path of the fragments is not what bounds this kernel.)  One workgroup
-// barrier per chunk; the loaders run ahead across tile boundaries, so the consumers' epilogue overlaps with the staging of the next tile's
-// first chunks.
+// What the round-3/4 kernel was (git history): eight loader waves fetching single dwords of a 5 x 5 x 65 input box (x positions are not
+// 16-byte aligned under stride 2), one dword (hi | lo << 16) per value, four consumer waves forming all FOUR partial products with a 16-bit
+// rotate of the weight fragments, weights straight from L2 -- 216 KB of fragment loads per chunk and CU through the one vector-memory path,
+// 216 v_alignbit per chunk and wave, 7 vector instructions per staged value: MFMA phase 6.2 k cycles for 3.5 k of issue, loaders 5.1 k;
+// moving the weights to LDS alone, or the loader alone, changed nothing ("needs both sides rebuilt").
+//
+// Now the stride-1 pair kernel's structure (conv3d_k3_bf16_ws.hip) on a PARITY-SPLIT LDS tile.  With o the output voxel, tap k reads input
+// 2 o + k - 1: k = 0 -> odd input o - 1, k = 1 -> even input o, k = 2 -> odd input o (per axis).  The 5 x 5 x 65 box is staged as its eight
+// parity sub-tiles (even: T voxels per axis, odd: T + 1), so that
+//   * the loaders fetch ALIGNED quads of the input rows (one 16-byte load per channel, 17 per row) and only the LDS address of a voxel
+//     knows about parity: the stride-1 loader with another placement rule, 6 vector instructions per value;
+//   * a tap's B operand is 32 CONSECUTIVE voxels of one sub-tile row: conflict-free ds_read_b128 under the same XOR swizzle, the image is
+//     [hi piece | lo piece] per voxel, and the stride-1 kernel's THREE-partial-product schedule applies unchanged (41 MFMAs per output row
+//     and chunk instead of 54, no rotates): every operand of its 41 groups is a per-lane byte address computed once per wave;
+//   * the weights come through LDS (one buffer, dropped in between two barriers) in the stride-1 image.
+// One 768-thread workgroup per CU: waves 0-3 consume (wave w = output row (z, y) = (w >> 1, w & 1) of the 2 x 2 x 32 tile x 64 output
+// channels), waves 4-11 load (a stride-2 tile stages 12.7 voxels per output voxel: with four loader waves, two quads per thread and chunk, the
+// loaders took 6.4 k cycles per chunk against the consumers' 3.3 k).  LDS: two activation buffers of 1625 voxels x 32 B + 55 KB of weight
+// fragments = 159.3 KB.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 #include "conv3d_common.h"
 
-typedef short s2_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s2_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 s2_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 s2_f16x2 __attribute__((ext_vector_type(2)));
 typedef float s2_f32x2 __attribute__((ext_vector_type(2)));
+typedef float s2_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned s2_u32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t s2_rsrc;
 
+typedef ConvCfg<2, 32, 1, 2, 2, 1, 1, 2, 2, 6> S2Cfg;       // = BCfg1 of conv3d_k3_bf16.hip: tile 2 x 2 x 32, one row per wave, 64 channels
+
+namespace {
 // uniform read of a value no kernel in flight writes: a scalar-cache load (conv3d_k3_bf16_ws.hip::ld_uniform)
 __device__ __forceinline__ float s2_ld_uniform(const float* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<unsigned long long>(p));
 }
+template <int... I, class F>
+__device__ __forceinline__ void s2_static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
-// v -> (hi | lo << 16): hi = v cut to fp16's 11 significant bits (a mask: exact in fp16's normal range), lo = the remainder rounded to
-// nearest by v_cvt_pk_f16_f32 (conv3d_k3_wgrad_f16x2.hip::wp_split; |v| >= 65520 gives a non-finite high part)
-__device__ __forceinline__ unsigned s2_split(float v) {
-    const float hi = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xFFFFE000u);
-    const float lo = v - hi;
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(s2_f32x2{hi, lo}, s2_f16x2));
+// ---- the parity-split tile -------------------------------------------------------------------------------------------------------
+// sub-tile s = pz 4 + py 2 + px holds the input voxels of parity (pz, py, px): even (p = 0): indices 0 .. T - 1 (taps k = 1); odd (p = 1):
+// indices 0 .. T (input o - 1 .. o + T - 1: taps k = 0 at index o, k = 2 at index o + 1)
+constexpr int S2_TZ = 2, S2_TY = 2, S2_TX = 32;
+constexpr int s2_nz(int p) { return S2_TZ + p; }
+constexpr int s2_ny(int p) { return S2_TY + p; }
+constexpr int s2_nx(int p) { return S2_TX + p; }
+constexpr int s2_base(int s) {
+    int b = 0;
+    for (int t = 0; t < s; ++t) b += s2_nz((t >> 2) & 1) * s2_ny((t >> 1) & 1) * s2_nx(t & 1);
+    return b;
+}
+constexpr int S2_VOX = s2_base(8);                           // 1625 = 5 x 5 x 65
+static_assert(S2_VOX == 1625, "5 x 5 x 65 input box");
+constexpr int S2_ACT_BYTES = S2_VOX * 32;                    // one activation buffer
+constexpr int S2_W_OFF = 2 * S2_ACT_BYTES;
+constexpr int S2_WQ = 27 * 2 * 64;                           // 16-byte weight pieces per chunk (NT = 2)
+constexpr int S2_LDS = S2_W_OFF + S2_WQ * 16;
+static_assert(S2_LDS <= 160 * 1024, "LDS");
+// tap k (0..2 along an axis) of output index o reads parity P(k) at sub-tile index o + SH(k)
+constexpr int s2_par(int k) { return k == 1 ? 0 : 1; }
+constexpr int s2_shift(int k) { return k == 2 ? 1 : 0; }
+// voxel index (without the lane's x) of tap (kd, kr, kw) for output row (tzi, tyi)
+__device__ __forceinline__ int s2_tap_row(int kd, int kr, int kw, int tzi, int tyi) {
+    const int pz = s2_par(kd), py = s2_par(kr), px = s2_par(kw);
+    return s2_base(pz * 4 + py * 2 + px) + ((tzi + s2_shift(kd)) * s2_ny(py) + (tyi + s2_shift(kr))) * s2_nx(px) + s2_shift(kw);
 }
 
-typedef ConvCfg<2, 32, 1, 2, 2, 1, 1, 2, 2, 6> S2Cfg;       // = BCfg1 of conv3d_k3_bf16.hip: tile 2 x 2 x 32, one row per wave, 64 channels
+// the stride-1 pair kernel's 41 groups (conv3d_k3_bf16_ws.hip::p3_grp): per (kd, kr) the three taps' [w_hi | w_hi] x [x_hi | x_lo] (pr 0..2),
+// [w_lo(kw 0) | w_lo(kw 1)] x [x_hi(kw 0) | x_hi(kw 1)] (pr 3) and one more that pairs the remaining w_lo x_hi terms of kw = 2 across kr / kd
+struct S2Grp { int kd, kr, pr; };
+constexpr int S2_NG = 41;
+constexpr S2Grp s2_grp(int gi) {
+    int n = 0;
+    for (int kd = 0; kd < 3; ++kd)
+        for (int kr = 0; kr < 3; ++kr)
+            for (int pr = 0; pr < 5; ++pr) {
+                if (pr == 4 && (kr == 0 || (kr == 2 && kd == 0))) continue;
+                if (n == gi) return S2Grp{kd, kr, pr};
+                ++n;
+            }
+    return S2Grp{0, 0, 0};
+}
+}  // namespace
 
 __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArgs a, const int T /*tiles x cout groups*/) {
     typedef S2Cfg C;
     constexpr int NT = C::NT, MT = C::MT, LTH = 512;
-    constexpr int APF = 4;                                      // weight-fragment ring, taps ahead (2 and 8 measured the same)
-    constexpr int SPP = (C::SP + 7) / 8 * 8;                    // voxels of an LDS buffer (the last one takes the stores of idle slots)
-    constexpr int NITL = (C::SP + LTH - 1) / LTH;              // staged voxels per loader thread and chunk
     static_assert(MT == 1 && NT == 2 && C::WM == 4, "one output row per consumer wave, 64 output channels");
-    extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];   // [2][SPP voxels][2 pieces: channels 0-3 | 4-7 as (hi, lo) dwords, swapped where (x >> 3) & 1]
+    extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];   // [2][S2_VOX voxels][hi | lo piece, swapped where (ix >> 3) & 1], then [27][NT][64] weight pieces
+    uint4* const wlds = ldsq + S2_W_OFF / 16;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,257 +111,250 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
     for (int v = blockIdx.x; v < T; v += gridDim.x) ++ntiles_mine;
     const int total = ntiles_mine * nch;                        // chunk iterations of this workgroup
 
-    if (wave < 4) {
-        // ============================================ consumers ===========================================================
-        const int j = lane & 31, kh = lane >> 5;
-        const int dx = j;                                       // LX = 32, LY = LZ = 1
-        const int ts0 = wave;                                   // M-tile (output row) of this wave
-        const int tyi = ts0 % C::MY, tzi = ts0 / C::MY;
-        int badr[3];
+    if (wave >= 4) {
+        // ================================================ loaders =================================================================
+        __builtin_amdgcn_s_setprio(3);
+        const int lt = tid - 256;
+        // Staging unit = an aligned quad of 4 consecutive x of one row of the 5 x 5 x 65 box: the row [2 ox0 - 1, 2 ox0 + 63] lies in the
+        // aligned span [2 ox0 - 4, 2 ox0 + 64), 17 quads; 425 per chunk, one per thread.
+        constexpr int QPR = 17, NQ = 25 * QPR;
+        // this thread's quad: box row (bz, by) and quad q -> where its voxels go: LDS voxel index of sub-tile row (px = 0: odd x, px = 1: even x)
+        const int row = lt / QPR, q = lt - row * QPR;
+        const bool mine = lt < NQ;
+        int rb0, rb1;
         {
-            const int e0 = 2 * (tzi * C::ZS + tyi * C::YS + dx);
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) badr[kw] = (e0 + kw) * 32 + 16 * (kh ^ (((2 * dx + kw) >> 3) & 1));
+            const int bz = (row / 5) % 5, by = row % 5;
+            const int pz = (bz & 1) ^ 1, py = (by & 1) ^ 1, iz = bz >> 1, iy = by >> 1;
+            const int r0 = (iz * (S2_TY + py) + iy);
+            rb0 = (pz ? (py ? s2_base(6) : s2_base(4)) : (py ? s2_base(2) : s2_base(0))) + r0 * s2_nx(0);
+            rb1 = (pz ? (py ? s2_base(7) : s2_base(5)) : (py ? s2_base(3) : s2_base(1))) + r0 * s2_nx(1);
         }
-        const char* const ldsb = reinterpret_cast<const char*>(ldsq);
-        // weight fragments: [g][nch][27 taps][NT][64 lanes] x 16 bytes; the ring runs APF taps ahead, across chunk and tile boundaries.
-        // Everything about a ring load except the chunk's base is a compile-time constant of the unrolled step loop.
-        const char* const wbytes = reinterpret_cast<const char*>(a.wf) + lane * 16;
-        constexpr size_t CHB = (size_t)27 * NT * 64 * 16;       // bytes of a chunk's fragments
-        s2_bf16x8 aring[APF][NT];
-        auto group_of = [&](int k) __attribute__((always_inline)) {
+        int q_off = 0; unsigned q_ok = 0; int n0_cur = 0, g_cur = 0;
+        auto setup = [&](int v) __attribute__((always_inline)) {
             int g, tx, ty, tz, n0;
-            tile_of(blockIdx.x + min(k, ntiles_mine - 1) * gridDim.x, g, tx, ty, tz, n0);
-            return __builtin_amdgcn_readfirstlane(g);
+            tile_of(v, g, tx, ty, tz, n0);
+            n0_cur = __builtin_amdgcn_readfirstlane(n0); g_cur = __builtin_amdgcn_readfirstlane(g);
+            tx = __builtin_amdgcn_readfirstlane(tx); ty = __builtin_amdgcn_readfirstlane(ty); tz = __builtin_amdgcn_readfirstlane(tz);
+            const int gx = tx * (2 * S2_TX) - 4 + 4 * q, gy = ty * (2 * S2_TY) - 1 + row % 5, gz = tz * (2 * S2_TZ) - 1 + (row / 5) % 5;
+            const bool ok = mine && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
+            q_off = ok ? gz * HW + gy * a.W + gx : 0;
+            q_ok = ok ? 1u : 0u;
         };
-        auto frag = [&](const char* base, int st, s2_bf16x8 (&dst)[NT]) __attribute__((always_inline)) {
+        constexpr int WIT = (S2_WQ + LTH - 1) / LTH;
+        s2_u32x4 wst[WIT];                                         // the weight fragments of the chunk being converted (this thread's pieces)
+        s2_f32x4 v[2][8]; unsigned okv[2] = {0, 0}; int set_n0[2] = {0, 0}, set_c[2] = {0, 0}, set_g[2] = {0, 0};
+        int pk = 0, pc = 0, pq = 0;                                // (tile counter, chunk) of the NEXT issue; pq: its linear index (clamped)
+        const unsigned pstride = 4u * (unsigned)DHW;
+        auto issue = [&](auto sc) __attribute__((always_inline)) {
+            constexpr int s_ = decltype(sc)::value;
+            const int c0 = pc * 8, cmax = a.C0 - 1 - c0;          // channels past the end re-read the last one (scaled to zero)
+            const char* base = reinterpret_cast<const char*>(a.x0 + ((size_t)n0_cur * a.C0 + c0) * DHW);
+            const unsigned qo = 4u * (unsigned)q_off;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) dst[nt] = *reinterpret_cast<const s2_bf16x8*>(base + ((size_t)wmh_tap_of(st) * NT + nt) * 64 * 16);
-        };
-        if (total > 0) {
-            const char* w0 = wbytes + (size_t)group_of(0) * nch * CHB;
-#pragma unroll
-            for (int d = 0; d < APF; ++d) frag(w0, d, aring[d]);
-        }
-        unsigned long long tm = 0, tb = 0, te = 0, t0 = 0;
-        __syncthreads();                                        // chunk 0 is staged
-        int q = 0;
-        for (int k = 0; k < ntiles_mine; ++k) {
-            int g, tx, ty, tz, n0;
-            tile_of(blockIdx.x + k * gridDim.x, g, tx, ty, tz, n0);
-            f32x16 acc[NT][MT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = (g * NT + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    acc[nt][0][r] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] * WMH_PAIR_WSCALE : 0.f;
-                }
-            const int g_next = group_of(k + 1);
-            for (int ch = 0; ch < nch; ++ch, ++q) {
-                if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
-                const char* cur = ldsb + (size_t)(q & 1) * SPP * 32;
-                // this chunk's fragments and the next one's (the next tile's first chunk behind the last; past the end: re-read, never used)
-                const char* wc = wbytes + ((size_t)g * nch + ch) * CHB;
-                const char* wn = ch + 1 < nch ? wc + CHB : wbytes + (size_t)g_next * nch * CHB;
-                // B operands one tap ahead of their MFMAs (a wave issues in order: a read placed in front of its own use waits out the
-                // LDS latency with the matrix pipe empty)
-                s2_bf16x8 bbuf[2];
-                auto loadB = [&](int st) __attribute__((always_inline)) {
-                    const int tap = wmh_tap_of(st);
-                    return *reinterpret_cast<const s2_bf16x8*>(cur + badr[tap % 3] + ((tap / 9) * C::ZS + ((tap / 3) % 3) * C::YS) * 32);
-                };
-                bbuf[0] = loadB(0);
-#pragma unroll
-                for (int step = 0; step < 27; ++step) {
-                    s2_bf16x8 anew[NT];
-                    if (step + APF < 27) frag(wc, step + APF, anew); else frag(wn, step + APF - 27, anew);
-                    if (step + 1 < 27) bbuf[(step + 1) & 1] = loadB(step + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // A = 4 channels x (w_hi, w_lo) as stored; A' = the same dwords rotated by 16 bits.  With B = 4 channels x (x_hi, x_lo):
-                    // A B = hi hi + lo lo, A' B = lo hi + hi lo -- all four products.  (The first version kept the one-role kernel's image
-                    // -- high parts on lanes 0-31, low parts on lanes 32-63 -- and split it with v_permlane32_swap_b32: 8 swaps + 8 moves
-                    // per tap that do not overlap with the MFMAs, 7.1 k instead of 4.2 k cycles per chunk.)
-                    s2_u32x4 ahi[NT], alo[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        ahi[nt] = __builtin_bit_cast(s2_u32x4, aring[0][nt]);
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) alo[nt][d] = __builtin_amdgcn_alignbit(ahi[nt][d], ahi[nt][d], 16);
-                    }
-                    const s2_bf16x8 bv = bbuf[step & 1];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s2_f16x8, ahi[nt]), __builtin_bit_cast(s2_f16x8, bv), acc[nt][0], 0, 0, 0);
-                        acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s2_f16x8, alo[nt]), __builtin_bit_cast(s2_f16x8, bv), acc[nt][0], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int d = 0; d + 1 < APF; ++d)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) aring[d][nt] = aring[d + 1][nt];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) aring[APF - 1][nt] = anew[nt];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
-                __syncthreads();                                // this chunk is consumed, the next one is staged
-                if (WMH_STAMPS(a)) tb += __builtin_amdgcn_s_memtime() - t0;
+            for (int c = 0; c < 8; ++c) v[s_][c] = *reinterpret_cast<const s2_f32x4*>(base + (qo + (unsigned)min(c, cmax) * pstride));
+            okv[s_] = q_ok; set_n0[s_] = n0_cur; set_c[s_] = pc; set_g[s_] = g_cur;
+            if (pq + 1 < total) {                                  // past the last chunk the cursor stays: branch-free loads, exact vmcnt
+                ++pq;
+                if (++pc == nch) { pc = 0; ++pk; setup(blockIdx.x + pk * gridDim.x); }
             }
-            if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
+        };
+        auto w_issue = [&](auto sc) __attribute__((always_inline)) {   // the weight fragments of the chunk in set s
+            constexpr int s_ = decltype(sc)::value;
+            const int g = __builtin_amdgcn_readfirstlane(set_g[s_]), c = __builtin_amdgcn_readfirstlane(set_c[s_]);
+            const s2_u32x4* wsrc = reinterpret_cast<const s2_u32x4*>(a.wf) + ((size_t)g * nch + c) * S2_WQ;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][0] *= (1.f / WMH_PAIR_WSCALE);      // undo the weights' 2^8 (exact)
-            conv_epilogue<C>(a, acc, g, 0, n0, wave, j, kh, dx, 0, 0, ts0, tz * C::TZ, ty * C::TY, tx * C::TX, (tz * a.nty + ty) * a.ntx + tx);
-            if (WMH_STAMPS(a)) te += __builtin_amdgcn_s_memtime() - t0;
+            for (int i = 0; i < WIT; ++i) wst[i] = wsrc[min(lt + i * LTH, S2_WQ - 1)];
+        };
+        auto write_w = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < WIT; ++i) { const int k = lt + i * LTH; if (WIT * LTH == S2_WQ || k < S2_WQ) reinterpret_cast<s2_u32x4*>(wlds)[k] = wst[i]; }
+        };
+        float scv[8], shv[8], slope_eff = 1.f;
+        static __device__ const float ident2[2] = {1.f, 0.f};
+        auto load_ss = [&](auto sc) __attribute__((always_inline)) {
+            constexpr int s_ = decltype(sc)::value;
+            const bool has_ss = a.ss0 != nullptr;
+            slope_eff = has_ss ? a.slope : 1.f;
+            const int c0 = __builtin_amdgcn_readfirstlane(set_c[s_]) * 8, sn0 = __builtin_amdgcn_readfirstlane(set_n0[s_]);
+            const float* tab = has_ss ? a.ss0 + ((size_t)sn0 * a.C0 + c0) * 2 : ident2;
+            const int mul = has_ss ? 2 : 0, cmax = a.C0 - 1 - c0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float sc1 = s2_ld_uniform(tab + mul * min(c, cmax)), sh1 = s2_ld_uniform(tab + mul * min(c, cmax) + 1);
+                scv[c] = c <= cmax ? sc1 : 0.f;
+                shv[c] = c <= cmax ? sh1 : 0.f;
+            }
+        };
+        auto convert = [&](auto sc, int buf) __attribute__((always_inline)) {
+            constexpr int s_ = decltype(sc)::value;
+            uint4* dst = ldsq + (size_t)buf * (S2_ACT_BYTES / 16);
+            const unsigned keep = okv[s_] ? 0xFFFFFFFFu : 0u;     // quad outside the volume: zeros
+            unsigned w[4][4], wlo[4][4];                           // [voxel of the quad][channel pair]: high / low parts
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) {
+                s2_f32x4 t[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float sc1 = scv[c + e], sh1 = shv[c + e];
+                    t[e] = s2_f32x4{wmh_norm_lrelu(v[s_][c + e][0], sc1, sh1, slope_eff), wmh_norm_lrelu(v[s_][c + e][1], sc1, sh1, slope_eff),
+                                    wmh_norm_lrelu(v[s_][c + e][2], sc1, sh1, slope_eff), wmh_norm_lrelu(v[s_][c + e][3], sc1, sh1, slope_eff)};
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {                      // fp16 pair: high part toward zero, the remainder to nearest (the pair kernel's split)
+                    const auto h2 = __builtin_amdgcn_cvt_pkrtz(t[0][k], t[1][k]);
+                    w[k][c >> 1] = __builtin_bit_cast(unsigned, h2) & keep;
+                    float l0, l1;
+                    asm("v_sub_f32 %0, %1, %2" : "=v"(l0) : "v"(t[0][k]), "v"((float)h2[0]));
+                    asm("v_sub_f32 %0, %1, %2" : "=v"(l1) : "v"(t[1][k]), "v"((float)h2[1]));
+                    wlo[k][c >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(s2_f32x2{l0, l1}, s2_f16x2)) & keep;
+                }
+            }
+            // voxel k of the quad sits at box x = 4 q - 3 + k: k = 0, 2 odd (px = 0, sub-row index 2 q - 2 | 2 q - 1), k = 1, 3 even (px = 1, 2 q - 1 | 2 q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = 4 * q - 3 + k, ix = 2 * q - 2 + ((k + 1) >> 1);
+                if (mine && x >= 0 && x < 65) {
+                    const int e = ((k & 1) ? rb1 : rb0) + ix;
+                    dst[e * 2 + (0 ^ ((ix >> 3) & 1))] = make_uint4(w[k][0], w[k][1], w[k][2], w[k][3]);
+                    dst[e * 2 + (1 ^ ((ix >> 3) & 1))] = make_uint4(wlo[k][0], wlo[k][1], wlo[k][2], wlo[k][3]);
+                }
+            }
+        };
+        constexpr auto S0 = std::integral_constant<int, 0>{};
+        constexpr auto S1 = std::integral_constant<int, 1>{};
+        unsigned long long tw = 0, tb = 0, t0 = 0;
+        if (total > 0) {
+            setup(blockIdx.x);
+            issue(S0);                                             // chunk 0 (exposed once per workgroup)
+            w_issue(S0);
+            issue(S1);                                             // chunk 1 in flight across the barrier
+            load_ss(S0);
+            convert(S0, 0);
+            write_w();
         }
-        if (WMH_STAMPS(a) && tid == 0) {
+        __syncthreads();
+        // iteration it: the consumers are on chunk it (buffer it & 1).  The weights of chunk it + 1 first (from L2), then the activation loads of
+        // chunk it + 2 into the register set chunk it came from, then chunk it + 1 (in flight since the previous iteration) is normalised,
+        // split and written into the other buffer; its weights drop into the single weight buffer between the two barriers.
+        auto iteration = [&](auto s_conv, auto s_issue, int buf) __attribute__((always_inline)) {
+            if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
+            w_issue(s_conv);
+            load_ss(s_conv);
+            issue(s_issue);
+            convert(s_conv, buf);
+            if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; t0 = t; }
+            __syncthreads();                                       // consumers are done with chunk `it`: its weights may go
+            write_w();
+            __syncthreads();
+            if (WMH_STAMPS(a)) tb += __builtin_amdgcn_s_memtime() - t0;
+        };
+        for (int it = 0; it < total; it += 2) {
+            iteration(S1, S0, 1);
+            if (it + 1 >= total) break;
+            iteration(S0, S1, 0);
+        }
+        if (WMH_STAMPS(a) && tid == 256) {
             unsigned long long* o = WMH_STAMPS(a) + (size_t)blockIdx.x * 8;
-            o[0] = tm; o[1] = tb; o[2] = te; o[3] = (unsigned long long)total;
+            o[4] = tw; o[5] = tb;
         }
         return;
     }
 
-    // ================================================ loaders =================================================================
-    const int lt = tid - 256;
-    const unsigned cstride = 4u * (unsigned)DHW;                // bytes between channel planes (host checks the range)
-    // slot i of this thread = voxel e = lt + 512 i of the 65 x 5 x 5 input box: where its two 16-byte pieces go (tile-invariant) ...
-    unsigned lhi[NITL];                                        // (the second piece sits at lhi ^ 16)
-#pragma unroll
-    for (int i = 0; i < NITL; ++i) {
-        const int e = lt + i * LTH;
-        const int ew = e < C::SP ? e : SPP - 1;
-        const int key = e < C::SP ? (((e % C::IX) >> 3) & 1) : 0;
-        lhi[i] = (unsigned)((ew * 2 + (0 ^ key)) * 16);
-    }
-    // ... and, per tile, where it comes from (byte offset in a channel plane) and whether it lies in the volume
-    unsigned exyz[NITL];                                        // x | y << 8 | z << 16 of the slot's voxel in the input box
-#pragma unroll
-    for (int i = 0; i < NITL; ++i) {
-        const int e = lt + i * LTH;
-        exyz[i] = (unsigned)(e % C::IX) | ((unsigned)((e / C::IX) % C::IY) << 8) | ((unsigned)(e / (C::IX * C::IY)) << 16);
-    }
-    unsigned voff[NITL], vbits = 0; int s_n0 = 0;               // vbits: bit i = slot i lies in the volume
-    auto setup = [&](int v) __attribute__((always_inline)) {
+    // ================================================== consumers =================================================================
+    const int j = lane & 31, kh = lane >> 5;
+    const int dx = j;
+    const int tzi = wave >> 1, tyi = wave & 1;
+    // the 41 B operands of a chunk: byte addresses inside an activation buffer, computed once (they do not depend on the tile)
+    int bG[S2_NG];
+    s2_static_for(std::make_integer_sequence<int, S2_NG>{}, [&](auto gc) __attribute__((always_inline)) {
+        constexpr int gi = decltype(gc)::value;
+        constexpr S2Grp G = s2_grp(gi);
+        auto full = [&](int kd, int kr, int kw) { const int ix = dx + s2_shift(kw); return (s2_tap_row(kd, kr, kw, tzi, tyi) + dx) * 32 + 16 * (kh ^ ((ix >> 3) & 1)); };
+        auto hi = [&](int kd, int kr, int kw) { const int ix = dx + s2_shift(kw); return (s2_tap_row(kd, kr, kw, tzi, tyi) + dx) * 32 + 16 * ((ix >> 3) & 1); };
+        if constexpr (G.pr < 3) bG[gi] = full(G.kd, G.kr, G.pr);                                          // [x_hi | x_lo](tap kw)
+        else if constexpr (G.pr == 3) bG[gi] = kh ? hi(G.kd, G.kr, 1) : hi(G.kd, G.kr, 0);                // [x_hi(kw 0) | x_hi(kw 1)]
+        else if constexpr (G.kr == 1) bG[gi] = kh ? hi(G.kd, 1, 2) : hi(G.kd, 0, 2);                      // [x_hi(kr 0, kw 2) | x_hi(kr 1, kw 2)]
+        else if constexpr (G.kd == 1) bG[gi] = kh ? hi(1, 2, 2) : hi(0, 2, 2);                            // [x_hi(kd 0, kr 2, kw 2) | x_hi(kd 1, kr 2, kw 2)]
+        else bG[gi] = full(2, 2, 2);                                                                       // [x_hi | x_lo](2, 2, 2) once more (A's upper half is zero)
+    });
+    const char* const ldsb = reinterpret_cast<const char*>(ldsq);
+    // weight pieces: a tap's fragment = [hi of cout 0..31 | lo of cout 0..31] per nt; both lane halves read piece j
+    const s2_h8* wl = reinterpret_cast<const s2_h8*>(wlds) + j;
+    const s2_h8* wlp = wl + 32 + kh * (NT * 64);                  // lo piece of tap + kh
+    const s2_h8* wlq = wl + 32 + kh * (3 * NT * 64);              // lo piece of tap + 3 kh (next kr)
+    const s2_h8* wlr = wl + 32 + kh * (9 * NT * 64);              // lo piece of tap + 9 kh (next kd)
+    const s2_h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tm = 0, tb = 0, te = 0, t0 = 0;
+    __syncthreads();                                             // chunk 0 is staged
+    int it = 0;
+    for (int k = 0; k < ntiles_mine; ++k) {
         int g, tx, ty, tz, n0;
-        tile_of(v, g, tx, ty, tz, n0);
-        s_n0 = __builtin_amdgcn_readfirstlane(n0);
-        const int ix0 = __builtin_amdgcn_readfirstlane(tx * C::TX * 2 - 1), iy0 = __builtin_amdgcn_readfirstlane(ty * C::TY * 2 - 1),
-                  iz0 = __builtin_amdgcn_readfirstlane(tz * C::TZ * 2 - 1);
+        tile_of(blockIdx.x + k * gridDim.x, g, tx, ty, tz, n0);
+        f32x16 acc[NT][MT];
 #pragma unroll
-        for (int i = 0; i < NITL; ++i) {
-            const int e = lt + i * LTH;
-            // the slot's position in the box, unpacked from ONE register per slot behind an opaque copy: left visible, the loop-invariant
-            // divisions of all four slots were hoisted out of the chunk loop into twelve registers -- the spills that followed made every
-            // iteration reload them with a scratch load that waits for the whole prefetch
-            unsigned pk = exyz[i];
-            asm volatile("" : "+v"(pk));
-            const int x = (int)(pk & 0xFFu), y = (int)((pk >> 8) & 0xFFu), z = (int)(pk >> 16);
-            const int gx = ix0 + x, gy = iy0 + y, gz = iz0 + z;
-            const bool ok = (e < C::SP) & ((unsigned)gx < (unsigned)a.W) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gz < (unsigned)a.D);
-            vbits = i == 0 ? (ok ? 1u : 0u) : (vbits | (ok ? (1u << i) : 0u));
-            voff[i] = ok ? 4u * (unsigned)(gz * HW + gy * a.W + gx) : 0u;
-        }
-    };
-    // two register sets: the chunk fetched during iteration q is converted during iteration q + 1
-    float xr[2][NITL][8]; unsigned kbits[2] = {0, 0}; int set_n0[2] = {0, 0}, set_ch[2] = {0, 0};
-    int pk = 0, pc = 0;                                         // (tile counter, chunk) of the NEXT issue
-    // issue(set, i): voxel slot i of the next chunk (8 channel loads); i == NITL - 1 also moves the cursor on.  convert(set, buf, i): slot i.
-    // (The loaders' loads, not their conversions, are what slows the consumers down -- 4.3 k -> 6.5 k cycles of MFMA phase per chunk with
-    //  the loads alone: they share the CU's vector-memory queue with the weight-fragment loads.  Issuing them slot by slot between the
-    //  conversions instead of back to back made the loaders themselves slower (5.1 k -> 8.5 k) and the kernel no faster.)
-    auto issue = [&](int set, int i) __attribute__((always_inline)) {
-        const int c0 = pc * 8;
-        const s2_rsrc rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)s_n0 * a.C0 * DHW), 0, (int)((unsigned)a.C0 * cstride), 0x00020000);
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const unsigned soff = (unsigned)min(c0 + c, a.C0 - 1) * cstride;          // channels past the end re-read the last one (scaled to zero)
-            xr[set][i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff[i], (int)soff, 0));
-        }
-        if (i == 0) kbits[set] = vbits;
-        if (i == NITL - 1) {
-            set_n0[set] = s_n0; set_ch[set] = pc;
-            if (++pc == nch) { pc = 0; ++pk; if (pk < ntiles_mine) setup(blockIdx.x + pk * gridDim.x); }
-        }
-    };
-    float scv[8], shv[8], slope_eff = 1.f;
-    auto load_ss = [&](int set) __attribute__((always_inline)) {
-        // InstanceNorm scale / shift of the chunk's 8 channels (1, 0 without a pending normalisation; 0, 0 past the last channel).
-        // Uniform reads through the constant address space: scalar-cache loads on their own counter.  As vector loads they queue
-        // behind the prefetch on the in-order vmcnt, and waiting for them waits for the whole prefetch (HBM latency per chunk: that
-        // was 2.5 k of the loaders' 7.6 k cycles).  Branch-free: without a pending normalisation the reads go to {1, 0}.
-        const int c0 = __builtin_amdgcn_readfirstlane(set_ch[set]) * 8, sn0 = __builtin_amdgcn_readfirstlane(set_n0[set]);
-        const bool has_ss = a.ss0 != nullptr;
-        slope_eff = has_ss ? a.slope : 1.f;
-        static __device__ const float ident2[2] = {1.f, 0.f};
-        const float* tab = has_ss ? a.ss0 + ((size_t)sn0 * a.C0 + c0) * 2 : ident2;
-        const int mul = has_ss ? 2 : 0, cmax = a.C0 - 1 - c0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float sc = s2_ld_uniform(tab + mul * min(c, cmax)), sh = s2_ld_uniform(tab + mul * min(c, cmax) + 1);
-            scv[c] = c <= cmax ? sc : 0.f;
-            shv[c] = c <= cmax ? sh : 0.f;
-        }
-    };
-    auto convert = [&](int set, int buf, int i) __attribute__((always_inline)) {
-        char* dst = reinterpret_cast<char*>(ldsq) + (size_t)buf * SPP * 32;
-        unsigned w[8];
-        const unsigned keep = 0u - ((kbits[set] >> i) & 1u);   // all ones inside the volume
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {                           // one dword per channel: (hi | lo << 16)
-            float t = fmaf(xr[set][i][c], scv[c], shv[c]);
-            t = fmaxf(t, t * slope_eff);
-            w[c] = s2_split(t) & keep;
-        }
-        *reinterpret_cast<uint4*>(dst + lhi[i]) = make_uint4(w[0], w[1], w[2], w[3]);
-        *reinterpret_cast<uint4*>(dst + (lhi[i] ^ 16u)) = make_uint4(w[4], w[5], w[6], w[7]);
-    };
-    unsigned long long tw = 0, tbw = 0, t0 = 0;
-    if (total > 0) {
-        setup(blockIdx.x);
-#pragma unroll
-        for (int i = 0; i < NITL; ++i) issue(0, i);             // chunk 0, exposed once per workgroup
-        load_ss(0);
-#pragma unroll
-        for (int i = 0; i < NITL; ++i) convert(0, 0, i);
-        if (total > 1) {                                        // chunk 1 in flight across the barrier
-#pragma unroll
-            for (int i = 0; i < NITL; ++i) issue(1, i);
-        }
-    }
-    __syncthreads();
-    for (int q = 0; q < total; q += 2) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                           // iteration q + h: the consumers are on chunk q + h (buffer h)
-            const int qq = q + h;
-            if (qq >= total) break;
+            for (int r = 0; r < 16; ++r) {
+                const int co = (g * NT + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                acc[nt][0][r] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] * WMH_PAIR_WSCALE : 0.f;
+            }
+        for (int ch = 0; ch < nch; ++ch, ++it) {
             if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
-            // chunk qq + 2 is fetched into the set chunk qq came from, then chunk qq + 1 (fetched during the previous iteration, set
-            // h ^ 1) is converted into the other buffer
-            const bool cv = qq + 1 < total, is = qq + 2 < total;
-            if (cv) load_ss(h ^ 1);
-            // (sched_barrier: one slot's conversion at a time.  Without these fences the whole iteration is one basic block -- it was not
-            //  while cycle stamps were compiled in -- and the scheduler interleaves all four slots' conversions: 60 registers spilled, and
-            //  every scratch reload waits for the whole prefetch; the kernel ran 1.6x slower)
-            if (is) {
+            const char* cur = ldsb + (size_t)(it & 1) * S2_ACT_BYTES;
+            constexpr int RING = 5;
+            s2_h8 ring[RING], aF[2][NT];
+            auto loadA = [&](auto gc, s2_h8 (&dst)[NT]) __attribute__((always_inline)) {
+                constexpr S2Grp G = s2_grp(decltype(gc)::value);
+                constexpr int t0_ = G.kd * 9 + G.kr * 3;
 #pragma unroll
-                for (int i = 0; i < NITL; ++i) issue(h, i);
-            }
+                for (int nt = 0; nt < NT; ++nt) {
+                    if constexpr (G.pr < 3) dst[nt] = wl[((t0_ + G.pr) * NT + nt) * 64];
+                    else if constexpr (G.pr == 3) dst[nt] = wlp[(t0_ * NT + nt) * 64];
+                    else if constexpr (G.kr == 1) dst[nt] = wlq[((t0_ - 3 + 2) * NT + nt) * 64];          // [w_lo(kr 0, kw 2) | w_lo(kr 1, kw 2)]
+                    else if constexpr (G.kd == 1) dst[nt] = wlr[((6 + 2) * NT + nt) * 64];               // [w_lo(kd 0, kr 2, kw 2) | w_lo(kd 1, kr 2, kw 2)]
+                    else dst[nt] = wl[((t0_ + 2) * NT + nt) * 64 + 32];                                   // w_lo(2, 2, 2): the upper half is zeroed at use
+                }
+            };
+            loadA(std::integral_constant<int, 0>{}, aF[0]);
+            s2_static_for(std::make_integer_sequence<int, RING>{}, [&](auto ic) __attribute__((always_inline)) {
+                ring[decltype(ic)::value] = *reinterpret_cast<const s2_h8*>(cur + bG[decltype(ic)::value]);
+            });
             __builtin_amdgcn_sched_barrier(0);
-            if (cv) {
+            s2_static_for(std::make_integer_sequence<int, S2_NG>{}, [&](auto sc) __attribute__((always_inline)) {
+                constexpr int gi = decltype(sc)::value;
+                constexpr S2Grp G = s2_grp(gi);
+                if constexpr (gi + 1 < S2_NG) loadA(std::integral_constant<int, gi + 1>{}, aF[(gi + 1) & 1]);
+                if constexpr (G.pr == 4 && G.kr == 2 && G.kd == 2) {
 #pragma unroll
-                for (int i = 0; i < NITL; ++i) { convert(h ^ 1, h ^ 1, i); __builtin_amdgcn_sched_barrier(0); }
-            }
-            if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tw += t - t0; t0 = t; }
+                    for (int nt = 0; nt < NT; ++nt) aF[gi & 1][nt] = kh ? zero8 : aF[gi & 1][nt];              // A = [w_lo | 0]
+                }
+                const s2_h8 bv = ring[gi % RING];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s2_f16x8, aF[gi & 1][nt]), __builtin_bit_cast(s2_f16x8, bv), acc[nt][0], 0, 0, 0);
+                if constexpr (gi + RING < S2_NG) ring[gi % RING] = *reinterpret_cast<const s2_h8*>(cur + bG[gi + RING]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
             __syncthreads();
-            if (WMH_STAMPS(a)) tbw += __builtin_amdgcn_s_memtime() - t0;
+            __syncthreads();                                       // the loaders swap the weight fragments in between
+            if (WMH_STAMPS(a)) tb += __builtin_amdgcn_s_memtime() - t0;
         }
+        if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt][0] *= (1.f / WMH_PAIR_WSCALE);      // undo the weights' 2^8 (exact)
+        // (the shared epilogue: 9 k cycles per tile, 6 k of them the moments' recursive halving, which costs the same for one row per wave as for
+        //  eight.  A row-by-row version with DPP adds instead of LDS permutes took 15 k: dependent DPP steps wait out their hazards.)
+        conv_epilogue<C>(a, acc, g, 0, n0, wave, j, kh, dx, 0, 0, wave, tz * C::TZ, ty * C::TY, tx * C::TX, (tz * a.nty + ty) * a.ntx + tx);
+        if (WMH_STAMPS(a)) te += __builtin_amdgcn_s_memtime() - t0;
     }
-    if (WMH_STAMPS(a) && lane == 0 && wave == 4) {
+    if (WMH_STAMPS(a) && tid == 0) {
         unsigned long long* o = WMH_STAMPS(a) + (size_t)blockIdx.x * 8;
-        o[4] = tw; o[5] = tbw;
+        o[0] = tm; o[1] = tb; o[2] = te; o[3] = (unsigned long long)total;
     }
 }
 
-// a: fully prepared by wmh_conv3d_k3_fwd_f16x2 (configuration 1, one source, no split-K)
+// a: fully prepared by wmh_conv3d_k3_fwd_f16x2 (configuration 1, one source, no split-K; W % 4 == 0 and a 16-byte aligned source: checked there)
 int wmh_launch_conv_s2_f16x2_ws(const ConvArgs& a_in, hipStream_t st) {
     static int ncu = 0;
     if (!ncu) {
@@ -331,17 +364,15 @@ int wmh_launch_conv_s2_f16x2_ws(const ConvArgs& a_in, hipStream_t st) {
         if (ncu < 8) ncu = 8;
         ncu &= ~7;
     }
-    constexpr int lds = 2 * ((S2Cfg::SP + 7) / 8 * 8) * 32;
-    static_assert(lds <= 160 * 1024, "LDS");
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3s2_f16x2_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3s2_f16x2_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);
     const long long T = (long long)a_in.ntx * a_in.nty * a_in.ntz * a_in.N * a_in.G;
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 stride 2 f16x2 (wave-specialised): too many tiles");
-    if ((size_t)a_in.C0 * a_in.D * a_in.H * a_in.W * 4 >= ((size_t)1 << 32))
-        return wmh_fail(WMH_EINVAL, "conv3d_k3 stride 2 f16x2 (wave-specialised): a sample of the source must stay below 4 GB (32-bit buffer offsets)");
+    if ((size_t)8 * a_in.D * a_in.H * a_in.W * 4 >= ((size_t)1 << 32))
+        return wmh_fail(WMH_EINVAL, "conv3d_k3 stride 2 f16x2 (wave-specialised): 8 source channel planes must stay below 4 GB (32-bit lane offsets)");
     const int grid = T < ncu ? (int)T : ncu;
     ConvArgs a = a_in;
     static const int supertile = wmh_diag_env("WMH_SUPERTILE", 1);
     if (supertile && (a.xcd_swizzle & 1)) wmh_pick_supertile(a, S2Cfg::TY, S2Cfg::TZ, grid / 8 > 0 ? grid / 8 : 1);
-    hipLaunchKernelGGL(conv3d_k3s2_f16x2_ws_kernel, dim3(grid), dim3(768), lds, st, a, (int)T);
+    hipLaunchKernelGGL(conv3d_k3s2_f16x2_ws_kernel, dim3(grid), dim3(768), S2_LDS, st, a, (int)T);
     return wmh_check_launch("conv3d_k3s2_f16x2_ws_kernel");
 }

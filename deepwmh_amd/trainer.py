@@ -172,7 +172,7 @@ class UNetTrainer:
         # their data gradients stay on the fp32 gather kernel
         if stride == 2 and not (fwd and cfg_b in (1, 3, 5)):
             return False
-        return (self.x3 and (C1 == 0 or C0 % 8 == 0) and (W % 4 == 0 or cfg_b in (1, 3, 4, 5)) and bool(self.lib.wmh_conv3d_k3_f16x2_supported(cfg_b)))
+        return (self.x3 and (C1 == 0 or C0 % 8 == 0) and (W % 4 == 0 or cfg_b in (3, 4, 5)) and bool(self.lib.wmh_conv3d_k3_f16x2_supported(cfg_b)))
 
     def _pack_x3(self, conv, cfg, mode, ci_off, ci_cnt):
         key = (conv.name, cfg, mode, ci_off, ci_cnt, 'x3')

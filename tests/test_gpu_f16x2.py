@@ -28,9 +28,9 @@ CASES = [  # N, D, H, W, C0, C1, Cout, pending norm on source 0 / 1 [, stride]
     (2, 8, 32, 32, 32, 0, 128, True, False, 2),   # stride 2, output rows of 16 (configuration 3)
     (1, 7, 20, 27, 16, 0, 64, False, False, 2),   # ... odd extents
     (2, 8, 16, 64, 32, 0, 64, True, False, 2),    # stride 2, output rows of 32 (configuration 1: the first convolution of the 64^3 / 32^3 stages)
-    (1, 7, 9, 50, 16, 0, 40, True, False, 2),     # ... ragged tiles, channel counts that are not multiples of the chunk / the tile
+    (1, 7, 9, 52, 16, 0, 40, True, False, 2),     # ... ragged tiles, channel counts that are not multiples of the chunk / the tile (rows: multiples of 4 voxels)
     (1, 6, 6, 128, 8, 0, 128, False, False, 2),   # ... two tiles per row, no pending norm
-    (3, 9, 21, 70, 20, 0, 72, True, False, 2),    # ... a channel count that is no multiple of the chunk, two output-channel groups with a tail, many tiles per workgroup
+    (3, 9, 21, 72, 20, 0, 72, True, False, 2),    # ... a channel count that is no multiple of the chunk, two output-channel groups with a tail, many tiles per workgroup
     (1, 5, 9, 36, 12, 0, 40, True, False),        # channel counts that are not multiples of the chunk / the tile; ragged tiles
     (1, 6, 10, 32, 16, 24, 32, False, True),      # two sources (the decoder's concatenation), the second one normalised
     (2, 4, 12, 64, 64, 64, 64, True, True),       # the 64-channel tile (configuration 21)
@@ -89,6 +89,19 @@ def test_conv_f16x2_against_float64(lib, case):
     mean, var = ref.mean((2, 3, 4)), ref.var((2, 3, 4), unbiased=False)
     ss_ref = torch.stack([1 / torch.sqrt(var + 1e-5), -mean / torch.sqrt(var + 1e-5)], -1)
     assert float((ss.cpu().double() - ss_ref).abs().max()) <= 2e-4 * (1 + float(ss_ref.abs().max()))
+
+
+def test_strided_pair_kernel_refuses_rows_that_are_not_multiples_of_four(lib):
+    """Configuration 1 (stride 2, output rows of 32) loads aligned 16-byte quads since round 5: an input row of 50 voxels is refused by the
+    library (the engine then runs the exact-fp32 kernel for that layer), not computed wrongly."""
+    from deepwmh_amd import _lib
+    P = _lib.ptr
+    N, D, H, W, Cin, Cout = 1, 6, 6, 50, 8, 32
+    cfg = lib.wmh_conv3d_k3_bf16_config(lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, 2), Cout, W)
+    assert cfg == 1
+    x = torch.zeros(N, Cin, D, H, W, device='cuda'); y = torch.zeros(N, Cout, 3, 3, 25, device='cuda')
+    wf = torch.zeros(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cin, Cout), dtype=torch.int16, device='cuda')
+    assert lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(x), None, Cin, None, None, 0, P(wf), None, P(y), None, None, N, D, H, W, Cout, 0.01, None) != 0
 
 
 @pytest.mark.parametrize('shape', [(2, 32, 64, 8, 8, 32), (1, 24, 40, 5, 6, 16), (2, 64, 128, 4, 8, 8)], ids=str)

@@ -122,9 +122,9 @@ def run_s2(N, S, Cin, Cout, reps=5):
         n = st[:, 3].mean()
         cyc = float((st[:, 0] + st[:, 1] + st[:, 2]).mean())
         print('   per chunk iteration (cycles): consumer mfma %.0f + barrier wait %.0f, epilogue %.0f per iteration (%.0f per tile); loader work %.0f + barrier wait %.0f; '
-              '%d workgroups x %.0f iterations; the CUs ran at %.0f MHz; 108 MFMAs = 3456 cycles of issue = %.2f of the cycles'
+              '%d workgroups x %.0f iterations; the CUs ran at %.0f MHz; 82 MFMAs = 2624 cycles of issue = %.2f of the cycles'
               % (st[:, 0].mean() / n, st[:, 1].mean() / n, st[:, 2].mean() / n, st[:, 2].mean() / n * (Cin / 8.0), st[:, 4].mean() / n, st[:, 5].mean() / n, len(st), n,
-                 cyc / e0.elapsed_time(e1) / 1e3, 3456.0 * n / cyc), flush=True)
+                 cyc / e0.elapsed_time(e1) / 1e3, 2624.0 * n / cyc), flush=True)
 
 
 run_s2(2, 64, 32, 64)

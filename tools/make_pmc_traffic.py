@@ -54,8 +54,8 @@ for mode, needle in KERNEL.items():
     print(mode, json.dumps({k: out[mode][k] for k in ('launches', 'fetch_kib_mean', 'write_kib_mean', 'fetch_correction',
                                                       'write_correction', 'traffic_bytes_per_launch')}))
 out['how'] = ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/pmc_traffic.py (WMH_PMC_MODE = '
-              'the key), batch-8 forwards of the BASELINE network; mean over every launch of the named kernel; corrections from the '
-              'calibration launch of the same run')
+              'the key; tools/profile_round.sh), forwards of the BASELINE network at WMH_BATCH = 16 patches -- what the bench\'s predictor puts into one '
+              'forward; mean over every launch of the named kernel; corrections from the calibration launch of the same run')
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'pmc_traffic.json')
 json.dump(out, open(dst, 'w'), indent=2)
 print('wrote', dst)

@@ -1,6 +1,6 @@
 """Workload for the HBM-traffic PMC passes (run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE):
 a calibration launch of known byte count in the conv kernels' own access width (4 B per lane),
-then one batch-8 forward of the BASELINE network.  tools/parse_pmc.py reads the CSVs."""
+then two forwards of the BASELINE network at WMH_BATCH patches (tools/profile_round.sh: 16, the bench's batch).  tools/parse_pmc.py reads the CSVs."""
 import os
 import sys
 
@@ -24,7 +24,7 @@ for _ in range(2):
     _lib.check(lib.wmh_instnorm_lrelu_apply(_lib.ptr(a), _lib.ptr(ss), _lib.ptr(b), 1, 1, n, 0.01, None), 'apply')
 torch.cuda.synchronize()
 del a, b
-B = int(os.environ.get('WMH_BATCH', '8'))
+B = int(os.environ.get('WMH_BATCH', '16'))
 x = torch.randn(B, 1, 128, 128, 128, device='cuda')
 for _ in range(2):
     eng.forward_features(x)
