@@ -136,8 +136,16 @@ class CheckpointProcess:
         import sys
         import tempfile
         self._json = json
+        # snapshots are raw copies of the arenas (2 x 4 bytes per parameter and snapshot, two snapshots alive at most): memory-backed /dev/shm when it
+        # has the room (containers often give it 64 MB), else next to the checkpoints
+        need = 4 * 4 * int(offsets[-1] + int(np.prod(param_order[-1][1]))) + (64 << 20)
         shm = '/dev/shm'
-        self.dir = tempfile.mkdtemp(prefix='wmh_ckpt_', dir=shm if os.path.isdir(shm) and os.access(shm, os.W_OK) else scratch_dir)
+        try:
+            st = os.statvfs(shm)
+            shm_ok = os.access(shm, os.W_OK) and st.f_bavail * st.f_frsize >= need
+        except OSError:
+            shm_ok = False
+        self.dir = tempfile.mkdtemp(prefix='wmh_ckpt_', dir=shm if shm_ok else scratch_dir)
         plans_file = os.path.join(self.dir, 'plans.pkl')
         with open(plans_file, 'wb') as f:
             pickle.dump(plans, f)
