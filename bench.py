@@ -552,7 +552,7 @@ def training_parity_tiny():
 # ------------------------------------------------------------------------------------------------------------
 # the boundary DeepWMH sees: the three commands as fresh child processes
 # ------------------------------------------------------------------------------------------------------------
-def measure_cli(plan, sd, shape, n_mirror=12, n_softmax=24, train_batches=40):
+def measure_cli(plan, sd, shape, n_mirror=12, n_softmax=40, train_batches=40):
     """`bin/nnUNet_predict` and `bin/nnUNet_train` exactly as /root/reference/deepwmh/main/predict.py:153-156 and
     deepwmh/pipeline/DCNN_multistage.py:292-309,331-344 run them -- child processes found on PATH, talking through folders of .nii.gz
     files -- on BASELINE-sized synthetic cases: prediction with mirroring (DeepWMH_predict), prediction with `--disable_tta --save_softmax`
