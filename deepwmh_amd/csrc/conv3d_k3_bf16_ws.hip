@@ -49,6 +49,16 @@ __device__ __forceinline__ float ld_uniform(const float* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<unsigned long long>(p));
 }
 
+// The low parts of two values as one dword: fp16(t0 - hi0) | fp16(t1 - hi1) << 16 with hi = the two halves of h2.  v_fma_mixlo / mixhi_f16 take the
+// fp16 operand as it is, subtract in fp32 and round once to fp16: two instructions per pair where v_cvt_f32_f16 x 2 + v_sub_f32 x 2 +
+// v_cvt_pk_f16_f32 were five.  Same bits: t - hi is exact in fp32 (hi is t cut to 11 significant bits), so both forms round the same number once.
+__device__ __forceinline__ unsigned ws_lo_pair(unsigned h2, float t0, float t1) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(t0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(h2), "v"(t1));
+    return d;
+}
+
 // ---- the pair kernel's MFMA sequence (three partial products), flattened ------------------------------------------------------------
 // Per 8-channel chunk a consumer wave issues, for every output row m of its MT rows, 41 A fragments' worth of MFMAs ("groups"):
 // per (kd, kr) the three taps' [w_hi | w_hi] against [x_hi | x_lo] (pr 0..2), [w_lo(kw 0) | w_lo(kw 1)] against [x_hi(v) | x_hi(v + 1)]
@@ -278,13 +288,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if constexpr (PAIR) {                            // fp16 pair: high part toward zero, the remainder to nearest
-                        const auto h2 = __builtin_amdgcn_cvt_pkrtz(t[0][k], t[1][k]);
-                        w[k][c >> 1] = __builtin_bit_cast(unsigned, h2) & keep;
-                        float l0, l1;                                // (unpacked subtraction, see above)
-                        asm("v_sub_f32 %0, %1, %2" : "=v"(l0) : "v"(t[0][k]), "v"((float)h2[0]));
-                        asm("v_sub_f32 %0, %1, %2" : "=v"(l1) : "v"(t[1][k]), "v"((float)h2[1]));
-                        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-                        wlo[k][c >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{l0, l1}, f16x2_t)) & keep;
+                        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t[0][k], t[1][k]));
+                        w[k][c >> 1] = h2 & keep;
+                        wlo[k][c >> 1] = ws_lo_pair(h2, t[0][k], t[1][k]) & keep;
                     } else {
                         w[k][c >> 1] = ws_pack_bf16x2(t[0][k], t[1][k]) & keep;
                     }

@@ -41,6 +41,15 @@ namespace {
 __device__ __forceinline__ float s2_ld_uniform(const float* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<unsigned long long>(p));
 }
+// The low parts of two values as one dword: fp16(t0 - hi0) | fp16(t1 - hi1) << 16, hi = the two halves of h2.  v_fma_mixlo / mixhi_f16 take
+// the fp16 operand as it is, subtract in fp32 and round ONCE to fp16: two instructions per pair where v_cvt_f32_f16 x 2 + v_sub_f32 x 2 +
+// v_cvt_pk_f16_f32 are five -- the loaders are bound by their instruction count (two loader waves share a SIMD with a consumer).
+__device__ __forceinline__ unsigned s2_lo_pair(unsigned h2, float t0, float t1) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(t0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(h2), "v"(t1));
+    return d;
+}
 template <int... I, class F>
 __device__ __forceinline__ void s2_static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
@@ -150,6 +159,8 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
             const int c0 = pc * 8, cmax = a.C0 - 1 - c0;          // channels past the end re-read the last one (scaled to zero)
             const char* base = reinterpret_cast<const char*>(a.x0 + ((size_t)n0_cur * a.C0 + c0) * DHW);
             const unsigned qo = 4u * (unsigned)q_off;
+            // (lanes beyond the 425 quads re-read voxel 0: masking them off turns the loads into a divergent region and the compiler's counted
+            //  waits for the ring into vmcnt(0); measured no faster either)
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[s_][c] = *reinterpret_cast<const s2_f32x4*>(base + (qo + (unsigned)min(c, cmax) * pstride));
             okv[s_] = q_ok; set_n0[s_] = n0_cur; set_c[s_] = pc; set_g[s_] = g_cur;
@@ -189,6 +200,8 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
             constexpr int s_ = decltype(sc)::value;
             uint4* dst = ldsq + (size_t)buf * (S2_ACT_BYTES / 16);
             const unsigned keep = okv[s_] ? 0xFFFFFFFFu : 0u;     // quad outside the volume: zeros
+            // (interior tiles -- nearly all -- have every quad of the wave inside: the masks are skipped on a wave-uniform branch)
+            const bool all_in = __builtin_amdgcn_readfirstlane((int)(__ballot(okv[s_] != 0u || !mine) == ~0ull)) != 0;
             unsigned w[4][4], wlo[4][4];                           // [voxel of the quad][channel pair]: high / low parts
 #pragma unroll
             for (int c = 0; c < 8; c += 2) {
@@ -200,14 +213,17 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
                                     wmh_norm_lrelu(v[s_][c + e][2], sc1, sh1, slope_eff), wmh_norm_lrelu(v[s_][c + e][3], sc1, sh1, slope_eff)};
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {                      // fp16 pair: high part toward zero, the remainder to nearest (the pair kernel's split)
-                    const auto h2 = __builtin_amdgcn_cvt_pkrtz(t[0][k], t[1][k]);
-                    w[k][c >> 1] = __builtin_bit_cast(unsigned, h2) & keep;
-                    float l0, l1;
-                    asm("v_sub_f32 %0, %1, %2" : "=v"(l0) : "v"(t[0][k]), "v"((float)h2[0]));
-                    asm("v_sub_f32 %0, %1, %2" : "=v"(l1) : "v"(t[1][k]), "v"((float)h2[1]));
-                    wlo[k][c >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(s2_f32x2{l0, l1}, s2_f16x2)) & keep;
+                for (int k = 0; k < 4; ++k) {                      // fp16 pair: high part toward zero, the remainder rounded once to nearest
+                    const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t[0][k], t[1][k]));
+                    w[k][c >> 1] = h2;
+                    wlo[k][c >> 1] = s2_lo_pair(h2, t[0][k], t[1][k]);
                 }
+            }
+            if (!all_in) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { w[k][e] &= keep; wlo[k][e] &= keep; }
             }
             // voxel k of the quad sits at box x = 4 q - 3 + k: k = 0, 2 odd (px = 0, sub-row index 2 q - 2 | 2 q - 1), k = 1, 3 even (px = 1, 2 q - 1 | 2 q)
 #pragma unroll
@@ -256,6 +272,10 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
         if (WMH_STAMPS(a) && tid == 256) {
             unsigned long long* o = WMH_STAMPS(a) + (size_t)blockIdx.x * 8;
             o[4] = tw; o[5] = tb;
+        }
+        if (WMH_STAMPS(a) && lane == 0) {                          // every loader wave's work: record block (wave - 3), entry 6
+            unsigned long long* o = WMH_STAMPS(a) + ((size_t)(wave - 3) * gridDim.x + blockIdx.x) * 8;
+            o[6] = tw;
         }
         return;
     }
@@ -351,6 +371,10 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
     if (WMH_STAMPS(a) && tid == 0) {
         unsigned long long* o = WMH_STAMPS(a) + (size_t)blockIdx.x * 8;
         o[0] = tm; o[1] = tb; o[2] = te; o[3] = (unsigned long long)total;
+    }
+    if (WMH_STAMPS(a) && lane == 0) {                              // every consumer wave's MFMA phases: record block (9 + wave), entry 6
+        unsigned long long* o = WMH_STAMPS(a) + ((size_t)(9 + wave) * gridDim.x + blockIdx.x) * 8;
+        o[6] = tm; o[7] = te;
     }
 }
 

@@ -57,6 +57,14 @@ constexpr int UP_W_OFF = 40960, UP_W_BYTES = 32768;          // two weight buffe
 constexpr int UP_WIT = UP_W_BYTES / 16 / 256;                // 16-byte pieces per loader thread and chunk
 constexpr int UP_FRAG_BYTES = 8 * 1024;                      // image per (cout group, chunk, class): 8 taps x (32 hi + 32 lo pieces) x 16 B
 
+// fp16(t0 - hi0) | fp16(t1 - hi1) << 16, hi = the halves of h2: two mixed-precision FMAs (conv3d_k3_bf16_ws.hip::ws_lo_pair; same bits as
+// convert + subtract + convert)
+__device__ __forceinline__ unsigned up_lo_pair(unsigned h2, float t0, float t1) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(t0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(h2), "v"(t1));
+    return d;
+}
 __device__ __forceinline__ float up_ld_uniform(const float* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<unsigned long long>(p));
 }
@@ -124,6 +132,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
                 if (++pc == nch) { pc = 0; ++pk; setup(blockIdx.x + pk * gridDim.x); }
             }
         };
+        // (the 16 scalar loads of a chunk's scale / shift issued an iteration ahead of their use: measured, no faster)
         float scv[8], shv[8], slope_eff = 1.f;
         static __device__ const float ident2[2] = {1.f, 0.f};
         auto load_ss = [&](auto sc) __attribute__((always_inline)) {
@@ -140,6 +149,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
                 shv[c] = c <= cmax ? sh1 : 0.f;
             }
         };
+        const int abl = a.KS;                                         // diagnostics (timing only): 2 = weights loaded at the start only, 4 = conflict-free LDS writes
         auto convert = [&](auto sc, int buf) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
             uint4* dst = ldsq + (size_t)buf * LVOX * 2;
@@ -156,12 +166,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {                      // fp16 pair: high part toward zero, the remainder to nearest (the pair kernel's split)
-                    const auto h2 = __builtin_amdgcn_cvt_pkrtz(t[0][k], t[1][k]);
-                    w[k][c >> 1] = __builtin_bit_cast(unsigned, h2) & keep;
-                    float l0, l1;
-                    asm("v_sub_f32 %0, %1, %2" : "=v"(l0) : "v"(t[0][k]), "v"((float)h2[0]));
-                    asm("v_sub_f32 %0, %1, %2" : "=v"(l1) : "v"(t[1][k]), "v"((float)h2[1]));
-                    wlo[k][c >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(up_f32x2{l0, l1}, up_f16x2)) & keep;
+                    const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t[0][k], t[1][k]));
+                    w[k][c >> 1] = h2 & keep;
+                    wlo[k][c >> 1] = up_lo_pair(h2, t[0][k], t[1][k]) & keep;
                 }
             }
 #pragma unroll
@@ -169,15 +176,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
                 const int x = 4 * q - 3 + k;                       // position in the halo row (0 .. LIX - 1)
                 if (mine && x >= 0 && x < LIX) {
                     const int e = row * LYS + x;
-                    dst[e * 2 + (0 ^ ((x >> 3) & 1))] = make_uint4(w[k][0], w[k][1], w[k][2], w[k][3]);
-                    dst[e * 2 + (1 ^ ((x >> 3) & 1))] = make_uint4(wlo[k][0], wlo[k][1], wlo[k][2], wlo[k][3]);
+                    const int ea = (abl == 4) ? (lt & 255) + 256 * (k & 1) : e;          // diagnostics (timing only): 4 = conflict-free write addresses
+                    dst[ea * 2 + (0 ^ ((x >> 3) & 1))] = make_uint4(w[k][0], w[k][1], w[k][2], w[k][3]);
+                    dst[ea * 2 + (1 ^ ((x >> 3) & 1))] = make_uint4(wlo[k][0], wlo[k][1], wlo[k][2], wlo[k][3]);
                 }
             }
         };
         constexpr auto S0 = std::integral_constant<int, 0>{};
         constexpr auto S1 = std::integral_constant<int, 1>{};
         constexpr auto S2 = std::integral_constant<int, 2>{};
-        const int abl = a.KS;                                         // diagnostics (timing only): 2 = weights loaded at the start only
         auto w_issue = [&](auto sc) __attribute__((always_inline)) {   // the weight image (the four classes of the tile's pz) of the chunk in activation set s
             constexpr int s = decltype(sc)::value;
             if (abl == 2 && pq > 3) return;

@@ -117,9 +117,15 @@ def run_s2(N, S, Cin, Cout, reps=5):
         lib.wmh_debug_set_conv_stamps(C.c_void_p(stamps.data_ptr()))
         e0.record(); x3(); e1.record(); torch.cuda.synchronize()
         lib.wmh_debug_set_conv_stamps(None)
-        st = stamps.view(-1, 8).cpu().numpy().astype('float64')
-        st = st[st[:, 3] > 0]
+        raw = stamps.view(-1, 8).cpu().numpy().astype('float64')
+        st = raw[:256][raw[:256, 3] > 0]
         n = st[:, 3].mean()
+        nb = len(st)
+        if raw[nb:13 * nb, 6].sum() > 0:
+            print('   work per chunk of loader waves 4..11: %s; MFMA phase of consumer waves 0..3: %s, their epilogue per tile: %s'
+                  % (' '.join('%.0f' % (raw[(w - 3) * nb:(w - 2) * nb, 6].mean() / n) for w in range(4, 12)),
+                     ' '.join('%.0f' % (raw[(9 + w) * nb:(10 + w) * nb, 6].mean() / n) for w in range(4)),
+                     ' '.join('%.0f' % (raw[(9 + w) * nb:(10 + w) * nb, 7].mean() / n * (Cin / 8.0)) for w in range(4))))
         cyc = float((st[:, 0] + st[:, 1] + st[:, 2]).mean())
         print('   per chunk iteration (cycles): consumer mfma %.0f + barrier wait %.0f, epilogue %.0f per iteration (%.0f per tile); loader work %.0f + barrier wait %.0f; '
               '%d workgroups x %.0f iterations; the CUs ran at %.0f MHz; 82 MFMAs = 2624 cycles of issue = %.2f of the cycles'
