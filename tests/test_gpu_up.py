@@ -88,3 +88,32 @@ def test_composed_up_convolution_matches_float64(lib, case):
     er = float((mr[..., 1].cpu().double() * torch.sqrt(var + 1e-5) - 1).abs().max())
     print('whole stage: rel L2 %.3g, max err / max|ref| %.3g; InstanceNorm mean err %.3g, rstd rel err %.3g' % (e, emax, em, er))
     assert e <= 2e-6 and emax <= 1e-5 and em <= 2e-5 and er <= 2e-5
+
+
+def test_network_with_composed_stage_matches_the_two_kernel_form_and_the_oracle():
+    """A network whose last decoder stage qualifies for the composed kernel (32 feature maps at 32^3): logits with and without it, and against
+    the CPU oracle -- the engine's wiring of the stage (skip-half image, composed image, moments of the sum feeding the next layer and the head)."""
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.plan import tiny_plan
+    from oracle.generic_unet import perturb_like_trained, state_dict_numpy, unet_from_plan
+    torch.manual_seed(0)
+    plan = tiny_plan(patch=32, base=32, num_pool=2, max_feat=128)
+    net = perturb_like_trained(unet_from_plan(plan), seed=5).eval()
+    net.do_ds = False
+    sd = state_dict_numpy(net)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 1, 32, 32, 32, generator=g)
+    with torch.no_grad():
+        ref = net(x).numpy()
+    out = {}
+    for fused in (False, True):
+        eng = UNetEngine(plan, sd, 'cuda:0', precision='f16x2', fuse_up=fused)
+        out[fused] = eng.forward_logits(x.cuda()).cpu().numpy()
+        took = [k for k in eng._bufs if k.startswith('tu')]
+        # the last stage's transposed convolution ran (its buffer exists) only in the two-kernel form
+        assert ('tu%d.y' % (len(eng.dec) - 1) in took) == (not fused), took
+    scale = float(np.abs(ref).max())
+    d = float(np.abs(out[True] - out[False]).max()) / scale
+    e = float(np.abs(out[True] - ref).max()) / scale
+    print('composed vs two-kernel stage: max |d logits| / max |logits| %.3g; composed vs the oracle %.3g' % (d, e))
+    assert d <= 2e-5 and e <= 5e-5
