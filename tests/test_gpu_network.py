@@ -168,6 +168,41 @@ def test_full_size_patch_forward_vs_oracle():
     assert perr <= TOL and mism == 0
 
 
+@pytest.mark.parametrize('patch', [(96, 160, 128), (160, 96, 192), (64, 224, 96)])
+def test_full_width_net_non_cubic_patch_vs_oracle(patch):
+    """Patch sizes an nnU-Net planner really emits are seldom cubes (`plans_per_stage[...]['patch_size']`, read by
+    `UNetPlan.from_nnunet_plans`): the full-width net on one patch of such a plan, default (f16x2) and exact fp32 modes,
+    against the CPU oracle.  The rows are 6, 5 and 3 voxels long at the bottleneck; the composed decoder stages, the strided
+    pair kernels and the one-role kernels all meet shapes the 128^3 plan never gives them."""
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.plan import UNetPlan
+    from oracle.generic_unet import unet_from_plan, perturb_like_trained, state_dict_numpy
+    from oracle.sliding_window import synthetic_flair
+    torch.manual_seed(0)
+    plan = UNetPlan(patch_size=list(patch))
+    net = perturb_like_trained(unet_from_plan(plan), seed=3).eval()
+    net.do_ds = False
+    vol = synthetic_flair(patch, seed=4)
+    with torch.no_grad():
+        ref = net(torch.from_numpy(vol[None])).numpy()
+    sm = lambda a: np.exp(a - a.max(1, keepdims=True)) / np.exp(a - a.max(1, keepdims=True)).sum(1, keepdims=True)
+    margin = np.abs(ref[:, 1] - ref[:, 0])
+    x = torch.from_numpy(vol[None]).cuda()
+    for precision in ('f16x2', 'fp32'):
+        eng = UNetEngine(plan, state_dict_numpy(net), 'cuda:0', precision=precision)
+        got = eng.forward_logits(x).cpu().numpy()
+        # a batch of two different patches: items independent of each other and of the batch size
+        x2 = torch.cat([x, x.flip(4)])
+        got2 = eng.forward_logits(x2).cpu().numpy()
+        perr = float(np.abs(sm(got) - sm(ref)).max())
+        mism = int(((got.argmax(1) != ref.argmax(1)) & (margin > 4 * TOL)).sum())
+        print('patch %s, %s: max|logit err| %.3g, max|softmax err| %.3g, argmax mismatches outside the band %d; batch item 0 '
+              'against the single run: max|d| %.3g' % (patch, precision, np.abs(got - ref).max(), perr, mism, np.abs(got2[0] - got[0]).max()))
+        assert perr <= TOL and mism == 0
+        assert float(np.abs(sm(got2[:1]) - sm(ref)).max()) <= TOL
+        del eng
+
+
 @pytest.fixture(scope='module')
 def baseline_pair():
     """BASELINE.json architecture (31.2 M parameters): the oracle net with trained-like parameters and the HIP engine
