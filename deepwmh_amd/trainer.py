@@ -113,6 +113,9 @@ class UNetTrainer:
         self._avg = None
         self.load_state_dict(state_dict)
         self.first_step = True
+        # weight gradients on a second stream beside the InstanceNorm backward of the next layer (WMH_TRAIN_OVERLAP=0: one stream)
+        self.overlap_wgrad = os.environ.get('WMH_TRAIN_OVERLAP', '1') != '0'
+        self._side, self._wgrad_pending = None, []
         self._bufs, self._packed, self._version = {}, {}, 0
         self._x3_jobs, self._x3_table, self._x3_batched_version, self._x3_used = OrderedDict(), None, -1, {}
         self.clip_out = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -415,33 +418,55 @@ class UNetTrainer:
         x0, x1 = rec['x0'], rec['x1']
         _, C0, D, H, W = x0.shape
         C1 = 0 if x1 is None else x1.shape[1]
-        if not conv.iso:                                     # anisotropic stage: the general fp32 kernel
-            nws = lib.wmh_conv3d_wgrad_workspace_floats(C0 + C1, Cc, N, D, H, W, conv.kz, conv.sz, conv.stride)
-            ws = self._buf('b.wgrad.ws', (nws,))
-            _lib.check(lib.wmh_conv3d_wgrad(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
-                                            _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, conv.kz, conv.sz,
-                                            conv.stride, LRELU_SLOPE, st), 'wmh_conv3d_wgrad')
-        elif self.x3 and lib.wmh_conv3d_k3_wgrad_f16x2_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
-            # pair form (fp16 hi + lo of dy and of the activated input): the loss scale keeps dy inside fp16's range
-            nws = lib.wmh_conv3d_k3_wgrad_f16x2_workspace_floats(C0 + C1, Cc, N, D, H, W)
-            ws = self._buf('b.wgrad.ws', (nws,))
-            _lib.check(lib.wmh_conv3d_k3_wgrad_f16x2(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
-                                                     _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, LRELU_SLOPE, st),
-                       'wmh_conv3d_k3_wgrad_f16x2')
-        elif self.bf16_wgrad and lib.wmh_conv3d_k3_wgrad_bf16_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
-            nws = lib.wmh_conv3d_k3_wgrad_bf16_workspace_floats(C0 + C1, Cc, N, D, H, W)
-            ws = self._buf('b.wgrad.ws', (nws,))
-            _lib.check(lib.wmh_conv3d_k3_wgrad_bf16(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
-                                                    _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, LRELU_SLOPE, st),
-                       'wmh_conv3d_k3_wgrad_bf16')
-        else:
-            nws = lib.wmh_conv3d_k3_wgrad_workspace_floats(C0 + C1, Cc, N, D, H, W, conv.stride)
-            ws = self._buf('b.wgrad.ws', (nws,))
-            _lib.check(lib.wmh_conv3d_k3_wgrad(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
-                                             _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, conv.stride,
-                                             LRELU_SLOPE, st), 'wmh_conv3d_k3_wgrad')
-        self._ready([conv.name + '.conv.weight', conv.name + '.conv.bias', conv.name + '.instnorm.weight', conv.name + '.instnorm.bias']
-                    + ([wseg_name] if (wseg_name and dl is not None) else []))
+        wname = conv.name + '.conv.weight'
+        rest = [conv.name + '.conv.bias', conv.name + '.instnorm.weight', conv.name + '.instnorm.bias'] + ([wseg_name] if (wseg_name and dl is not None) else [])
+
+        def wgrad(st, wskey):
+            if not conv.iso:                                     # anisotropic stage: the general fp32 kernel
+                nws = lib.wmh_conv3d_wgrad_workspace_floats(C0 + C1, Cc, N, D, H, W, conv.kz, conv.sz, conv.stride)
+                ws = self._buf(wskey, (nws,))
+                _lib.check(lib.wmh_conv3d_wgrad(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
+                                                _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, conv.kz, conv.sz,
+                                                conv.stride, LRELU_SLOPE, st), 'wmh_conv3d_wgrad')
+            elif self.x3 and lib.wmh_conv3d_k3_wgrad_f16x2_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
+                # pair form (fp16 hi + lo of dy and of the activated input): the loss scale keeps dy inside fp16's range
+                nws = lib.wmh_conv3d_k3_wgrad_f16x2_workspace_floats(C0 + C1, Cc, N, D, H, W)
+                ws = self._buf(wskey, (nws,))
+                _lib.check(lib.wmh_conv3d_k3_wgrad_f16x2(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
+                                                         _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, LRELU_SLOPE, st),
+                           'wmh_conv3d_k3_wgrad_f16x2')
+            elif self.bf16_wgrad and lib.wmh_conv3d_k3_wgrad_bf16_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
+                nws = lib.wmh_conv3d_k3_wgrad_bf16_workspace_floats(C0 + C1, Cc, N, D, H, W)
+                ws = self._buf(wskey, (nws,))
+                _lib.check(lib.wmh_conv3d_k3_wgrad_bf16(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
+                                                        _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, LRELU_SLOPE, st),
+                           'wmh_conv3d_k3_wgrad_bf16')
+            else:
+                nws = lib.wmh_conv3d_k3_wgrad_workspace_floats(C0 + C1, Cc, N, D, H, W, conv.stride)
+                ws = self._buf(wskey, (nws,))
+                _lib.check(lib.wmh_conv3d_k3_wgrad(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
+                                                 _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, conv.stride,
+                                                 LRELU_SLOPE, st), 'wmh_conv3d_k3_wgrad')
+
+        if not self.overlap_wgrad:
+            wgrad(st, 'b.wgrad.ws')
+            self._ready([wname] + rest)
+            return self._block_dgrad(rec, dy, need_dx)
+        # The weight gradient is off the chain IN backward -> data gradient -> IN backward of the layer below: it goes to a second
+        # stream behind this layer's data gradient and runs beside the (bandwidth-bound) InstanceNorm backward of the next layer.
+        self._ready(rest)
+        outs = self._block_dgrad(rec, dy, need_dx)
+        self._wgrad_flush()
+        self._wgrad_behind(wgrad, wname)
+        return outs
+
+    def _block_dgrad(self, rec, dy, need_dx):
+        lib, st = self.lib, self._st()
+        conv, y = rec['conv'], rec['y']
+        N, Cc = y.shape[:2]
+        x0, x1 = rec['x0'], rec['x1']
+        _, C0, D, H, W = x0.shape
+        C1 = 0 if x1 is None else x1.shape[1]
         if not need_dx:
             return None
         if conv.stride == 2 and conv.iso and self.x3 and self.x3_s2_dgrad:   # gather form on fp16 pairs (dy is loss-scaled into fp16's range)
@@ -495,6 +520,27 @@ class UNetTrainer:
             outs.append(dx)
         return outs
 
+    def _wgrad_behind(self, launch, wname):
+        """Queue `launch(stream, workspace key)` on the weight-gradient stream behind everything the launch stream holds so far.  The
+        gradient is reported ready one layer later (`_wgrad_flush`, behind the next block's data gradient), after the launch stream has
+        been made to wait for it: the wait delays nothing on the chain."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._side.wait_event(ev)
+        launch(C.c_void_p(self._side.cuda_stream), 'b.wgrad.ws.side')
+        done = torch.cuda.Event()
+        done.record(self._side)
+        self._wgrad_pending.append((done, wname))
+
+    def _wgrad_flush(self):
+        for done, wname in self._wgrad_pending:
+            torch.cuda.current_stream().wait_event(done)
+            self._ready([wname])
+        self._wgrad_pending = []
+
     def _ready(self, names):
         """The gradients of these parameters are final on the launch stream: the data-parallel exchange may start."""
         if self._avg is not None:
@@ -546,10 +592,11 @@ class UNetTrainer:
             # dW on the matrix cores; dX as a stride-2 convolution of dY with the 2-window embedded in the 3-window
             kt = self.dec[u]['kt']
             nws = lib.wmh_convtranspose3d_wgrad_workspace_floats(Cin, cskip, N, D, H, W, kt)
-            ws = self._buf('b.wgrad.ws', (max(nws, 1),))
-            _lib.check(lib.wmh_convtranspose3d_wgrad(_lib.ptr(x_in), _lib.ptr(ss_in), _lib.ptr(d_up), _lib.ptr(self.g[tu]), _lib.ptr(ws),
-                                                     N, Cin, cskip, D, H, W, kt, LRELU_SLOPE, st), 'wmh_convtranspose3d_wgrad')
-            self._ready([tu])
+            if not self.overlap_wgrad:
+                ws = self._buf('b.wgrad.ws', (max(nws, 1),))
+                _lib.check(lib.wmh_convtranspose3d_wgrad(_lib.ptr(x_in), _lib.ptr(ss_in), _lib.ptr(d_up), _lib.ptr(self.g[tu]), _lib.ptr(ws),
+                                                         N, Cin, cskip, D, H, W, kt, LRELU_SLOPE, st), 'wmh_convtranspose3d_wgrad')
+                self._ready([tu])
             # (1,2,2): the window embedded in a (1,3,3) one, stride (1,2,2)
             cfg = _lib.check(lib.wmh_conv3d_config(cskip, Cin, kt * D, 2 * H, 2 * W, 3 if kt == 2 else 1, kt, 2), 'config')
             cfg_x3 = lib.wmh_conv3d_k3_bf16_config(cfg, Cin, 2 * W) if (self.x3 and kt == 2 and self.x3_tu_dgrad) else -1
@@ -566,6 +613,12 @@ class UNetTrainer:
                 wf = self._pack_tu_dgrad(u, self.p[tu], cfg, Cin, cskip)
                 g_in, _, _ = self._run_conv('b.tu%d.dx' % u, cfg, d_up, None, None, None, wf, None, Cin, 2, False, kt)
             g_next = g_in
+            if self.overlap_wgrad:                           # behind the data gradient, like the convolutions' weight gradients
+                def tu_wgrad(sst, wskey, x_in=x_in, ss_in=ss_in, d_up=d_up, tu=tu, nws=nws, dims=(N, Cin, cskip, D, H, W, kt)):
+                    ws = self._buf(wskey + '.tu', (max(nws, 1),))
+                    _lib.check(lib.wmh_convtranspose3d_wgrad(_lib.ptr(x_in), _lib.ptr(ss_in), _lib.ptr(d_up), _lib.ptr(self.g[tu]), _lib.ptr(ws),
+                                                             *dims, LRELU_SLOPE, sst), 'wmh_convtranspose3d_wgrad')
+                self._wgrad_behind(tu_wgrad, tu)
         # encoder: bottleneck back to the first layer; stage outputs also receive the decoder's skip gradient
         nenc = len(self.enc)
         g = g_next
@@ -575,6 +628,7 @@ class UNetTrainer:
                 g2 = gskip[nd - 1 - i // 2]
             outs = self._block_bwd(tape['enc'][i], g, g2, None, None, i > 0)
             g = outs[0] if outs else None
+        self._wgrad_flush()
         self._avg.finish()
         if self.loss_scale != 1.0:                           # exact: power of two
             self.grads.mul_(1.0 / self.loss_scale)
