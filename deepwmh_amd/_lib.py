@@ -25,6 +25,7 @@ SIGNATURES = {
     'wmh_conv3d_k3_fwd': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_bf16_supported': (_i, [_i]),
     'wmh_conv3d_k3_bf16_config': (_i, [_i, _i, _i]),
+    'wmh_conv3d_k3_f16x2_config': (_i, [_i, _i, _i]),
     'wmh_conv3d_k3_packed_halfs_bf16': (_sz, [_i, _i, _i]),
     'wmh_conv3d_k3_pack_weights_bf16': (_i, [_i, _vp, _i, _i, _vp]),
     'wmh_conv3d_k3_num_partials_bf16': (_i, [_i, _i, _i, _i, _i]),

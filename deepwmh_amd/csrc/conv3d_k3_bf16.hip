@@ -284,11 +284,17 @@ typedef ConvCfg<2, 8, 4, 4, 8, 1, 2, 1, 2, 6> BCfg5;      // stride 2, 8-wide ou
 // geometry only -- the kernel is the wave-specialised one of conv3d_k3s2_f16x2_ws.hip (a 2 x 2 x 32 output tile x 64 channels reads a
 // 5 x 5 x 65 input box; the one-role form that first served these layers spent half its time in its in-order staging).
 typedef ConvCfg<2, 32, 1, 2, 2, 1, 1, 2, 2, 6> BCfg1;
-static int bf16_nt(int cfg) { return (cfg == 0 || cfg == 4 || cfg == 5) ? 1 : (cfg == 1 || cfg == 2 || cfg == 3 || cfg == WMH_BF16_CFG_WIDE) ? 2 : 0; }
+// Configuration 24 (f16x2 only, round 5): rows of 8 voxels on the wave-specialised kernel -- a tile is a whole 8 x 8 x 8 block x 64 output
+// channels, split-K slices fill the chip (the 8^3 level: 320 channels, 16 x 5 tiles).  The one-role kernel of configuration 4 ran these
+// layers at 150-220 TFLOP/s (every chunk ends in a barrier that nothing hides); it keeps the rows that are no multiple of 4 voxels.
+#define WMH_F16X2_CFG_ROWS8 24
+typedef ConvCfg<1, 8, 4, 8, 8, 1, 4, 2, 4, 6> BCfg8;
+static int bf16_nt(int cfg) { return (cfg == 0 || cfg == 4 || cfg == 5) ? 1 : (cfg == 1 || cfg == 2 || cfg == 3 || cfg == WMH_BF16_CFG_WIDE || cfg == WMH_F16X2_CFG_ROWS8) ? 2 : 0; }
 static int bf16_stride(int cfg) { return (cfg == 1 || cfg == 3 || cfg == 5) ? 2 : 1; }
 struct BGeo { int TX, TY, TZ, WPS; };
 static BGeo bf16_geo(int cfg, bool w8) {
     if (cfg == WMH_BF16_CFG_WIDE) return BGeo{BCfgW::TX, BCfgW::TY, BCfgW::TZ, BCfgW::WPS};
+    if (cfg == WMH_F16X2_CFG_ROWS8) return BGeo{BCfg8::TX, BCfg8::TY, BCfg8::TZ, BCfg8::WPS};
     if (cfg == 1) return BGeo{BCfg1::TX, BCfg1::TY, BCfg1::TZ, BCfg1::WPS};
     if (cfg == 3) return BGeo{BCfg3::TX, BCfg3::TY, BCfg3::TZ, BCfg3::WPS};
     if (cfg == 4) return BGeo{BCfg4::TX, BCfg4::TY, BCfg4::TZ, BCfg4::WPS};
@@ -304,7 +310,16 @@ extern "C" int wmh_conv3d_k3_bf16_config(int cfg, int Cout, int W) {
     return cfg;
 }
 
-extern "C" int wmh_conv3d_k3_bf16_supported(int cfg) { return cfg != 1 && bf16_nt(cfg) > 0; }      // configuration 1: f16x2 only
+// The configuration wmh_conv3d_k3_fwd_f16x2 should be called with: the one above, and rows of 8 voxels go to configuration 24 when the
+// wave-specialised kernel can load them (aligned quads)
+extern "C" int wmh_conv3d_k3_f16x2_config(int cfg, int Cout, int W) {
+    static const int rows8 = wmh_diag_env("WMH_F16X2_ROWS8", 1);
+    const int c = wmh_conv3d_k3_bf16_config(cfg, Cout, W);
+    if (c == 4 && rows8 && W % 4 == 0) return WMH_F16X2_CFG_ROWS8;
+    return c;
+}
+
+extern "C" int wmh_conv3d_k3_bf16_supported(int cfg) { return cfg != 1 && cfg != WMH_F16X2_CFG_ROWS8 && bf16_nt(cfg) > 0; }      // configurations 1, 24: f16x2 only
 // InstanceNorm partial records per (n, c) row the bf16 kernel writes (its wave split differs from the fp32 kernel's)
 extern "C" int wmh_conv3d_k3_num_partials_bf16(int cfg, int N, int Do, int Ho, int Wo) {
     if (!bf16_nt(cfg)) return wmh_fail(WMH_EINVAL, "num_partials_bf16: configuration has no bf16 kernel");
@@ -347,7 +362,7 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16(int cfg, const float* w, int Cin,
 // ---- the "pair" mode (entry points keep round 2's f16x2 names; conv3d_k3_bf16_ws.hip, PAIR): chunks of 8 input channels, a lane's
 // 16 bytes are the HIGH fp16 parts of its output channel's 8 weights (lanes 0-31) or the LOW parts (lanes 32-63), of the
 // weights scaled by 2^8: 256 w = hi + lo + O(2^-22 w).  |w| must stay below 255 (fp16's range after the scaling).
-extern "C" int wmh_conv3d_k3_f16x2_supported(int cfg) { return cfg == 0 || cfg == 1 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE || cfg == 3 || cfg == 4 || cfg == 5; }
+extern "C" int wmh_conv3d_k3_f16x2_supported(int cfg) { return cfg == 0 || cfg == 1 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE || cfg == WMH_F16X2_CFG_ROWS8 || cfg == 3 || cfg == 4 || cfg == 5; }
 extern "C" size_t wmh_conv3d_k3_packed_halfs_f16x2(int cfg, int Cin, int Cout) {
     const int NT = bf16_nt(cfg);
     if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg)) return 0;
@@ -623,7 +638,34 @@ int wmh_launch_conv_f16x2_ws(int cfg, const ConvArgs& a, hipStream_t st);
 // y = conv3x3x3 with both operands split into two bf16 numbers each and all four partial products accumulated in fp32
 // (16 mantissa bits per operand): fp32 tensors in and out, stride 1, wf from wmh_conv3d_k3_pack_weights_f16x2.  Same
 // geometry, moments records (wmh_conv3d_k3_num_partials_bf16) and epilogue as wmh_conv3d_k3_fwd_bf16.
+// Split-K factor of the wave-specialised stride-1 pair kernels (configurations 0, 2, 21): one workgroup per CU, so a layer with fewer
+// tiles than half the CUs (16^3 and 8^3 levels at batch 2: 64 tiles) leaves most of the chip idle for the whole launch.  KS slices of the
+// channel chunks per tile, as many as fit the chip once, each at least two chunks.
+static int ws_ksplit(long long tiles, int nchunks) {
+    static const int force = wmh_diag_env("WMH_WS_KSPLIT", 0);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu < 8) ncu = 8;
+    }
+    if (force > 0) return force < nchunks ? force : nchunks;
+    if (tiles < 1 || tiles * 2 > ncu) return 1;
+    int ks = (int)(ncu / tiles);
+    if (ks > 16) ks = 16;
+    if (ks > nchunks / 2) ks = nchunks / 2;
+    return ks < 2 ? 1 : ks;
+}
+static long long ws_tiles(int cfg, int N, int D, int H, int W, int Cout) {
+    const BGeo ge = bf16_geo(cfg, false);
+    return (long long)cdiv(W, ge.TX) * cdiv(H, ge.TY) * cdiv(D, ge.TZ) * N * cdiv(Cout, 32 * bf16_nt(cfg));
+}
 extern "C" size_t wmh_conv3d_k3_f16x2_workspace_floats(int cfg, int Cin, int N, int D, int H, int W, int Cout) {
+    if (cfg == 0 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE || cfg == WMH_F16X2_CFG_ROWS8) {
+        const int ks = ws_ksplit(ws_tiles(cfg, N, D, H, W, Cout), cdiv(Cin, 8));
+        return ks > 1 ? (size_t)ks * N * Cout * D * H * W : 0;
+    }
     if (!(cfg == 3 || cfg == 4 || cfg == 5)) return 0;           // (configuration 1: wave-specialised, no split-K)
     const int S = bf16_stride(cfg);
     const int ks = bf16_ksplit(bf16_small_blocks(cfg, N, D, H, W, Cout), cdiv(Cin, 8));
@@ -662,7 +704,13 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     a.stamps = g_conv_stamps;
     a.by = a.bz = 1;
     hipStream_t st = (hipStream_t)stream;
-    if (!small) return wmh_launch_conv_f16x2_ws(cfg, a, st);
+    if (!small) {
+        a.KS = workspace != nullptr ? ws_ksplit(ws_tiles(cfg, N, D, H, W, Cout), a.nchunks) : 1;
+        if (a.KS > 1) a.y = workspace;                       // slabs [KS][N][Cout][D][H][W]; bias and moments come with the reduce
+        const int rc = wmh_launch_conv_f16x2_ws(cfg, a, st);
+        if (rc != WMH_OK || a.KS == 1) return rc;
+        return wmh_launch_splitk_reduce(workspace, bias, y, partials, a.npart, a.KS, N, Cout, (size_t)a.Do * a.Ho * a.Wo, st);
+    }
     // rows of 16 / 8 voxels (stride 1 and 2): the one-role kernel, split-K when slab memory is given (wmh_conv3d_k3_fwd_bf16_splitk)
     const long long nblk = (long long)a.ntx * a.nty * a.ntz * N * a.G;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: grid too large");

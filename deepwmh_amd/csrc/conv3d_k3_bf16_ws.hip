@@ -131,14 +131,25 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
     const size_t DHW = (size_t)a.D * HW;
     const int nch = a.nchunks;
 
-    auto tile_of = [&](int v, int& g, int& tx, int& ty, int& tz, int& n0) {
+    // Split-K (a.KS > 1; T counts the parts): part t of the order below is slice t % KS of the channel chunks of tile t / KS -- the slices
+    // of a tile run side by side on different workgroups and leave raw partial sums in slab ks of a.y (bias and moments come with
+    // the reduce, wmh_launch_splitk_reduce).  For layers whose tiles alone do not fill the chip (16^3 / 8^3 levels at batch 2).
+    const int KS = a.KS;
+    auto tile_of = [&](int v, int& g, int& tx, int& ty, int& tz, int& n0, int& ks) {
         const int q = T >> 3, r = T & 7, xcd = v & 7;
         int t = (a.xcd_swizzle & 1) ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3) : v;
+        ks = 0;
+        if (KS > 1) { ks = t % KS; t /= KS; }
         wmh_tile_coords(a, t, g, tx, ty, tz, n0);
     };
-    int ntiles_mine = 0;
-    for (int v = blockIdx.x; v < T; v += gridDim.x) ++ntiles_mine;
-    const int total = ntiles_mine * nch;                    // chunk iterations of this workgroup
+    auto ch_lo_of = [&](int ks) { return KS > 1 ? (nch * ks) / KS : 0; };            // (nch * KS < 2^31: the host checks)
+    auto ch_hi_of = [&](int ks) { return KS > 1 ? (nch * (ks + 1)) / KS : nch; };
+    int ntiles_mine = 0, total = 0;                         // parts / chunk iterations of this workgroup
+    for (int v = blockIdx.x; v < T; v += gridDim.x) {
+        ++ntiles_mine;
+        if (KS > 1) { int g, tx, ty, tz, n0, ks; tile_of(v, g, tx, ty, tz, n0, ks); total += ch_hi_of(ks) - ch_lo_of(ks); }
+    }
+    if (KS == 1) total = ntiles_mine * nch;
 
     if (loader) {
         // ================================ loader waves =====================================================
@@ -153,8 +164,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         int q_off[NSL]; unsigned q_ok = 0;                        // of the tile the NEXT issue() reads
         int n0_cur = 0;
         auto setup = [&](int v) __attribute__((always_inline)) {
-            int g, tx, ty, tz, n0;
-            tile_of(v, g, tx, ty, tz, n0);
+            int g, tx, ty, tz, n0, ks_;
+            tile_of(v, g, tx, ty, tz, n0, ks_);
             // the tile coordinates come out of VALU divisions: make them scalar again, or everything indexed with them
             // (the InstanceNorm scale/shift reads above all) turns into vector loads on the in-order vmcnt queue
             n0_cur = __builtin_amdgcn_readfirstlane(n0);
@@ -179,12 +190,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         // The chunk being produced: linear index pq of this workgroup's sequence = (tile counter pk, channel chunk pc), and the
         // cout group pg of that tile.  Kept as counters: `q / nch`, `q % nch` and tile_of() per chunk were ~400 scalar
         // instructions of the ~1700 a loader wave issues per chunk -- and the loader's instruction count is what bounds it.
-        int pq = 0, pk = 0, pc = 0, pg = 0;
+        int pq = 0, pk = 0, pc = 0, pg = 0, p_hi = nch;   // p_hi: one past the last chunk of part pk
         unsigned long long t_issue = 0, t_conv = 0;      // diagnostics (WMH_STAMPS(a)): loads issued / conversion + LDS writes
-        auto group_of = [&](int k) __attribute__((always_inline)) {
-            int g, tx, ty, tz, n0;
-            tile_of(blockIdx.x + k * gridDim.x, g, tx, ty, tz, n0);
-            return __builtin_amdgcn_readfirstlane(g);
+        auto part_of = [&](int k, int& grp, int& lo, int& hi) __attribute__((always_inline)) {   // cout group and chunk range of my k-th part
+            int g, tx, ty, tz, n0, ks;
+            tile_of(blockIdx.x + k * gridDim.x, g, tx, ty, tz, n0, ks);
+            ks = __builtin_amdgcn_readfirstlane(ks);
+            grp = __builtin_amdgcn_readfirstlane(g);
+            lo = ch_lo_of(ks); hi = ch_hi_of(ks);
         };
         auto issue_w = [&]() __attribute__((always_inline)) {                               // the weights of chunk (pk, pc)
             const u32x4_t* wsrc = reinterpret_cast<const u32x4_t*>(a.wf) + ((size_t)pg * nch + pc) * WQ;
@@ -307,10 +320,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             }
         };
         // (tile, chunk) after (pk, pc) in the sequence; the last chunk is followed by itself
-        auto next_of = [&](int& nk, int& nc) __attribute__((always_inline)) {
-            const bool last = pq + 1 >= total, wrap = pc + 1 == nch;
-            nc = last ? pc : (wrap ? 0 : pc + 1);
-            nk = last ? pk : (wrap ? pk + 1 : pk);
+        auto next_of = [&](int& nk, int& nc, bool& newpart) __attribute__((always_inline)) {
+            const bool last = pq + 1 >= total, wrap = pc + 1 == p_hi;
+            newpart = wrap && !last;
+            nk = newpart ? pk + 1 : pk;
+            int lo = 0;
+            if (KS > 1 && newpart) { int g_, hi_; part_of(nk, g_, lo, hi_); }
+            nc = last ? pc : (wrap ? lo : pc + 1);
         };
         // one step: put half-slot (h + RS - 1) of the running sequence in flight, then convert half-slot h of chunk q.
         // Branch-free on purpose (past the last chunk the ring re-reads the last chunk): the weight fragments issued at the
@@ -324,9 +340,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             if constexpr (hn < NHS) {
                 issue(std::integral_constant<int, hn>{}, pc);
             } else {
-                int nk, nc;
-                next_of(nk, nc);
-                if constexpr (hn == NHS) { if (nc == 0) setup(blockIdx.x + nk * gridDim.x); }   // first half-slot of the next chunk: maybe a new tile
+                int nk, nc; bool newpart;
+                next_of(nk, nc, newpart);
+                if constexpr (hn == NHS) { if (newpart) setup(blockIdx.x + nk * gridDim.x); }   // first half-slot of the next chunk: maybe a new tile
                 issue(std::integral_constant<int, hn - NHS>{}, nc);
             }
             if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_issue += t - ts0; ts0 = t; }
@@ -342,20 +358,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
             if constexpr (NHS > 4) { step(std::integral_constant<int, 4>{}, buf); step(std::integral_constant<int, 5>{}, buf); }
         };
         auto advance = [&]() __attribute__((always_inline)) {                                  // to the next chunk of the sequence (clamped)
-            int nk, nc;
-            next_of(nk, nc);
+            int nk, nc; bool newpart;
+            next_of(nk, nc, newpart);
             if (pq + 1 < total) ++pq;
-            if (nk != pk) pg = group_of(nk);
+            if (nk != pk) { int lo_; part_of(nk, pg, lo_, p_hi); }
             pk = nk; pc = nc;
         };
         if (total > 0) {
-            pg = group_of(0);
+            part_of(0, pg, pc, p_hi);
             setup(blockIdx.x);
-            issue(std::integral_constant<int, 0>{}, 0);
-            if constexpr (RS > 2) issue(std::integral_constant<int, 1>{}, 0);
-            if constexpr (RS > 3) issue(std::integral_constant<int, 2>{}, 0);
-            if constexpr (RS > 4) issue(std::integral_constant<int, 3>{}, 0);
-            if constexpr (RS > 5) issue(std::integral_constant<int, 4>{}, 0);
+            issue(std::integral_constant<int, 0>{}, pc);
+            if constexpr (RS > 2) issue(std::integral_constant<int, 1>{}, pc);
+            if constexpr (RS > 3) issue(std::integral_constant<int, 2>{}, pc);
+            if constexpr (RS > 4) issue(std::integral_constant<int, 3>{}, pc);
+            if constexpr (RS > 5) issue(std::integral_constant<int, 4>{}, pc);
             produce(0);
             write_w();
         }
@@ -395,23 +411,24 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
         const char* ldsb = reinterpret_cast<const char*>(ldsq);
         // PAIR: a fragment's 64 pieces are [hi of cout 0..31 | lo of cout 0..31]; both lane halves read the same piece
         const bf16x8* wl = reinterpret_cast<const bf16x8*>(wlds) + (PAIR ? j : lane);
-        int g, tx, ty, tz, n0;
+        int g, tx, ty, tz, n0, ks;
         __syncthreads();
         int it = 0;
         unsigned long long tm = 0, tb = 0, te = 0, t0 = 0, tbl = 0;
         for (int vb = blockIdx.x; vb < T; vb += gridDim.x) {
-            tile_of(vb, g, tx, ty, tz, n0);
+            tile_of(vb, g, tx, ty, tz, n0, ks);
+            const int ch_lo = ch_lo_of(ks), ch_hi = ch_hi_of(ks);
             f32x16 acc[NT][MT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = (g * NT + nt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] * (PAIR ? WMH_PAIR_WSCALE : 1.f) : 0.f;
+                    const float bv = (KS == 1 && a.bias != nullptr && co < a.Cout) ? a.bias[co] * (PAIR ? WMH_PAIR_WSCALE : 1.f) : 0.f;
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[nt][m][r] = bv;
                 }
-            for (int ch = 0; ch < nch; ++ch, ++it) {
+            for (int ch = ch_lo; ch < ch_hi; ++ch, ++it) {
                 const char* cur = ldsb + (size_t)(it & 1) * CS * 32;
                 if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
                 // Taps are processed in the order (kd, kw, kr) -- wmh_tap_of(), the one-role kernel's order too -- three kr taps per
@@ -528,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
                 if (WMH_STAMPS(a)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm += t - t0; t0 = t; }
                 __syncthreads();
                 __syncthreads();                             // the loaders swap the weight fragments in between
-                if (WMH_STAMPS(a)) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; tb += d; if (ch == 0) tbl += d; }
+                if (WMH_STAMPS(a)) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; tb += d; if (ch == ch_lo) tbl += d; }
             }
             if (WMH_STAMPS(a)) t0 = __builtin_amdgcn_s_memtime();
             if constexpr (PAIR) {                               // undo the weights' 2^8 (exact)
@@ -537,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[nt][m] *= (1.f / WMH_PAIR_WSCALE);
             }
-            conv_epilogue<C, OUT16>(a, acc, g, 0, n0, wave, j, kh, dx, dy, dz, ts0, tz * C::TZ, ty * C::TY, tx * C::TX,
+            conv_epilogue<C, OUT16>(a, acc, g, ks, n0, wave, j, kh, dx, dy, dz, ts0, tz * C::TZ, ty * C::TY, tx * C::TX,
                              (tz * a.nty + ty) * a.ntx + tx);
             if (WMH_STAMPS(a)) te += __builtin_amdgcn_s_memtime() - t0;
         }
@@ -551,6 +568,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_bf16_ws_kernel(const ConvArg
 typedef ConvCfg<1, 32, 1, 4, 8, 1, 8, 1, 4, 6> WBCfg0;
 typedef ConvCfg<1, 16, 2, 2, 16, 1, 4, 2, 4, 6> WBCfg2;
 typedef ConvCfg<1, 32, 1, 4, 4, 1, 4, 2, 4, 6> WBCfgW;      // configuration 21: 4 x 4 x 32 voxels x 64 output channels
+typedef ConvCfg<1, 8, 4, 8, 8, 1, 4, 2, 4, 6> WBCfg8;       // configuration 24 (f16x2): 8 x 8 x 8 voxels x 64 output channels, an M-tile = 4 rows of 8
 
 template <class C, bool IN16 = false, bool OUT16 = false, bool PAIR = false>
 static int launch_bf16_ws(const ConvArgs& a_in, hipStream_t st) {
@@ -566,7 +584,7 @@ static int launch_bf16_ws(const ConvArgs& a_in, hipStream_t st) {
     constexpr int lds = 2 * NITL * 256 * 32 + 27 * C::NT * 64 * 16;
     static_assert(lds <= 160 * 1024, "LDS");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_bf16_ws_kernel<C, IN16, OUT16, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    const long long T = (long long)a_in.ntx * a_in.nty * a_in.ntz * a_in.N * a_in.G;
+    const long long T = (long long)a_in.ntx * a_in.nty * a_in.ntz * a_in.N * a_in.G * (a_in.KS > 1 ? a_in.KS : 1);      // parts
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 bf16 (wave-specialised): too many tiles");
     const int grid = T < ncu ? (int)T : ncu;
     ConvArgs a = a_in;
@@ -592,5 +610,6 @@ int wmh_launch_conv_f16x2_ws(int cfg, const ConvArgs& a, hipStream_t st) {
     if (cfg == 21) return launch_bf16_ws<WBCfgW, false, false, true>(a, st);
     if (cfg == 0) return launch_bf16_ws<WBCfg0, false, false, true>(a, st);
     if (cfg == 2) return launch_bf16_ws<WBCfg2, false, false, true>(a, st);
-    return wmh_fail(WMH_EINVAL, "conv3d_k3 f16x2: configurations 0, 2 and 21");
+    if (cfg == 24) return launch_bf16_ws<WBCfg8, false, false, true>(a, st);
+    return wmh_fail(WMH_EINVAL, "conv3d_k3 f16x2: configurations 0, 2, 21 and 24");
 }

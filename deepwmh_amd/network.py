@@ -211,11 +211,11 @@ class UNetEngine:
         # 'f16x2': the 3x3x3 convolutions that have a 16-bit-operand kernel (stride 1: rows of >= 8 voxels; stride 2: output rows of 8 or 16)
         # form their products from fp16 pairs (x = hi + lo, 21-22 significant bits per operand; the stride-1 kernels form three of the four partial products, lo x lo -- 2^-22 of a product -- being left out; fp32
         # accumulation): results at the exact-fp32 kernel's error level at 2-2.7x its speed.  Everything else is the exact-fp32 path.
-        cfg_x = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
+        cfg_x = self.lib.wmh_conv3d_k3_f16x2_config(cfg, layer.cout, W)
         use_x3 = (self.precision == 'f16x2' and layer.kz == 3 and layer.sz == s and (C1 == 0 or C0 % 8 == 0)
                   and bool(self.lib.wmh_conv3d_k3_f16x2_supported(cfg_x)) and (cfg_x in (3, 4, 5) or W % 4 == 0))      # (1: the strided wave-specialised kernel loads aligned quads too)
         if use_x3:
-            cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
+            cfg = cfg_x
         if use_bf16 and not (in16 or out16):       # wide tile for >= 64 output channels (bf16 kernel only)
             cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, layer.cout, W)
         if use_x3:

@@ -54,6 +54,7 @@ class UNetTrainer:
         # (network.py, DESIGN.md 3.2: fp32-grade, 2-2.7x the fp32 instruction's speed); weight gradients and everything else fp32
         self.x3 = precision == 'f16x2'
         self.x3_s2_dgrad = self.x3_tu_dgrad = True         # diagnostic attributes (tools/grad_compare.py): False = those data gradients on the exact-fp32 kernels
+        self.x3_splitk = True                              # diagnostic attribute (tools/train_bench.py): False = no slab memory for the pair kernels (no split-K)
         # fp16's exponent range: the data gradients (dLoss/dy ~ 1e-8 .. 1e-2 at 2 x 128^3 voxels) sit below fp16's normal range, so in
         # this mode the backward pass runs on the loss scaled by 2^16 -- the static form of the GradScaler nnU-Net's own fp16 AMP
         # training uses -- and loss and gradient arena are scaled back (exactly: a power of two) at the end of backward().  Without it
@@ -238,7 +239,7 @@ class UNetTrainer:
         if want_stats:
             npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_f16x2(cfg, N, Do, Ho, Wo), 'num_partials_f16x2')
             part = self._buf(key + '.part', (N, cout, npart, 4))
-        nws = self.lib.wmh_conv3d_k3_f16x2_workspace_floats(cfg, C0 + C1, N, D, H, W, cout)
+        nws = self.lib.wmh_conv3d_k3_f16x2_workspace_floats(cfg, C0 + C1, N, D, H, W, cout) if self.x3_splitk else 0
         ws = self._buf('splitk.ws', (nws,)) if nws else None
         _lib.check(self.lib.wmh_conv3d_k3_fwd_f16x2(cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wf),
                                                      _lib.ptr(bias), _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws), N, D, H, W, cout, LRELU_SLOPE,
@@ -294,7 +295,7 @@ class UNetTrainer:
         N, _, D, H, W = x0.shape
         cfg = _lib.check(self.lib.wmh_conv3d_config(conv.cin, conv.cout, D, H, W, conv.kz, conv.sz, conv.stride), 'config')
         C1 = 0 if x1 is None else x1.shape[1]
-        cfg_x3 = self.lib.wmh_conv3d_k3_bf16_config(cfg, conv.cout, W) if (self.x3 and conv.iso) else -1
+        cfg_x3 = self.lib.wmh_conv3d_k3_f16x2_config(cfg, conv.cout, W) if (self.x3 and conv.iso) else -1
         if cfg_x3 >= 0 and self._use_x3(cfg_x3, conv.stride, x0.shape[1], C1, W, fwd=True):
             wf = self._pack_x3(conv, cfg_x3, 0, 0, conv.cin)
             y, part, npart = self._run_conv_x3(key, cfg_x3, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout, True, conv.stride)
@@ -506,7 +507,7 @@ class UNetTrainer:
         outs = []
         for part, (off, cnt) in enumerate([(0, C0)] + ([(C0, C1)] if C1 else [])):
             cfg = _lib.check(lib.wmh_conv3d_config(Cc, cnt, D, H, W, conv.kz, 1, 1), 'config')
-            cfg_x3 = lib.wmh_conv3d_k3_bf16_config(cfg, cnt, W) if (self.x3 and conv.kz == 3) else -1
+            cfg_x3 = lib.wmh_conv3d_k3_f16x2_config(cfg, cnt, W) if (self.x3 and conv.kz == 3) else -1
             if cfg_x3 >= 0 and self._use_x3(cfg_x3, 1, Cc, 0, W):
                 wf = self._pack_x3(conv, cfg_x3, 1, off, cnt)
                 dx, _, _ = self._run_conv_x3('b.dx%d.%s' % (part, rec['key']), cfg_x3, src, None, None, None, wf, None, cnt, False)

@@ -101,6 +101,10 @@ int wmh_conv3d_k3_pack_weights_bf16_device(int cfg, const float* w, int Cin_tota
  * (configuration 21, this kernel only), which halves the staging work per output; everything else keeps its cfg.
  * packed_halfs / pack_weights / num_partials / fwd must all be called with the returned value. */
 int wmh_conv3d_k3_bf16_config(int cfg, int Cout, int W);
+/* The same for the f16x2 entry points (wmh_conv3d_k3_*_f16x2): the value above, except that rows of 8 voxels that are whole 16-byte
+ * quads (W % 4 == 0) go to configuration 24 -- the wave-specialised pair kernel on tiles of 8 x 8 x 8 voxels x 64 channels, with
+ * split-K slices when the tiles alone do not fill the chip (wmh_conv3d_k3_f16x2_workspace_floats).  f16x2 only. */
+int wmh_conv3d_k3_f16x2_config(int cfg, int Cout, int W);
 int wmh_conv3d_k3_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, const float* x1, const float* ss1,
                            int C1, const uint16_t* wf, const float* bias, float* y, float* partials, int N, int D,
                            int H, int W, int Cout, float lrelu_slope, void* stream);

@@ -22,7 +22,8 @@ def lib():
 
 CASES = [  # N, D, H, W, C0, C1, Cout, pending norm on source 0 / 1 [, stride]
     (2, 8, 8, 32, 32, 0, 32, True, False),
-    (2, 8, 8, 8, 48, 16, 64, True, True, 1),      # rows of 8 voxels (configuration 4, one-role kernel, split-K slabs)
+    (2, 8, 8, 8, 48, 16, 64, True, True, 1),      # rows of 8 voxels (configuration 24: wave-specialised, split-K slices; and configuration 4, one-role kernel)
+    (3, 8, 16, 8, 40, 0, 96, True, False, 1),     # ... several tiles per sample, a channel-group tail
     (1, 5, 9, 7, 24, 0, 40, True, False, 1),      # ... ragged
     (2, 16, 16, 16, 32, 0, 64, True, False, 2),   # stride 2, output rows of 8 (configuration 5)
     (2, 8, 32, 32, 32, 0, 128, True, False, 2),   # stride 2, output rows of 16 (configuration 3)
@@ -35,11 +36,14 @@ CASES = [  # N, D, H, W, C0, C1, Cout, pending norm on source 0 / 1 [, stride]
     (1, 6, 10, 32, 16, 24, 32, False, True),      # two sources (the decoder's concatenation), the second one normalised
     (2, 4, 12, 64, 64, 64, 64, True, True),       # the 64-channel tile (configuration 21)
     (2, 18, 6, 16, 48, 0, 64, True, False),       # rows of 16 voxels (configuration 2)
+    (2, 16, 16, 16, 256, 0, 256, True, False),    # a 16^3 level at the training batch: 64 tiles, so the wave-specialised kernel runs four slices of the channel chunks per tile
+    (2, 8, 16, 32, 40, 24, 64, True, True),       # ... two sources, chunk slices of unequal length
 ]
 
 
+@pytest.mark.parametrize('slabs', [True, False], ids=['split-K where the library picks it', 'no slab memory'])
 @pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
-def test_conv_f16x2_against_float64(lib, case):
+def test_conv_f16x2_against_float64(lib, case, slabs):
     from deepwmh_amd import _lib
     P = _lib.ptr
     N, D, H, W, C0, C1, Cout, has0, has1 = case[:9]
@@ -60,35 +64,36 @@ def test_conv_f16x2_against_float64(lib, case):
     ref = torch.nn.functional.conv3d(xin, w.double(), bias.double(), padding=1, stride=stride)
     Do, Ho, Wo = ref.shape[2:]
     cfg0 = _lib.check(lib.wmh_conv3d_k3_config(Cin, Cout, D, H, W, stride), 'config')
-    cfg = lib.wmh_conv3d_k3_bf16_config(cfg0, Cout, W)
-    assert lib.wmh_conv3d_k3_f16x2_supported(cfg)
-    wh = np.ascontiguousarray(w.numpy().reshape(Cout, Cin, 27))
-    wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cin, Cout), np.uint16)
-    _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2(cfg, wh.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
-    wfd = torch.from_numpy(wf.view(np.int16)).cuda()
-    y = torch.full((N, Cout, Do, Ho, Wo), float('nan'), device='cuda')
-    npart = _lib.check(lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, Do, Ho, Wo), 'npart')
-    nws = lib.wmh_conv3d_k3_f16x2_workspace_floats(cfg, Cin, N, D, H, W, Cout)
-    ws = torch.empty(nws, device='cuda') if nws else None
-    part = torch.full((N, Cout, npart, 4), float('nan'), device='cuda')
-    x0d, x1d = x0.cuda(), (x1.cuda() if C1 else None)
-    ss0d, ss1d, bd = (ss0.cuda() if ss0 is not None else None), (ss1.cuda() if ss1 is not None else None), bias.cuda()
-    _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(x0d), P(ss0d), C0, P(x1d), P(ss1d), C1, P(wfd), P(bd), P(y), P(part), P(ws), N, D, H, W, Cout,
-                                            0.01, None), 'wmh_conv3d_k3_fwd_f16x2')
-    torch.cuda.synchronize()
-    got = y.cpu().double()
-    assert bool(torch.isfinite(got).all())
-    rel = float((got - ref).norm() / ref.norm())
-    mx = float((got - ref).abs().max()) / float(ref.abs().max())
-    # 21-22 significant bits per operand; the exact-fp32 kernel's own figures on these shapes are 0.5-1.4e-6 / 1.6-3.7e-6
-    # (measured for this kernel: 3.5e-7 .. 9e-7 / 0.9 .. 2.9e-6; round 2's bf16 pairs: 3.4e-6 / 4e-6)
-    assert rel <= 2e-6 and mx <= 6e-6, (rel, mx)
-    # InstanceNorm statistics from the fp32 accumulators, through the usual finalisation
-    ss = torch.empty(N, Cout, 2, device='cuda')
-    _lib.check(lib.wmh_instnorm_finalize(P(part), npart, None, None, 1e-5, P(ss), None, N, Cout, None), 'finalize')
-    mean, var = ref.mean((2, 3, 4)), ref.var((2, 3, 4), unbiased=False)
-    ss_ref = torch.stack([1 / torch.sqrt(var + 1e-5), -mean / torch.sqrt(var + 1e-5)], -1)
-    assert float((ss.cpu().double() - ss_ref).abs().max()) <= 2e-4 * (1 + float(ss_ref.abs().max()))
+    # the configuration the engine uses, and -- where that is the wave-specialised one for rows of 8 voxels (24) -- the one-role kernel as well
+    for cfg in sorted({lib.wmh_conv3d_k3_f16x2_config(cfg0, Cout, W), lib.wmh_conv3d_k3_bf16_config(cfg0, Cout, W)}):
+        assert lib.wmh_conv3d_k3_f16x2_supported(cfg)
+        wh = np.ascontiguousarray(w.numpy().reshape(Cout, Cin, 27))
+        wf = np.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cin, Cout), np.uint16)
+        _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2(cfg, wh.ctypes.data_as(C.c_void_p), Cin, Cout, wf.ctypes.data_as(C.c_void_p)), 'pack')
+        wfd = torch.from_numpy(wf.view(np.int16)).cuda()
+        y = torch.full((N, Cout, Do, Ho, Wo), float('nan'), device='cuda')
+        npart = _lib.check(lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, Do, Ho, Wo), 'npart')
+        nws = lib.wmh_conv3d_k3_f16x2_workspace_floats(cfg, Cin, N, D, H, W, Cout) if slabs else 0
+        ws = torch.full((nws,), float('nan'), device='cuda') if nws else None
+        part = torch.full((N, Cout, npart, 4), float('nan'), device='cuda')
+        x0d, x1d = x0.cuda(), (x1.cuda() if C1 else None)
+        ss0d, ss1d, bd = (ss0.cuda() if ss0 is not None else None), (ss1.cuda() if ss1 is not None else None), bias.cuda()
+        _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(x0d), P(ss0d), C0, P(x1d), P(ss1d), C1, P(wfd), P(bd), P(y), P(part), P(ws), N, D, H, W, Cout,
+                                                0.01, None), 'wmh_conv3d_k3_fwd_f16x2')
+        torch.cuda.synchronize()
+        got = y.cpu().double()
+        assert bool(torch.isfinite(got).all())
+        rel = float((got - ref).norm() / ref.norm())
+        mx = float((got - ref).abs().max()) / float(ref.abs().max())
+        # 21-22 significant bits per operand; the exact-fp32 kernel's own figures on these shapes are 0.5-1.4e-6 / 1.6-3.7e-6
+        # (measured for this kernel: 3.5e-7 .. 9e-7 / 0.9 .. 2.9e-6; round 2's bf16 pairs: 3.4e-6 / 4e-6)
+        assert rel <= 2e-6 and mx <= 6e-6, (rel, mx)
+        # InstanceNorm statistics from the fp32 accumulators, through the usual finalisation
+        ss = torch.empty(N, Cout, 2, device='cuda')
+        _lib.check(lib.wmh_instnorm_finalize(P(part), npart, None, None, 1e-5, P(ss), None, N, Cout, None), 'finalize')
+        mean, var = ref.mean((2, 3, 4)), ref.var((2, 3, 4), unbiased=False)
+        ss_ref = torch.stack([1 / torch.sqrt(var + 1e-5), -mean / torch.sqrt(var + 1e-5)], -1)
+        assert float((ss.cpu().double() - ss_ref).abs().max()) <= 2e-4 * (1 + float(ss_ref.abs().max()))
 
 
 def test_strided_pair_kernel_refuses_rows_that_are_not_multiples_of_four(lib):

@@ -1,5 +1,5 @@
 """Time one nnUNetTrainerV2 iteration (BASELINE plan, batch 2 of 128^3 patches) on the HIP kernels.
-env: WMH_BATCH (2), WMH_ITERS (4), WMH_PRECISION (fp32 | bf16 | f16x2)."""
+env: WMH_BATCH (2), WMH_ITERS (4), WMH_PRECISION (fp32 | bf16 | f16x2), WMH_X3_SPLITK=0 (pair kernels without split-K slabs)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,6 +9,8 @@ from deepwmh_amd.trainer import UNetTrainer, downsample_targets
 plan = baseline_plan()
 B = int(os.environ.get('WMH_BATCH', '2'))
 tr = UNetTrainer(plan, he_init_state_dict(plan, 0), 'cuda:0', precision=os.environ.get('WMH_PRECISION', 'fp32'))
+if os.environ.get('WMH_X3_SPLITK') == '0':
+    tr.x3_splitk = False
 torch.manual_seed(0)
 x = torch.randn(B, 1, 128, 128, 128, device='cuda')
 lab = (torch.rand(B, 128, 128, 128, device='cuda') < 0.05).to(torch.uint8)
