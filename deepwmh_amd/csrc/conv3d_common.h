@@ -122,7 +122,7 @@ static inline void wmh_pick_supertile(ConvArgs& a, int TY, int TZ, int per_xcd) 
 int wmh_launch_conv_ws_in16(int cfg, const ConvArgs& a, hipStream_t st);   // config 1 with bf16 sources
 int wmh_launch_conv_ws(int cfg, const ConvArgs& a, hipStream_t st);     // cfg 0..3: 32- and 16-wide rows, stride 1 and 2
 int wmh_conv_ws_min_tiles();
-int wmh_launch_conv_s2_f16x2_ws(const ConvArgs& a, hipStream_t st);   // f16x2, stride 2, 32-voxel output rows (conv3d_k3s2_f16x2_ws.hip)
+int wmh_launch_conv_s2_f16x2_ws(int cfg, const ConvArgs& a, hipStream_t st);   // f16x2, stride 2: output rows of 32 / 16 / 8 voxels = configurations 1 / 25 / 26 (conv3d_k3s2_f16x2_ws.hip)
 // split-K reduce (conv3d_k3.hip): y = bias + sum of KS slabs in fixed order, one moments record per (n, c), rest of the row zeroed
 int wmh_launch_splitk_reduce(const float* slabs, const float* bias, float* y, float* partials, int npart, int KS, int N, int Cout,
                              size_t spatial, hipStream_t st);

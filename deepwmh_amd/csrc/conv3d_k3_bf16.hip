@@ -289,12 +289,23 @@ typedef ConvCfg<2, 32, 1, 2, 2, 1, 1, 2, 2, 6> BCfg1;
 // layers at 150-220 TFLOP/s (every chunk ends in a barrier that nothing hides); it keeps the rows that are no multiple of 4 voxels.
 #define WMH_F16X2_CFG_ROWS8 24
 typedef ConvCfg<1, 8, 4, 8, 8, 1, 4, 2, 4, 6> BCfg8;
-static int bf16_nt(int cfg) { return (cfg == 0 || cfg == 4 || cfg == 5) ? 1 : (cfg == 1 || cfg == 2 || cfg == 3 || cfg == WMH_BF16_CFG_WIDE || cfg == WMH_F16X2_CFG_ROWS8) ? 2 : 0; }
-static int bf16_stride(int cfg) { return (cfg == 1 || cfg == 3 || cfg == 5) ? 2 : 1; }
+// Configurations 25 / 26 (f16x2 only, round 5): stride 2 with output rows of 16 / 8 voxels on the wave-specialised strided kernel
+// (conv3d_k3s2_f16x2_ws.hip: tiles of 2 x 4 x 16 / 4 x 4 x 8 outputs x 64 channels) -- configuration 1's kernel on two more geometries.
+// The one-role kernels of configurations 3 / 5 ran these layers at 120-170 TFLOP/s; they keep the rows that are no multiple of 4 voxels.
+#define WMH_F16X2_CFG_S2_ROWS16 25
+#define WMH_F16X2_CFG_S2_ROWS8 26
+static bool f16x2_s2_ws(int cfg) { return cfg == 1 || cfg == WMH_F16X2_CFG_S2_ROWS16 || cfg == WMH_F16X2_CFG_S2_ROWS8; }
+static int bf16_nt(int cfg) {
+    return (cfg == 0 || cfg == 4 || cfg == 5) ? 1
+         : (cfg == 1 || cfg == 2 || cfg == 3 || cfg == WMH_BF16_CFG_WIDE || cfg == WMH_F16X2_CFG_ROWS8 || cfg == WMH_F16X2_CFG_S2_ROWS16 || cfg == WMH_F16X2_CFG_S2_ROWS8) ? 2 : 0;
+}
+static int bf16_stride(int cfg) { return (cfg == 1 || cfg == 3 || cfg == 5 || cfg == WMH_F16X2_CFG_S2_ROWS16 || cfg == WMH_F16X2_CFG_S2_ROWS8) ? 2 : 1; }
 struct BGeo { int TX, TY, TZ, WPS; };
 static BGeo bf16_geo(int cfg, bool w8) {
     if (cfg == WMH_BF16_CFG_WIDE) return BGeo{BCfgW::TX, BCfgW::TY, BCfgW::TZ, BCfgW::WPS};
     if (cfg == WMH_F16X2_CFG_ROWS8) return BGeo{BCfg8::TX, BCfg8::TY, BCfg8::TZ, BCfg8::WPS};
+    if (cfg == WMH_F16X2_CFG_S2_ROWS16) return BGeo{16, 4, 2, 4};      // (TX, TY, TZ, one record per consumer wave)
+    if (cfg == WMH_F16X2_CFG_S2_ROWS8) return BGeo{8, 4, 4, 4};
     if (cfg == 1) return BGeo{BCfg1::TX, BCfg1::TY, BCfg1::TZ, BCfg1::WPS};
     if (cfg == 3) return BGeo{BCfg3::TX, BCfg3::TY, BCfg3::TZ, BCfg3::WPS};
     if (cfg == 4) return BGeo{BCfg4::TX, BCfg4::TY, BCfg4::TZ, BCfg4::WPS};
@@ -316,10 +327,13 @@ extern "C" int wmh_conv3d_k3_f16x2_config(int cfg, int Cout, int W) {
     static const int rows8 = wmh_diag_env("WMH_F16X2_ROWS8", 1);
     const int c = wmh_conv3d_k3_bf16_config(cfg, Cout, W);
     if (c == 4 && rows8 && W % 4 == 0) return WMH_F16X2_CFG_ROWS8;
+    static const int s2ws = wmh_diag_env("WMH_F16X2_S2_WS", 1);
+    if (c == 3 && s2ws && W % 4 == 0) return WMH_F16X2_CFG_S2_ROWS16;      // (W: the INPUT row)
+    if (c == 5 && s2ws && W % 4 == 0) return WMH_F16X2_CFG_S2_ROWS8;
     return c;
 }
 
-extern "C" int wmh_conv3d_k3_bf16_supported(int cfg) { return cfg != 1 && cfg != WMH_F16X2_CFG_ROWS8 && bf16_nt(cfg) > 0; }      // configurations 1, 24: f16x2 only
+extern "C" int wmh_conv3d_k3_bf16_supported(int cfg) { return !f16x2_s2_ws(cfg) && cfg != WMH_F16X2_CFG_ROWS8 && bf16_nt(cfg) > 0; }      // configurations 1, 24, 25, 26: f16x2 only
 // InstanceNorm partial records per (n, c) row the bf16 kernel writes (its wave split differs from the fp32 kernel's)
 extern "C" int wmh_conv3d_k3_num_partials_bf16(int cfg, int N, int Do, int Ho, int Wo) {
     if (!bf16_nt(cfg)) return wmh_fail(WMH_EINVAL, "num_partials_bf16: configuration has no bf16 kernel");
@@ -362,7 +376,7 @@ extern "C" int wmh_conv3d_k3_pack_weights_bf16(int cfg, const float* w, int Cin,
 // ---- the "pair" mode (entry points keep round 2's f16x2 names; conv3d_k3_bf16_ws.hip, PAIR): chunks of 8 input channels, a lane's
 // 16 bytes are the HIGH fp16 parts of its output channel's 8 weights (lanes 0-31) or the LOW parts (lanes 32-63), of the
 // weights scaled by 2^8: 256 w = hi + lo + O(2^-22 w).  |w| must stay below 255 (fp16's range after the scaling).
-extern "C" int wmh_conv3d_k3_f16x2_supported(int cfg) { return cfg == 0 || cfg == 1 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE || cfg == WMH_F16X2_CFG_ROWS8 || cfg == 3 || cfg == 4 || cfg == 5; }
+extern "C" int wmh_conv3d_k3_f16x2_supported(int cfg) { return cfg == 0 || cfg == 1 || cfg == 2 || cfg == WMH_BF16_CFG_WIDE || cfg == WMH_F16X2_CFG_ROWS8 || cfg == 3 || cfg == 4 || cfg == 5 || cfg == WMH_F16X2_CFG_S2_ROWS16 || cfg == WMH_F16X2_CFG_S2_ROWS8; }
 extern "C" size_t wmh_conv3d_k3_packed_halfs_f16x2(int cfg, int Cin, int Cout) {
     const int NT = bf16_nt(cfg);
     if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg)) return 0;
@@ -499,7 +513,7 @@ static int pack_job_f16x2(int cfg, const float* w, int Cin_total, int Cout, int 
     const int NT = bf16_nt(cfg);
     if (!NT || !wmh_conv3d_k3_f16x2_supported(cfg) || !w || !wf || ci_off < 0 || ci_cnt < 1 || ci_off + ci_cnt > Cin_total || (mode != 0 && mode != 1 && mode != 2))
         return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: bad args or configuration without a f16x2 kernel");
-    if (cfg == 1 && mode == 1) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: configuration 1 (stride 2) has no data-gradient image");
+    if (f16x2_s2_ws(cfg) && mode == 1) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: configurations 1, 25, 26 (stride 2) have no data-gradient image");
     if (mode == 2 && bf16_stride(cfg) != 2) return wmh_fail(WMH_EINVAL, "pack_weights_f16x2_device: mode 2 (transposed convolution's data gradient) is a stride-2 image");
     const int eCin = mode == 1 ? Cout : ci_cnt, eCout = mode == 1 ? ci_cnt : Cout;
     J.w = w; J.wf = wf; J.Cin_total = Cin_total; J.Cout = Cout; J.ci_off = ci_off; J.ci_cnt = ci_cnt; J.mode = mode; J.NT = NT;
@@ -568,7 +582,7 @@ static int conv_fwd_bf16(int cfg, const float* x0, const float* ss0, int C0, con
                          float* partials, int N, int D, int H, int W, int Cout, float lrelu_slope,
                          int in16, int out16, void* stream, float* workspace = nullptr) {
     const int NT = bf16_nt(cfg);
-    if (!NT || cfg == 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: configuration has no bf16 kernel");
+    if (!NT || !wmh_conv3d_k3_bf16_supported(cfg)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: configuration has no bf16 kernel");
     if (!x0 || !wf || !y || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: null/empty argument");
     if (x1 == nullptr) C1 = 0;
     if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_bf16: LeakyReLU slope must be in [0, 1]");
@@ -680,9 +694,10 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     if (x1 == nullptr) C1 = 0;
     if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: LeakyReLU slope must be in [0, 1]");
     if (C1 > 0 && (C0 % 8) != 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: C0 must be a multiple of 8 with two sources");
-    if (cfg == 1 && C1 > 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: the strided 32-row configuration takes one source");
-    const bool small = cfg == 1 || cfg == 3 || cfg == 4 || cfg == 5;           // the one-role kernel (3, 4, 5) / the strided wave-specialised one (1)
-    if ((!small || cfg == 1) && ((W % 4) != 0 || (size_t)16 * D * H * W * 4 >= ((size_t)1 << 32) || (reinterpret_cast<uintptr_t>(x0) & 15) != 0 ||
+    const bool s2ws = f16x2_s2_ws(cfg);
+    if (s2ws && C1 > 0) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: the wave-specialised strided configurations take one source");
+    const bool small = s2ws || cfg == 3 || cfg == 4 || cfg == 5;           // the one-role kernel (3, 4, 5) / the strided wave-specialised one (1, 25, 26)
+    if ((!small || s2ws) && ((W % 4) != 0 || (size_t)16 * D * H * W * 4 >= ((size_t)1 << 32) || (reinterpret_cast<uintptr_t>(x0) & 15) != 0 ||
                    (x1 && (reinterpret_cast<uintptr_t>(x1) & 15) != 0)))
         return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: needs W % 4 == 0 and 16-byte aligned sources");
     ConvArgs a;
@@ -714,12 +729,12 @@ extern "C" int wmh_conv3d_k3_fwd_f16x2(int cfg, const float* x0, const float* ss
     // rows of 16 / 8 voxels (stride 1 and 2): the one-role kernel, split-K when slab memory is given (wmh_conv3d_k3_fwd_bf16_splitk)
     const long long nblk = (long long)a.ntx * a.nty * a.ntz * N * a.G;
     if (nblk > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3_fwd_f16x2: grid too large");
-    a.KS = (workspace != nullptr && cfg != 1) ? bf16_ksplit(nblk, a.nchunks) : 1;
+    a.KS = (workspace != nullptr && !s2ws) ? bf16_ksplit(nblk, a.nchunks) : 1;
     if (a.KS > 1) a.y = workspace;
     const unsigned nb = (unsigned)(nblk * a.KS);
     int rc;
-    // stride 2, 32-voxel output rows: the wave-specialised kernel of conv3d_k3s2_f16x2_ws.hip (its own weight image: one source, no split-K)
-    if (cfg == 1) return wmh_launch_conv_s2_f16x2_ws(a, st);
+    // stride 2 on the wave-specialised kernel of conv3d_k3s2_f16x2_ws.hip (one source, no split-K)
+    if (s2ws) return wmh_launch_conv_s2_f16x2_ws(cfg, a, st);
     if (cfg == 3) rc = launch_bf16<BCfg3, 4, true>(a, nb, st);
     else if (cfg == 4) rc = launch_bf16<BCfg4, 3, true>(a, nb, st);
     else rc = launch_bf16<BCfg5, 4, true>(a, nb, st);

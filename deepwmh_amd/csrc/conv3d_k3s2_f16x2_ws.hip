@@ -34,7 +34,45 @@ typedef float s2_f32x2 __attribute__((ext_vector_type(2)));
 typedef float s2_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned s2_u32x4 __attribute__((ext_vector_type(4)));
 
-typedef ConvCfg<2, 32, 1, 2, 2, 1, 1, 2, 2, 6> S2Cfg;       // = BCfg1 of conv3d_k3_bf16.hip: tile 2 x 2 x 32, one row per wave, 64 channels
+// Tile geometries: four consumer waves, one M-tile (32 output voxels = LY rows of TX) x 64 output channels each.
+//   configuration 1:  output rows of 32 voxels, tile 2 x 2 x 32 (z, y, x), input box 5 x 5 x 65
+//   configuration 25: output rows of 16 voxels, tile 2 x 4 x 16, an M-tile = 2 rows,   input box 5 x 9 x 33   (round 5: the strided layer into the 16^3 level)
+//   configuration 26: output rows of 8 voxels,  tile 4 x 4 x 8,  an M-tile = 4 rows,   input box 9 x 9 x 17   (... into the 8^3 level)
+template <int TZ_, int TY_, int TX_>
+struct S2Geo {
+    static constexpr int TZ = TZ_, TY = TY_, TX = TX_, LX = TX_, LY = 32 / TX_, MY = TY_ / LY;
+    typedef ConvCfg<2, TX_, LY, TZ_, TY_, 1, 1, 2, 2, 6> C;     // (= BCfg1 of conv3d_k3_bf16.hip for configuration 1)
+    static_assert(LX * LY == 32 && TY % LY == 0 && TZ * MY == 4, "four M-tiles of 32 output voxels");
+    // sub-tile s = pz 4 + py 2 + px holds the input voxels of parity (pz, py, px): even (p = 0): indices 0 .. T - 1 (taps k = 1); odd (p = 1):
+    // indices 0 .. T (input o - 1 .. o + T - 1: taps k = 0 at index o, k = 2 at index o + 1)
+    static constexpr int nz(int p) { return TZ + p; }
+    static constexpr int ny(int p) { return TY + p; }
+    static constexpr int nx(int p) { return TX + p; }
+    static constexpr int base(int s) {
+        int b = 0;
+        for (int t = 0; t < s; ++t) b += nz((t >> 2) & 1) * ny((t >> 1) & 1) * nx(t & 1);
+        return b;
+    }
+    static constexpr int BZ = 2 * TZ + 1, BY = 2 * TY + 1, BX = 2 * TX + 1;          // the input box
+    static constexpr int VOX = base(8);
+    static_assert(VOX == BZ * BY * BX, "input box");
+    static constexpr int QPR = TX / 2 + 1, NQ = BZ * BY * QPR;                        // aligned quads per box row / per chunk
+    static_assert(NQ <= 512, "one quad per loader thread");
+    static constexpr int ACT_BYTES = VOX * 32;                                        // one activation buffer
+    static constexpr int W_OFF = 2 * ACT_BYTES;
+    static constexpr int WQ = 27 * 2 * 64;                                            // 16-byte weight pieces per chunk (NT = 2)
+    static constexpr int LDS = W_OFF + WQ * 16;
+    static_assert(LDS <= 160 * 1024, "LDS");
+    // voxel index (without the lane's x) of tap (kd, kr, kw) for output row (tzi, tyi)
+    static __device__ __forceinline__ int tap_row(int kd, int kr, int kw, int tzi, int tyi) {
+        const int pz = kd == 1 ? 0 : 1, py = kr == 1 ? 0 : 1, px = kw == 1 ? 0 : 1;
+        return base(pz * 4 + py * 2 + px) + ((tzi + (kd == 2 ? 1 : 0)) * ny(py) + (tyi + (kr == 2 ? 1 : 0))) * nx(px) + (kw == 2 ? 1 : 0);
+    }
+};
+typedef S2Geo<2, 2, 32> S2Geo32;
+typedef S2Geo<2, 4, 16> S2Geo16;
+typedef S2Geo<4, 4, 8> S2Geo8;
+static_assert(S2Geo32::VOX == 1625, "5 x 5 x 65 input box");
 
 namespace {
 // uniform read of a value no kernel in flight writes: a scalar-cache load (conv3d_k3_bf16_ws.hip::ld_uniform)
@@ -53,33 +91,8 @@ __device__ __forceinline__ unsigned s2_lo_pair(unsigned h2, float t0, float t1) 
 template <int... I, class F>
 __device__ __forceinline__ void s2_static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
-// ---- the parity-split tile -------------------------------------------------------------------------------------------------------
-// sub-tile s = pz 4 + py 2 + px holds the input voxels of parity (pz, py, px): even (p = 0): indices 0 .. T - 1 (taps k = 1); odd (p = 1):
-// indices 0 .. T (input o - 1 .. o + T - 1: taps k = 0 at index o, k = 2 at index o + 1)
-constexpr int S2_TZ = 2, S2_TY = 2, S2_TX = 32;
-constexpr int s2_nz(int p) { return S2_TZ + p; }
-constexpr int s2_ny(int p) { return S2_TY + p; }
-constexpr int s2_nx(int p) { return S2_TX + p; }
-constexpr int s2_base(int s) {
-    int b = 0;
-    for (int t = 0; t < s; ++t) b += s2_nz((t >> 2) & 1) * s2_ny((t >> 1) & 1) * s2_nx(t & 1);
-    return b;
-}
-constexpr int S2_VOX = s2_base(8);                           // 1625 = 5 x 5 x 65
-static_assert(S2_VOX == 1625, "5 x 5 x 65 input box");
-constexpr int S2_ACT_BYTES = S2_VOX * 32;                    // one activation buffer
-constexpr int S2_W_OFF = 2 * S2_ACT_BYTES;
-constexpr int S2_WQ = 27 * 2 * 64;                           // 16-byte weight pieces per chunk (NT = 2)
-constexpr int S2_LDS = S2_W_OFF + S2_WQ * 16;
-static_assert(S2_LDS <= 160 * 1024, "LDS");
-// tap k (0..2 along an axis) of output index o reads parity P(k) at sub-tile index o + SH(k)
-constexpr int s2_par(int k) { return k == 1 ? 0 : 1; }
+// ---- the parity-split tile: S2Geo above.  Tap k (0..2 along an axis) of output index o reads parity P(k) at sub-tile index o + SH(k) ----
 constexpr int s2_shift(int k) { return k == 2 ? 1 : 0; }
-// voxel index (without the lane's x) of tap (kd, kr, kw) for output row (tzi, tyi)
-__device__ __forceinline__ int s2_tap_row(int kd, int kr, int kw, int tzi, int tyi) {
-    const int pz = s2_par(kd), py = s2_par(kr), px = s2_par(kw);
-    return s2_base(pz * 4 + py * 2 + px) + ((tzi + s2_shift(kd)) * s2_ny(py) + (tyi + s2_shift(kr))) * s2_nx(px) + s2_shift(kw);
-}
 
 // the stride-1 pair kernel's 41 groups (conv3d_k3_bf16_ws.hip::p3_grp): per (kd, kr) the three taps' [w_hi | w_hi] x [x_hi | x_lo] (pr 0..2),
 // [w_lo(kw 0) | w_lo(kw 1)] x [x_hi(kw 0) | x_hi(kw 1)] (pr 3) and one more that pairs the remaining w_lo x_hi terms of kw = 2 across kr / kd
@@ -98,9 +111,11 @@ constexpr S2Grp s2_grp(int gi) {
 }
 }  // namespace
 
+template <class GEO>
 __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArgs a, const int T /*tiles x cout groups*/) {
-    typedef S2Cfg C;
+    typedef typename GEO::C C;
     constexpr int NT = C::NT, MT = C::MT, LTH = 512;
+    constexpr int S2_ACT_BYTES = GEO::ACT_BYTES, S2_W_OFF = GEO::W_OFF, S2_WQ = GEO::WQ;
     static_assert(MT == 1 && NT == 2 && C::WM == 4, "one output row per consumer wave, 64 output channels");
     extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];   // [2][S2_VOX voxels][hi | lo piece, swapped where (ix >> 3) & 1], then [27][NT][64] weight pieces
     uint4* const wlds = ldsq + S2_W_OFF / 16;
@@ -126,17 +141,17 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
         const int lt = tid - 256;
         // Staging unit = an aligned quad of 4 consecutive x of one row of the 5 x 5 x 65 box: the row [2 ox0 - 1, 2 ox0 + 63] lies in the
         // aligned span [2 ox0 - 4, 2 ox0 + 64), 17 quads; 425 per chunk, one per thread.
-        constexpr int QPR = 17, NQ = 25 * QPR;
+        constexpr int QPR = GEO::QPR, NQ = GEO::NQ;
         // this thread's quad: box row (bz, by) and quad q -> where its voxels go: LDS voxel index of sub-tile row (px = 0: odd x, px = 1: even x)
         const int row = lt / QPR, q = lt - row * QPR;
         const bool mine = lt < NQ;
         int rb0, rb1;
         {
-            const int bz = (row / 5) % 5, by = row % 5;
+            const int bz = (row / GEO::BY) % GEO::BZ, by = row % GEO::BY;
             const int pz = (bz & 1) ^ 1, py = (by & 1) ^ 1, iz = bz >> 1, iy = by >> 1;
-            const int r0 = (iz * (S2_TY + py) + iy);
-            rb0 = (pz ? (py ? s2_base(6) : s2_base(4)) : (py ? s2_base(2) : s2_base(0))) + r0 * s2_nx(0);
-            rb1 = (pz ? (py ? s2_base(7) : s2_base(5)) : (py ? s2_base(3) : s2_base(1))) + r0 * s2_nx(1);
+            const int r0 = (iz * (GEO::TY + py) + iy);
+            rb0 = (pz ? (py ? GEO::base(6) : GEO::base(4)) : (py ? GEO::base(2) : GEO::base(0))) + r0 * GEO::nx(0);
+            rb1 = (pz ? (py ? GEO::base(7) : GEO::base(5)) : (py ? GEO::base(3) : GEO::base(1))) + r0 * GEO::nx(1);
         }
         int q_off = 0; unsigned q_ok = 0; int n0_cur = 0, g_cur = 0;
         auto setup = [&](int v) __attribute__((always_inline)) {
@@ -144,7 +159,7 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
             tile_of(v, g, tx, ty, tz, n0);
             n0_cur = __builtin_amdgcn_readfirstlane(n0); g_cur = __builtin_amdgcn_readfirstlane(g);
             tx = __builtin_amdgcn_readfirstlane(tx); ty = __builtin_amdgcn_readfirstlane(ty); tz = __builtin_amdgcn_readfirstlane(tz);
-            const int gx = tx * (2 * S2_TX) - 4 + 4 * q, gy = ty * (2 * S2_TY) - 1 + row % 5, gz = tz * (2 * S2_TZ) - 1 + (row / 5) % 5;
+            const int gx = tx * (2 * GEO::TX) - 4 + 4 * q, gy = ty * (2 * GEO::TY) - 1 + row % GEO::BY, gz = tz * (2 * GEO::TZ) - 1 + (row / GEO::BY) % GEO::BZ;
             const bool ok = mine && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
             q_off = ok ? gz * HW + gy * a.W + gx : 0;
             q_ok = ok ? 1u : 0u;
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int x = 4 * q - 3 + k, ix = 2 * q - 2 + ((k + 1) >> 1);
-                if (mine && x >= 0 && x < 65) {
+                if (mine && x >= 0 && x < GEO::BX) {
                     const int e = ((k & 1) ? rb1 : rb0) + ix;
                     dst[e * 2 + (0 ^ ((ix >> 3) & 1))] = make_uint4(w[k][0], w[k][1], w[k][2], w[k][3]);
                     dst[e * 2 + (1 ^ ((ix >> 3) & 1))] = make_uint4(wlo[k][0], wlo[k][1], wlo[k][2], wlo[k][3]);
@@ -282,15 +297,15 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
 
     // ================================================== consumers =================================================================
     const int j = lane & 31, kh = lane >> 5;
-    const int dx = j;
-    const int tzi = wave >> 1, tyi = wave & 1;
+    const int dx = j % GEO::LX, dy = j / GEO::LX;                    // the lane's output voxel inside its M-tile: LY rows of LX
+    const int tzi = wave / GEO::MY, tyi = (wave % GEO::MY) * GEO::LY + dy;
     // the 41 B operands of a chunk: byte addresses inside an activation buffer, computed once (they do not depend on the tile)
     int bG[S2_NG];
     s2_static_for(std::make_integer_sequence<int, S2_NG>{}, [&](auto gc) __attribute__((always_inline)) {
         constexpr int gi = decltype(gc)::value;
         constexpr S2Grp G = s2_grp(gi);
-        auto full = [&](int kd, int kr, int kw) { const int ix = dx + s2_shift(kw); return (s2_tap_row(kd, kr, kw, tzi, tyi) + dx) * 32 + 16 * (kh ^ ((ix >> 3) & 1)); };
-        auto hi = [&](int kd, int kr, int kw) { const int ix = dx + s2_shift(kw); return (s2_tap_row(kd, kr, kw, tzi, tyi) + dx) * 32 + 16 * ((ix >> 3) & 1); };
+        auto full = [&](int kd, int kr, int kw) { const int ix = dx + s2_shift(kw); return (GEO::tap_row(kd, kr, kw, tzi, tyi) + dx) * 32 + 16 * (kh ^ ((ix >> 3) & 1)); };
+        auto hi = [&](int kd, int kr, int kw) { const int ix = dx + s2_shift(kw); return (GEO::tap_row(kd, kr, kw, tzi, tyi) + dx) * 32 + 16 * ((ix >> 3) & 1); };
         if constexpr (G.pr < 3) bG[gi] = full(G.kd, G.kr, G.pr);                                          // [x_hi | x_lo](tap kw)
         else if constexpr (G.pr == 3) bG[gi] = kh ? hi(G.kd, G.kr, 1) : hi(G.kd, G.kr, 0);                // [x_hi(kw 0) | x_hi(kw 1)]
         else if constexpr (G.kr == 1) bG[gi] = kh ? hi(G.kd, 1, 2) : hi(G.kd, 0, 2);                      // [x_hi(kr 0, kw 2) | x_hi(kr 1, kw 2)]
@@ -365,7 +380,7 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
         for (int nt = 0; nt < NT; ++nt) acc[nt][0] *= (1.f / WMH_PAIR_WSCALE);      // undo the weights' 2^8 (exact)
         // (the shared epilogue: 9 k cycles per tile, 6 k of them the moments' recursive halving, which costs the same for one row per wave as for
         //  eight.  A row-by-row version with DPP adds instead of LDS permutes took 15 k: dependent DPP steps wait out their hazards.)
-        conv_epilogue<C>(a, acc, g, 0, n0, wave, j, kh, dx, 0, 0, wave, tz * C::TZ, ty * C::TY, tx * C::TX, (tz * a.nty + ty) * a.ntx + tx);
+        conv_epilogue<C>(a, acc, g, 0, n0, wave, j, kh, dx, dy, 0, wave, tz * C::TZ, ty * C::TY, tx * C::TX, (tz * a.nty + ty) * a.ntx + tx);
         if (WMH_STAMPS(a)) te += __builtin_amdgcn_s_memtime() - t0;
     }
     if (WMH_STAMPS(a) && tid == 0) {
@@ -378,8 +393,9 @@ __global__ __launch_bounds__(768) void conv3d_k3s2_f16x2_ws_kernel(const ConvArg
     }
 }
 
-// a: fully prepared by wmh_conv3d_k3_fwd_f16x2 (configuration 1, one source, no split-K; W % 4 == 0 and a 16-byte aligned source: checked there)
-int wmh_launch_conv_s2_f16x2_ws(const ConvArgs& a_in, hipStream_t st) {
+// a: fully prepared by wmh_conv3d_k3_fwd_f16x2 (configurations 1, 25, 26: one source, no split-K; W % 4 == 0 and a 16-byte aligned source: checked there)
+template <class G>
+static int launch_s2(const ConvArgs& a_in, hipStream_t st) {
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
@@ -388,7 +404,7 @@ int wmh_launch_conv_s2_f16x2_ws(const ConvArgs& a_in, hipStream_t st) {
         if (ncu < 8) ncu = 8;
         ncu &= ~7;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3s2_f16x2_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3s2_f16x2_ws_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     const long long T = (long long)a_in.ntx * a_in.nty * a_in.ntz * a_in.N * a_in.G;
     if (T > 0x7fffffffLL) return wmh_fail(WMH_EINVAL, "conv3d_k3 stride 2 f16x2 (wave-specialised): too many tiles");
     if ((size_t)8 * a_in.D * a_in.H * a_in.W * 4 >= ((size_t)1 << 32))
@@ -396,7 +412,13 @@ int wmh_launch_conv_s2_f16x2_ws(const ConvArgs& a_in, hipStream_t st) {
     const int grid = T < ncu ? (int)T : ncu;
     ConvArgs a = a_in;
     static const int supertile = wmh_diag_env("WMH_SUPERTILE", 1);
-    if (supertile && (a.xcd_swizzle & 1)) wmh_pick_supertile(a, S2Cfg::TY, S2Cfg::TZ, grid / 8 > 0 ? grid / 8 : 1);
-    hipLaunchKernelGGL(conv3d_k3s2_f16x2_ws_kernel, dim3(grid), dim3(768), S2_LDS, st, a, (int)T);
+    if (supertile && (a.xcd_swizzle & 1)) wmh_pick_supertile(a, G::TY, G::TZ, grid / 8 > 0 ? grid / 8 : 1);
+    hipLaunchKernelGGL(conv3d_k3s2_f16x2_ws_kernel<G>, dim3(grid), dim3(768), G::LDS, st, a, (int)T);
     return wmh_check_launch("conv3d_k3s2_f16x2_ws_kernel");
+}
+int wmh_launch_conv_s2_f16x2_ws(int cfg, const ConvArgs& a, hipStream_t st) {
+    if (cfg == 1) return launch_s2<S2Geo32>(a, st);
+    if (cfg == 25) return launch_s2<S2Geo16>(a, st);
+    if (cfg == 26) return launch_s2<S2Geo8>(a, st);
+    return wmh_fail(WMH_EINVAL, "conv3d_k3 stride 2 f16x2 (wave-specialised): configurations 1, 25 and 26");
 }

@@ -174,7 +174,7 @@ class UNetTrainer:
     def _use_x3(self, cfg_b, stride, C0, C1, W, fwd=False):
         # the forward pass also has pair kernels for the strided layers (configurations 1, 3, 5: as the inference engine uses them);
         # their data gradients stay on the fp32 gather kernel
-        if stride == 2 and not (fwd and cfg_b in (1, 3, 5)):
+        if stride == 2 and not (fwd and cfg_b in (1, 3, 5, 25, 26)):
             return False
         return (self.x3 and (C1 == 0 or C0 % 8 == 0) and (W % 4 == 0 or cfg_b in (3, 4, 5)) and bool(self.lib.wmh_conv3d_k3_f16x2_supported(cfg_b)))
 
