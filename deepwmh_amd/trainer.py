@@ -600,8 +600,8 @@ class UNetTrainer:
                 self._ready([tu])
             # (1,2,2): the window embedded in a (1,3,3) one, stride (1,2,2)
             cfg = _lib.check(lib.wmh_conv3d_config(cskip, Cin, kt * D, 2 * H, 2 * W, 3 if kt == 2 else 1, kt, 2), 'config')
-            cfg_x3 = lib.wmh_conv3d_k3_bf16_config(cfg, Cin, 2 * W) if (self.x3 and kt == 2 and self.x3_tu_dgrad) else -1
-            if cfg_x3 in (1, 3, 5) and bool(lib.wmh_conv3d_k3_f16x2_supported(cfg_x3)):     # the strided pair kernels on the embedded image
+            cfg_x3 = lib.wmh_conv3d_k3_f16x2_config(cfg, Cin, 2 * W) if (self.x3 and kt == 2 and self.x3_tu_dgrad) else -1
+            if cfg_x3 in (1, 3, 5, 25, 26) and bool(lib.wmh_conv3d_k3_f16x2_supported(cfg_x3)):     # the strided pair kernels on the embedded image
                 key = ('tu.dgrad.x3', u, cfg_x3)
                 hit = self._packed.get(key)
                 if hit is None or hit[0] != self._version:

@@ -123,25 +123,26 @@ def test_convtranspose_data_gradient_on_the_strided_pair_kernels(lib, shape):
     torch.nn.functional.conv_transpose3d(x, w.double(), None, stride=2).backward(dy.double())
     ref = x.grad
     cfg0 = _lib.check(lib.wmh_conv3d_k3_config(Cs, Ci, 2 * D, 2 * H, 2 * W, 2), 'config')
-    cfg = lib.wmh_conv3d_k3_bf16_config(cfg0, Ci, 2 * W)
-    assert cfg in (1, 3, 5) and lib.wmh_conv3d_k3_f16x2_supported(cfg)
-    wd = w.cuda()
-    wf = torch.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cs, Ci), dtype=torch.int16, device='cuda')
-    _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(wd), Cs, Ci, 0, Cs, 2, P(wf), None), 'pack')
-    dx = torch.full((N, Ci, D, H, W), float('nan'), device='cuda')
-    nws = lib.wmh_conv3d_k3_f16x2_workspace_floats(cfg, Cs, N, 2 * D, 2 * H, 2 * W, Ci)
-    ws = torch.empty(nws, device='cuda') if nws else None
-    dyd = dy.cuda()
-    _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(dyd), None, Cs, None, None, 0, P(wf), None, P(dx), None, P(ws), N, 2 * D, 2 * H, 2 * W, Ci,
-                                            0.01, None), 'wmh_conv3d_k3_fwd_f16x2')
-    torch.cuda.synchronize()
-    got = dx.cpu().double()
-    assert bool(torch.isfinite(got).all())
-    rel = float((got - ref).norm() / ref.norm())
-    assert rel <= 2e-6, rel
-    # mode 1 (the flipped, transposed image of a stride-1 layer) has no meaning for the interleaved image of configuration 1
-    if cfg == 1:
-        assert lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(wd), Cs, Ci, 0, Cs, 1, P(wf), None) != 0
+    # the configuration the trainer uses (the wave-specialised strided kernels: 1, 25, 26) and the one-role kernels (3, 5) behind them
+    for cfg in sorted({lib.wmh_conv3d_k3_f16x2_config(cfg0, Ci, 2 * W), lib.wmh_conv3d_k3_bf16_config(cfg0, Ci, 2 * W)}):
+        assert cfg in (1, 3, 5, 25, 26) and lib.wmh_conv3d_k3_f16x2_supported(cfg)
+        wd = w.cuda()
+        wf = torch.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cs, Ci), dtype=torch.int16, device='cuda')
+        _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(wd), Cs, Ci, 0, Cs, 2, P(wf), None), 'pack')
+        dx = torch.full((N, Ci, D, H, W), float('nan'), device='cuda')
+        nws = lib.wmh_conv3d_k3_f16x2_workspace_floats(cfg, Cs, N, 2 * D, 2 * H, 2 * W, Ci)
+        ws = torch.empty(nws, device='cuda') if nws else None
+        dyd = dy.cuda()
+        _lib.check(lib.wmh_conv3d_k3_fwd_f16x2(cfg, P(dyd), None, Cs, None, None, 0, P(wf), None, P(dx), None, P(ws), N, 2 * D, 2 * H, 2 * W, Ci,
+                                                0.01, None), 'wmh_conv3d_k3_fwd_f16x2')
+        torch.cuda.synchronize()
+        got = dx.cpu().double()
+        assert bool(torch.isfinite(got).all())
+        rel = float((got - ref).norm() / ref.norm())
+        assert rel <= 2e-6, rel
+        # mode 1 (the flipped, transposed image of a stride-1 layer) has no meaning for the interleaved image of configuration 1
+        if cfg in (1, 25, 26):
+            assert lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(wd), Cs, Ci, 0, Cs, 1, P(wf), None) != 0
 
 
 def test_cycle_stamps_exist_in_the_diagnostic_library_only_and_leave_the_results_alone(lib):
