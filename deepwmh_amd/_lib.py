@@ -88,7 +88,9 @@ SIGNATURES = {
     'wmh_conv3d_k3_wgrad_bf16': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_wgrad_f16x2_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_wgrad_f16x2_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3s2_wgrad_f16x2_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_wgrad_f16x2': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    'wmh_conv3d_k3s2_wgrad_f16x2': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_wgrad_f16x2_stamp_count': (_sz, [_i, _i, _i, _i, _i, _i]),
     'wmh_debug_set_conv_stamps': (None, [_vp]),
     'wmh_diag_build': (_i, []),

@@ -38,7 +38,8 @@ struct WgradPArgs {
     const float* x0; const float* ss0; int C0;
     const float* x1; const float* ss1; int C1;
     const float* dy; float* part;
-    int N, D, H, W, Cout, Cin;
+    int N, D, H, W, Cout, Cin;          // (D, H, W): the INPUT extent
+    int Do, Ho, Wo;                      // the output extent (= the input's for stride 1)
     int ntx, nty, ntz, ntiles;
     int NG, NCG, P;
     int order, m, q, nk;            // tile order (the loaders' cursor); nk: tiles per workgroup (orders 1, 2)
@@ -70,16 +71,22 @@ __device__ __forceinline__ float wp_norm_lrelu(float x, float sc, float sh, floa
     return __builtin_fmaxf(z, z * slope);
 }
 
-template <int TX, int TY, int TZ, int NLW>
+// S: the convolution's stride (1 or 2).  Stride 2 (round 5: the first convolution of the 64^3 / 32^3 / 16^3 stages): tap k of output o reads
+// input 2 o + k - 1, so a halo ROW is kept parity-split -- [odd inputs -1, 1, ... | even inputs 0, 2, ...] -- and a lane's B operand (4
+// consecutive OUTPUT voxels of its tap) is again 4 consecutive dwords: the odd part at index o (k = 0) or o + 1 (k = 2), the even part at index
+// o (k = 1); rows and planes are addressed with twice the step.  The halo of an output tile is 8 x as many voxels per output as at stride 1, so
+// the tile is 16 x 2 x 2 outputs (33 x 5 x 5 inputs: the same 13 elements per loader lane and channel as the stride-1 tiles).
+template <int S, int TX, int TY, int TZ, int NLW>
 struct WpGeo {
-    static constexpr int IX = TX + 2, IY = TY + 2, IZ = TZ + 2, ZS = IY * IX, SPX = IZ * ZS;
+    static constexpr int IX = S * (TX - 1) + 3, IY = S * (TY - 1) + 3, IZ = S * (TZ - 1) + 3, ZS = IY * IX, SPX = IZ * ZS;
     static constexpr int NK = (SPX + 63) / 64;                 // halo elements per loader lane and channel
     // x' in LDS: [channel][IZ planes][IY rows][IX voxels] dwords with the row stride RS and the plane stride PS padded so that the
     // 27 taps of a B operand read -- dword PS/4 kz + RS/4 ky + kx of the tile, one 32-lane group of a ds_read2_b32 (banks = dword
     // index mod 32) -- fall on 27 different banks; unpadded (RS = 4 IX, PS = IY RS) every such read is a 2-way conflict and the LDS,
     // not the matrix pipe, sets the pace.  The last dword of a channel takes the stores of the lanes beyond the tile.
-    static constexpr int RS = TX == 32 ? 140 : 72, PS = TX == 32 ? 852 : 724;
-    static constexpr int CS = IZ * PS + 16;                    // bytes per channel
+    // Stride 2: XE = where the even part of a row starts; (RS, PS, XE) = (39, 203, 20) dwords give the 27 taps 27 different banks too.
+    static constexpr int RS = S == 2 ? 156 : (TX == 32 ? 140 : 72), PS = S == 2 ? 812 : (TX == 32 ? 852 : 724), XE = S == 2 ? 80 : 0;
+    static constexpr int CS = (IZ * PS + 16 + 15) / 16 * 16;   // bytes per channel
     static constexpr int XB = 16 * CS;                         // one x' buffer: the workgroup's 16 channels
     static constexpr int UV = TY * TX;                         // voxels per unit (one z slice of the tile)
     static constexpr int DYSB = UV * 4 + 16, DYB = 32 * DYSB;  // bytes: dy row (one output channel), dy buffer
@@ -87,15 +94,19 @@ struct WpGeo {
     static constexpr int NDY = 32 * UV / LT, CPK = LT / UV;    // dy values per loader lane and unit / co rows per pass
     static constexpr int LCH = 16 / NLW, XPU = LCH / TZ;       // x' channels per loader wave: of the group / staged per unit
     static constexpr int LDS = 2 * XB + 2 * DYB;
-    static_assert(TZ == 2 && UV % 64 == 0 && LT % UV == 0 && TX % 8 == 0 && XPU >= 1 && (NLW == 4 || NLW == 8), "tile geometry");
-    static_assert((TY - 1) * RS + (TX - 8) * 4 + 12 <= 1020, "ds_read2_b32 offset range");
-    static_assert(RS >= IX * 4 && PS >= IY * RS && (TX == 32 || TX == 16) && CS % 16 == 0, "x' layout");
+    // byte position of halo x index xi inside a row / of tap kx's first voxel
+    static constexpr __host__ __device__ int xpos(int xi) { return S == 2 ? ((xi & 1) ? XE + (xi >> 1) * 4 : (xi >> 1) * 4) : xi * 4; }
+    static constexpr __host__ __device__ int xtap(int kx) { return S == 2 ? (kx == 1 ? XE : kx == 2 ? 4 : 0) : kx * 4; }
+    static_assert(S == 1 || S == 2, "stride");
+    static_assert(TZ == 2 && (UV % 64 == 0 || 64 % UV == 0) && LT % UV == 0 && TX % 8 == 0 && XPU >= 1 && NDY >= 1 && (NLW == 4 || NLW == 8), "tile geometry");
+    static_assert((TY - 1) * S * RS + (TX - 8) * 4 + 12 <= 1020, "ds_read2_b32 offset range");
+    static_assert(RS >= (S == 2 ? XE + TX * 4 : IX * 4) && (S == 1 || XE >= (TX + 1) * 4) && PS >= IY * RS && (TX == 32 || TX == 16) && CS % 16 == 0 && CS >= IZ * PS + 16, "x' layout");
     static_assert(LDS <= 160 * 1024, "LDS");
 };
 
-template <int TX, int TY, int TZ, int NLW>
+template <int S, int TX, int TY, int TZ, int NLW>
 __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(const WgradPArgs a) {
-    typedef WpGeo<TX, TY, TZ, NLW> G;
+    typedef WpGeo<S, TX, TY, TZ, NLW> G;
     constexpr int IX = G::IX, IY = G::IY, ZS = G::ZS, SPX = G::SPX, NK = G::NK, RS = G::RS, PS = G::PS, CS = G::CS, XB = G::XB, UV = G::UV;
     constexpr int DYSB = G::DYSB, DYB = G::DYB, NDY = G::NDY, CPK = G::CPK, XPU = G::XPU, LCH = G::LCH;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
@@ -109,8 +120,8 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
     // workgroups p, p + 8, ... run on one XCD: give them neighbouring places in the step
     const int pp = (a.P % 8 == 0) ? (p % 8) * (a.P / 8) + p / 8 : p;
     const int nk = a.order == 0 ? (pp < a.ntiles ? (a.ntiles - pp + a.P - 1) / a.P : 0) : a.nk;
-    const int HW = a.H * a.W;
-    const size_t DHW = (size_t)a.D * HW;
+    const int HW = a.H * a.W, HWo = a.Ho * a.Wo;
+    const size_t DHW = (size_t)a.D * HW, DHWo = (size_t)a.Do * HWo;
 
     unsigned long long st_work = 0, st_wait = 0, st_t = 0;
     const bool stamping = WMH_STAMPS(a) != nullptr;
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
     if (wave < 4) {
         // ---------------------------------------------------------------- consumers: MFMAs only
         const int i = lane & 31, kh = lane >> 5, tapj = min(i, 26);
-        const int LB = (tapj / 9) * PS + ((tapj / 3) % 3) * RS + (tapj % 3 + 4 * kh) * 4;
+        const int LB = (tapj / 9) * PS + ((tapj / 3) % 3) * RS + G::xtap(tapj % 3) + 16 * kh;
         const int LA = i * DYSB + kh * 16;
         const int ci0 = cg * 16 + 4 * wave;
         const bool any = ci0 < a.Cin;                          // uniform: this wave holds input channels (absent ones are staged as zeros)
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
                     wp_lds_cp bc[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        unsigned o = (unsigned)(uintptr_t)(wp_lds_cp)(xb + c * CS + z * PS);
+                        unsigned o = (unsigned)(uintptr_t)(wp_lds_cp)(xb + c * CS + z * S * PS);
                         asm("" : "+v"(o));
                         bc[c] = (wp_lds_cp)(uintptr_t)o;
                     }
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
                         a4[set][st & 1] = *reinterpret_cast<const wp_u32x4*>(ap + ((st / (TX / 8)) * TX + 8 * (st % (TX / 8))) * 4);
                     };
                     auto fetch_b = [&](int st, int c) __attribute__((always_inline)) {
-                        const auto* q = reinterpret_cast<const __attribute__((address_space(3))) unsigned*>(bc[c] + (st / (TX / 8)) * RS + 32 * (st % (TX / 8)));
+                        const auto* q = reinterpret_cast<const __attribute__((address_space(3))) unsigned*>(bc[c] + (st / (TX / 8)) * S * RS + 32 * (st % (TX / 8)));
                         b[st & 1][c] = wp_u32x4{q[0], q[1], q[2], q[3]};               // dword alignment: two ds_read2_b32
                     };
                     fetch_a(0, 0); fetch_a(1, 0);
@@ -217,9 +228,11 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
     // (default wave priority: raising the loaders', as the forward kernels do, costs 3 % here -- the consumers are the slower side)
     const int lw = wave - 4, ltid = tid - 256;
     const int dv = ltid % UV;
-    const int dcol0 = __builtin_amdgcn_readfirstlane(ltid / UV);     // uniform per wave (UV is a multiple of 64)
+    constexpr bool DUNI = UV % 64 == 0;                       // a wave's lanes share their first dy row (UV is a multiple of 64)
+    const int dcol0 = DUNI ? __builtin_amdgcn_readfirstlane(ltid / UV) : ltid / UV;
     const int dvx = dv % TX, dvy = dv / TX;
-    const unsigned cstride = 4u * (unsigned)DHW;              // bytes between channels (host checks the range)
+    const unsigned cstride = 4u * (unsigned)DHW;              // bytes between channels of x' (host checks the range)
+    const unsigned dcstride = 4u * (unsigned)DHWo;            // ... of dy
 
     // Tile cursor: the workgroup's tiles in sequence -> sample and output origin (all scalar).  order 0: tiles pp, pp + P, ... in
     // x -> y -> z order (divisions).  orders 1 / 2: a step of the P workgroups covers (a part of | several) planes of tiles and the
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
 #pragma unroll
     for (int j = 0; j < NK; ++j) {
         const int s = lane + 64 * j;
-        loff[j] = (j * 64 + 63 < SPX || s < SPX) ? (unsigned)((s / ZS) * PS + ((s / IX) % IY) * RS + (s % IX) * 4) : (unsigned)(CS - 4);
+        loff[j] = (j * 64 + 63 < SPX || s < SPX) ? (unsigned)((s / ZS) * PS + ((s / IX) % IY) * RS + G::xpos(s % IX)) : (unsigned)(CS - 4);
     }
     // ... and, for the cursor's tile, their byte offsets in the volume and validity masks (zero padding)
     unsigned coff[NK], xm[NK]; int x_tn = 0;
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
             const int s = lane + 64 * j;
-            const int gx = c_ox0 - 1 + s % IX, gy = c_oy0 - 1 + (s / IX) % IY, gz = c_oz0 - 1 + s / ZS;
+            const int gx = S * c_ox0 - 1 + s % IX, gy = S * c_oy0 - 1 + (s / IX) % IY, gz = S * c_oz0 - 1 + s / ZS;
             const bool ok = (j * 64 + 63 < SPX || s < SPX) & ((unsigned)gx < (unsigned)a.W) & ((unsigned)gy < (unsigned)a.H) &
                             ((unsigned)gz < (unsigned)a.D);                          // (bitwise: no branches)
             xm[j] = ok ? 0xFFFFFFFFu : 0u;
@@ -309,18 +322,19 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
     float dyr[2][NDY]; unsigned dmk[2] = {0u, 0u};
     auto issue_dy = [&](int set, int z) __attribute__((always_inline)) {   // unit z of the cursor's tile
         const int ox = c_ox0 + dvx, oy = c_oy0 + dvy, oz = c_oz0 + z;
-        const bool dok = (ox < a.W) & (oy < a.H) & (oz < a.D);
+        const bool dok = (ox < a.Wo) & (oy < a.Ho) & (oz < a.Do);
         dmk[set] = dok ? 0xFFFFFFFFu : 0u;
-        const wp_rsrc rs = wp_make_rsrc(a.dy + (size_t)c_n * a.Cout * DHW, (unsigned)a.Cout * cstride);
+        const wp_rsrc rs = wp_make_rsrc(a.dy + (size_t)c_n * a.Cout * DHWo, (unsigned)a.Cout * dcstride);
         // rows walk down the channels by adding to the lane offset (one scalar live instead of NDY row offsets); a row beyond Cout
         // repeats the last channel: finite values into accumulator rows that are never stored
         int rows = a.Cout - g * 32 - dcol0;                   // rows of this lane's column that exist
-        asm volatile("" : "+s"(rows));                        // (opaque: keeps the per-row selects out of the loop-invariant SGPRs)
-        unsigned voff = ((4u * (unsigned)(oz * HW + oy * a.W + ox)) & dmk[set]) + (unsigned)(g * 32 + dcol0) * cstride;
+        if constexpr (DUNI) asm volatile("" : "+s"(rows));    // (opaque: keeps the per-row selects out of the loop-invariant SGPRs)
+        else asm volatile("" : "+v"(rows));
+        unsigned voff = ((4u * (unsigned)(oz * HWo + oy * a.Wo + ox)) & dmk[set]) + (unsigned)(g * 32 + dcol0) * dcstride;
 #pragma unroll
         for (int j = 0; j < NDY; ++j) {
             dyr[set][j] = wp_load(rs, voff, 0u);
-            voff += (j + 1) * CPK < rows ? CPK * cstride : 0u;
+            voff += (j + 1) * CPK < rows ? CPK * dcstride : 0u;
         }
     };
     auto write_dy = [&](int set, int buf) __attribute__((always_inline)) {
@@ -376,8 +390,10 @@ __global__ __launch_bounds__(256) void wgrad_f16x2_reduce_kernel(const float* pa
 
 struct WPPlan { int TX, TY, TZ, ntx, nty, ntz, ntiles, NG, NCG, P, order, m, q, nk; };
 static inline int wp_cdiv(int a, int b) { return (a + b - 1) / b; }
-static bool plan_wp(int Cin, int Cout, int N, int D, int H, int W, WPPlan& q) {
-    if (W >= 24) { q.TX = 32; q.TY = 4; q.TZ = 2; } else if (W >= 12) { q.TX = 16; q.TY = 8; q.TZ = 2; } else return false;
+// (D, H, W): the OUTPUT extent
+static bool plan_wp(int Cin, int Cout, int N, int D, int H, int W, int stride, WPPlan& q) {
+    if (stride == 2) { if (W >= 12) { q.TX = 16; q.TY = 2; q.TZ = 2; } else return false; }
+    else if (W >= 24) { q.TX = 32; q.TY = 4; q.TZ = 2; } else if (W >= 12) { q.TX = 16; q.TY = 8; q.TZ = 2; } else return false;
     q.ntx = wp_cdiv(W, q.TX); q.nty = wp_cdiv(H, q.TY); q.ntz = wp_cdiv(D, q.TZ);
     q.ntiles = N * q.ntx * q.nty * q.ntz;
     q.NG = wp_cdiv(Cout, 32); q.NCG = wp_cdiv(Cin, 16);
@@ -392,43 +408,55 @@ static bool plan_wp(int Cin, int Cout, int N, int D, int H, int W, WPPlan& q) {
     else { q.order = 0; q.m = 1; q.q = 1; q.nk = wp_cdiv(q.ntiles, P); }
     return true;
 }
-// 1 when the pair form serves this layer (stride 1, rows of >= 12 voxels); the small layers stay on the fp32 kernel
+static inline int wp_out(int v, int stride) { return (v - 1) / stride + 1; }
+// 1 when the pair form serves this layer (stride 1: rows of >= 12 voxels; stride 2 -- round 5 -- output rows of >= 12 voxels); the other
+// layers stay on the fp32 kernel.  (D, H, W): the input extent
 extern "C" int wmh_conv3d_k3_wgrad_f16x2_supported(int Cin, int Cout, int N, int D, int H, int W, int stride) {
     WPPlan q;
-    return stride == 1 && Cin >= 1 && Cout >= 1 && N >= 1 && plan_wp(Cin, Cout, N, D, H, W, q) ? 1 : 0;
+    return (stride == 1 || stride == 2) && Cin >= 1 && Cout >= 1 && N >= 1 &&
+           plan_wp(Cin, Cout, N, wp_out(D, stride), wp_out(H, stride), wp_out(W, stride), stride, q) ? 1 : 0;
 }
 extern "C" size_t wmh_conv3d_k3_wgrad_f16x2_workspace_floats(int Cin, int Cout, int N, int D, int H, int W) {
     WPPlan q;
-    if (!plan_wp(Cin, Cout, N, D, H, W, q)) return 0;
+    if (!plan_wp(Cin, Cout, N, D, H, W, 1, q)) return 0;
     return (size_t)q.P * Cout * Cin * 27;
 }
-template <int TX, int TY, int TZ, int NLW>
+extern "C" size_t wmh_conv3d_k3s2_wgrad_f16x2_workspace_floats(int Cin, int Cout, int N, int D, int H, int W) {
+    WPPlan q;
+    if (!plan_wp(Cin, Cout, N, wp_out(D, 2), wp_out(H, 2), wp_out(W, 2), 2, q)) return 0;
+    return (size_t)q.P * Cout * Cin * 27;
+}
+template <int S, int TX, int TY, int TZ, int NLW>
 static int launch_wp(const WgradPArgs& a, unsigned nblk, hipStream_t st) {
-    constexpr int lds = WpGeo<TX, TY, TZ, NLW>::LDS;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_f16x2_kernel<TX, TY, TZ, NLW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((conv3d_k3_wgrad_f16x2_kernel<TX, TY, TZ, NLW>), dim3(nblk), dim3(256 + 64 * NLW), lds, st, a);
+    constexpr int lds = WpGeo<S, TX, TY, TZ, NLW>::LDS;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_f16x2_kernel<S, TX, TY, TZ, NLW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_f16x2_kernel<S, TX, TY, TZ, NLW>), dim3(nblk), dim3(256 + 64 * NLW), lds, st, a);
     return wmh_check_launch("conv3d_k3_wgrad_f16x2_kernel");
 }
 static int wgrad_f16x2_impl(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy, float* dW,
-                            float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, unsigned long long* stamps, void* stream) {
+                            float* workspace, int N, int D, int H, int W, int Cout, int stride, float lrelu_slope, unsigned long long* stamps, void* stream) {
     if (!x0 || !dy || !dW || !workspace || C0 < 1 || N < 1 || Cout < 1) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2: bad args");
     if (!(lrelu_slope >= 0.f && lrelu_slope <= 1.f)) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2: LeakyReLU slope must be in [0, 1]");
     if (!x1) C1 = 0;
     const int Cin = C0 + C1;
+    const int Do = wp_out(D, stride), Ho = wp_out(H, stride), Wo = wp_out(W, stride);
     WPPlan q;
-    if (!plan_wp(Cin, Cout, N, D, H, W, q)) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2: layer not served (rows shorter than 12 voxels)");
-    if ((size_t)(Cout > C0 ? (Cout > C1 ? Cout : C1) : (C0 > C1 ? C0 : C1)) * D * H * W * 4 >= ((size_t)1 << 32)) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2: volume too large for 32-bit lane offsets");
+    if (!plan_wp(Cin, Cout, N, Do, Ho, Wo, stride, q)) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2: layer not served (output rows shorter than 12 voxels)");
+    if ((size_t)(C0 > C1 ? C0 : C1) * D * H * W * 4 >= ((size_t)1 << 32) || (size_t)Cout * Do * Ho * Wo * 4 >= ((size_t)1 << 32))
+        return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2: volume too large for 32-bit lane offsets");
     WgradPArgs a;
     a.x0 = x0; a.ss0 = ss0; a.C0 = C0; a.x1 = x1; a.ss1 = ss1; a.C1 = C1; a.dy = dy; a.part = workspace;
-    a.N = N; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.Cin = Cin;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.Cin = Cin; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
     a.ntx = q.ntx; a.nty = q.nty; a.ntz = q.ntz; a.ntiles = q.ntiles; a.NG = q.NG; a.NCG = q.NCG; a.P = q.P;
     a.order = q.order; a.m = q.m; a.q = q.q; a.nk = q.nk; a.slope = lrelu_slope; a.stamps = stamps;
     if (wmh_diag_env_set("WMH_WGRAD_PLAIN_ORDER")) { a.order = 0; }      // diagnostic: x -> y -> z tile order
     const unsigned nblk = (unsigned)(q.NG * q.NCG * q.P);
     hipStream_t st = (hipStream_t)stream;
     static const bool four = wmh_diag_env_set("WMH_WGRAD_LOADERS4");   // diagnostic: 4 loader waves instead of 8
-    const int rc = four ? (q.TX == 32 ? launch_wp<32, 4, 2, 4>(a, nblk, st) : launch_wp<16, 8, 2, 4>(a, nblk, st))
-                        : (q.TX == 32 ? launch_wp<32, 4, 2, 8>(a, nblk, st) : launch_wp<16, 8, 2, 8>(a, nblk, st));
+    int rc;
+    if (stride == 2) rc = launch_wp<2, 16, 2, 2, 8>(a, nblk, st);
+    else rc = four ? (q.TX == 32 ? launch_wp<1, 32, 4, 2, 4>(a, nblk, st) : launch_wp<1, 16, 8, 2, 4>(a, nblk, st))
+                   : (q.TX == 32 ? launch_wp<1, 32, 4, 2, 8>(a, nblk, st) : launch_wp<1, 16, 8, 2, 8>(a, nblk, st));
     if (rc != WMH_OK) return rc;
     const size_t n = (size_t)Cout * Cin * 27;
     unsigned rb = (unsigned)((n + 255) / 256); if (rb > 2048) rb = 2048;
@@ -437,12 +465,18 @@ static int wgrad_f16x2_impl(const float* x0, const float* ss0, int C0, const flo
 }
 extern "C" int wmh_conv3d_k3_wgrad_f16x2(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
                                          float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream) {
-    return wgrad_f16x2_impl(x0, ss0, C0, x1, ss1, C1, dy, dW, workspace, N, D, H, W, Cout, lrelu_slope, nullptr, stream);
+    return wgrad_f16x2_impl(x0, ss0, C0, x1, ss1, C1, dy, dW, workspace, N, D, H, W, Cout, 1, lrelu_slope, nullptr, stream);
+}
+// The same for the 3x3x3 convolution with stride 2 (pad 1): (D, H, W) is the INPUT extent, dy has ((D - 1) / 2 + 1, ...); workspace >=
+// wmh_conv3d_k3s2_wgrad_f16x2_workspace_floats floats
+extern "C" int wmh_conv3d_k3s2_wgrad_f16x2(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
+                                           float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream) {
+    return wgrad_f16x2_impl(x0, ss0, C0, x1, ss1, C1, dy, dW, workspace, N, D, H, W, Cout, 2, lrelu_slope, nullptr, stream);
 }
 // diagnostics: the same launch with per-workgroup cycle counts (4 per workgroup: consumer work / wait, loader work / wait)
 extern "C" size_t wmh_conv3d_k3_wgrad_f16x2_stamp_count(int Cin, int Cout, int N, int D, int H, int W) {
     WPPlan q;
-    if (!plan_wp(Cin, Cout, N, D, H, W, q)) return 0;
+    if (!plan_wp(Cin, Cout, N, D, H, W, 1, q)) return 0;
     return (size_t)q.NG * q.NCG * q.P * 4;
 }
 extern "C" int wmh_conv3d_k3_wgrad_f16x2_stamped(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
@@ -451,5 +485,5 @@ extern "C" int wmh_conv3d_k3_wgrad_f16x2_stamped(const float* x0, const float* s
 #ifndef WMH_DIAG
     if (stamps) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2_stamped: cycle stamps exist in libdeepwmh_amd_diag.so only");
 #endif
-    return wgrad_f16x2_impl(x0, ss0, C0, x1, ss1, C1, dy, dW, workspace, N, D, H, W, Cout, lrelu_slope, stamps, stream);
+    return wgrad_f16x2_impl(x0, ss0, C0, x1, ss1, C1, dy, dW, workspace, N, D, H, W, Cout, 1, lrelu_slope, stamps, stream);
 }

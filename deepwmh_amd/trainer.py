@@ -54,6 +54,7 @@ class UNetTrainer:
         # (network.py, DESIGN.md 3.2: fp32-grade, 2-2.7x the fp32 instruction's speed); weight gradients and everything else fp32
         self.x3 = precision == 'f16x2'
         self.x3_s2_dgrad = self.x3_tu_dgrad = True         # diagnostic attributes (tools/grad_compare.py): False = those data gradients on the exact-fp32 kernels
+        self.x3_s2_wgrad = True                            # diagnostic attribute: False = the strided weight gradients on the exact-fp32 kernel
         self.x3_splitk = True                              # diagnostic attribute (tools/train_bench.py): False = no slab memory for the pair kernels (no split-K)
         # fp16's exponent range: the data gradients (dLoss/dy ~ 1e-8 .. 1e-2 at 2 x 128^3 voxels) sit below fp16's normal range, so in
         # this mode the backward pass runs on the loss scaled by 2^16 -- the static form of the GradScaler nnU-Net's own fp16 AMP
@@ -429,13 +430,15 @@ class UNetTrainer:
                 _lib.check(lib.wmh_conv3d_wgrad(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
                                                 _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, conv.kz, conv.sz,
                                                 conv.stride, LRELU_SLOPE, st), 'wmh_conv3d_wgrad')
-            elif self.x3 and lib.wmh_conv3d_k3_wgrad_f16x2_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
+            elif self.x3 and (conv.stride == 1 or self.x3_s2_wgrad) and lib.wmh_conv3d_k3_wgrad_f16x2_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
                 # pair form (fp16 hi + lo of dy and of the activated input): the loss scale keeps dy inside fp16's range
-                nws = lib.wmh_conv3d_k3_wgrad_f16x2_workspace_floats(C0 + C1, Cc, N, D, H, W)
+                s2 = conv.stride == 2                            # (round 5: the strided layers with output rows of >= 12 voxels too)
+                nws = (lib.wmh_conv3d_k3s2_wgrad_f16x2_workspace_floats if s2 else lib.wmh_conv3d_k3_wgrad_f16x2_workspace_floats)(C0 + C1, Cc, N, D, H, W)
                 ws = self._buf(wskey, (nws,))
-                _lib.check(lib.wmh_conv3d_k3_wgrad_f16x2(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
-                                                         _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, LRELU_SLOPE, st),
-                           'wmh_conv3d_k3_wgrad_f16x2')
+                fn = lib.wmh_conv3d_k3s2_wgrad_f16x2 if s2 else lib.wmh_conv3d_k3_wgrad_f16x2
+                _lib.check(fn(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
+                              _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, LRELU_SLOPE, st),
+                           'wmh_conv3d_k3s2_wgrad_f16x2' if s2 else 'wmh_conv3d_k3_wgrad_f16x2')
             elif self.bf16_wgrad and lib.wmh_conv3d_k3_wgrad_bf16_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
                 nws = lib.wmh_conv3d_k3_wgrad_bf16_workspace_floats(C0 + C1, Cc, N, D, H, W)
                 ws = self._buf(wskey, (nws,))

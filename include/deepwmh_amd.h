@@ -322,7 +322,7 @@ void wmh_debug_set_conv_stamps(void* stamps);
 /* The same weight gradient in the f16x2 "pair" mode (fp32-grade training, the default of nnUNet_train): dy and the activated input
  * are each split into two fp16 numbers (hi toward zero, lo = the remainder: 21-22 significant bits) and kept as one dword per voxel;
  * two v_mfma_f32_32x32x16_f16 per 8 voxels and channel form dy_hi (x_hi + x_lo) + dy_lo (x_hi + x_lo) in fp32 accumulators.
- * |dy|, |x'| up to 131008 (callers scale the loss, as the f16x2 data gradient needs).  Stride 1, rows of >= 12 voxels
+ * |dy|, |x'| up to 131008 (callers scale the loss, as the f16x2 data gradient needs).  Stride 1, rows of >= 12 voxels (stride 2: below)
  * (wmh_conv3d_k3_wgrad_f16x2_supported); workspace >= wmh_conv3d_k3_wgrad_f16x2_workspace_floats(...) floats.  The _stamped form
  * also writes wmh_conv3d_k3_wgrad_f16x2_stamp_count(...) cycle counters (4 per workgroup: consumer work / wait, loader work /
  * wait) -- diagnostics (tools/wgrad_check.py). */
@@ -330,6 +330,12 @@ int wmh_conv3d_k3_wgrad_f16x2_supported(int Cin, int Cout, int N, int D, int H, 
 size_t wmh_conv3d_k3_wgrad_f16x2_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
 int wmh_conv3d_k3_wgrad_f16x2(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
                               float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
+/* ... of the convolution with stride 2 (round 5; the fp32 kernel wmh_conv3d_k3_wgrad served it before): (D, H, W) is the INPUT extent, dy
+ * has ((D - 1) / 2 + 1, ...); output rows of >= 12 voxels (wmh_conv3d_k3_wgrad_f16x2_supported(..., stride 2)).  The halo rows of the activated
+ * input are kept parity-split in LDS (odd inputs | even inputs), so that a tap's operand is consecutive dwords as at stride 1. */
+size_t wmh_conv3d_k3s2_wgrad_f16x2_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
+int wmh_conv3d_k3s2_wgrad_f16x2(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
+                                float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
 size_t wmh_conv3d_k3_wgrad_f16x2_stamp_count(int Cin, int Cout, int N, int D, int H, int W);
 int wmh_conv3d_k3_wgrad_f16x2_stamped(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
                                       float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope,

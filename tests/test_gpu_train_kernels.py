@@ -352,7 +352,7 @@ def test_conv3d_wgrad_f16x2_pairs(lib, shape):
     F.conv3d(act.double(), w, None, padding=1).backward(dy.double())
     ref = w.grad.reshape(Cout, Cin, 27)
     assert lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, W, 1) == 1
-    assert lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, 8, 1) == 0 and lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, W, 2) == 0
+    assert lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, 8, 1) == 0
     d = [t.cuda() if t is not None else None for t in (x0, s0, x1, s1, dy)]
     ws = torch.full((lib.wmh_conv3d_k3_wgrad_f16x2_workspace_floats(Cin, Cout, N, D, H, W),), float('nan'), device='cuda')
     outs = []
@@ -372,6 +372,50 @@ def test_conv3d_wgrad_f16x2_pairs(lib, shape):
     e16 = float(((outs[0].double() - ref).abs() / scale).max()); e32 = float(((dW32.cpu().double() - ref).abs() / scale).max())
     r16 = float((outs[0].double() - ref).norm() / ref.norm())
     print('f16x2 max err / channel max %.2e (exact-fp32 kernel %.2e), rel. L2 %.2e' % (e16, e32, r16))
+    assert e16 <= 4e-6 and r16 <= 1e-6, (e16, e32, r16)
+
+
+F16X2_WG_S2 = [(2, 16, 0, 32, 8, 8, 32), (1, 24, 0, 40, 7, 13, 30), (2, 32, 0, 64, 16, 32, 64), (1, 8, 8, 48, 9, 10, 52), (2, 64, 0, 128, 8, 16, 32),
+               (3, 20, 0, 36, 4, 6, 25)]
+
+
+@pytest.mark.parametrize('shape', F16X2_WG_S2, ids=[str(c) for c in F16X2_WG_S2])
+def test_conv3d_wgrad_f16x2_pairs_stride2(lib, shape):
+    """The pair-form weight gradient of the stride-2 convolution (round 5: halo rows parity-split in LDS, tiles of 16 x 2 x 2 outputs) against
+    float64 autograd, beside the exact-fp32 kernel that served these layers before: even and odd input extents, ragged tiles, channel tails,
+    two sources, the tile orders; bit-reproducible."""
+    N, C0, C1, Cout, D, H, W = shape                  # the INPUT extent
+    Cin = C0 + C1
+    g = torch.Generator().manual_seed(93)
+    x0 = torch.randn(N, C0, D, H, W, generator=g); s0 = torch.stack([0.5 + torch.rand(N, C0, generator=g), 0.3 * torch.randn(N, C0, generator=g)], -1)
+    x1 = torch.randn(N, C1, D, H, W, generator=g) if C1 else None
+    s1 = torch.stack([0.5 + torch.rand(N, C1, generator=g), 0.3 * torch.randn(N, C1, generator=g)], -1) if C1 else None
+    Do, Ho, Wo = (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(N, Cout, Do, Ho, Wo, generator=g) * torch.exp(torch.empty(N, Cout, 1, 1, 1).uniform_(-4, 3, generator=g))
+    act = torch.cat([_act(x0, s0)] + ([_act(x1, s1)] if C1 else []), 1)
+    w = torch.zeros(Cout, Cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(act.double(), w, None, padding=1, stride=2).backward(dy.double())
+    ref = w.grad.reshape(Cout, Cin, 27)
+    assert lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, W, 2) == 1
+    assert lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, 20, 2) == 0          # output rows of 10 voxels: the fp32 kernel
+    d = [t.cuda() if t is not None else None for t in (x0, s0, x1, s1, dy)]
+    ws = torch.full((lib.wmh_conv3d_k3s2_wgrad_f16x2_workspace_floats(Cin, Cout, N, D, H, W),), float('nan'), device='cuda')
+    outs = []
+    for _ in range(2):
+        dW = torch.full((Cout, Cin, 27), float('nan'), device='cuda')
+        check(lib.wmh_conv3d_k3s2_wgrad_f16x2(P(d[0]), P(d[1]), C0, P(d[2]), P(d[3]), C1, P(d[4]), P(dW), P(ws), N, D, H, W, Cout, SLOPE, None), 'wgrad f16x2 s2')
+        torch.cuda.synchronize()
+        outs.append(dW.cpu())
+    assert torch.equal(outs[0], outs[1])                                          # fixed-order reduction
+    assert not torch.isnan(outs[0]).any()
+    dW32 = torch.full((Cout, Cin, 27), float('nan'), device='cuda')
+    ws32 = torch.empty(lib.wmh_conv3d_k3_wgrad_workspace_floats(Cin, Cout, N, D, H, W, 2), device='cuda')
+    check(lib.wmh_conv3d_k3_wgrad(P(d[0]), P(d[1]), C0, P(d[2]), P(d[3]), C1, P(d[4]), P(dW32), P(ws32), N, D, H, W, Cout, 2, SLOPE, None), 'wgrad')
+    torch.cuda.synchronize()
+    scale = ref.abs().amax((1, 2), keepdim=True)
+    e16 = float(((outs[0].double() - ref).abs() / scale).max()); e32 = float(((dW32.cpu().double() - ref).abs() / scale).max())
+    r16 = float((outs[0].double() - ref).norm() / ref.norm())
+    print('stride 2, f16x2 max err / channel max %.2e (exact-fp32 kernel %.2e), rel. L2 %.2e' % (e16, e32, r16))
     assert e16 <= 4e-6 and r16 <= 1e-6, (e16, e32, r16)
 
 

@@ -1,5 +1,6 @@
 """Time one nnUNetTrainerV2 iteration (BASELINE plan, batch 2 of 128^3 patches) on the HIP kernels.
-env: WMH_BATCH (2), WMH_ITERS (4), WMH_PRECISION (fp32 | bf16 | f16x2), WMH_X3_SPLITK=0 (pair kernels without split-K slabs)."""
+env: WMH_BATCH (2), WMH_ITERS (4), WMH_PRECISION (fp32 | bf16 | f16x2), WMH_X3_SPLITK=0 (pair kernels without split-K slabs),
+WMH_X3_S2_WGRAD=0 (strided weight gradients on the exact-fp32 kernel)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,6 +12,8 @@ B = int(os.environ.get('WMH_BATCH', '2'))
 tr = UNetTrainer(plan, he_init_state_dict(plan, 0), 'cuda:0', precision=os.environ.get('WMH_PRECISION', 'fp32'))
 if os.environ.get('WMH_X3_SPLITK') == '0':
     tr.x3_splitk = False
+if os.environ.get('WMH_X3_S2_WGRAD') == '0':
+    tr.x3_s2_wgrad = False
 torch.manual_seed(0)
 x = torch.randn(B, 1, 128, 128, 128, device='cuda')
 lab = (torch.rand(B, 128, 128, 128, device='cuda') < 0.05).to(torch.uint8)
