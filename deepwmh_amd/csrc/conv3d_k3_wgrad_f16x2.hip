@@ -85,7 +85,8 @@ struct WpGeo {
     // index mod 32) -- fall on 27 different banks; unpadded (RS = 4 IX, PS = IY RS) every such read is a 2-way conflict and the LDS,
     // not the matrix pipe, sets the pace.  The last dword of a channel takes the stores of the lanes beyond the tile.
     // Stride 2: XE = where the even part of a row starts; (RS, PS, XE) = (39, 203, 20) dwords give the 27 taps 27 different banks too.
-    static constexpr int RS = S == 2 ? 156 : (TX == 32 ? 140 : 72), PS = S == 2 ? 812 : (TX == 32 ? 852 : 724), XE = S == 2 ? 80 : 0;
+    // Rows of 8 voxels (stride 1; round 5: the 8^3 level): (RS, PS) = (11, 131) dwords.
+    static constexpr int RS = S == 2 ? 156 : (TX == 32 ? 140 : TX == 16 ? 72 : 44), PS = S == 2 ? 812 : (TX == 32 ? 852 : TX == 16 ? 724 : 524), XE = S == 2 ? 80 : 0;
     static constexpr int CS = (IZ * PS + 16 + 15) / 16 * 16;   // bytes per channel
     static constexpr int XB = 16 * CS;                         // one x' buffer: the workgroup's 16 channels
     static constexpr int UV = TY * TX;                         // voxels per unit (one z slice of the tile)
@@ -100,7 +101,7 @@ struct WpGeo {
     static_assert(S == 1 || S == 2, "stride");
     static_assert(TZ == 2 && (UV % 64 == 0 || 64 % UV == 0) && LT % UV == 0 && TX % 8 == 0 && XPU >= 1 && NDY >= 1 && (NLW == 4 || NLW == 8), "tile geometry");
     static_assert((TY - 1) * S * RS + (TX - 8) * 4 + 12 <= 1020, "ds_read2_b32 offset range");
-    static_assert(RS >= (S == 2 ? XE + TX * 4 : IX * 4) && (S == 1 || XE >= (TX + 1) * 4) && PS >= IY * RS && (TX == 32 || TX == 16) && CS % 16 == 0 && CS >= IZ * PS + 16, "x' layout");
+    static_assert(RS >= (S == 2 ? XE + TX * 4 : IX * 4) && (S == 1 || XE >= (TX + 1) * 4) && PS >= IY * RS && (TX == 32 || TX == 16 || (TX == 8 && S == 1)) && CS % 16 == 0 && CS >= IZ * PS + 16, "x' layout");
     static_assert(LDS <= 160 * 1024, "LDS");
 };
 
@@ -393,7 +394,7 @@ static inline int wp_cdiv(int a, int b) { return (a + b - 1) / b; }
 // (D, H, W): the OUTPUT extent
 static bool plan_wp(int Cin, int Cout, int N, int D, int H, int W, int stride, WPPlan& q) {
     if (stride == 2) { if (W >= 12) { q.TX = 16; q.TY = 2; q.TZ = 2; } else return false; }
-    else if (W >= 24) { q.TX = 32; q.TY = 4; q.TZ = 2; } else if (W >= 12) { q.TX = 16; q.TY = 8; q.TZ = 2; } else return false;
+    else if (W >= 24) { q.TX = 32; q.TY = 4; q.TZ = 2; } else if (W >= 12) { q.TX = 16; q.TY = 8; q.TZ = 2; } else if (W >= 8) { q.TX = 8; q.TY = 8; q.TZ = 2; } else return false;
     q.ntx = wp_cdiv(W, q.TX); q.nty = wp_cdiv(H, q.TY); q.ntz = wp_cdiv(D, q.TZ);
     q.ntiles = N * q.ntx * q.nty * q.ntz;
     q.NG = wp_cdiv(Cout, 32); q.NCG = wp_cdiv(Cin, 16);
@@ -409,7 +410,7 @@ static bool plan_wp(int Cin, int Cout, int N, int D, int H, int W, int stride, W
     return true;
 }
 static inline int wp_out(int v, int stride) { return (v - 1) / stride + 1; }
-// 1 when the pair form serves this layer (stride 1: rows of >= 12 voxels; stride 2 -- round 5 -- output rows of >= 12 voxels); the other
+// 1 when the pair form serves this layer (stride 1: rows of >= 8 voxels; stride 2 -- round 5 -- output rows of >= 12 voxels); the other
 // layers stay on the fp32 kernel.  (D, H, W): the input extent
 extern "C" int wmh_conv3d_k3_wgrad_f16x2_supported(int Cin, int Cout, int N, int D, int H, int W, int stride) {
     WPPlan q;
@@ -441,7 +442,7 @@ static int wgrad_f16x2_impl(const float* x0, const float* ss0, int C0, const flo
     const int Cin = C0 + C1;
     const int Do = wp_out(D, stride), Ho = wp_out(H, stride), Wo = wp_out(W, stride);
     WPPlan q;
-    if (!plan_wp(Cin, Cout, N, Do, Ho, Wo, stride, q)) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2: layer not served (output rows shorter than 12 voxels)");
+    if (!plan_wp(Cin, Cout, N, Do, Ho, Wo, stride, q)) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2: layer not served (rows shorter than 8 voxels, or than 12 output voxels at stride 2)");
     if ((size_t)(C0 > C1 ? C0 : C1) * D * H * W * 4 >= ((size_t)1 << 32) || (size_t)Cout * Do * Ho * Wo * 4 >= ((size_t)1 << 32))
         return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2: volume too large for 32-bit lane offsets");
     WgradPArgs a;
@@ -455,6 +456,7 @@ static int wgrad_f16x2_impl(const float* x0, const float* ss0, int C0, const flo
     static const bool four = wmh_diag_env_set("WMH_WGRAD_LOADERS4");   // diagnostic: 4 loader waves instead of 8
     int rc;
     if (stride == 2) rc = launch_wp<2, 16, 2, 2, 8>(a, nblk, st);
+    else if (q.TX == 8) rc = launch_wp<1, 8, 8, 2, 8>(a, nblk, st);
     else rc = four ? (q.TX == 32 ? launch_wp<1, 32, 4, 2, 4>(a, nblk, st) : launch_wp<1, 16, 8, 2, 4>(a, nblk, st))
                    : (q.TX == 32 ? launch_wp<1, 32, 4, 2, 8>(a, nblk, st) : launch_wp<1, 16, 8, 2, 8>(a, nblk, st));
     if (rc != WMH_OK) return rc;

@@ -322,7 +322,7 @@ void wmh_debug_set_conv_stamps(void* stamps);
 /* The same weight gradient in the f16x2 "pair" mode (fp32-grade training, the default of nnUNet_train): dy and the activated input
  * are each split into two fp16 numbers (hi toward zero, lo = the remainder: 21-22 significant bits) and kept as one dword per voxel;
  * two v_mfma_f32_32x32x16_f16 per 8 voxels and channel form dy_hi (x_hi + x_lo) + dy_lo (x_hi + x_lo) in fp32 accumulators.
- * |dy|, |x'| up to 131008 (callers scale the loss, as the f16x2 data gradient needs).  Stride 1, rows of >= 12 voxels (stride 2: below)
+ * |dy|, |x'| up to 131008 (callers scale the loss, as the f16x2 data gradient needs).  Stride 1, rows of >= 8 voxels (stride 2: below)
  * (wmh_conv3d_k3_wgrad_f16x2_supported); workspace >= wmh_conv3d_k3_wgrad_f16x2_workspace_floats(...) floats.  The _stamped form
  * also writes wmh_conv3d_k3_wgrad_f16x2_stamp_count(...) cycle counters (4 per workgroup: consumer work / wait, loader work /
  * wait) -- diagnostics (tools/wgrad_check.py). */

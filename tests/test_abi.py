@@ -130,12 +130,13 @@ def test_wgrad_f16x2_plan_host_side(lib):
     (P slabs of Cout x Cin x 27 floats, P = the power of two that brings the grid of 32 co x 16 ci workgroups closest to 256 from below)."""
     sup, ws = lib.wmh_conv3d_k3_wgrad_f16x2_supported, lib.wmh_conv3d_k3_wgrad_f16x2_workspace_floats
     assert sup(32, 32, 2, 128, 128, 128, 1) == 1 and sup(256, 256, 2, 16, 16, 16, 1) == 1
-    assert sup(320, 320, 2, 8, 8, 8, 1) == 0            # rows shorter than 12 voxels: the fp32 kernel
+    assert sup(320, 320, 2, 8, 8, 8, 1) == 1            # rows of 8 voxels (round 5)
+    assert sup(320, 320, 2, 4, 4, 4, 1) == 0            # shorter rows: the fp32 kernel
     assert sup(32, 64, 2, 128, 128, 128, 2) == 1 and sup(128, 256, 2, 32, 32, 32, 2) == 1   # strided layers with output rows of >= 12 voxels (round 5)
     assert sup(256, 320, 2, 16, 16, 16, 2) == 0         # ... shorter ones: the fp32 kernel
     # 32 -> 64 at 2 x 128^3 (output 64^3): 2 x 2 channel groups -> P = 64
     assert lib.wmh_conv3d_k3s2_wgrad_f16x2_workspace_floats(32, 64, 2, 128, 128, 128) == 64 * 64 * 32 * 27
-    assert ws(320, 320, 2, 8, 8, 8) == 0
+    assert ws(320, 320, 2, 4, 4, 4) == 0 and ws(320, 320, 2, 8, 8, 8) == 1 * 320 * 320 * 27
     # 32 -> 32 at 2 x 128^3: 1 x 2 channel groups -> P = 128
     assert ws(32, 32, 2, 128, 128, 128) == 128 * 32 * 32 * 27
     # 256 -> 128 at 2 x 32^3: 4 x 16 groups -> P = 4

@@ -332,7 +332,8 @@ def test_conv3d_wgrad_bf16_operands(lib, shape):
 
 
 F16X2_WG = [(2, 16, 0, 8, 8, 8, 32), (1, 32, 24, 40, 5, 9, 45), (2, 20, 0, 36, 6, 16, 16), (1, 8, 8, 72, 3, 17, 20), (2, 1, 0, 32, 4, 8, 32),
-            (2, 64, 0, 128, 8, 32, 32), (1, 128, 0, 256, 6, 32, 32), (2, 32, 0, 32, 16, 32, 64), (3, 16, 0, 32, 4, 24, 40)]
+            (2, 64, 0, 128, 8, 32, 32), (1, 128, 0, 256, 6, 32, 32), (2, 32, 0, 32, 16, 32, 64), (3, 16, 0, 32, 4, 24, 40),
+            (2, 48, 0, 64, 8, 8, 8), (1, 24, 16, 40, 5, 11, 10), (2, 320, 0, 64, 8, 8, 8)]      # rows of 8 voxels (round 5: the 8^3 level)
 
 
 @pytest.mark.parametrize('shape', F16X2_WG, ids=[str(c) for c in F16X2_WG])
@@ -352,7 +353,7 @@ def test_conv3d_wgrad_f16x2_pairs(lib, shape):
     F.conv3d(act.double(), w, None, padding=1).backward(dy.double())
     ref = w.grad.reshape(Cout, Cin, 27)
     assert lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, W, 1) == 1
-    assert lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, 8, 1) == 0
+    assert lib.wmh_conv3d_k3_wgrad_f16x2_supported(Cin, Cout, N, D, H, 4, 1) == 0
     d = [t.cuda() if t is not None else None for t in (x0, s0, x1, s1, dy)]
     ws = torch.full((lib.wmh_conv3d_k3_wgrad_f16x2_workspace_floats(Cin, Cout, N, D, H, W),), float('nan'), device='cuda')
     outs = []
