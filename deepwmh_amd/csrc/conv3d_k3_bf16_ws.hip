@@ -15,7 +15,8 @@
 // buffer of the chunk's weight fragments (two do not fit in 160 KB): the loaders hold the next chunk's weights in
 // registers and drop them into LDS between two barriers at the end of a chunk (~300 cycles of a ~7000-cycle chunk).  Persistent (grid = number of CUs): loaders run one chunk ahead across tile boundaries and the
 // weight ring continues into the next tile, so a tile has no prologue.  Same arithmetic and k order as the one-role
-// kernel: bit-identical results.
+// kernel: bit-identical results.  Round 5: split-K slices of a tile's channel chunks as separate parts of the persistent sequence (a.KS,
+// for layers whose tiles do not fill the chip) and, in the pair mode, rows of 8 voxels (configuration 24: an M-tile = 4 rows of 8).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

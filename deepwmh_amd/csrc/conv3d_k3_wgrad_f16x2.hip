@@ -1,7 +1,7 @@
-// conv3d_k3_wgrad_f16x2.hip -- weight gradient of the 3x3x3 convolution (pad 1, stride 1) in the f16x2 "pair" mode: fp32-grade
-// results from the 16-bit matrix instruction (conv3d_common.h).
+// conv3d_k3_wgrad_f16x2.hip -- weight gradient of the 3x3x3 convolution (pad 1; stride 1, and since round 5 stride 2: WpGeo below) in the
+// f16x2 "pair" mode: fp32-grade results from the 16-bit matrix instruction (conv3d_common.h, DESIGN.md sections 3.2, 3.6).
 //
-//   dW[co][ci][tap] = sum_{n, o} dy[n, co, o] * x'[n, ci, o + tap - 1]
+//   dW[co][ci][tap] = sum_{n, o} dy[n, co, o] * x'[n, ci, S o + tap - 1]          (S = the stride; the text below describes S = 1)
 //
 // Voxels are the K dimension of v_mfma_f32_32x32x16_f16, one D tile [co 32][tap 32 (27 used)] per input channel.  Both operands are
 // split into two fp16 numbers (hi rounded toward zero, lo = the remainder rounded to nearest: 21-22 significant bits) and kept in LDS
