@@ -562,6 +562,7 @@ class UNetTrainer:
                                                    force_collective=force_collective)
             self._avg.forced = bool(force_collective)
         self._avg.begin()
+        self._wgrad_pending = []                             # (a backward pass that died half way must not report its gradients into this one)
         self._update_loss_scale()
         lib, st, tape = self.lib, self._st(), self.tape
         nd = len(self.dec)

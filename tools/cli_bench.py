@@ -1,6 +1,6 @@
 """End-to-end timing of the `nnUNet_predict` drop-in on BASELINE-sized cases (160x192x160, baseline plan, random-init
 weights): NIfTI read + preprocess, sliding-window predict, export + write, per case and as cases/s for the whole command.
-usage: python tools/cli_bench.py [ncases] [--tta] [--spacing sx sy sz]"""
+usage: python tools/cli_bench.py [ncases] [--tta] [--save_softmax] [--spacing sx sy sz]      (WMH_PREDICT_INFLIGHT: cases in flight without --tta)"""
 import os
 import sys
 import tempfile
@@ -37,7 +37,7 @@ def main():
         nifti.write(os.path.join(img, 'case%02d_0000.nii.gz' % c), vol.astype(np.float32), spacing=spacing)
     os.environ['RESULTS_FOLDER'] = os.path.join(tmp, 'model')
     argv = ['-i', img, '-o', out, '-tr', 'nnUNetTrainerV2', '-m', '3d_fullres', '-p', 'nnUNetPlansv2.1', '-t', 'Task002_FinalModel',
-            '-f', 'all', '-chk', 'model_best', '--disable_post_processing'] + ([] if tta else ['--disable_tta'])
+            '-f', 'all', '-chk', 'model_best', '--disable_post_processing'] + ([] if tta else ['--disable_tta']) + (['--save_softmax'] if '--save_softmax' in sys.argv else [])
     t0 = time.time()
     predict.main(argv)
     dt = time.time() - t0
