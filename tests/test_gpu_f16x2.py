@@ -36,6 +36,9 @@ CASES = [  # N, D, H, W, C0, C1, Cout, pending norm on source 0 / 1 [, stride]
     (1, 6, 10, 32, 16, 24, 32, False, True),      # two sources (the decoder's concatenation), the second one normalised
     (2, 4, 12, 64, 64, 64, 64, True, True),       # the 64-channel tile (configuration 21)
     (2, 18, 6, 16, 48, 0, 64, True, False),       # rows of 16 voxels (configuration 2)
+    (1, 5, 9, 8, 24, 0, 40, True, False, 1),      # configuration 24 on ragged tiles (5 x 9 rows of 8), channel counts that are no multiples of the chunk / the tile
+    (1, 7, 18, 28, 16, 0, 72, False, False, 2),   # configuration 25 (stride 2, output 4 x 9 x 14): ragged in every direction, a channel-group tail
+    (2, 9, 14, 12, 24, 0, 40, True, False, 2),    # configuration 26 (stride 2, output 5 x 7 x 6)
     (2, 16, 16, 16, 256, 0, 256, True, False),    # a 16^3 level at the training batch: 64 tiles, so the wave-specialised kernel runs four slices of the channel chunks per tile
     (2, 8, 16, 32, 40, 24, 64, True, True),       # ... two sources, chunk slices of unequal length
 ]
