@@ -117,7 +117,7 @@ class UNetTrainer:
         self.first_step = True
         # weight gradients on a second stream beside the InstanceNorm backward of the next layer (WMH_TRAIN_OVERLAP=0: one stream)
         self.overlap_wgrad = os.environ.get('WMH_TRAIN_OVERLAP', '1') != '0'
-        self._side, self._wgrad_pending = None, []
+        self._side, self._wgrad_pending, self._side_retired = None, [], []
         self._bufs, self._packed, self._version = {}, {}, 0
         self._x3_jobs, self._x3_table, self._x3_batched_version, self._x3_used = OrderedDict(), None, -1, {}
         self.clip_out = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -145,6 +145,10 @@ class UNetTrainer:
         n = int(np.prod(shape))
         t = self._bufs.get(key)
         if t is None or t.numel() < n or t.dtype != dtype:
+            if t is not None and key.startswith('b.wgrad.ws.side'):
+                # a workspace of the weight-gradient stream that has to grow: the kernel that used the old one may still be running there, and
+                # the caching allocator only knows the stream it was allocated on -- keep it alive until the streams have joined (backward())
+                self._side_retired.append(t)
             t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
             self._bufs[key] = t
         return t[:n].view(*shape)
@@ -563,6 +567,7 @@ class UNetTrainer:
             self._avg.forced = bool(force_collective)
         self._avg.begin()
         self._wgrad_pending = []                             # (a backward pass that died half way must not report its gradients into this one)
+        self._side_retired = []                              # (the previous pass ended with the two streams joined: its retired workspaces may go)
         self._update_loss_scale()
         lib, st, tape = self.lib, self._st(), self.tape
         nd = len(self.dec)
