@@ -353,7 +353,8 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
         for (int c0 = 0; c0 < LCH; c0 += XPU) { issue_x(0, c0); write_x(0, 0, c0); }
         write_dy(0, 0);
         issue_dy(1, 1);                                        // in flight across the barrier: unit (0, 1) and the first channels of tile 1
-        if (nk > 1) { advance(); x_desc(); issue_x(1, 0); }
+        if (nk > 1) { advance(); x_desc(); }
+        issue_x(1, 0);                                         // (a single tile: tile 0 once more, into a buffer nobody reads)
     }
     __syncthreads();
     if (stamping) st_t = __builtin_amdgcn_s_memtime();
@@ -363,16 +364,21 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
             // The consumers are on unit (k, z).  Register set z^1 holds what the previous unit fetched: dy of the next unit and
             // channels z XPU.. of tile k + 1.  First fetch, into set z, what the unit after the next needs (the cursor is on tile
             // k + 1 from the unit before) ...
+            // BRANCH-FREE (round 5): every unit issues its loads and writes its previous fetch, past the last tile too -- the cursor then
+            // stays on the last tile, whose data is fetched again and written into buffers nobody reads any more.  With the issues under
+            // `if (k + 1 < nk)` the compiler's counted waits in front of the LDS writes were the minimum over both paths, i.e. they assumed
+            // that nothing had been issued since: vmcnt(7) .. vmcnt(0) made every unit wait for the loads it had just issued -- a full memory
+            // latency (~4.4 k cycles) per unit of 3.1 k cycles of MFMA work.  (The forward kernels learnt this in round 3.)
             if (z == 0) {                                      // next unit (k, 1): then dy of (k + 1, 0), channels XPU.. of tile k + 1
-                if (k + 1 < nk) { issue_dy(0, 0); issue_x(0, XPU); }
+                issue_dy(0, 0); issue_x(0, XPU);
             } else {                                           // next unit (k + 1, 0): then dy of (k + 1, 1), channels 0.. of tile k + 2
-                if (k + 1 < nk) issue_dy(1, 1);
-                if (k + 2 < nk) { advance(); x_desc(); issue_x(1, 0); }
+                issue_dy(1, 1);
+                if (k + 2 < nk) { advance(); x_desc(); }       // (scalar cursor and lane offsets only: no loads under the branch)
+                issue_x(1, 0);
             }
             // ... then convert and write the previous fetch
-            const bool last = k == nk - 1 && z == TZ - 1;
-            if (!last) write_dy(z ^ 1, (z + 1) & 1);
-            if (k + 1 < nk) write_x(z ^ 1, (k + 1) & 1, z * XPU);
+            write_dy(z ^ 1, (z + 1) & 1);
+            write_x(z ^ 1, (k + 1) & 1, z * XPU);
             if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_work += t - st_t; st_t = t; }
             __syncthreads();
             if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_wait += t - st_t; st_t = t; }
