@@ -493,12 +493,71 @@ __global__ __launch_bounds__(256) void seghead_logits4_kernel(const float* x, co
         for (int k = 0; k < K; ++k) *reinterpret_cast<f4v*>(out + ((size_t)b * K + k) * P + 4 * q) = f4v{lg[k][0], lg[k][1], lg[k][2], lg[k][3]};
     }
 }
+// The deep-supervision heads of the smaller stages (64^3 and below at the training batch): with a whole channel loop per thread the 16^3 head
+// is 8 workgroups walking 256 channels in 32 dependent rounds of loads (40 us for 8 MB).  Here a workgroup is 64 voxel quads x 4 channel
+// slices (one slice per wave: scale / shift / weights stay scalar), the slices' partial logits are summed through LDS in slice order:
+// deterministic, but not the one-thread order of the kernels above (1e-7 relative).
+template <int K>
+__global__ __launch_bounds__(256) void seghead_logits4s_kernel(const float* x, const float* ss, const float* wseg,
+                                                               float* out, int C, size_t P, float slope) {
+    __shared__ float part[3][K][4][64];
+    const int b = blockIdx.y, qi = threadIdx.x & 63, cs = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* xb = x + (size_t)b * C * P;
+    const float* ssb = ss ? ss + (size_t)b * C * 2 : nullptr;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const size_t q = (size_t)blockIdx.x * 64 + qi, nq = P / 4;
+    const size_t qc = q < nq ? q : nq - 1;                      // (lanes beyond the end repeat the last quad and store nothing)
+    const int c0 = (int)(((long long)C * cs) / 4), c1 = (int)(((long long)C * (cs + 1)) / 4);
+    float lg[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lg[k][i] = 0.f;
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) {
+        const f4v v4 = *reinterpret_cast<const f4v*>(xb + (size_t)c * P + 4 * qc);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (ssb) {
+            const float sc = ssb[2 * c], sh = ssb[2 * c + 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = wmh_lrelu(fmaf(v[i], sc, sh), slope);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float wk = wseg[k * C + c];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lg[k][i] = fmaf(v[i], wk, lg[k][i]);
+        }
+    }
+    if (cs > 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[cs - 1][k][i][qi] = lg[k][i];
+    }
+    __syncthreads();
+    if (cs == 0 && q < nq) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lg[k][i] = ((lg[k][i] + part[0][k][i][qi]) + part[1][k][i][qi]) + part[2][k][i][qi];
+            *reinterpret_cast<f4v*>(out + ((size_t)b * K + k) * P + 4 * q) = f4v{lg[k][0], lg[k][1], lg[k][2], lg[k][3]};
+        }
+    }
+}
 static int seghead_logits(const float* x, const float* ss, const float* wseg, int K, float* out, int n, int C,
                           size_t spatial, float lrelu_slope, int in16, void* stream) {
     if (!x || !wseg || !out || n < 1 || C < 1 || spatial < 1) return wmh_fail(WMH_EINVAL, "seghead_logits: bad args");
     unsigned gx = cdivu(spatial, 256); if (gx > 65535) gx = 65535;
     hipStream_t st = (hipStream_t)stream;
     if (!in16 && spatial % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && K >= 2 && K <= 4) {
+        if (spatial / 4 <= 131072 && C >= 16) {                 // the smaller stages: channel slices per workgroup (seghead_logits4s_kernel)
+            const unsigned gs = cdivu(spatial / 4, 64);
+            if (K == 2) hipLaunchKernelGGL((seghead_logits4s_kernel<2>), dim3(gs, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+            else if (K == 3) hipLaunchKernelGGL((seghead_logits4s_kernel<3>), dim3(gs, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+            else hipLaunchKernelGGL((seghead_logits4s_kernel<4>), dim3(gs, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+            return wmh_check_launch("seghead_logits4s_kernel");
+        }
         unsigned g4 = cdivu(spatial / 4, 256); if (g4 > 65535) g4 = 65535;
         if (K == 2) hipLaunchKernelGGL((seghead_logits4_kernel<2>), dim3(g4, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
         else if (K == 3) hipLaunchKernelGGL((seghead_logits4_kernel<3>), dim3(g4, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);

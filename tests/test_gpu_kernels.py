@@ -378,6 +378,29 @@ def test_extract_patches_flips_and_padding(lib):
         assert np.array_equal(out[b].cpu().numpy(), ref), 'item %d' % b
 
 
+@pytest.mark.parametrize('shape', [(2, 37, 2, (8, 8, 12)), (1, 256, 2, (16, 16, 16)), (2, 64, 3, (6, 10, 14)), (2, 16, 4, (4, 4, 4))], ids=str)
+def test_seghead_logits_channel_sliced_form(lib, shape):
+    """The deep-supervision heads of the stages at 64^3 and below run four channel slices per workgroup and sum them through LDS
+    (seghead_logits4s_kernel): against the einsum of the activated tensor, channel counts that do not divide by four, a ragged last workgroup,
+    2-4 classes; twice the same bits."""
+    from deepwmh_amd import _lib
+    n, Cc, K, Pz = shape
+    g = torch.Generator().manual_seed(Cc)
+    x = torch.randn(n, Cc, *Pz, generator=g)
+    ss = torch.stack([0.5 + torch.rand(n, Cc, generator=g), 0.3 * torch.randn(n, Cc, generator=g)], -1)
+    wseg = torch.randn(K, Cc, generator=g) / np.sqrt(Cc)
+    xd, ssd, wd = x.cuda(), ss.cuda(), wseg.cuda()
+    outs = []
+    for _ in range(2):
+        lg = torch.full((n, K) + tuple(Pz), float('nan'), device='cuda')
+        _lib.check(lib.wmh_seghead_logits(P(xd), P(ssd), P(wd), K, P(lg), n, Cc, int(np.prod(Pz)), SLOPE, None), 'logits')
+        torch.cuda.synchronize()
+        outs.append(lg.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.einsum('kc,ncxyz->nkxyz', wseg.double(), _lrelu_affine(x, ss).double())
+    assert float((outs[0].double() - ref).abs().max()) <= 2e-6 * (1 + float(ref.abs().max()))
+
+
 def test_seghead_softmax_mirror_accumulate_and_finalize(lib):
     from deepwmh_amd import _lib
     from deepwmh_amd.sliding_window import get_gaussian
