@@ -293,13 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_pipe_kernel(const Wgra
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dW, size_t n, int P) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float s = part[i];
-        for (int p = 1; p < P; ++p) s += part[(size_t)p * n + i];       // fixed order
-        dW[i] = s;
-    }
-}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dW, size_t n, int P) { wmh_slab_reduce_body(part, dW, n, P); }   // wmh_common.h
 
 struct WgradPlan { int TX, TY, TZ, IZ, IY, IX, ntx, nty, ntz, ntiles, NG, NCG, P, dys, xcs, lds_bytes; };
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -407,7 +401,7 @@ extern "C" int wmh_conv3d_wgrad(const float* x0, const float* ss0, int C0, const
 #undef WA
     if (rc != WMH_OK) return rc;
     const size_t n = (size_t)Cout * Cin * 9 * kz;
-    unsigned rb = (unsigned)((n + 255) / 256); if (rb > 2048) rb = 2048;
+    const unsigned rb = wmh_slab_reduce_blocks(n);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, workspace, dW, n, q.P);
     return wmh_check_launch("wgrad_reduce_kernel");
 }

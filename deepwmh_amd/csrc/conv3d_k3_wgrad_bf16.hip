@@ -212,13 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16_kernel(const Wgra
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* part, float* dW, size_t n, int P) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float s = part[i];
-        for (int p = 1; p < P; ++p) s += part[(size_t)p * n + i];       // fixed order
-        dW[i] = s;
-    }
-}
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* part, float* dW, size_t n, int P) { wmh_slab_reduce_body(part, dW, n, P); }   // wmh_common.h
 
 struct WBPlan { int TX, TY, TZ, ntx, nty, ntz, ntiles, NG, NCG, P; };
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -266,7 +260,7 @@ extern "C" int wmh_conv3d_k3_wgrad_bf16(const float* x0, const float* ss0, int C
     const int rc = q.TX == 32 ? launch_wb<32, 4, 2>(a, nblk, st) : launch_wb<16, 8, 2>(a, nblk, st);
     if (rc != WMH_OK) return rc;
     const size_t n = (size_t)Cout * Cin * 27;
-    unsigned rb = (unsigned)((n + 255) / 256); if (rb > 2048) rb = 2048;
+    const unsigned rb = wmh_slab_reduce_blocks(n);
     hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(rb), dim3(256), 0, st, workspace, dW, n, q.P);
     return wmh_check_launch("wgrad_bf16_reduce_kernel");
 }

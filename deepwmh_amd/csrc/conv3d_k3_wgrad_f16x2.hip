@@ -387,13 +387,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv3d_k3_wgrad_f16x2_kernel(c
     if (stamping && lane == 0 && wave == 4) { WMH_STAMPS(a)[blockIdx.x * 4 + 2] = st_work; WMH_STAMPS(a)[blockIdx.x * 4 + 3] = st_wait; }
 }
 
-__global__ __launch_bounds__(256) void wgrad_f16x2_reduce_kernel(const float* part, float* dW, size_t n, int P) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float s = part[i];
-        for (int p = 1; p < P; ++p) s += part[(size_t)p * n + i];       // fixed order
-        dW[i] = s;
-    }
-}
+__global__ __launch_bounds__(256) void wgrad_f16x2_reduce_kernel(const float* part, float* dW, size_t n, int P) { wmh_slab_reduce_body(part, dW, n, P); }   // wmh_common.h
 
 struct WPPlan { int TX, TY, TZ, ntx, nty, ntz, ntiles, NG, NCG, P, order, m, q, nk; };
 static inline int wp_cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -467,7 +461,7 @@ static int wgrad_f16x2_impl(const float* x0, const float* ss0, int C0, const flo
                    : (q.TX == 32 ? launch_wp<1, 32, 4, 2, 8>(a, nblk, st) : launch_wp<1, 16, 8, 2, 8>(a, nblk, st));
     if (rc != WMH_OK) return rc;
     const size_t n = (size_t)Cout * Cin * 27;
-    unsigned rb = (unsigned)((n + 255) / 256); if (rb > 2048) rb = 2048;
+    const unsigned rb = wmh_slab_reduce_blocks(n);
     hipLaunchKernelGGL(wgrad_f16x2_reduce_kernel, dim3(rb), dim3(256), 0, st, workspace, dW, n, q.P);
     return wmh_check_launch("wgrad_f16x2_reduce_kernel");
 }

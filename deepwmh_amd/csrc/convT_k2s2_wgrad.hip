@@ -136,13 +136,7 @@ __global__ __launch_bounds__(256, 2) void convT_k2s2_wgrad_kernel(const CTWArgs 
     }
 }
 
-__global__ __launch_bounds__(256) void convT_wgrad_reduce_kernel(const float* part, float* dW, size_t n, int P) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float s = part[i];
-        for (int p = 1; p < P; ++p) s += part[(size_t)p * n + i];       // fixed order
-        dW[i] = s;
-    }
-}
+__global__ __launch_bounds__(256) void convT_wgrad_reduce_kernel(const float* part, float* dW, size_t n, int P) { wmh_slab_reduce_body(part, dW, n, P); }   // wmh_common.h
 
 struct CTWPlan { int TX, TY, TZ, ntx, nty, ntz, ntiles, NG, NCG, P; };
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -200,7 +194,7 @@ extern "C" int wmh_convtranspose3d_wgrad(const float* x, const float* ss, const 
     }
     if (rc != WMH_OK) return rc;
     const size_t n = (size_t)Cin * Cout * 4 * kt;
-    unsigned rb = (unsigned)((n + 255) / 256); if (rb > 2048) rb = 2048;
+    const unsigned rb = wmh_slab_reduce_blocks(n);
     hipLaunchKernelGGL(convT_wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, workspace, dW, n, q.P);
     return wmh_check_launch("convT_wgrad_reduce_kernel");
 }
