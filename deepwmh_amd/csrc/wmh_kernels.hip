@@ -551,7 +551,9 @@ static int seghead_logits(const float* x, const float* ss, const float* wseg, in
     unsigned gx = cdivu(spatial, 256); if (gx > 65535) gx = 65535;
     hipStream_t st = (hipStream_t)stream;
     if (!in16 && spatial % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && K >= 2 && K <= 4) {
-        if (spatial / 4 <= 131072 && C >= 16) {                 // the smaller stages: channel slices per workgroup (seghead_logits4s_kernel)
+        // the smaller stages (>= 64 channels below the full-resolution level: the 32-channel head keeps the one-thread summation order, which its
+        // bf16-tensor form shares bit for bit): channel slices per workgroup (seghead_logits4s_kernel)
+        if (spatial / 4 <= 131072 && C >= 64) {
             const unsigned gs = cdivu(spatial / 4, 64);
             if (K == 2) hipLaunchKernelGGL((seghead_logits4s_kernel<2>), dim3(gs, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
             else if (K == 3) hipLaunchKernelGGL((seghead_logits4s_kernel<3>), dim3(gs, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);

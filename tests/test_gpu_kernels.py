@@ -378,7 +378,7 @@ def test_extract_patches_flips_and_padding(lib):
         assert np.array_equal(out[b].cpu().numpy(), ref), 'item %d' % b
 
 
-@pytest.mark.parametrize('shape', [(2, 37, 2, (8, 8, 12)), (1, 256, 2, (16, 16, 16)), (2, 64, 3, (6, 10, 14)), (2, 16, 4, (4, 4, 4))], ids=str)
+@pytest.mark.parametrize('shape', [(2, 77, 2, (8, 8, 12)), (1, 256, 2, (16, 16, 16)), (2, 64, 3, (6, 10, 14)), (2, 320, 4, (4, 4, 4))], ids=str)
 def test_seghead_logits_channel_sliced_form(lib, shape):
     """The deep-supervision heads of the stages at 64^3 and below run four channel slices per workgroup and sum them through LDS
     (seghead_logits4s_kernel): against the einsum of the activated tensor, channel counts that do not divide by four, a ragged last workgroup,
