@@ -16,6 +16,7 @@ step, RCCL all-gather of the weighted tiles).  `--tta 0` drops nnU-Net's 8-fold 
 reference's `--disable_tta` stage-II predictions); the default keeps it, as `DeepWMH_predict` does.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -80,10 +81,15 @@ def parse_args(argv=None):
                          'step, its patches split over the ranks with an RCCL all-gather of the weighted tiles (strong)')
     ap.add_argument('--also', choices=['auto', 'off'], default='auto',
                     help='auto (N=1, fp32 headline only): after the headline, measure configs[2] (channels-last bf16, 8 volumes per '
-                         'step), the f16x2 mode and one training iteration (fp32, bf16) and report them in an "also" object')
+                         'step), the exact-fp32 kernels and one training iteration (fp32, f16x2) and report them in an "also" object')
     ap.add_argument('--cli', choices=['auto', 'off'], default='auto',
                     help='auto (with --also auto): after everything else, run bin/nnUNet_predict (with mirroring; with --disable_tta --save_softmax) '
                          'and bin/nnUNet_train as child processes on BASELINE-sized cases and report their rates in `cli` / `summary.cli`')
+    ap.add_argument('--legs', choices=['auto', 'off', 'only'], default='auto',
+                    help='the two collective paths north_star names, on the ranks of this run, after the headline: configs[3] (ONE volume, its patches over '
+                         'the ranks, RCCL all_gather_into_tensor of the weighted tiles) and configs[4] (f16x2 training iterations, gradient all-reduce under '
+                         'the backward pass) -> `summary.configs3_patch_sharded` / `summary.configs4_ddp`.  auto: at N > 1 in-process; at N = 1 in a child '
+                         'process whose ONE-rank RCCL group forces every collective (the rehearsal).  only: nothing but the two legs')
     ap.add_argument('--detail-file', default='auto',
                     help='where the FULL record goes (every mode with its clock samples, phases, parity objects, sample descriptions); the one '
                          'printed line carries the numbers only.  auto: gpurun_out/bench_detail.json when gpurun_out/ exists, else nowhere')
@@ -528,7 +534,7 @@ def training_parity_tiny():
     loss = ot.multiple_output_loss(net(x.double()), tgt, weights)
     loss.backward()
     out = {}
-    for precision in ('fp32', 'f16x2', 'bf16'):
+    for precision in ('fp32', 'f16x2'):
         tr = UNetTrainer(plan, sd, 'cuda:0', precision=precision)
         tr.forward(x.cuda())
         l = float(tr.backward(downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)).cpu())
@@ -639,6 +645,225 @@ def measure_cli(plan, sd, shape, n_mirror=12, n_softmax=40, train_batches=40):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------
+# the two collective paths of north_star on the ranks of this run (BASELINE.json configs[3], configs[4])
+# ------------------------------------------------------------------------------------------------------------
+class _DryTileBackend:
+    """CPU stand-in of distributed.HipTileBackend for `--dry-run`: the geometry is the real one (steps, Gaussian, patch order), a tile is a
+    cheap deterministic function of the volume window -- enough to prove the exchange, the fixed accumulation order and the ragged last round."""
+
+    def __init__(self, patch):
+        self.patch = tuple(patch)
+
+    def geometry(self, V):
+        import torch
+        from deepwmh_amd.sliding_window import compute_steps_for_sliding_window, get_gaussian
+        A = tuple(max(v, p) for v, p in zip(V, self.patch))
+        self.pad_lo = tuple((a - v) // 2 for a, v in zip(A, V))
+        st = compute_steps_for_sliding_window(self.patch, A, 0.5)
+        origins = [(x, y, z) for x in st[0] for y in st[1] for z in st[2]]
+        self.gauss = torch.from_numpy(get_gaussian(self.patch)) if len(origins) > 1 else None
+        self.A = A
+        return A, self.pad_lo, origins, 2, self.patch
+
+    def zeros(self, shape):
+        import torch
+        return torch.zeros(shape, dtype=torch.float32)
+
+    def tile(self, vol, origin):
+        import torch
+        P, (x, y, z) = self.patch, origin
+        pad = torch.zeros((vol.shape[0],) + self.A)
+        lo = self.pad_lo
+        pad[:, lo[0]:lo[0] + vol.shape[1], lo[1]:lo[1] + vol.shape[2], lo[2]:lo[2] + vol.shape[3]] = vol
+        w = pad[0, x:x + P[0], y:y + P[1], z:z + P[2]]
+        p1 = torch.sigmoid(3.0 * w + 0.01 * (x + 2 * y + 3 * z))
+        t = torch.stack([1.0 - p1, p1])
+        return t * self.gauss if self.gauss is not None else t
+
+    def accumulate(self, agg, tile, origin):
+        P, (x, y, z) = self.patch, origin
+        agg[:, x:x + P[0], y:y + P[1], z:z + P[2]] += tile
+
+    def count_map(self, A, origins):
+        import torch
+        cnt, P = torch.zeros(A), self.patch
+        for (x, y, z) in origins:
+            cnt[x:x + P[0], y:y + P[1], z:z + P[2]] += self.gauss if self.gauss is not None else 1.0
+        return cnt
+
+    def finalize(self, agg, cnt, pad_lo, V):
+        sl = tuple(slice(l, l + v) for l, v in zip(pad_lo, V))
+        prob = (agg / cnt)[(slice(None),) + sl]
+        import torch
+        return prob.argmax(0).to(torch.uint8), prob
+
+
+def _predicted(section, world):
+    """profiles/r05g_shard_cost.json: what ONE rank does was measured on one MI355X (round 5), the wire was modelled at 100 / 153 GB/s per xGMI link."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r05g_shard_cost.json')) as f:
+            return json.load(f)[section]['predicted'].get('W%d' % world)
+    except Exception:
+        return None
+
+
+def multi_gpu_legs(args, rank, world, device, dry=False, volumes=10, iters=8):
+    """configs[3] and configs[4] with the headline's protocol (barrier + device synchronisation on both sides, MAX over ranks).  At world size 1
+    the collectives are forced through the one-rank group (`force_collective`): the RCCL kernels run, nothing crosses a link.  Every rank
+    calls this; the dict is complete on rank 0."""
+    import torch
+    import torch.distributed as dist
+    from deepwmh_amd.distributed import OverlappedGradientAverager, PatchShardedPredictor
+    force = world == 1
+    cuda = not dry
+
+    def barrier():
+        if dist.is_initialized():
+            dist.barrier()
+        if cuda:
+            torch.cuda.synchronize()
+
+    def timed(fn, n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if cuda else 'cpu')
+        if dist.is_initialized() and world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    out = {}
+    # ---- configs[3]: ONE volume at a time, patch r, r + W, ... on rank r, one all_gather_into_tensor per round --------------------------
+    if dry:
+        shape, patch = (40, 48, 40), (32, 32, 32)
+        backend = _DryTileBackend(patch)
+        vol = torch.randn((1,) + shape, generator=torch.Generator().manual_seed(0))
+        serial = PatchShardedPredictor.__new__(PatchShardedPredictor)      # the serial loop: a one-rank predictor without a group
+        serial.b, serial.group, serial.force, serial.rank, serial.world, serial.stall_marks = backend, None, False, 0, 1, None
+        serial_predict = lambda: serial.predict(vol)
+    else:
+        from deepwmh_amd.distributed import HipTileBackend
+        from deepwmh_amd.network import UNetEngine
+        from deepwmh_amd.plan import baseline_plan
+        from deepwmh_amd.sliding_window import SlidingWindowPredictor
+        from deepwmh_amd.synthetic import he_init_state_dict, synthetic_flair
+        plan = baseline_plan()
+        sd = he_init_state_dict(plan, seed=0)
+        eng = UNetEngine(plan, sd, device, precision='f16x2')
+        pred = SlidingWindowPredictor(eng, do_mirroring=True, batch=8)     # a rank's round = the 8 mirrored copies of ONE tile
+        backend = HipTileBackend(pred)
+        vol = torch.from_numpy(synthetic_flair(tuple(args.shape), seed=0)).to(device)
+        serial_predict = lambda: pred.predict_device(vol, return_prob=True)
+    sharded = PatchShardedPredictor(backend, force_collective=force)
+    seg, prob = sharded.predict(vol)                                        # warm-up (exchange buffers, RCCL channels)
+    seg, prob = seg.clone(), prob.clone()
+    identical = None
+    if rank == 0:
+        s0, p0 = serial_predict()
+        identical = bool(torch.equal(s0, seg) and torch.equal(p0, prob))
+    sharded.stall_marks = []
+    dt = timed(lambda: sharded.predict(vol), volumes)
+    exposed = sharded.exposed_exchange_ms() / volumes
+    sharded.stall_marks = None
+    ntile = len(backend.geometry(tuple(vol.shape[1:]))[2])
+    tile_bytes = 4 * 2 * int(np.prod(backend.patch if dry else pred.patch))
+    out['configs3_patch_sharded'] = dict(
+        world=dist.get_world_size() if dist.is_initialized() else 1, volumes=volumes, volumes_per_s=round(volumes / dt, 3), ms_per_volume=round(1e3 * dt / volumes, 2),
+        exposed_exchange_ms_per_volume_rank0=round(exposed, 3), rounds_per_volume=-(-ntile // world), all_gather_bytes_per_round=world * tile_bytes,
+        bit_identical_to_serial_rank0=identical, forced_one_rank_collective=force, predicted=_predicted('configs3_patch_sharded', world),
+        scaling='strong', dry_run=dry or None)
+    if not dry:
+        del sharded, backend, pred, eng
+        torch.cuda.empty_cache()
+    # ---- configs[4]: data-parallel training iterations, gradient all-reduce in >= 8 MB runs under the backward pass ---------------------
+    if dry:
+        sizes = [40, 8, 400, 12, 1000, 4, 36]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        ranges = {'p%d' % i: (int(offs[i]), int(offs[i + 1])) for i in range(len(sizes))}
+        g = torch.zeros(int(offs[-1]))
+        av = OverlappedGradientAverager(g, ranges, None, min_elems=300, force_collective=force)
+        base = torch.arange(int(offs[-1]), dtype=torch.float32)
+
+        def iteration():
+            g.copy_(base * (rank + 1))
+            for names in (['p6', 'p5'], ['p4'], ['p1'], ['p2', 'p3'], ['p0']):
+                av.ready(names)
+            av.finish()
+        iteration()
+        ok = bool(torch.equal(g, base * (sum(range(1, world + 1)) / world)))
+        dt = timed(iteration, iters)
+        nbytes, nmsg, losses = 4 * g.numel(), 3, None
+    else:
+        from deepwmh_amd.trainer import UNetTrainer, downsample_targets
+        tr = UNetTrainer(plan, sd, device, precision='f16x2')
+        gen = torch.Generator(device='cpu').manual_seed(rank)               # every rank its own two patches
+        x = torch.randn(2, 1, 128, 128, 128, generator=gen).to(device)
+        lab = (torch.rand(2, 128, 128, 128, generator=gen) < 0.05).to(torch.uint8).to(device)
+        td = downsample_targets(lab, plan.num_pool, plan.pool_op_kernel_sizes)
+        nmsg = [0]
+
+        def iteration():
+            tr.forward(x)
+            loss = tr.backward(td, None, force_collective=force)
+            nmsg[0] = getattr(tr._avg, 'last_messages', 0)
+            tr.optimizer_step(1e-2)
+            return loss
+        losses = [float(iteration().cpu()) for _ in range(2)]
+        dt = timed(iteration, iters)
+        # the parameters must be the same on every rank after the averaged steps
+        chk = tr.params.double().sum().reshape(1)
+        ok = True
+        if world > 1:
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            ok = bool((lo == hi).item())
+        nbytes, nmsg = 4 * int(tr.grads.numel()), nmsg[0]
+        del tr
+        torch.cuda.empty_cache()
+    out['configs4_ddp'] = dict(
+        world=dist.get_world_size() if dist.is_initialized() else 1, iterations=iters, ms_per_iteration=round(1e3 * dt / iters, 3), patches_per_s=round(2 * world * iters / dt, 2),
+        all_reduce_bytes_per_iteration=nbytes, all_reduce_messages_per_iteration=nmsg, parameters_identical_on_all_ranks=ok,
+        forced_one_rank_collective=force, predicted=_predicted('configs4_data_parallel_training', world), scaling='weak',
+        loss_first_two=losses, dry_run=dry or None)
+    return out
+
+
+def legs_child():
+    """The N = 1 form of the two legs: a fresh child process whose first GPU act is a ONE-rank RCCL group (the parent keeps its context; never an
+    exec).  Returns the child's dict or {'error': ...}."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), '--legs', 'only', '--gpus', '1'], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    for ln in reversed(p.stdout.splitlines()):
+        if ln.startswith('LEGS '):
+            return json.loads(ln[5:])
+    return dict(error='rc %d: %s' % (p.returncode, p.stdout[-300:]))
+
+
+
+def legs_summary(legs):
+    """The two legs' figures for the printed line: numbers only (the full dicts go to the detail file).  `pred`: the round-5 cost model's
+    figure for this world size at 100 / 153 GB/s per link (profiles/r05g_shard_cost.json), None at world size 1."""
+    if 'error' in legs:
+        return dict(legs_error=legs['error'][-200:])
+    c3, c4 = legs['configs3_patch_sharded'], legs['configs4_ddp']
+    p3, p4 = c3.get('predicted') or {}, c4.get('predicted') or {}
+    return dict(
+        configs3_patch_sharded=dict(world=c3['world'], volumes_per_s=c3['volumes_per_s'], exposed_exchange_ms=c3['exposed_exchange_ms_per_volume_rank0'],
+                                    bit_identical=c3['bit_identical_to_serial_rank0'], forced=c3['forced_one_rank_collective'],
+                                    pred=[v['volumes_per_s'] for k, v in sorted(p3.items()) if k.startswith('link_')] or None),
+        configs4_ddp=dict(world=c4['world'], ms_per_iteration=c4['ms_per_iteration'], patches_per_s=c4['patches_per_s'],
+                          all_reduce_mbytes=round(c4['all_reduce_bytes_per_iteration'] / 1e6, 1), same_params=c4['parameters_identical_on_all_ranks'],
+                          pred_ms=[v['iteration_ms'] for k, v in sorted(p4.items()) if k.startswith('link_')] or None))
+
+
 def compact_line(res):
     """The ONE printed line.  The driver keeps the last 2000 characters of stdout, so: the contract's keys, numbers only (prose lives in
     DESIGN.md, the full record in --detail-file), and LAST a `summary` that holds every mode's headline figure."""
@@ -690,7 +915,7 @@ def compact_line(res):
             pmax['configs2_bf16_vs_fp32_path'] = rnd(pf['max_abs_softmax_diff'], 3)
             summary['configs2_dice_vs_fp32_mask'] = rnd(pf['dice_vs_fp32_mask'], 6)
     tm, tpar = {}, {}
-    for prec in ('fp32', 'f16x2', 'bf16'):
+    for prec in ('fp32', 'f16x2'):
         t = also.get('train_' + prec)
         if t:
             tm[prec] = rnd(t['ms_per_step'])
@@ -733,6 +958,8 @@ def compact_line(res):
         if errs:
             c['failed'] = errs
         summary['cli'] = c
+    if res.get('legs'):
+        summary.update(legs_summary(res['legs']))
     line['summary'] = summary                      # last key: it must survive the driver's 2000-character tail
     return line
 
@@ -760,10 +987,14 @@ def run_rank(args):
             t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        legs = multi_gpu_legs(args, rank, world, 'cpu', dry=True, volumes=2, iters=2) if (world > 1 and args.legs != 'off') else None
         if rank == 0:
-            print(json.dumps(dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=None,
-                                  unit='volumes/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
-                                  ms_per_step=1e3 * dt / args.steps, dry_run=True)), flush=True)
+            res = dict(metric='FLAIR volumes/sec sliding-window inference (160x192x160)', value=None,
+                       unit='volumes/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                       ms_per_step=1e3 * dt / args.steps, dry_run=True)
+            if legs:
+                res['summary'] = legs_summary(legs)
+            print(json.dumps(res), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return 0
@@ -777,6 +1008,17 @@ def run_rank(args):
     if world > 1:
         dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL
     device = 'cuda:%d' % local_rank
+
+    if args.legs == 'only':
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', rank=0, world_size=1)       # one-rank RCCL group: every collective is forced through it
+        legs = multi_gpu_legs(args, rank, world, device)
+        if rank == 0:
+            print('LEGS ' + json.dumps(legs), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return 0
 
     plan = baseline_plan()
     sd = he_init_state_dict(plan, seed=0)
@@ -838,6 +1080,16 @@ def run_rank(args):
                 roofline['in_kernel'] = ik
         except Exception as e:                          # diagnostics only
             roofline['in_kernel'] = dict(error=str(e))
+
+    legs = None
+    if world > 1 and args.legs == 'auto':
+        # the collective paths on the same ranks, after the headline's timed region (its buffers are released first)
+        eng._bufs.clear()
+        torch.cuda.empty_cache()
+        try:
+            legs = multi_gpu_legs(args, rank, world, device)
+        except Exception as e:                          # (every rank raises or none: the legs' collectives are symmetric)
+            legs = dict(error='%s: %s' % (type(e).__name__, e))
 
     if rank == 0:
         forwards = 8 * (8 if tta else 1)
@@ -910,12 +1162,12 @@ def run_rank(args):
             also['configs2_bf16_storage'] = m
             del e16, ref32
             torch.cuda.empty_cache()
-            for prec in ('fp32', 'f16x2', 'bf16'):
+            for prec in ('fp32', 'f16x2'):
                 also['train_' + prec] = measure_training_mode(plan, sd, device, prec, 8, 2)
                 torch.cuda.empty_cache()
             if args.cpu_baseline != 'off':
                 tp = training_parity_tiny()
-                for prec in ('fp32', 'f16x2', 'bf16'):
+                for prec in ('fp32', 'f16x2'):
                     also['train_' + prec]['parity'] = tp[prec]
             res['also'] = also
         if world == 1 and args.cpu_baseline != 'off':
@@ -935,13 +1187,19 @@ def run_rank(args):
             # the boundary: the commands themselves, as children, after everything this process measures (its tensors are released first)
             del pred
             eng._bufs.clear()
-            import gc
             gc.collect()
             torch.cuda.empty_cache()
             nm_kernel = measure_no_mirroring_rate(plan, sd, device, args.shape)
             res['cli'] = measure_cli(plan, sd, args.shape)
             res['cli']['kernel_only'] = dict(mirroring_volumes_per_s=round(res['value'], 3), no_mirroring_volumes_per_s=nm_kernel,
                                              train_ms_f16x2=res['also']['train_f16x2']['ms_per_step'])
+        if legs is None and also_on and args.legs == 'auto':
+            del eng
+            gc.collect()
+            torch.cuda.empty_cache()
+            legs = legs_child()
+        if legs:
+            res['legs'] = legs
         detail = args.detail_file
         if detail in ('none', 'off', ''):
             detail = None

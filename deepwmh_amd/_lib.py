@@ -79,22 +79,17 @@ SIGNATURES = {
     'wmh_convtranspose3d_wgrad': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_dice_ce_loss_workspace_doubles': (_sz, []),
     'wmh_dice_ce_loss_fwd_bwd': (_i, [_vp, _vp, _i, _i, _sz, _f, _f, _vp, _vp, _vp, _vp]),
+    'wmh_online_eval_counts': (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp]),
     'wmh_in_lrelu_bwd_scratch_doubles': (_sz, [_i, _i, _sz]),
     'wmh_in_lrelu_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _sz, _f, _vp]),
     'wmh_channel_sum': (_i, [_vp, _vp, _i, _i, _sz, _vp]),
     'wmh_convtranspose3d_k2s2_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
-    'wmh_conv3d_k3_wgrad_bf16_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
-    'wmh_conv3d_k3_wgrad_bf16_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i]),
-    'wmh_conv3d_k3_wgrad_bf16': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3_wgrad_f16x2_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_wgrad_f16x2_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3s2_wgrad_f16x2_workspace_floats': (_sz, [_i, _i, _i, _i, _i, _i]),
     'wmh_conv3d_k3_wgrad_f16x2': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'wmh_conv3d_k3s2_wgrad_f16x2': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    'wmh_conv3d_k3_wgrad_f16x2_stamp_count': (_sz, [_i, _i, _i, _i, _i, _i]),
-    'wmh_debug_set_conv_stamps': (None, [_vp]),
     'wmh_diag_build': (_i, []),
-    'wmh_conv3d_k3_wgrad_f16x2_stamped': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     'wmh_convtranspose3d_packed_dwords_f16x2': (_sz, [_i, _i, _i]),
     'wmh_convtranspose3d_pack_weights_f16x2_device': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'wmh_convtranspose3d_fwd_f16x2': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
@@ -187,6 +182,14 @@ def load():
     return lib
 
 
+# include/deepwmh_amd_diag.h: exported by libdeepwmh_amd_diag.so only
+DIAG_SIGNATURES = {
+    'wmh_debug_set_conv_stamps': (None, [_vp]),
+    'wmh_conv3d_k3_wgrad_f16x2_stamp_count': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'wmh_conv3d_k3_wgrad_f16x2_stamped': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+}
+
+
 def load_diag():
     """The diagnostic library as a SECOND handle beside the product library (bench.py's in-kernel clock leg, tools/): same ABI."""
     global _diag
@@ -195,7 +198,7 @@ def load_diag():
             raise ImportError('deepwmh_amd: %s not found (python deepwmh_amd/build.py builds it next to the product library)' % DIAG_LIB_PATH)
         import torch  # noqa: F401
         lib = C.CDLL(DIAG_LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(DIAG_SIGNATURES.items()):
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

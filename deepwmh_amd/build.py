@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdeepwmh_amd.so')
 DIAG_LIB = os.path.join(LIBDIR, 'libdeepwmh_amd_diag.so')      # -DWMH_DIAG: cycle stamps + WMH_* variant switches (csrc/wmh_common.h)
-SOURCES = ['conv3d_k3.hip', 'conv3d_k3_ws.hip', 'conv3d_k3_bf16.hip', 'conv3d_k3_bf16_ws.hip', 'conv3d_k3s2_f16x2_ws.hip', 'conv3d_up_f16x2.hip', 'conv3d_k3_wgrad.hip', 'conv3d_k3_wgrad_bf16.hip', 'conv3d_k3_wgrad_f16x2.hip', 'conv3d_k3s2_dgrad.hip', 'conv3d_k3s2_dgrad_f16x2.hip', 'convT_k2s2.hip', 'convT_k2s2_f16x2.hip', 'convT_k2s2_wgrad.hip', 'train_kernels.hip', 'volume_ops.hip', 'resample.hip', 'stage1_kernels.hip', 'wmh_kernels.hip', 'cl_conv3.hip', 'cl_misc.hip']
+SOURCES = ['conv3d_k3.hip', 'conv3d_k3_ws.hip', 'conv3d_k3_bf16.hip', 'conv3d_k3_bf16_ws.hip', 'conv3d_k3s2_f16x2_ws.hip', 'conv3d_up_f16x2.hip', 'conv3d_k3_wgrad.hip', 'conv3d_k3_wgrad_f16x2.hip', 'conv3d_k3s2_dgrad.hip', 'conv3d_k3s2_dgrad_f16x2.hip', 'convT_k2s2.hip', 'convT_k2s2_f16x2.hip', 'convT_k2s2_wgrad.hip', 'train_kernels.hip', 'volume_ops.hip', 'resample.hip', 'stage1_kernels.hip', 'wmh_kernels.hip', 'cl_conv3.hip', 'cl_misc.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-result', '-Rpass-analysis=kernel-resource-usage']
 

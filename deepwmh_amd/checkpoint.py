@@ -154,7 +154,7 @@ class CheckpointProcess:
                    PYTHONPATH=root + (os.pathsep + os.environ['PYTHONPATH'] if os.environ.get('PYTHONPATH') else ''))
         self.proc = subprocess.Popen([sys.executable, '-m', 'deepwmh_amd.cli._ckpt_writer'], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
                                      env=env, text=True, bufsize=1)
-        self.pending = 0
+        self.pending = self._since_snap = 0
         self._send(dict(op='init', order=[[n, list(s)] for n, s in param_order], offsets=[int(v) for v in offsets], plans=plans_file))
         self._snap, self._n = None, 0
 
@@ -162,12 +162,17 @@ class CheckpointProcess:
         self.proc.stdin.write(self._json.dumps(job) + '\n')
         self.proc.stdin.flush()
         self.pending += 1
+        self._since_snap += 1
 
     def snapshot(self, params_flat, momentum_flat=None):
         """params_flat / momentum_flat: host float32 arrays (the whole arenas).  Files of the previous snapshot are dropped once the
         jobs that use them have run (the drop is queued behind them)."""
+        # at most TWO snapshots alive (what `need` budgets): everything older than the current snapshot's own jobs -- in particular the
+        # drop of the snapshot before it -- has to be acknowledged before a new one is written (a failed write surfaces here, too)
+        self.drain(keep=self._since_snap)
         if self._snap:
             self._send(dict(op='drop', files=[f for f in self._snap if f]))
+        self._since_snap = 0
         self._n += 1
         pf = os.path.join(self.dir, 'params_%d.f32' % self._n)
         params_flat.tofile(pf)
@@ -197,6 +202,16 @@ class CheckpointProcess:
             self.pending -= 1
             if not line.startswith('ok'):
                 raise RuntimeError('checkpoint writer: ' + line.strip())
+
+    def abort(self):
+        """The training loop is going down with an exception: no waiting, no half-written promises -- end the helper, remove the arenas."""
+        import shutil
+        try:
+            self.proc.kill()
+            self.proc.wait(timeout=10)
+        except Exception:
+            pass
+        shutil.rmtree(self.dir, ignore_errors=True)
 
     def close(self):
         import shutil

@@ -286,10 +286,23 @@ def main(argv=None):
         saves = []
         nxt = [0]
 
+        warmed = threading.Event()
+
         def lane(k):
             p_k, stream = lanes[k]
             with torch.cuda.stream(stream):
-                p_k.warm_up()       # buffers + code objects while the first cases are being read (0.5 s that the first case used to carry)
+                # buffers + code objects while the first cases are being read (0.5 s that the first case used to carry).  The lanes share the
+                # lazily built weight images (UNetEngine.clone is shallow): lane 0 builds them all, the others start behind it -- on the host
+                # (no image is composed twice) and on the device (their streams wait for the stream the images were built on)
+                if k == 0:
+                    try:
+                        p_k.warm_up()
+                    finally:
+                        warmed.set()
+                else:
+                    warmed.wait()
+                    stream.wait_stream(lanes[0][1])
+                    p_k.warm_up()
                 while True:
                     with lock:
                         i = nxt[0]

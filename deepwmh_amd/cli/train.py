@@ -49,6 +49,7 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     from .. import checkpoint as ck
+    from ..criterion import NUM_VAL_BATCHES_PER_EPOCH, ModelBestCriterion, epoch_metric
     from ..data import DATA_ID, PatchLoader, PrefetchLoader
     from ..plan import UNetPlan
     from ..synthetic import he_init_state_dict
@@ -86,11 +87,8 @@ def main(argv=None):
     precision = os.environ.get('WMH_TRAIN_PRECISION', 'f16x2')
     if args.fp32:
         precision = 'fp32'
-    # (bf16 operands -- UNetTrainer(precision='bf16') -- are a library switch only, reachable here through WMH_TRAIN_PRECISION=bf16: its
-    #  gradients are 8.6 % off float64 autograd on the tiny net (bench.py, summary.train_gradient_rel_l2_vs_float64_tiny_net), so the
-    #  command DeepWMH runs 22 500 iterations with does not offer it as a flag)
-    if precision not in ('fp32', 'f16x2', 'bf16'):
-        sys.exit('nnUNet_train (deepwmh_amd): WMH_TRAIN_PRECISION must be fp32, f16x2 or bf16, got %r' % precision)
+    if precision not in ('fp32', 'f16x2'):              # (the bf16 mixed-precision mode of rounds 1-5 -- gradients 8.6 % off -- is gone)
+        sys.exit('nnUNet_train (deepwmh_amd): WMH_TRAIN_PRECISION must be fp32 or f16x2, got %r' % precision)
     start_epoch, best, ma_resume = 0, None, None
     latest = os.path.join(fdir, 'model_latest.model')
     if args.continue_training and os.path.isfile(latest):
@@ -101,7 +99,7 @@ def main(argv=None):
         if mom is not None:
             tr.mom.copy_(torch.as_tensor(np.asarray(mom)).to(tr.mom.device))
             tr.first_step = False
-        # the loss scale belongs to the precision it was found in: a checkpoint of an fp32 / bf16 run stores 1.0, and continuing it with
+        # the loss scale belongs to the precision it was found in: a checkpoint of an fp32 run stores 1.0, and continuing it with
         # the f16x2 backward at scale 1 would run fp16-pair gradients in the regime trainer.py documents as 7 % off
         saved_scale, saved_prec = info['checkpoint'].get('deepwmh_amd_loss_scale'), info['checkpoint'].get('deepwmh_amd_precision')
         if saved_scale and tr.loss_scale != 1.0 and saved_prec == precision:
@@ -123,8 +121,8 @@ def main(argv=None):
         dist.broadcast(tr.params, 0); dist.broadcast(tr.mom, 0)
     loader = PrefetchLoader(PatchLoader(stage_dir, train_cases, plan.patch_size, bs, seed=args.seed + 1000 * rank + start_epoch))
     vloader = PatchLoader(stage_dir, val_cases, plan.patch_size, bs, seed=args.seed + 77, mirror=False)
-    nval = args.val_batches if args.val_batches is not None else max(1, min(50, args.batches_per_epoch // 5))
-    ma = ma_resume                                      # the smoothed criterion continues across `-c` (it decides model_best)
+    nval = args.val_batches if args.val_batches is not None else NUM_VAL_BATCHES_PER_EPOCH      # nnU-Net: 50, whatever -b says
+    crit = ModelBestCriterion(ma_resume, best)          # nnU-Net's rule (criterion.py); the moving average continues across `-c`
 
     # Checkpoint files are written by a helper PROCESS, in order (cli/_ckpt_writer.py says why not a thread): the training process only takes
     # the host snapshot -- one D2H copy of the flat parameter arena per epoch (and of the momentum where training can continue from), one raw
@@ -139,8 +137,7 @@ def main(argv=None):
         if rank != 0:
             return
         if snap['epoch'] != epoch:                           # parameters as they are now; later files of this epoch reuse the snapshot
-            writer.drain(keep=4)                             # bounded: at most one epoch's files in flight
-            snap['epoch'] = epoch
+            snap['epoch'] = epoch                            # (snapshot() itself waits until at most one older snapshot is alive)
             writer.snapshot(tr.params.detach().cpu().numpy())
         # nnU-Net's checkpoint carries plain types; the json line does too (best / ma are floats or None)
         extra = dict(deepwmh_amd_best=None if best is None else float(best), deepwmh_amd_ma=None if ma is None else float(ma),
@@ -150,39 +147,53 @@ def main(argv=None):
             writer.add_momentum(tr.mom.detach().cpu().numpy())
         writer.save(folder, args.fold, name, epoch, extra, with_momentum=latest)
 
-    for epoch in range(start_epoch, args.epochs):
-        lr = poly_lr(epoch, args.epochs, 1e-2, 0.9)
-        t0, losses = time.time(), []
-        for _ in range(args.batches_per_epoch):
-            data, seg = loader.next_batch()
-            x = torch.from_numpy(data).to(device)
-            tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool, plan.pool_op_kernel_sizes)
-            losses.append(tr.run_iteration(x, tg, lr).clone())           # stays on the device: no per-iteration sync
-        losses = [float(v) for v in torch.stack(losses).cpu()]          # synchronises: the epoch's iterations are done
-        t_train = time.time() - t0
-        skipped_before, losses = getattr(tr, '_skipped_reported', 0), [v for v in losses if np.isfinite(v)] or [float('nan')]
-        vl = []
-        for _ in range(nval):
-            data, seg = vloader.next_batch()
-            x = torch.from_numpy(data).to(device)
-            tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool, plan.pool_op_kernel_sizes)
-            vl.append(float(tr.run_iteration(x, tg, lr, do_backprop=False).cpu()))
-        v = float(np.mean(vl))
-        ma = -v if ma is None else 0.9 * ma + 0.1 * (-v)           # moving-average criterion (higher is better)
-        if rank == 0:
-            print('epoch %d/%d: lr %.6f train loss %.4f val loss %.4f (%.1f s: %d iterations at %.1f ms, validation %.2f s)'
-                  % (epoch + 1, args.epochs, lr, float(np.mean(losses)), v, time.time() - t0, args.batches_per_epoch,
-                     1e3 * t_train / max(1, args.batches_per_epoch), time.time() - t0 - t_train), flush=True)
-            if tr.skipped_steps != skipped_before:      # GradScaler semantics: the device skipped updates whose gradient norm was not finite
-                print('  %d optimizer step(s) skipped (non-finite gradients); loss scale now %g' % (tr.skipped_steps - skipped_before, tr.loss_scale), flush=True)
-        tr._skipped_reported = tr.skipped_steps
-        if best is None or ma > best:
-            best = ma
-            save('model_best', epoch + 1)
-        if args.save_every_epoch:
-            save('model_ep_%04d' % (epoch + 1), epoch + 1)
-        save('model_latest', epoch + 1)                  # last: carries this epoch's `best`, so a `-c` run cannot overwrite a better model_best
-    save('model_final_checkpoint', args.epochs)
+    ma = ma_resume
+    try:
+        for epoch in range(start_epoch, args.epochs):
+            lr = poly_lr(epoch, args.epochs, 1e-2, 0.9)
+            t0, losses = time.time(), []
+            for _ in range(args.batches_per_epoch):
+                data, seg = loader.next_batch()
+                x = torch.from_numpy(data).to(device)
+                tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool, plan.pool_op_kernel_sizes)
+                losses.append(tr.run_iteration(x, tg, lr).clone())           # stays on the device: no per-iteration sync
+            losses = [float(v) for v in torch.stack(losses).cpu()]          # synchronises: the epoch's iterations are done
+            t_train = time.time() - t0
+            skipped_before, losses = getattr(tr, '_skipped_reported', 0), [v for v in losses if np.isfinite(v)] or [float('nan')]
+            vl = []
+            if getattr(tr, 'eval_counts', None) is not None:
+                tr.eval_counts.zero_()
+            for _ in range(nval):
+                data, seg = vloader.next_batch()
+                x = torch.from_numpy(data).to(device)
+                tg = downsample_targets(torch.from_numpy(seg).to(device), plan.num_pool, plan.pool_op_kernel_sizes)
+                vl.append(tr.run_iteration(x, tg, lr, do_backprop=False).clone())
+                tr.online_eval(tg[0])                             # hard tp / fp / fn of the full-resolution output, summed over the epoch's batches
+            vl = [float(t) for t in torch.stack(vl).cpu()]
+            v = float(np.mean(vl))
+            metric = epoch_metric(tr.eval_counts.cpu().numpy(), plan.num_classes)
+            is_best = crit.update(metric, v)
+            ma, best = crit.ma, crit.best
+            if rank == 0:
+                print('epoch %d/%d: lr %.6f train loss %.4f val loss %.4f val dice %s MA %.4f%s (%.1f s: %d iterations at %.1f ms, validation %.2f s)'
+                      % (epoch + 1, args.epochs, lr, float(np.mean(losses)), v, 'n/a' if metric is None else '%.4f' % metric, ma,
+                         ' -> model_best' if is_best else '', time.time() - t0, args.batches_per_epoch,
+                         1e3 * t_train / max(1, args.batches_per_epoch), time.time() - t0 - t_train), flush=True)
+                if tr.skipped_steps != skipped_before:      # GradScaler semantics: the device skipped updates whose gradient norm was not finite
+                    print('  %d optimizer step(s) skipped (non-finite gradients); loss scale now %g' % (tr.skipped_steps - skipped_before, tr.loss_scale), flush=True)
+            tr._skipped_reported = tr.skipped_steps
+            if is_best:
+                save('model_best', epoch + 1)
+            if args.save_every_epoch:
+                save('model_ep_%04d' % (epoch + 1), epoch + 1)
+            save('model_latest', epoch + 1)                  # last: carries this epoch's `best`, so a `-c` run cannot overwrite a better model_best
+        save('model_final_checkpoint', args.epochs)
+    except BaseException:
+        # (an exception, Ctrl-C or sys.exit inside the loop: the helper process and its several hundred MB of raw arenas in /dev/shm must not stay behind)
+        if writer is not None:
+            writer.abort()
+        loader.close()
+        raise
     if writer is not None:
         writer.close()                                       # waits for every file; a failed write fails the command
     loader.close()

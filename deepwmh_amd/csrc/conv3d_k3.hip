@@ -404,7 +404,9 @@ static const CfgInfo& cfg_info(int cfg) {
 unsigned long long* g_conv_stamps = nullptr;       // diagnostics: also read by the bf16 launcher
 // diagnostics: device buffer of 4 x uint64 per workgroup that the next conv launches fill (NULL = off)
 // (libdeepwmh_amd_diag.so only: the product library has no stamp code in its kernels, wmh_common.h)
+#ifdef WMH_DIAG
 extern "C" void wmh_debug_set_conv_stamps(void* p) { g_conv_stamps = (unsigned long long*)p; }
+#endif
 extern "C" int wmh_diag_build(void) {
 #ifdef WMH_DIAG
     return 1;

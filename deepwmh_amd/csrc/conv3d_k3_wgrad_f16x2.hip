@@ -475,7 +475,9 @@ extern "C" int wmh_conv3d_k3s2_wgrad_f16x2(const float* x0, const float* ss0, in
                                            float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream) {
     return wgrad_f16x2_impl(x0, ss0, C0, x1, ss1, C1, dy, dW, workspace, N, D, H, W, Cout, 2, lrelu_slope, nullptr, stream);
 }
-// diagnostics: the same launch with per-workgroup cycle counts (4 per workgroup: consumer work / wait, loader work / wait)
+// diagnostics (libdeepwmh_amd_diag.so only, include/deepwmh_amd_diag.h): the same launch with per-workgroup cycle counts (4 per workgroup:
+// consumer work / wait, loader work / wait)
+#ifdef WMH_DIAG
 extern "C" size_t wmh_conv3d_k3_wgrad_f16x2_stamp_count(int Cin, int Cout, int N, int D, int H, int W) {
     WPPlan q;
     if (!plan_wp(Cin, Cout, N, D, H, W, 1, q)) return 0;
@@ -484,8 +486,6 @@ extern "C" size_t wmh_conv3d_k3_wgrad_f16x2_stamp_count(int Cin, int Cout, int N
 extern "C" int wmh_conv3d_k3_wgrad_f16x2_stamped(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
                                                  float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope,
                                                  unsigned long long* stamps, void* stream) {
-#ifndef WMH_DIAG
-    if (stamps) return wmh_fail(WMH_EINVAL, "conv3d_k3_wgrad_f16x2_stamped: cycle stamps exist in libdeepwmh_amd_diag.so only");
-#endif
     return wgrad_f16x2_impl(x0, ss0, C0, x1, ss1, C1, dy, dW, workspace, N, D, H, W, Cout, 1, lrelu_slope, stamps, stream);
 }
+#endif

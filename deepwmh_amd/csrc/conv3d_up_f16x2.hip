@@ -149,7 +149,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_up_f16x2_kernel(const ConvArgs 
                 shv[c] = c <= cmax ? sh1 : 0.f;
             }
         };
-        const int abl = a.KS;                                         // diagnostics (timing only): 2 = weights loaded at the start only, 4 = conflict-free LDS writes
+#ifdef WMH_DIAG
+        const int abl = a.KS;                                         // diagnostic library (timing only; WMH_UP_ABL): 2 = weights loaded at the start only, 4 = conflict-free LDS writes
+#else
+        constexpr int abl = 1;                                        // the product build has no such switch
+#endif
         auto convert = [&](auto sc, int buf) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
             uint4* dst = ldsq + (size_t)buf * LVOX * 2;
@@ -474,8 +478,9 @@ extern "C" int wmh_conv3d_up_pack_weights_f16x2(const float* w3, int Cin_total, 
                             const int ci = ch * 8 + e;
                             float v = (co < Cout && ci < Clow) ? (float)wc[(size_t)co * Clow + ci] : 0.f;
                             v *= WMH_PAIR_WSCALE;
-                            if (!(v > -65000.f)) v = -65000.f;
-                            if (!(v < 65000.f)) v = 65000.f;
+                            // a composed weight sums up to Cup products: it can leave fp16's range although both layers pass their own checks;
+                            // refused like the other packers refuse (NaN fails the comparison too); the engine then keeps the two-kernel stage
+                            if (!(fabsf(v) < 65000.f)) return wmh_fail(WMH_EINVAL, "conv3d_up_pack_weights_f16x2: composed weight not finite or beyond fp16's range (|256 w| >= 65000)");
                             const _Float16 h = (_Float16)v;
                             const _Float16 l = (_Float16)(v - (float)h);
                             memcpy(&hi[e], &h, 2); memcpy(&lo[e], &l, 2);

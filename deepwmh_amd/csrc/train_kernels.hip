@@ -155,6 +155,65 @@ extern "C" int wmh_dice_ce_loss_fwd_bwd(const float* logits, const uint8_t* targ
 extern "C" size_t wmh_dice_ce_loss_workspace_doubles(void) { return 16 + 1024 * 13; }
 
 // =================================================================================================
+// Online evaluation of a validation batch (nnUNetTrainer.run_online_evaluation [nnU-Net, not in tree]; what decides `model_best`,
+// which DeepWMH releases and predicts with: /root/reference/deepwmh/pipeline/DCNN_multistage.py:529-533, 608-611)
+// =================================================================================================
+// seg = argmax_k logits (== argmax of the softmax; first index on ties, as torch.argmax); per foreground class c:
+// counts[c-1] += #(seg == c & y == c), counts[(K-1)+c-1] += #(seg == c & y != c), counts[2(K-1)+c-1] += #(seg != c & y == c).
+// Integer sums: the atomics' order cannot change them.
+template <int K>
+__global__ __launch_bounds__(256) void online_eval_counts_kernel(const float* logits, const uint8_t* target,
+                                                                 unsigned long long* counts, int N, size_t S) {
+    __shared__ unsigned sh[4][3 * (K - 1)];
+    const size_t M = (size_t)N * S;
+    unsigned acc[3 * (K - 1)];
+#pragma unroll
+    for (int q = 0; q < 3 * (K - 1); ++q) acc[q] = 0u;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < M; idx += (size_t)gridDim.x * 256) {
+        const size_t n = idx / S, v = idx - n * S;
+        float best = logits[(n * K) * S + v];
+        int seg = 0;
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+            const float l = logits[(n * K + k) * S + v];
+            if (l > best) { best = l; seg = k; }
+        }
+        const int y = target[idx];
+#pragma unroll
+        for (int c = 1; c < K; ++c) {
+            acc[c - 1] += (seg == c && y == c);
+            acc[(K - 1) + c - 1] += (seg == c && y != c);
+            acc[2 * (K - 1) + c - 1] += (seg != c && y == c);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3 * (K - 1); ++q) {
+        unsigned t = acc[q];
+        for (int m = 1; m < 64; m <<= 1) t += __shfl_xor(t, m);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][q] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * (K - 1)) {
+        const unsigned long long t = (unsigned long long)sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        if (t) atomicAdd(counts + threadIdx.x, t);
+    }
+}
+extern "C" int wmh_online_eval_counts(const float* logits, const uint8_t* target, int N, int K, size_t S,
+                                      unsigned long long* counts, void* stream) {
+    if (!logits || !target || !counts || N <= 0 || S == 0) return wmh_fail(WMH_EINVAL, "online_eval_counts: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t M = (size_t)N * S;
+    unsigned nblk = cdivu(M, 256 * 8); if (nblk > 2048) nblk = 2048; if (nblk < 1) nblk = 1;
+    switch (K) {
+        case 2: hipLaunchKernelGGL((online_eval_counts_kernel<2>), dim3(nblk), dim3(256), 0, st, logits, target, counts, N, S); break;
+        case 3: hipLaunchKernelGGL((online_eval_counts_kernel<3>), dim3(nblk), dim3(256), 0, st, logits, target, counts, N, S); break;
+        case 4: hipLaunchKernelGGL((online_eval_counts_kernel<4>), dim3(nblk), dim3(256), 0, st, logits, target, counts, N, S); break;
+        default: return wmh_fail(WMH_EINVAL, "online_eval_counts: K must be 2, 3 or 4");
+    }
+    return wmh_check_launch("online_eval_counts_kernel");
+}
+
+// =================================================================================================
 // InstanceNorm + LeakyReLU backward (with the segmentation head folded in)
 // =================================================================================================
 // Upstream gradient of the activated tensor a = lrelu(z), z = y*scale+shift:

@@ -23,7 +23,7 @@ int wmh_check_launch(const char* what) {
     return WMH_OK;
 }
 extern "C" const char* wmh_last_error(void) { return g_err; }
-extern "C" int wmh_abi_version(void) { return 1; }
+extern "C" int wmh_abi_version(void) { return 6; }
 extern "C" int wmh_device_check(int dev) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) != hipSuccess) return wmh_fail(WMH_ENODEV, "no HIP device");

@@ -97,6 +97,7 @@ class OverlappedGradientAverager:
         assert self.sent == sum(hi - lo for lo, hi in self.ranges.values())
         for w in self.works:
             w.wait()
+        self.last_messages = len(self.works)
         if self.active and self.world > 1:
             self.flat.div_(self.world)
         self.begin()
@@ -120,6 +121,22 @@ class PatchShardedPredictor:
         self.force = bool(force_collective) and dist.is_initialized()
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.stall_marks = None            # a list: bench.py's configs[3] leg asks how long the accumulate stream stood waiting for the exchange
+
+    def _mark(self, like):
+        """A time mark on the stream the tiles are computed on (HIP event) or on the host (CPU stand-ins: gloo's wait blocks the host)."""
+        if like.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        import time
+        return time.perf_counter()
+
+    def exposed_exchange_ms(self):
+        """Sum over the marked waits of (stream released by the exchange) - (stream arrived at the wait): the part of the all-gathers
+        that the next round's forwards did not cover.  Call after a device synchronisation; clears the marks."""
+        marks, self.stall_marks = self.stall_marks or [], []
+        return sum((a.elapsed_time(b) if hasattr(a, 'elapsed_time') else 1e3 * (b - a)) for a, b in marks)
 
     def _exchange_buffers(self, W, K, P):
         """Two send tiles and two gather buffers (W x 16.8 MB each at the BASELINE plan), allocated once per geometry."""
@@ -142,7 +159,10 @@ class PatchShardedPredictor:
         def drain(item):                                     # round rd's tiles, in the fixed global patch order
             work, gathered, rd = item
             if work is not None:
+                a = self._mark(gathered) if self.stall_marks is not None else None
                 work.wait()
+                if a is not None:
+                    self.stall_marks.append((a, self._mark(gathered)))
             for w in range(W):
                 j = rd * W + w
                 if j < len(origins):

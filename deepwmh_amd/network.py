@@ -289,9 +289,11 @@ class UNetEngine:
             wimg = np.zeros(self.lib.wmh_conv3d_up_packed_bytes_f16x2(Cl, layer.cout), np.uint8)
             w3 = np.ascontiguousarray(layer.w_host.reshape(layer.cout, layer.cin, 27))
             wt = np.ascontiguousarray(st['tu_host'].reshape(Cl, Cu, 8))
-            _lib.check(self.lib.wmh_conv3d_up_pack_weights_f16x2(w3.ctypes.data_as(C.c_void_p), layer.cin, Cu, wt.ctypes.data_as(C.c_void_p), Cl,
-                                                                 layer.cout, wimg.ctypes.data_as(C.c_void_p)), 'wmh_conv3d_up_pack_weights_f16x2')
-            st['up_wimg'] = torch.from_numpy(wimg).to(self.device)
+            rc = self.lib.wmh_conv3d_up_pack_weights_f16x2(w3.ctypes.data_as(C.c_void_p), layer.cin, Cu, wt.ctypes.data_as(C.c_void_p), Cl,
+                                                           layer.cout, wimg.ctypes.data_as(C.c_void_p))
+            # a composed weight beyond fp16's range (or not finite): this stage is "not fusable" for good -- transposed convolution + two-source
+            # convolution, whose own packers decide about the two layers' weights
+            st['up_wimg'] = torch.from_numpy(wimg).to(self.device) if rc == 0 else None
         return st['up_wimg']
 
     def _dec_first_fused(self, key, st, low, low_ss, skip, skip_ss):
@@ -310,8 +312,10 @@ class UNetEngine:
         cfg = lib.wmh_conv3d_k3_bf16_config(_lib.check(lib.wmh_conv3d_config(Cs, layer.cout, D, H, W, 3, 1, 1), 'wmh_conv3d_config'), layer.cout, W)
         if cfg not in (0, 2, 21) or not lib.wmh_conv3d_k3_f16x2_supported(cfg):
             return None
-        wf = layer.packed_f16x2_slice(cfg, Cu, Cs)
         wimg = self._up_image(st)
+        if wimg is None:
+            return None
+        wf = layer.packed_f16x2_slice(cfg, Cu, Cs)
         npart = _lib.check(lib.wmh_conv3d_up_num_partials_f16x2(D, H, W), 'wmh_conv3d_up_num_partials_f16x2')
         y = self._buf(key + '.y', (N, layer.cout, D, H, W))
         part = self._buf(key + '.part', (N, layer.cout, npart, 4))

@@ -42,14 +42,11 @@ class _Conv:
 
 class UNetTrainer:
     def __init__(self, plan: UNetPlan, state_dict, device='cuda:0', momentum=0.99, weight_decay=3e-5, clip=12.0, precision='fp32'):
-        """precision 'fp32', or 'bf16' = mixed precision in the spirit of the reference's AMP default [nnU-Net run_iteration,
-        fp16=True]: the stride-1 convolutions of the >= 16-wide levels (forward and data gradient) multiply bf16-rounded
-        operands with fp32 accumulation; weights, activations, statistics, weight gradients, loss and optimizer stay fp32
-        (bf16 keeps fp32's exponent range, so no loss scaling)."""
-        if precision not in ('fp32', 'bf16', 'f16x2'):
-            raise ValueError('precision must be fp32, bf16 or f16x2')
+        """precision 'fp32' (the exact-fp32 kernels) or 'f16x2'.  (Rounds 1-5 also had a 'bf16' mixed-precision mode -- bf16 matrix-core
+        operands in the wide layers; gradients 8.6 % off float64 autograd on the tiny net -- removed in round 6: f16x2 is as fast and exact.)"""
+        if precision not in ('fp32', 'f16x2'):
+            raise ValueError('precision must be fp32 or f16x2')
         self.precision = precision
-        self.bf16_forward = self.bf16_dgrad = self.bf16_wgrad = precision == 'bf16'      # diagnostic switches (tools/diag_bf16_train.py)
         # 'f16x2': forward and stride-1 data-gradient convolutions with rows of >= 16 voxels form their products from fp16 pairs
         # (network.py, DESIGN.md 3.2: fp32-grade, 2-2.7x the fp32 instruction's speed); weight gradients and everything else fp32
         self.x3 = precision == 'f16x2'
@@ -172,10 +169,6 @@ class UNetTrainer:
         self._packed[key] = (self._version, wf)
         return wf
 
-    def _use_bf16(self, cfg, stride, C0, C1, which='fwd'):
-        return ((self.bf16_forward if which == 'fwd' else self.bf16_dgrad) and stride == 1 and cfg in (0, 2) and bool(self.lib.wmh_conv3d_k3_bf16_supported(cfg))
-                and (C1 == 0 or C0 % 16 == 0))
-
     def _use_x3(self, cfg_b, stride, C0, C1, W, fwd=False):
         # the forward pass also has pair kernels for the strided layers (configurations 1, 3, 5: as the inference engine uses them);
         # their data gradients stay on the fp32 gather kernel
@@ -252,33 +245,6 @@ class UNetTrainer:
                    'wmh_conv3d_k3_fwd_f16x2')
         return y, part, npart
 
-    def _pack_bf16(self, conv, cfg, mode, ci_off, ci_cnt):
-        key = (conv.name, cfg, mode, ci_off, ci_cnt, 'bf16')
-        hit = self._packed.get(key)
-        if hit is not None and hit[0] == self._version:
-            return hit[1]
-        ecin, ecout = (ci_cnt, conv.cout) if mode == 0 else (conv.cout, ci_cnt)
-        n = self.lib.wmh_conv3d_k3_packed_halfs_bf16(cfg, ecin, ecout)
-        wf = hit[1] if hit is not None else torch.empty(n, dtype=torch.int16, device=self.device)
-        _lib.check(self.lib.wmh_conv3d_k3_pack_weights_bf16_device(cfg, _lib.ptr(self.p[conv.name + '.conv.weight']), conv.cin, conv.cout,
-                                                                   ci_off, ci_cnt, mode, _lib.ptr(wf), self._st()),
-                   'wmh_conv3d_k3_pack_weights_bf16_device')
-        self._packed[key] = (self._version, wf)
-        return wf
-
-    def _run_conv_bf16(self, key, cfg, x0, ss0, x1, ss1, wf, bias, cout, want_stats):
-        N, C0, D, H, W = x0.shape
-        C1 = 0 if x1 is None else x1.shape[1]
-        y = self._buf(key + '.y', (N, cout, D, H, W))
-        part, npart = None, 0
-        if want_stats:
-            npart = _lib.check(self.lib.wmh_conv3d_k3_num_partials_bf16(cfg, N, D, H, W), 'num_partials_bf16')
-            part = self._buf(key + '.part', (N, cout, npart, 4))
-        _lib.check(self.lib.wmh_conv3d_k3_fwd_bf16(cfg, _lib.ptr(x0), _lib.ptr(ss0), C0, _lib.ptr(x1), _lib.ptr(ss1), C1, _lib.ptr(wf),
-                                                   _lib.ptr(bias), _lib.ptr(y), _lib.ptr(part), N, D, H, W, cout, LRELU_SLOPE, self._st()),
-                   'wmh_conv3d_k3_fwd_bf16')
-        return y, part, npart
-
     def _run_conv(self, key, cfg, x0, ss0, x1, ss1, wf, bias, cout, stride, want_stats, sz=0):
         N, C0, D, H, W = x0.shape
         C1 = 0 if x1 is None else x1.shape[1]
@@ -304,10 +270,6 @@ class UNetTrainer:
         if cfg_x3 >= 0 and self._use_x3(cfg_x3, conv.stride, x0.shape[1], C1, W, fwd=True):
             wf = self._pack_x3(conv, cfg_x3, 0, 0, conv.cin)
             y, part, npart = self._run_conv_x3(key, cfg_x3, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout, True, conv.stride)
-        elif conv.iso and self._use_bf16(cfg, conv.stride, x0.shape[1], C1):
-            cfg = self.lib.wmh_conv3d_k3_bf16_config(cfg, conv.cout, W)          # wide tile for >= 64 output channels
-            wf = self._pack_bf16(conv, cfg, 0, 0, conv.cin)
-            y, part, npart = self._run_conv_bf16(key, cfg, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout, True)
         else:
             wf = self._pack(conv, cfg, 0, 0, conv.cin)
             y, part, npart = self._run_conv(key, cfg, x0, ss0, x1, ss1, wf, self.p[conv.name + '.conv.bias'], conv.cout,
@@ -443,12 +405,6 @@ class UNetTrainer:
                 _lib.check(fn(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
                               _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, LRELU_SLOPE, st),
                            'wmh_conv3d_k3s2_wgrad_f16x2' if s2 else 'wmh_conv3d_k3_wgrad_f16x2')
-            elif self.bf16_wgrad and lib.wmh_conv3d_k3_wgrad_bf16_supported(C0 + C1, Cc, N, D, H, W, conv.stride):
-                nws = lib.wmh_conv3d_k3_wgrad_bf16_workspace_floats(C0 + C1, Cc, N, D, H, W)
-                ws = self._buf(wskey, (nws,))
-                _lib.check(lib.wmh_conv3d_k3_wgrad_bf16(_lib.ptr(x0), _lib.ptr(rec['ss0']), C0, _lib.ptr(x1), _lib.ptr(rec['ss1']), C1, _lib.ptr(dy),
-                                                        _lib.ptr(self.g[conv.name + '.conv.weight']), _lib.ptr(ws), N, D, H, W, Cc, LRELU_SLOPE, st),
-                           'wmh_conv3d_k3_wgrad_bf16')
             else:
                 nws = lib.wmh_conv3d_k3_wgrad_workspace_floats(C0 + C1, Cc, N, D, H, W, conv.stride)
                 ws = self._buf(wskey, (nws,))
@@ -518,10 +474,6 @@ class UNetTrainer:
             if cfg_x3 >= 0 and self._use_x3(cfg_x3, 1, Cc, 0, W):
                 wf = self._pack_x3(conv, cfg_x3, 1, off, cnt)
                 dx, _, _ = self._run_conv_x3('b.dx%d.%s' % (part, rec['key']), cfg_x3, src, None, None, None, wf, None, cnt, False)
-            elif conv.kz == 3 and self._use_bf16(cfg, 1, Cc, 0, 'dgrad'):
-                cfg = lib.wmh_conv3d_k3_bf16_config(cfg, cnt, W)
-                wf = self._pack_bf16(conv, cfg, 1, off, cnt)
-                dx, _, _ = self._run_conv_bf16('b.dx%d.%s' % (part, rec['key']), cfg, src, None, None, None, wf, None, cnt, False)
             else:
                 wf = self._pack(conv, cfg, 1, off, cnt)
                 dx, _, _ = self._run_conv('b.dx%d.%s' % (part, rec['key']), cfg, src, None, None, None, wf, None, cnt, 1, False)
@@ -613,6 +565,7 @@ class UNetTrainer:
             if cfg_x3 in (1, 3, 5, 25, 26) and bool(lib.wmh_conv3d_k3_f16x2_supported(cfg_x3)):     # the strided pair kernels on the embedded image
                 key = ('tu.dgrad.x3', u, cfg_x3)
                 hit = self._packed.get(key)
+                self._x3_used[key] = self._version          # (as _pack_x3: an image nobody records is dropped by repack_x3_batch)
                 if hit is None or hit[0] != self._version:
                     wfx = hit[1] if hit is not None else torch.empty(lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg_x3, cskip, Cin), dtype=torch.int16,
                                                                      device=self.device)
@@ -689,6 +642,17 @@ class UNetTrainer:
         if do_backprop:
             self.optimizer_step(lr)
         return loss
+
+    def online_eval(self, target_full):
+        """nnUNetTrainerV2.run_online_evaluation on the batch the last forward() saw: the hard tp / fp / fn counts of every foreground class at
+        full resolution, ADDED to `self.eval_counts` (int64 [3 (K - 1)], zero it where an epoch's validation starts).  What `model_best` is
+        decided by (criterion.py)."""
+        if getattr(self, 'eval_counts', None) is None:
+            self.eval_counts = torch.zeros(3 * (self.K - 1), dtype=torch.int64, device=self.device)
+        lg = self.tape['dec'][len(self.dec) - 1]['logits']
+        _lib.check(self.lib.wmh_online_eval_counts(_lib.ptr(lg), _lib.ptr(target_full), lg.shape[0], self.K, int(np.prod(lg.shape[2:])),
+                                                   _lib.ptr(self.eval_counts), self._st()), 'wmh_online_eval_counts')
+        return self.eval_counts
 
     def loss_only(self, targets):
         nd = len(self.dec)

@@ -34,7 +34,7 @@ extern "C" {
 #define WMH_MAX_BATCH_ITEMS 16
 
 const char* wmh_last_error(void);
-int wmh_abi_version(void);
+int wmh_abi_version(void);        /* 6 (round 6); 1 through rounds 1-5 although entry points were added every round */
 /* Returns 0 when device `dev` is a gfx950 part this library was built for. */
 int wmh_device_check(int dev);
 
@@ -301,31 +301,16 @@ size_t wmh_conv3d_k3_wgrad_workspace_floats(int Cin, int Cout, int N, int D, int
 int wmh_conv3d_k3_wgrad(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1,
                         const float* dy, float* dW, float* workspace, int N, int D, int H, int W, int Cout,
                         int stride, float lrelu_slope, void* stream);
-/* The same weight gradient with bf16 matrix-core operands (mixed-precision training): dy and the activated input are rounded
- * to bf16 on their way into LDS, products accumulate in fp32, slabs / reduction / dW stay fp32.  Stride 1, rows of >= 12
- * voxels (wmh_conv3d_k3_wgrad_bf16_supported); workspace >= wmh_conv3d_k3_wgrad_bf16_workspace_floats(...) floats. */
-int wmh_conv3d_k3_wgrad_bf16_supported(int Cin, int Cout, int N, int D, int H, int W, int stride);
-size_t wmh_conv3d_k3_wgrad_bf16_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
-int wmh_conv3d_k3_wgrad_bf16(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
-                             float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
 /* 1 in libdeepwmh_amd_diag.so (the same sources compiled with -DWMH_DIAG: s_memtime stamps in the persistent kernels, WMH_* environment
- * switches that select kernel variants), 0 in libdeepwmh_amd.so, the product, which contains neither. */
+ * switches that select kernel variants, and the extra entry points of include/deepwmh_amd_diag.h), 0 in libdeepwmh_amd.so, the product,
+ * which contains none of them. */
 int wmh_diag_build(void);
-/* Diagnostics (effective in libdeepwmh_amd_diag.so only; the product's kernels hold no stamp code): with a non-NULL buffer (device memory, 8 x 8 bytes per workgroup and zero-filled by the caller; 2 x grid records for
- * the wave-specialised 16-bit kernels) the persistent convolution kernels launched afterwards add s_memtime cycle counts per workgroup:
- * [0] the first consumer wave's MFMA phases, [1] its barrier waits, [2] its epilogues, [3] chunk iterations, [4..6] a loader wave's work /
- * barrier wait / work beside an epilogue.  s_memtime counts shader-clock cycles, so [0]+[1]+[2] over the launch's duration is the clock the
- * CUs actually ran at (bench.py: roofline.in_kernel; tools/f16x2_check.py).  NULL (the default) switches the stamps off.  Not stream
- * ordered: set it, launch, synchronise, clear it. */
-void wmh_debug_set_conv_stamps(void* stamps);
 
 /* The same weight gradient in the f16x2 "pair" mode (fp32-grade training, the default of nnUNet_train): dy and the activated input
  * are each split into two fp16 numbers (hi toward zero, lo = the remainder: 21-22 significant bits) and kept as one dword per voxel;
  * two v_mfma_f32_32x32x16_f16 per 8 voxels and channel form dy_hi (x_hi + x_lo) + dy_lo (x_hi + x_lo) in fp32 accumulators.
  * |dy|, |x'| up to 131008 (callers scale the loss, as the f16x2 data gradient needs).  Stride 1, rows of >= 8 voxels (stride 2: below)
- * (wmh_conv3d_k3_wgrad_f16x2_supported); workspace >= wmh_conv3d_k3_wgrad_f16x2_workspace_floats(...) floats.  The _stamped form
- * also writes wmh_conv3d_k3_wgrad_f16x2_stamp_count(...) cycle counters (4 per workgroup: consumer work / wait, loader work /
- * wait) -- diagnostics (tools/wgrad_check.py). */
+ * (wmh_conv3d_k3_wgrad_f16x2_supported); workspace >= wmh_conv3d_k3_wgrad_f16x2_workspace_floats(...) floats. */
 int wmh_conv3d_k3_wgrad_f16x2_supported(int Cin, int Cout, int N, int D, int H, int W, int stride);
 size_t wmh_conv3d_k3_wgrad_f16x2_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
 int wmh_conv3d_k3_wgrad_f16x2(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
@@ -336,10 +321,6 @@ int wmh_conv3d_k3_wgrad_f16x2(const float* x0, const float* ss0, int C0, const f
 size_t wmh_conv3d_k3s2_wgrad_f16x2_workspace_floats(int Cin, int Cout, int N, int D, int H, int W);
 int wmh_conv3d_k3s2_wgrad_f16x2(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
                                 float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope, void* stream);
-size_t wmh_conv3d_k3_wgrad_f16x2_stamp_count(int Cin, int Cout, int N, int D, int H, int W);
-int wmh_conv3d_k3_wgrad_f16x2_stamped(const float* x0, const float* ss0, int C0, const float* x1, const float* ss1, int C1, const float* dy,
-                                      float* dW, float* workspace, int N, int D, int H, int W, int Cout, float lrelu_slope,
-                                      unsigned long long* stamps, void* stream);
 /* Data gradient of the stride-2 3x3x3 convolution in gather form (each of the 27 taps feeds exactly one of the 8 output
  * parity classes: the ideal MFMA count, 1/8 of the zero-insert route below).  w = torch layout [Cout][Cin][27] in HBM;
  * wp = its image, wmh_conv3d_k3s2_dgrad_packed_floats(Cin, Cout) floats; dy = [N][Cout][Do][Ho][Wo] with Do = (D-1)/2+1;
@@ -364,6 +345,12 @@ int wmh_upsample_zero2(const float* dy, float* up, int N, int C, int Do, int Ho,
 size_t wmh_dice_ce_loss_workspace_doubles(void);
 int wmh_dice_ce_loss_fwd_bwd(const float* logits, const uint8_t* target, int N, int K, size_t S, float weight,
                              float smooth, float* dlogits, double* loss_accum, double* workspace, void* stream);
+/* Online evaluation of a validation batch (nnUNetTrainer.run_online_evaluation [nnU-Net, not in tree]: the hard counts behind the
+ * `model_best` criterion; reference: deepwmh/pipeline/DCNN_multistage.py:529-533, 608-611 use model_best).  seg = argmax_k logits[n,k,v]
+ * (first index on ties); for each foreground class c = 1..K-1: counts[c-1] += tp, counts[(K-1)+c-1] += fp, counts[2(K-1)+c-1] += fn
+ * (ADDED to what the caller's 3(K-1) 64-bit counters hold: zero them at the start of an epoch's validation). */
+int wmh_online_eval_counts(const float* logits, const uint8_t* target, int N, int K, size_t S,
+                           unsigned long long* counts, void* stream);
 /* Backward of a = lrelu(instnorm(y)) given dA = g1 + g2 + wseg^T dlogits (any subset): writes dy (the gradient of
  * the raw conv output) and the parameter gradients dgamma[C], dbeta[C], dwseg[K][C] and dbias[C] = sum dy (any may
  * be NULL).  scratch = wmh_in_lrelu_bwd_scratch_doubles(N, C, S) doubles. */

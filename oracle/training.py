@@ -109,3 +109,59 @@ def run_iteration(net, optimizer, data, target_list, weights, do_backprop=True):
         torch.nn.utils.clip_grad_norm_(net.parameters(), 12)
         optimizer.step()
     return float(l.detach())
+
+
+# ---- which epoch becomes model_best ----------------------------------------------------------------------------------------------
+# [nnU-Net, not in tree] network_training/nnUNetTrainer.py (`run_online_evaluation`, `finish_online_evaluation`),
+# nnUNetTrainerV2.py (`run_online_evaluation`: full-resolution output / target only), network_trainer.py
+# (`update_eval_criterion_MA`, `manage_patience`, val_eval_criterion_alpha = 0.9, num_val_batches_per_epoch = 50).
+# Reference call sites: /root/reference/deepwmh/pipeline/DCNN_multistage.py:529-533, 608-611 and deepwmh/main/predict.py:149 (`-chk model_best`).
+def run_online_evaluation(output, target):
+    """One validation batch: output [N, K, ...] logits (full resolution), target [N, 1, ...] labels.  Returns (tp, fp, fn) arrays of
+    K - 1 hard counts summed over the batch."""
+    with torch.no_grad():
+        num_classes = output.shape[1]
+        output_seg = torch.softmax(output, 1).argmax(1)
+        target = target[:, 0]
+        axes = tuple(range(1, len(target.shape)))
+        tp = torch.zeros((target.shape[0], num_classes - 1))
+        fp = torch.zeros((target.shape[0], num_classes - 1))
+        fn = torch.zeros((target.shape[0], num_classes - 1))
+        for c in range(1, num_classes):
+            tp[:, c - 1] = ((output_seg == c).float() * (target == c).float()).sum(axes)
+            fp[:, c - 1] = ((output_seg == c).float() * (target != c).float()).sum(axes)
+            fn[:, c - 1] = ((output_seg != c).float() * (target == c).float()).sum(axes)
+        return tp.sum(0).numpy(), fp.sum(0).numpy(), fn.sum(0).numpy()
+
+
+def finish_online_evaluation(tps, fps, fns):
+    """End of an epoch's validation batches: lists of per-batch count arrays -> the epoch's metric (mean global foreground Dice;
+    classes that never occurred and were never predicted drop out; `np.mean([])` = nan when none is left)."""
+    tp, fp, fn = np.sum(tps, 0), np.sum(fps, 0), np.sum(fns, 0)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        per_class = [i for i in [2 * i / (2 * i + j + k) for i, j, k in zip(tp, fp, fn)] if not np.isnan(i)]
+        return np.mean(per_class)
+
+
+def update_eval_criterion_MA(ma, all_val_eval_metrics, all_val_losses, alpha=0.9):
+    if ma is None:
+        return -all_val_losses[-1] if len(all_val_eval_metrics) == 0 else all_val_eval_metrics[-1]
+    if len(all_val_eval_metrics) == 0:
+        return alpha * ma - (1 - alpha) * all_val_losses[-1]
+    return alpha * ma + (1 - alpha) * all_val_eval_metrics[-1]
+
+
+def model_best_epochs(val_eval_metrics, val_losses=None):
+    """Runs `on_epoch_end`'s criterion over a sequence of epochs and returns the (0-based) epochs at which network_trainer.manage_patience
+    writes model_best.model: the first epoch only initialises `best_val_eval_criterion_MA`, afterwards a strictly larger MA saves."""
+    ma, best, saved, metrics, losses = None, None, [], [], []
+    for e, m in enumerate(val_eval_metrics):
+        metrics.append(m)
+        losses.append(0.0 if val_losses is None else val_losses[e])
+        ma = update_eval_criterion_MA(ma, metrics, losses)
+        if best is None:
+            best = ma
+        if ma > best:
+            best = ma
+            saved.append(e)
+    return saved

@@ -27,7 +27,17 @@ def test_header_symbols_all_exported_and_bound(lib):
     for name in declared:
         assert hasattr(lib, name), 'library does not export %s' % name
     assert declared == set(_lib.SIGNATURES), 'ctypes table and header disagree'
-    assert lib.wmh_abi_version() == 1
+    assert lib.wmh_abi_version() == 6                   # bumped in round 6 (it had stayed 1 while entry points were added every round)
+    # measurement aids live in the diagnostic library only (include/deepwmh_amd_diag.h): the product exports none of them
+    dhdr = open(os.path.join(ROOT, 'include', 'deepwmh_amd_diag.h')).read()
+    diag_declared = set(re.findall(r'\b(wmh_[a-z0-9_]+)\s*\(', dhdr))
+    assert diag_declared == set(_lib.DIAG_SIGNATURES) and not (diag_declared & declared)
+    for name in diag_declared:
+        assert not hasattr(lib, name), 'product library exports the diagnostic entry point %s' % name
+    if os.path.exists(_lib.DIAG_LIB_PATH):
+        dlib = C.CDLL(_lib.DIAG_LIB_PATH)
+        for name in declared | diag_declared:
+            assert hasattr(dlib, name), 'diagnostic library does not export %s' % name
 
 
 def test_config_selection(lib):
@@ -145,6 +155,5 @@ def test_wgrad_f16x2_plan_host_side(lib):
     assert ws(640, 320, 1, 16, 16, 16) == 1 * 320 * 640 * 27
     # a single tile: P cannot exceed the tile count
     assert ws(16, 32, 1, 2, 4, 32) == 1 * 32 * 16 * 27
-    assert lib.wmh_conv3d_k3_wgrad_f16x2_stamp_count(32, 32, 2, 128, 128, 128) == 256 * 4
     # argument checks fail loudly
     assert lib.wmh_conv3d_k3_wgrad_f16x2(None, None, 32, None, None, 0, None, None, None, 2, 128, 128, 128, 32, 0.01, None) == -1

@@ -29,6 +29,21 @@ def test_gpus2_from_a_bare_shell_spawns_its_own_ranks():
     assert len(lines) == 1, out.stdout          # rank 0 only
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['steps'] == 2 and res['dry_run'] is True
+    # at N > 1 the same command runs the two collective paths north_star names on the same ranks
+    # (here: gloo, CPU stand-ins for the tiles / the backward pass) and reports them in `summary`
+    c3, c4 = res['summary']['configs3_patch_sharded'], res['summary']['configs4_ddp']
+    assert c3['world'] == 2 and c3['bit_identical'] is True and c3['forced'] is False and c3['volumes_per_s'] > 0
+    assert c3['exposed_exchange_ms'] >= 0 and len(c3['pred']) == 2          # the round-5 cost model's figures for 2 GPUs, beside the measurement
+    assert c4['world'] == 2 and c4['same_params'] is True and c4['ms_per_iteration'] > 0 and len(c4['pred_ms']) == 2
+
+
+@pytest.mark.timeout(300)
+def test_legs_off_keeps_the_collective_free_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '1', '--legs', 'off'],
+                         env=_bare_env(), capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    assert 'summary' not in res
 
 
 @pytest.mark.timeout(300)
@@ -129,12 +144,17 @@ def test_the_printed_line_ends_with_a_summary_that_fits_the_drivers_tail():
                also=dict(fp32_exact=dict(mode(2.175, 0.882, 2393), parity_vs_oracle=dict(max_abs_softmax_err=1.4e-5, argmax_mismatches=0, argmax_mismatches_any_margin=1)),
                          configs2_bf16_storage=dict(mode(12.97, 0.43, 1960), parity_vs_fp32_path=dict(max_abs_softmax_diff=0.0203, dice_vs_fp32_mask=0.998596)),
                          train_fp32=dict(ms_per_step=59.006, roofline=dict(frac=0.617), parity=dict(gradient_rel_l2_err=1.1e-6)),
-                         train_f16x2=dict(ms_per_step=31.779, roofline=dict(frac=0.2163), parity=dict(gradient_rel_l2_err=1.2e-6)),
-                         train_bf16=dict(ms_per_step=26.809, roofline=dict(frac=0.0854), parity=dict(gradient_rel_l2_err=0.086))),
+                         train_f16x2=dict(ms_per_step=31.779, roofline=dict(frac=0.2163), parity=dict(gradient_rel_l2_err=1.2e-6))),
                cli=dict(predict_mirroring=dict(cases=12, cases_per_s=4.83219, first_case_s=0.31, cases_per_s_after_first=5.1234, command_wall_s=5.1, files_written=12),
                         predict_disable_tta_save_softmax=dict(cases=24, cases_per_s=27.512, first_case_s=0.2, cases_per_s_after_first=31.04, command_wall_s=3.3, files_written=48),
                         train=dict(batches_per_epoch=40, ms_per_iteration_in_epoch=28.91, epoch_wall_s=1.21, ms_per_iteration_all_in=30.25, command_wall_s=6.0),
-                        kernel_only=dict(mirroring_volumes_per_s=4.805, no_mirroring_volumes_per_s=38.2, train_ms_f16x2=31.779)))
+                        kernel_only=dict(mirroring_volumes_per_s=4.805, no_mirroring_volumes_per_s=38.2, train_ms_f16x2=31.779)),
+               legs=dict(configs3_patch_sharded=dict(world=1, volumes=10, volumes_per_s=5.512, ms_per_volume=181.4, exposed_exchange_ms_per_volume_rank0=0.213, rounds_per_volume=8,
+                                                     all_gather_bytes_per_round=16777216, bit_identical_to_serial_rank0=True, forced_one_rank_collective=True, predicted=None,
+                                                     scaling='strong', dry_run=None),
+                         configs4_ddp=dict(world=1, iterations=8, ms_per_iteration=25.612, patches_per_s=78.09, all_reduce_bytes_per_iteration=124812288,
+                                           all_reduce_messages_per_iteration=9, parameters_identical_on_all_ranks=True, forced_one_rank_collective=True, predicted=None,
+                                           scaling='weak', loss_first_two=[0.66, 0.65], dry_run=None)))
     line = bench.compact_line(res)
     text = json.dumps(line)
     assert list(line)[-1] == 'summary'
@@ -142,12 +162,14 @@ def test_the_printed_line_ends_with_a_summary_that_fits_the_drivers_tail():
     start = tail.index('"summary"')
     sm = json.loads(tail[start + len('"summary": '):-1])
     assert sm['configs1_f16x2'] == 4.805 and sm['configs1_fp32_exact'] == 2.175 and sm['configs2_bf16'] == 12.97
-    assert sm['train_ms'] == {'fp32': 59.01, 'f16x2': 31.78, 'bf16': 26.81} and sm['frac']['configs1_f16x2'] == 0.4012
+    assert sm['train_ms'] == {'fp32': 59.01, 'f16x2': 31.78} and sm['frac']['configs1_f16x2'] == 0.4012
     assert sm['parity_max_abs']['f16x2_vs_oracle'] == 1.11e-05 and sm['parity_max_abs']['fp32_exact_vs_oracle'] == 1.4e-05
     assert sm['cli'] == {'predict_mirroring': [4.832, 5.123, 4.805], 'predict_disable_tta_save_softmax': [27.51, 31.04, 38.2], 'train_ms': [28.91, 30.25, 31.78]}
+    assert sm['configs3_patch_sharded'] == dict(world=1, volumes_per_s=5.512, exposed_exchange_ms=0.213, bit_identical=True, forced=True, pred=None)
+    assert sm['configs4_ddp'] == dict(world=1, ms_per_iteration=25.612, patches_per_s=78.09, all_reduce_mbytes=124.8, same_params=True, pred_ms=None)
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
                 'roofline', 'cpu_baseline'):
         assert key in line
     assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(line['roofline'])
     assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(line['cpu_baseline'])
-    assert len(text) < 3400 and 'prose' not in text
+    assert len(text) < 3900 and 'prose' not in text

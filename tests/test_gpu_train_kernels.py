@@ -139,6 +139,27 @@ def test_dice_ce_loss(lib, K, shape):
     assert err <= 1e-6 + 1e-4 * float(logits.grad.abs().max()), err
 
 
+@pytest.mark.parametrize('K,shape', [(2, (2, 9, 10, 11)), (3, (1, 16, 16, 16)), (4, (3, 4, 4, 4)), (2, (2, 64, 64, 64))])
+def test_online_eval_counts(lib, K, shape):
+    """The hard tp / fp / fn counts behind nnU-Net's model_best criterion against the oracle's run_online_evaluation: exact integers, added
+    to what the counters hold, ties to the first class (torch.argmax)."""
+    from oracle.training import run_online_evaluation
+    g = torch.Generator().manual_seed(43)
+    N, sp = shape[0], shape[1:]
+    S = int(np.prod(sp))
+    counts = torch.zeros(3 * (K - 1), dtype=torch.int64, device='cuda')
+    want = np.zeros(3 * (K - 1))
+    for b in range(2):
+        logits = torch.randn(N, K, *sp, generator=g)
+        logits[0, :, 0, 0, :3] = 0.25                                   # ties: class 0 wins
+        target = torch.randint(0, K, (N, 1) + tuple(sp), generator=g)
+        tp, fp, fn = run_online_evaluation(logits, target.float())
+        want += np.concatenate([tp, fp, fn])
+        check(lib.wmh_online_eval_counts(P(logits.cuda()), P(target.to(torch.uint8).cuda()), N, K, S, P(counts), None), 'online_eval_counts')
+    torch.cuda.synchronize()
+    assert np.array_equal(counts.cpu().numpy(), want.astype(np.int64))
+
+
 @pytest.mark.parametrize('with_g1,with_g2,with_head', [(True, False, False), (True, True, False), (False, False, True), (True, False, True)])
 def test_in_lrelu_bwd(lib, with_g1, with_g2, with_head):
     g = torch.Generator().manual_seed(51)
@@ -294,41 +315,6 @@ def test_conv3d_stride2_dgrad_f16x2_pairs(lib, shape):
     e32, r32 = float((dX32.cpu().double() - ref).abs().max()) / sc, float((dX32.cpu().double() - ref).norm() / ref.norm())
     print('f16x2 max err / max|ref| %.2e, rel. L2 %.2e  (exact-fp32 kernel %.2e / %.2e)' % (e16, r16, e32, r32))
     assert e16 <= 2e-6 and r16 <= 1e-6
-
-
-@pytest.mark.parametrize('shape', [(2, 16, 0, 8, 8, 8, 32), (1, 32, 24, 40, 5, 9, 45), (2, 20, 0, 36, 6, 16, 16), (1, 8, 8, 72, 3, 17, 20)])
-def test_conv3d_wgrad_bf16_operands(lib, shape):
-    """bf16-operand weight gradient: against autograd on bf16-rounded dy and x' (tight: only the summation order differs) and
-    against the fp32 kernel (bf16 rounding of the operands); two sources, channel tails, ragged tiles, both tile geometries."""
-    N, C0, C1, Cout, D, H, W = shape
-    Cin = C0 + C1
-    g = torch.Generator().manual_seed(91)
-    x0 = torch.randn(N, C0, D, H, W, generator=g); s0 = torch.stack([0.5 + torch.rand(N, C0, generator=g), 0.3 * torch.randn(N, C0, generator=g)], -1)
-    x1 = torch.randn(N, C1, D, H, W, generator=g) if C1 else None
-    s1 = torch.stack([0.5 + torch.rand(N, C1, generator=g), 0.3 * torch.randn(N, C1, generator=g)], -1) if C1 else None
-    dy = torch.randn(N, Cout, D, H, W, generator=g)
-    act = torch.cat([_act(x0, s0)] + ([_act(x1, s1)] if C1 else []), 1)
-    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
-    w = torch.zeros(Cout, Cin, 3, 3, 3, requires_grad=True)
-    F.conv3d(rb(act), w, None, padding=1).backward(rb(dy))
-    ref = w.grad.reshape(Cout, Cin, 27)
-    assert lib.wmh_conv3d_k3_wgrad_bf16_supported(Cin, Cout, N, D, H, W, 1) == 1
-    assert lib.wmh_conv3d_k3_wgrad_bf16_supported(Cin, Cout, N, D, H, 8, 1) == 0 and lib.wmh_conv3d_k3_wgrad_bf16_supported(Cin, Cout, N, D, H, W, 2) == 0
-    d = [t.cuda() if t is not None else None for t in (x0, s0, x1, s1, dy)]
-    ws = torch.empty(lib.wmh_conv3d_k3_wgrad_bf16_workspace_floats(Cin, Cout, N, D, H, W), device='cuda')
-    outs = []
-    for _ in range(2):
-        dW = torch.full((Cout, Cin, 27), float('nan'), device='cuda')
-        check(lib.wmh_conv3d_k3_wgrad_bf16(P(d[0]), P(d[1]), C0, P(d[2]), P(d[3]), C1, P(d[4]), P(dW), P(ws), N, D, H, W, Cout, SLOPE, None), 'wgrad bf16')
-        torch.cuda.synchronize()
-        outs.append(dW.cpu())
-    assert torch.equal(outs[0], outs[1])                                          # fixed-order reduction
-    scale = float(ref.abs().max())
-    assert float((outs[0] - ref).abs().max()) <= 2e-4 * scale + 1e-5, float((outs[0] - ref).abs().max())
-    w32 = torch.zeros(Cout, Cin, 3, 3, 3, requires_grad=True)
-    F.conv3d(act, w32, None, padding=1).backward(dy)
-    g32 = w32.grad.reshape(Cout, Cin, 27)
-    assert float((outs[0] - g32).norm() / g32.norm()) <= 1e-2
 
 
 F16X2_WG = [(2, 16, 0, 8, 8, 8, 32), (1, 32, 24, 40, 5, 9, 45), (2, 20, 0, 36, 6, 16, 16), (1, 8, 8, 72, 3, 17, 20), (2, 1, 0, 32, 4, 8, 32),

@@ -89,44 +89,12 @@ def test_training_step_is_bit_reproducible(tiny_net, tiny_io):
     assert np.array_equal(res[0], res[1])
 
 
-def test_mixed_precision_step_close_to_fp32_and_reproducible(tiny_net, tiny_io):
-    """precision='bf16': forward / data-gradient convolutions of the wide levels on bf16 operands (fp32 accumulate),
-    everything else fp32 -- gradients stay within bf16 rounding of the fp32 step, and the step is still bit-reproducible."""
+def test_only_the_two_shipped_precisions_exist(tiny_net):
+    """Round 6 removed the bf16 mixed-precision training mode (gradients 8.6 % off float64 autograd): the library refuses it loudly."""
     from deepwmh_amd.trainer import UNetTrainer
-    plan, net, tr32, data, labels, downsample_targets = _setup(tiny_net, tiny_io)
-    xd = torch.from_numpy(data).cuda()
-    td = downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
-    tr32.forward(xd); l32 = float(tr32.backward(td).cpu())
-    g32 = {k: v.clone() for k, v in tr32.g.items()}
-    runs = []
-    for _ in range(2):
-        tr = UNetTrainer(plan, tiny_net[2], 'cuda:0', precision='bf16')
-        tr.forward(xd); l16 = float(tr.backward(td).cpu())
-        runs.append((l16, {k: v.clone() for k, v in tr.g.items()}, tr))
-    assert abs(runs[0][0] - l32) <= 2e-2 * (1 + abs(l32)) and runs[0][0] != l32        # close, and really a different arithmetic
-    num = den = 0.0
-    for k in g32:
-        a, b = runs[0][1][k], g32[k]
-        num += float(((a - b) ** 2).sum()); den += float((b ** 2).sum())
-        assert torch.equal(runs[0][1][k], runs[1][1][k]), k                                # fixed-order reductions in this mode too
-    # The bf16 forward moves the operating point (logits differ by ~1 %), and the gradient field of a random-init net is
-    # sensitive to that: ~10 % relative difference but the same direction.  The backward arithmetic itself is tight:
-    # with an fp32 forward and only the data-gradient convolutions in bf16 the gradients agree to a few 1e-3.
-    assert (num / den) ** 0.5 <= 0.2, 'relative L2 gradient difference %.3g' % ((num / den) ** 0.5)
-    ga = torch.cat([runs[0][1][k].reshape(-1) for k in g32]); gb = torch.cat([g32[k].reshape(-1) for k in g32])
-    assert float((ga * gb).sum() / (ga.norm() * gb.norm())) >= 0.99
-    trd = UNetTrainer(plan, tiny_net[2], 'cuda:0', precision='bf16')
-    trd.bf16_forward = False
-    trd.forward(xd); trd.backward(td)
-    gd = torch.cat([trd.g[k].reshape(-1) for k in g32])
-    assert float((gd - gb).norm() / gb.norm()) <= 1e-2
-    # two optimizer steps stay finite and close to the fp32 trajectory
-    tra, trb = runs[0][2], tr32
-    for _ in range(2):
-        la = float(tra.run_iteration(xd, td, 1e-2).cpu()); lb = float(trb.run_iteration(xd, td, 1e-2).cpu())
-        assert np.isfinite(la) and abs(la - lb) <= 3e-2 * (1 + abs(lb))
-    with pytest.raises(ValueError):
-        UNetTrainer(plan, tiny_net[2], 'cuda:0', precision='fp16')
+    for bad in ('bf16', 'fp16'):
+        with pytest.raises(ValueError):
+            UNetTrainer(tiny_net[0], tiny_net[2], 'cuda:0', precision=bad)
 
 
 @pytest.mark.timeout(1500)
@@ -493,3 +461,25 @@ def test_f16x2_weight_images_rebuilt_in_one_launch_equal_the_single_builds(tiny_
         tr2.run_iteration(xd, td, 1e-2)
     torch.cuda.synchronize()
     assert torch.equal(tr.params, tr2.params)
+
+
+def test_f16x2_job_table_and_images_stay_put_across_iterations(tiny_net, tiny_io):
+    """the transposed convolutions' data-gradient images (key ('tu.dgrad.x3', u, cfg)) were never recorded as used, so every
+    step dropped them, re-allocated them and rebuilt the job table on the host (a pageable upload that synchronises the launch stream).
+    From the second iteration on neither the table object nor any image address may change."""
+    from deepwmh_amd.trainer import UNetTrainer, downsample_targets
+    plan, _net, sd = tiny_net
+    vol = tiny_io['volume'][0]
+    data = np.stack([vol[4:36, 8:40, 4:36], vol[8:40, 0:32, 2:34][::-1].copy()])[:, None].astype(np.float32)
+    labels = np.stack([(tiny_io['seg_tta'][4:36, 8:40, 4:36] > 0)] * 2).astype(np.uint8)
+    xd = torch.from_numpy(data).cuda()
+    td = downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
+    tr = UNetTrainer(plan, sd, 'cuda:0', precision='f16x2')
+    for _ in range(2):
+        tr.run_iteration(xd, td, 1e-2)
+    table, ptrs = tr._x3_table, {k: a[7].data_ptr() for k, a in tr._x3_jobs.items()}
+    assert table is not None
+    for _ in range(3):
+        tr.run_iteration(xd, td, 1e-2)
+        assert tr._x3_table is table
+        assert {k: a[7].data_ptr() for k, a in tr._x3_jobs.items()} == ptrs

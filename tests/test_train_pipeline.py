@@ -136,11 +136,28 @@ def test_plan_train_continue_predict_through_the_executables(tmp_path):
               'model_ep_0002.model', 'model_ep_0002.model.pkl'):
         assert f in have, f
     assert os.path.isfile(os.path.join(os.path.dirname(fdir), 'plans.pkl'))
+    # model_best by nnU-Net's rule (criterion.py): the epochs the log marks are the ones the rule picks from the logged metrics, and
+    # model_best.model holds the LAST of them
+    import re
+    import torch
+    from deepwmh_amd.criterion import ModelBestCriterion
+    rows = re.findall(r'epoch (\d+)/2: .* val loss (-?[0-9.]+) val dice (n/a|[0-9.]+) MA (-?[0-9.]+)( -> model_best)?', p.stdout)
+    assert [int(r[0]) for r in rows] == [1, 2]
+    crit, marked = ModelBestCriterion(), []
+    for ep, vloss, dice, ma, mark in rows:
+        is_best = crit.update(None if dice == 'n/a' else float(dice), float(vloss))
+        assert abs(crit.ma - float(ma)) < 2e-4 and is_best == bool(mark)
+        if mark:
+            marked.append(int(ep))
+    assert marked and marked[0] == 1
+    assert torch.load(os.path.join(fdir, 'model_best.model'), map_location='cpu', weights_only=False)['epoch'] == marked[-1]
     assert 'precision f16x2' in p.stdout                             # the default mode; the switches that select the others:
-    for extra, envx, want in (('--fp32', {}, 'fp32'), ('', dict(WMH_TRAIN_PRECISION='bf16'), 'bf16')):      # (no --bf16 flag: library switch only)
-        q = subprocess.run(shlex.split(train.replace('-e 2', '-e 1').replace('-b 3', '-b 1') + ' ' + extra), env=dict(env, RESULTS_FOLDER=str(tmp_path / ('res_' + want + extra[2:])), **envx),
+    for extra, envx, want in (('--fp32', {}, 'fp32'), ('', dict(WMH_TRAIN_PRECISION='fp32'), 'fp32')):
+        q = subprocess.run(shlex.split(train.replace('-e 2', '-e 1').replace('-b 3', '-b 1') + ' ' + extra), env=dict(env, RESULTS_FOLDER=str(tmp_path / ('res_' + want + extra[2:] + ''.join(envx.values()))), **envx),
                            capture_output=True, text=True)
         assert q.returncode == 0 and ('precision ' + want) in q.stdout, (extra, envx, q.stdout[-500:], q.stderr[-500:])
+    q = subprocess.run(shlex.split(train), env=dict(env, WMH_TRAIN_PRECISION='bf16'), capture_output=True, text=True)       # removed in round 6
+    assert q.returncode != 0 and 'fp32 or f16x2' in (q.stdout + q.stderr)
     p = run(train.replace('-e 2', '-e 3') + ' -c')                  # the reference appends -c when model_latest exists
     assert p.returncode == 0 and 'continuing from' in p.stdout and 'epoch 3/3' in p.stdout and 'epoch 1/3' not in p.stdout
     out = str(tmp_path / 'softmax')

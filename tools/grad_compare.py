@@ -13,12 +13,12 @@ x = torch.randn(2, 1, 128, 128, 128, generator=g).cuda()
 lab = (torch.rand(2, 128, 128, 128, generator=g) < 0.05).to(torch.uint8).cuda()
 td = downsample_targets(lab, plan.num_pool)
 res = {}
-for prec in ('fp32', 'f16x2', 'bf16'):
+for prec in ('fp32', 'f16x2'):
     tr = UNetTrainer(plan, sd, 'cuda:0', precision=prec)
     tr.forward(x); l = float(tr.backward(td).cpu())
     res[prec] = (l, {k: v.clone() for k, v in tr.g.items()})
     del tr; torch.cuda.empty_cache()
-for prec in ('f16x2', 'bf16'):
+for prec in ('f16x2',):
     num = den = 0.0; worst = ('', 0.0)
     for k, v in res['fp32'][1].items():
         a = res[prec][1][k]

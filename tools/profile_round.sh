@@ -13,7 +13,7 @@ python3 bench.py --precision bf16 --storage bf16 > $out/bench_bf16_storage.json 
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_default -o s -- python3 bench.py --cpu-baseline off --also off > $out/stats_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_fp32 -o s -- python3 bench.py --precision fp32 --cpu-baseline off --also off > $out/stats_fp32.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_bf16_storage -o s -- python3 bench.py --precision bf16 --storage bf16 --cpu-baseline off > $out/stats_bf16_storage.log 2>&1
-for p in fp32 f16x2 bf16; do
+for p in fp32 f16x2; do
   WMH_ITERS=3 WMH_PRECISION=$p rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_train_$p -o s -- python3 tools/train_bench.py > $out/stats_train_$p.log 2>&1
 done
 for mode in f16x2 fp32 bf16_storage; do

@@ -1,5 +1,5 @@
 """Time one nnUNetTrainerV2 iteration (BASELINE plan, batch 2 of 128^3 patches) on the HIP kernels.
-env: WMH_BATCH (2), WMH_ITERS (4), WMH_PRECISION (fp32 | bf16 | f16x2), WMH_X3_SPLITK=0 (pair kernels without split-K slabs),
+env: WMH_BATCH (2), WMH_ITERS (4), WMH_PRECISION (fp32 | f16x2), WMH_X3_SPLITK=0 (pair kernels without split-K slabs),
 WMH_X3_S2_WGRAD=0 (strided weight gradients on the exact-fp32 kernel)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -39,7 +39,7 @@ def batch(it):
 
 out = dict(workload='BASELINE plan (31.2 M parameters), batch 2 x 128^3 crops of 4 synthetic volumes (labels = their bright blobs), %d iterations, '
                     'poly LR from 1e-2, He init, identical patch sequence in every mode' % iters, modes={})
-for prec in ('fp32', 'f16x2', 'bf16'):
+for prec in ('fp32', 'f16x2'):
     tr = UNetTrainer(plan, sd, 'cuda:0', precision=prec)
     losses = []
     torch.cuda.synchronize()
@@ -56,7 +56,7 @@ for prec in ('fp32', 'f16x2', 'bf16'):
     del tr
     torch.cuda.empty_cache()
 ref = np.array(out['modes']['fp32']['losses'])
-for prec in ('f16x2', 'bf16'):
+for prec in ('f16x2',):
     cur = np.array(out['modes'][prec]['losses'])
     out['modes'][prec]['max_abs_diff_vs_fp32_curve'] = float(np.abs(cur - ref).max())
     out['modes'][prec]['mean_abs_diff_vs_fp32_curve_last_50'] = float(np.abs(cur - ref)[-50:].mean())
