@@ -155,8 +155,9 @@ def test_online_eval_counts(lib, K, shape):
         target = torch.randint(0, K, (N, 1) + tuple(sp), generator=g)
         tp, fp, fn = run_online_evaluation(logits, target.float())
         want += np.concatenate([tp, fp, fn])
-        check(lib.wmh_online_eval_counts(P(logits.cuda()), P(target.to(torch.uint8).cuda()), N, K, S, P(counts), None), 'online_eval_counts')
-    torch.cuda.synchronize()
+        ld, td = logits.cuda(), target.to(torch.uint8).cuda()           # (kept alive: the launch is asynchronous)
+        check(lib.wmh_online_eval_counts(P(ld), P(td), N, K, S, P(counts), None), 'online_eval_counts')
+        torch.cuda.synchronize()
     assert np.array_equal(counts.cpu().numpy(), want.astype(np.int64))
 
 
