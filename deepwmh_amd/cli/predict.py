@@ -263,7 +263,10 @@ def main(argv=None):
 
     # gunzip of one float32 case is ~0.2 s of one core and cannot be split, so the readers bound a --disable_tta run (0.03 s of GPU per case):
     # as many as --num_threads_preprocessing allows (nnU-Net's default is 6)
-    nread = max(1, min(args.num_threads_preprocessing, 8))
+    # (round 6: with nnU-Net's default of 6 the readers delivered 30 cases/s at best and the command ran at 27.6 -- the readers were the bound,
+    #  not the GPU (45 cases/s); on hosts with cores to spare their number follows the host, up to 16)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    nread = max(1, min(max(args.num_threads_preprocessing, ncpu // 8), 16))
     # Cases in flight: without mirroring a case is 25 ms of GPU work between two synchronising copies (the volume in, label map and
     # probabilities out) and the host work around them -- a second case on a second stream, with its own activation buffers on the same
     # weights, fills those gaps (the Stage-II predictions, DCNN_multistage.py:331-344: 5 x N cases with --disable_tta --save_softmax).

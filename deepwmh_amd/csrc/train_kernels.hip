@@ -362,6 +362,167 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(const float* y,
     const double t = block_sum_256(acc, sh);
     if (threadIdx.x == 0) dysum[nc * gridDim.x + blockIdx.x] = t;
 }
+// ---- round 6: the two 16-byte passes without a branch between their loads --------------------------------------------------------------
+// As compiled, the V4 kernels above test `src.g1`, `src.g2`, `src.dl` inside the loop; every test ends a basic block and the counted waits
+// become `s_waitcnt vmcnt(0)` behind each load: one or two 16-byte loads in flight per lane (4.3 TB/s on the reduce pass; a read-only stream
+// with eight in flight reads at 6.2-7 TB/s on this part: tools/micro/read_rate.hip).  Here the sources are a template parameter (SRC: bit 0 g1,
+// bit 1 g2, bit 2 the head's dlogits with K classes), a step's loads are issued together and U steps are in flight per lane.  The sums are
+// formed in the same order as above (a thread's steps in sequence): same bits.
+template <int SRC, int K>
+struct BwdStep {
+    float4 y, g1, g2, l[K > 0 ? K : 1];
+};
+template <int SRC, int K>
+__device__ __forceinline__ void bwd_step_load(BwdStep<SRC, K>& s, const float* __restrict__ yp, const float* __restrict__ g1p, const float* __restrict__ g2p,
+                                              const float* __restrict__ dlp, size_t S, size_t v) {
+    s.y = *reinterpret_cast<const float4*>(yp + v);
+    if constexpr ((SRC & 1) != 0) s.g1 = *reinterpret_cast<const float4*>(g1p + v);
+    if constexpr ((SRC & 2) != 0) s.g2 = *reinterpret_cast<const float4*>(g2p + v);
+    if constexpr ((SRC & 4) != 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) s.l[k] = *reinterpret_cast<const float4*>(dlp + (size_t)k * S + v);
+    }
+}
+template <int SRC, int K>
+__device__ __forceinline__ void bwd_step_upstream(const BwdStep<SRC, K>& s, const float (&wk)[4], float (&dA)[4]) {
+    float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr ((SRC & 1) != 0) { d4.x += s.g1.x; d4.y += s.g1.y; d4.z += s.g1.z; d4.w += s.g1.w; }
+    if constexpr ((SRC & 2) != 0) { d4.x += s.g2.x; d4.y += s.g2.y; d4.z += s.g2.z; d4.w += s.g2.w; }
+    if constexpr ((SRC & 4) != 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            d4.x = fmaf(wk[k], s.l[k].x, d4.x); d4.y = fmaf(wk[k], s.l[k].y, d4.y); d4.z = fmaf(wk[k], s.l[k].z, d4.z); d4.w = fmaf(wk[k], s.l[k].w, d4.w);
+        }
+    }
+    dA[0] = d4.x; dA[1] = d4.y; dA[2] = d4.z; dA[3] = d4.w;
+}
+template <int SRC, int K>
+__global__ __launch_bounds__(256) void in_lrelu_bwd_reduce4_kernel(const float* __restrict__ y, const float* __restrict__ ss, const float* __restrict__ mr,
+                                                                   BwdSrc src, double* __restrict__ psums, int C, size_t S, float slope, int nq) {
+    __shared__ double sh[4];
+    constexpr int U = 4;                                       // steps in flight per lane
+    const size_t nc = blockIdx.y, n = nc / C;
+    const int c = (int)(nc % C);
+    size_t chunk = (S + gridDim.x - 1) / gridDim.x;
+    chunk = (chunk + 3) & ~(size_t)3;
+    const size_t v0 = (size_t)blockIdx.x * chunk < S ? (size_t)blockIdx.x * chunk : S, v1 = v0 + chunk < S ? v0 + chunk : S;
+    const float sc = ss[2 * nc], shf = ss[2 * nc + 1], mean = mr[2 * nc], rstd = mr[2 * nc + 1];
+    const float* yp = y + nc * S;
+    const float* g1p = (SRC & 1) ? src.g1 + nc * S : nullptr;
+    const float* g2p = (SRC & 2) ? src.g2 + nc * S : nullptr;
+    const float* dlp = (SRC & 4) ? src.dl + n * K * S : nullptr;
+    float wk[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr ((SRC & 4) != 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) wk[k] = src.wseg[k * C + c];
+    }
+    double a0 = 0.0, a1 = 0.0, ak[4] = {0.0, 0.0, 0.0, 0.0};
+    auto use = [&](const BwdStep<SRC, K>& s) __attribute__((always_inline)) {
+        float dA[4];
+        bwd_step_upstream<SRC, K>(s, wk, dA);
+        const float yv[4] = {s.y.x, s.y.y, s.y.z, s.y.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float z = fmaf(yv[e], sc, shf);
+            const float dz = z > 0.f ? dA[e] : dA[e] * slope;
+            const float xh = (yv[e] - mean) * rstd;
+            a0 += dz; a1 += (double)dz * xh;
+            if constexpr ((SRC & 4) != 0) {
+                const float act = z > 0.f ? z : z * slope;
+#pragma unroll
+                for (int k = 0; k < K; ++k) ak[k] += (double)act * (e == 0 ? s.l[k].x : e == 1 ? s.l[k].y : e == 2 ? s.l[k].z : s.l[k].w);
+            }
+        }
+    };
+    size_t v = v0 + 4 * (size_t)threadIdx.x;
+    for (; v + (U - 1) * 1024 < v1; v += U * 1024) {
+        BwdStep<SRC, K> st[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) bwd_step_load<SRC, K>(st[u], yp, g1p, g2p, dlp, S, v + (size_t)u * 1024);
+#pragma unroll
+        for (int u = 0; u < U; ++u) use(st[u]);
+    }
+    for (; v < v1; v += 1024) {
+        BwdStep<SRC, K> st;
+        bwd_step_load<SRC, K>(st, yp, g1p, g2p, dlp, S, v);
+        use(st);
+    }
+    double* out = psums + (nc * gridDim.x + blockIdx.x) * nq;
+    double t = block_sum_256(a0, sh); if (threadIdx.x == 0) out[0] = t;
+    t = block_sum_256(a1, sh);        if (threadIdx.x == 0) out[1] = t;
+    if constexpr ((SRC & 4) != 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { t = block_sum_256(ak[k], sh); if (threadIdx.x == 0) out[2 + k] = t; }
+    }
+}
+template <int SRC, int K>
+__global__ __launch_bounds__(256) void in_lrelu_bwd_apply4_kernel(const float* __restrict__ y, const float* __restrict__ ss, const float* __restrict__ mr,
+                                                                  const float* __restrict__ gamma, BwdSrc src, const double* __restrict__ psums, int split,
+                                                                  double* __restrict__ sums, float* __restrict__ dy, double* __restrict__ dysum, int C, size_t S,
+                                                                  float slope, int nq) {
+    __shared__ double sh[4];
+    constexpr int U = 2;
+    const size_t nc = blockIdx.y, n = nc / C;
+    const int c = (int)(nc % C);
+    const float sc = ss[2 * nc], shf = ss[2 * nc + 1], mean = mr[2 * nc], rstd = mr[2 * nc + 1];
+    double tot0 = 0.0, tot1 = 0.0;
+    {
+        constexpr int nused = 2 + ((SRC & 4) ? K : 0);
+#pragma unroll
+        for (int q = 0; q < nused; ++q) {
+            if (q >= 2 && blockIdx.x != 0) break;                 // uniform
+            const double part = (int)threadIdx.x < split ? psums[(nc * split + threadIdx.x) * nq + q] : 0.0;
+            const double t = block_sum_256(part, sh);
+            if (q == 0) tot0 = t;
+            if (q == 1) tot1 = t;
+            if (blockIdx.x == 0 && threadIdx.x == 0) sums[nc * nq + q] = t;
+        }
+    }
+    const float m1 = (float)(tot0 / (double)S), m2 = (float)(tot1 / (double)S);
+    const float gr = (gamma ? gamma[c] : 1.f) * rstd;
+    const float* yp = y + nc * S;
+    const float* g1p = (SRC & 1) ? src.g1 + nc * S : nullptr;
+    const float* g2p = (SRC & 2) ? src.g2 + nc * S : nullptr;
+    const float* dlp = (SRC & 4) ? src.dl + n * K * S : nullptr;
+    float* op = dy + nc * S;
+    float wk[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr ((SRC & 4) != 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) wk[k] = src.wseg[k * C + c];
+    }
+    double acc = 0.0;
+    auto use = [&](const BwdStep<SRC, K>& s, size_t v) __attribute__((always_inline)) {
+        float dA[4], o[4];
+        bwd_step_upstream<SRC, K>(s, wk, dA);
+        const float yv[4] = {s.y.x, s.y.y, s.y.z, s.y.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float z = fmaf(yv[e], sc, shf);
+            const float dz = z > 0.f ? dA[e] : dA[e] * slope;
+            const float xh = (yv[e] - mean) * rstd;
+            o[e] = gr * (dz - m1 - xh * m2);
+            acc += o[e];
+        }
+        *reinterpret_cast<float4*>(op + v) = make_float4(o[0], o[1], o[2], o[3]);
+    };
+    const size_t stride = (size_t)gridDim.x * 1024;
+    size_t v = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    for (; v + (U - 1) * stride < S; v += U * stride) {
+        BwdStep<SRC, K> st[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) bwd_step_load<SRC, K>(st[u], yp, g1p, g2p, dlp, S, v + (size_t)u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) use(st[u], v + (size_t)u * stride);
+    }
+    for (; v < S; v += stride) {
+        BwdStep<SRC, K> st;
+        bwd_step_load<SRC, K>(st, yp, g1p, g2p, dlp, S, v);
+        use(st, v);
+    }
+    const double t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) dysum[nc * gridDim.x + blockIdx.x] = t;
+}
+
 // dgamma[c] = sum_n sums[n,c,1], dbeta[c] = sum_n sums[n,c,0], dwseg[k][c] = sum_n sums[n,c,2+k], dbias[c] = sum dysum
 __global__ void in_param_grads_kernel(const double* sums, const double* dysum, int gx, int N, int C, int nq, int K,
                                       float* dgamma, float* dbeta, float* dwseg, float* dbias) {
@@ -411,6 +572,25 @@ extern "C" int wmh_in_lrelu_bwd(const float* y, const float* ss, const float* me
     double* dysum = psums + (size_t)NC * nq * split;
     // 16-byte form: four voxels per thread and step (every tensor is a whole number of 16-byte pieces per channel)
     const bool v4 = S % 4 == 0 && ((uintptr_t)y | (uintptr_t)dy | (uintptr_t)g1 | (uintptr_t)g2 | (uintptr_t)dlogits) % 16 == 0;
+    // the branch-free 16-byte kernels (round 6): every combination of sources without the head, and with the head for K = 2
+    const int srcmask = (g1 ? 1 : 0) | (g2 ? 2 : 0) | (dlogits ? 4 : 0);
+    static const int old_form = wmh_diag_env("WMH_IN_BWD_OLD", 0);
+    if (v4 && !old_form && (!dlogits || K == 2)) {
+#define IN_BWD4(M, KK)                                                                                                                          \
+        case M:                                                                                                                                 \
+            hipLaunchKernelGGL((in_lrelu_bwd_reduce4_kernel<M, KK>), dim3(split, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, src, psums, C, S, slope, nq);   \
+            hipLaunchKernelGGL((in_lrelu_bwd_apply4_kernel<M, KK>), dim3(gx, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, gamma, src, psums, (int)split, sums, dy, \
+                               dysum, C, S, slope, nq);                                                                                         \
+            break
+        switch (srcmask) {
+            IN_BWD4(1, 0); IN_BWD4(2, 0); IN_BWD4(3, 0); IN_BWD4(4, 2); IN_BWD4(5, 2); IN_BWD4(6, 2); IN_BWD4(7, 2);
+            default: return wmh_fail(WMH_EINVAL, "in_lrelu_bwd: no gradient source");
+        }
+#undef IN_BWD4
+        hipLaunchKernelGGL(in_param_grads_kernel, dim3(C), dim3(64), 0, st, sums, dysum, (int)gx, N, C, nq, src.K, dgamma,
+                           dbeta, dlogits ? dwseg : nullptr, dbias);
+        return wmh_check_launch("in_lrelu_bwd kernels");
+    }
     if (v4) hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel<true>, dim3(split, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, src, psums, C, S, slope, nq);
     else hipLaunchKernelGGL(in_lrelu_bwd_reduce_kernel<false>, dim3(split, (unsigned)NC), dim3(256), 0, st, y, ss, mean_rstd, src, psums, C,
                        S, slope, nq);

@@ -37,29 +37,10 @@ static inline unsigned cdivu(size_t a, size_t b) { return (unsigned)((a + b - 1)
 
 // ---- InstanceNorm --------------------------------------------------------------------------------
 struct Moments { double n, mean, m2; };
-__device__ __forceinline__ Moments chan_merge(Moments a, Moments b) {
-    Moments r;
-    r.n = a.n + b.n;
-    if (r.n == 0.0) { r.mean = 0.0; r.m2 = 0.0; return r; }
-    const double d = b.mean - a.mean;
-    r.mean = a.mean + d * (b.n / r.n);
-    r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
-    return r;
-}
 __device__ __forceinline__ double shfl_xor_d(double v, int m) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
     return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ Moments wave_merge(Moments a) {   // fixed butterfly: bit-reproducible
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        Moments b;
-        b.n = shfl_xor_d(a.n, m); b.mean = shfl_xor_d(a.mean, m); b.m2 = shfl_xor_d(a.m2, m);
-        const bool lower = ((threadIdx.x & m) == 0);
-        a = lower ? chan_merge(a, b) : chan_merge(b, a);
-    }
-    return a;
 }
 __device__ __forceinline__ void write_scale_shift(Moments t, const float* gamma, const float* beta, float eps,
                                                   float* ss, float* mean_rstd, int nc, int c) {
@@ -71,28 +52,60 @@ __device__ __forceinline__ void write_scale_shift(Moments t, const float* gamma,
     if (mean_rstd) { mean_rstd[2 * nc] = (float)t.mean; mean_rstd[2 * nc + 1] = (float)rstd; }
 }
 
-// One workgroup of four waves per (n, c) row: the records are dealt round-robin to the 256 threads, merged per thread, per wave
-// (fixed butterfly) and across the four waves in wave order -- a fixed association whatever the record count (bit-reproducible).
-__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float4* part, int np, const float* gamma,
-                                                                const float* beta, float eps, float* ss,
-                                                                float* mean_rstd, int C) {
-    __shared__ double sh[4][3];
+// One workgroup of four waves per (n, c) row.  The records (count n_i, sum s_i, M2_i about the record's own mean) are dealt round-robin to
+// the 256 threads, summed per thread, per wave (fixed butterfly) and across the four waves in wave order -- a fixed association whatever the
+// record count (bit-reproducible).
+// Round 6: in double precision the pooled moments need no pairwise merge --
+//     N = sum n_i,   S = sum s_i,   M2 = sum M2_i + sum s_i^2 / n_i - S^2 / N
+// (the cancellation in the last two terms costs ~(mean^2 / var) x 1e-16 relative: nothing at |mean| / std up to 1e4) -- and nearly every
+// record of a launch has the same count (a wave's voxels of a full tile), so s_i^2 is summed as it is and divided once; only records with
+// another count (ragged tiles) pay a division.  The Chan merge this replaces did two double divisions per record: 8192 records per row at 128^3
+// made the 22 launches of a forward 0.39 ms, most of it arithmetic on a 67 MB read.
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float4* __restrict__ part, int np, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, float* __restrict__ ss,
+                                                                float* __restrict__ mean_rstd, int C) {
+    __shared__ double sh[4][5];
     const int nc = blockIdx.x, c = nc % C;
     const float4* p = part + (size_t)nc * np;
-    Moments acc{0.0, 0.0, 0.0};
-    for (int i = threadIdx.x; i < np; i += 256) {
-        const float4 r = p[i];
-        Moments b;
-        b.n = r.x; b.mean = r.x > 0.f ? (double)r.y / (double)r.x : 0.0; b.m2 = r.z;
-        acc = chan_merge(acc, b);
+    const float n0 = p[0].x;                                     // the common count (uniform: every thread reads record 0)
+    double aN = 0.0, aS = 0.0, aM = 0.0, aQ = 0.0, aR = 0.0;    // counts, sums, M2s, s^2 of the common-count records, s^2 / n of the others
+    int i = threadIdx.x;
+    for (; i + 3 * 256 < np; i += 4 * 256) {                     // four 16-byte loads in flight per lane
+        float4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = p[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double sd = (double)r[u].y;
+            aN += (double)r[u].x; aS += sd; aM += (double)r[u].z;
+            if (r[u].x == n0) aQ += sd * sd;
+            else if (r[u].x > 0.f) aR += sd * sd / (double)r[u].x;
+        }
     }
-    acc = wave_merge(acc);
-    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = acc.n; sh[threadIdx.x >> 6][1] = acc.mean; sh[threadIdx.x >> 6][2] = acc.m2; }
+    for (; i < np; i += 256) {
+        const float4 r = p[i];
+        const double sd = (double)r.y;
+        aN += (double)r.x; aS += sd; aM += (double)r.z;
+        if (r.x == n0) aQ += sd * sd;
+        else if (r.x > 0.f) aR += sd * sd / (double)r.x;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        aN += shfl_xor_d(aN, m); aS += shfl_xor_d(aS, m); aM += shfl_xor_d(aM, m); aQ += shfl_xor_d(aQ, m); aR += shfl_xor_d(aR, m);
+    }
+    if ((threadIdx.x & 63) == 0) { double* o = sh[threadIdx.x >> 6]; o[0] = aN; o[1] = aS; o[2] = aM; o[3] = aQ; o[4] = aR; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        Moments t{sh[0][0], sh[0][1], sh[0][2]};
-        for (int w = 1; w < 4; ++w) t = chan_merge(t, Moments{sh[w][0], sh[w][1], sh[w][2]});
-        write_scale_shift(t, gamma, beta, eps, ss, mean_rstd, nc, c);
+        double t[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) t[q] = ((sh[0][q] + sh[1][q]) + sh[2][q]) + sh[3][q];
+        Moments tot{t[0], 0.0, 0.0};
+        if (t[0] > 0.0) {
+            tot.mean = t[1] / t[0];
+            const double between = (n0 > 0.f ? t[3] / (double)n0 : 0.0) + t[4] - t[1] * t[1] / t[0];
+            tot.m2 = t[2] + (between > 0.0 ? between : 0.0);
+        }
+        write_scale_shift(tot, gamma, beta, eps, ss, mean_rstd, nc, c);
     }
 }
 
@@ -318,14 +331,24 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum_kernel(const float*
 
 // Same arithmetic, 4 consecutive voxels of the last axis per thread with 16-byte loads (P2 % 4 == 0, aligned x):
 // a mirrored last axis reads the mirrored quad and reverses it in registers.
-template <int K, bool IN16 = false>
-__global__ __launch_bounds__(256) void seghead_softmax_accum4_kernel(const float* x, const float* ss, const float* wseg,
-                                                                     const float* gauss, float* agg, int C, int P0,
-                                                                     int P1, int P2, int A0, int A1, int A2, int g0,
-                                                                     int g1, int g2, const PatchList pl, float slope) {
+// Round 6: the loop over the channels is cut into groups of eight whose 16-byte loads are issued back to back before the first is used, with no
+// branch between them (HAS_SS is a template parameter) and every table value (scale, shift, head weights) read through the scalar cache
+// (__restrict__: the stores to `agg` cannot alias them).  As compiled until round 5 the `if (ss)` inside the loop and the vector loads of
+// the tables put an `s_waitcnt vmcnt(0)` behind every tensor load -- ONE 16-byte load in flight per lane, 3.65 TB/s on a read-only stream
+// (MI355X_MICROARCH.md, Indexed rows: 5.5-6.1 TB/s want >= 64 KiB in flight per CU).  Same operations in the same order: same bits.
+// AGG4: the accumulator quads are 16-byte aligned (A2 % 4 == 0, g2 % 4 == 0).
+template <int K, bool IN16, bool HAS_SS, bool AGG4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void seghead_softmax_accum4_kernel(const float* __restrict__ x, const float* __restrict__ ss, const float* __restrict__ wseg,
+                                   const float* __restrict__ gauss, float* __restrict__ agg, int C, int P0,
+                                   int P1, int P2, int A0, int A1, int A2, int g0,
+                                   int g1, int g2, const PatchList pl, float slope) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
     const size_t P = (size_t)P0 * P1 * P2, A = (size_t)A0 * A1 * A2, Q = P / 4;
     const int Q2 = P2 / 4;
     const float wgt = 1.f / (float)pl.n;
+    constexpr int G = 8;                                        // loads in flight per lane
     for (size_t qi = (size_t)blockIdx.x * 256 + threadIdx.x; qi < Q; qi += (size_t)gridDim.x * 256) {
         const int q2 = (int)(qi % Q2), p1 = (int)((qi / Q2) % P1), p0 = (int)(qi / ((size_t)Q2 * P1));
         const int p2 = 4 * q2;
@@ -341,25 +364,23 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum4_kernel(const float
             const size_t src = ((size_t)s0 * P1 + s1) * P2 + s2;
             const float* xb = x + (size_t)b * C * P + src;
             const unsigned short* xb16 = reinterpret_cast<const unsigned short*>(x) + (size_t)b * C * P + src;
-            const float* ssb = ss ? ss + (size_t)b * C * 2 : nullptr;
+            const float* ssb = HAS_SS ? ss + (size_t)b * C * 2 : nullptr;
             float lg[K][4];
 #pragma unroll
             for (int k = 0; k < K; ++k)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lg[k][i] = 0.f;
-#pragma unroll 8
-            for (int c = 0; c < C; ++c) {       // unrolled: 8 independent 16-byte loads in flight per lane
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                f4v v4;
+            auto load = [&](int c) __attribute__((always_inline)) -> f4v {
                 if constexpr (IN16) {
-                    typedef unsigned u2v __attribute__((ext_vector_type(2)));
                     const u2v u = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(xb16 + (size_t)c * P));
-                    v4 = f4v{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+                    return f4v{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
                 } else {
-                    v4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(xb + (size_t)c * P));   // read once
+                    return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(xb + (size_t)c * P));   // read once
                 }
+            };
+            auto use = [&](int c, const f4v v4) __attribute__((always_inline)) {
                 float v[4] = {fx ? v4.w : v4.x, fx ? v4.z : v4.y, fx ? v4.y : v4.z, fx ? v4.x : v4.w};
-                if (ssb) {
+                if constexpr (HAS_SS) {
                     const float sc = ssb[2 * c], sh = ssb[2 * c + 1];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = wmh_lrelu(fmaf(v[i], sc, sh), slope);
@@ -370,7 +391,16 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum4_kernel(const float
 #pragma unroll
                     for (int i = 0; i < 4; ++i) lg[k][i] = fmaf(v[i], wk, lg[k][i]);
                 }
+            };
+            int c = 0;
+            for (; c + G <= C; c += G) {
+                f4v t[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) t[j] = load(c + j);
+#pragma unroll
+                for (int j = 0; j < G; ++j) use(c + j, t[j]);
             }
+            for (; c < C; ++c) use(c, load(c));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float mx = lg[0][i];
@@ -389,13 +419,26 @@ __global__ __launch_bounds__(256) void seghead_softmax_accum4_kernel(const float
         const size_t dst = ((size_t)(g0 + p0) * A1 + (g1 + p1)) * A2 + (g2 + p2);
         {
 #pragma clang fp contract(off)
+            if constexpr (AGG4) {
+                f4v old[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k)
+                for (int k = 0; k < K; ++k) old[k] = *reinterpret_cast<const f4v*>(agg + (size_t)k * A + dst);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float t = res[k][i] * gw[i];
-                    agg[(size_t)k * A + dst + i] = agg[(size_t)k * A + dst + i] + t;
+                for (int k = 0; k < K; ++k) {
+                    f4v o = old[k];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float t = res[k][i] * gw[i]; o[i] = o[i] + t; }
+                    *reinterpret_cast<f4v*>(agg + (size_t)k * A + dst) = o;
                 }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float t = res[k][i] * gw[i];
+                        agg[(size_t)k * A + dst + i] = agg[(size_t)k * A + dst + i] + t;
+                    }
+            }
         }
     }
 }
@@ -414,9 +457,16 @@ static int seghead_softmax_accumulate(const float* x, const float* ss, const flo
     // 16-byte path: quads along the last axis must not straddle rows and every base must be 16-byte aligned
     const bool quad = (P2 % 4 == 0) && !(reinterpret_cast<uintptr_t>(x) & 15) && (!gauss || !(reinterpret_cast<uintptr_t>(gauss) & 15));
     unsigned gx = cdivu(quad ? P / 4 : P, 256);
+    {   // diagnostic library only (WMH_HEAD_BPC): persistent grid of that many workgroups per CU for the quad kernel (grid-stride loop)
+        static const int bpc = wmh_diag_env("WMH_HEAD_BPC", 0);
+        if (quad && bpc > 0 && gx > 256u * bpc) gx = 256u * bpc;
+    }
+    const bool agg4 = (A2 % 4 == 0) && (origin[2] % 4 == 0) && !(reinterpret_cast<uintptr_t>(agg) & 15);
+#define LAUNCH_HEAD_Q(KK, F, S, A4) hipLaunchKernelGGL((seghead_softmax_accum4_kernel<KK, F, S, A4>), dim3(gx), dim3(256), 0, st, x, ss, wseg, gauss, agg, \
+                                 C, P0, P1, P2, A0, A1, A2, origin[0], origin[1], origin[2], pl, lrelu_slope)
 #define LAUNCH_HEAD_F(KK, F)                                                                                             \
-    if (quad) hipLaunchKernelGGL((seghead_softmax_accum4_kernel<KK, F>), dim3(gx), dim3(256), 0, st, x, ss, wseg, gauss, agg, \
-                                 C, P0, P1, P2, A0, A1, A2, origin[0], origin[1], origin[2], pl, lrelu_slope);            \
+    if (quad) { if (ss) { if (agg4) LAUNCH_HEAD_Q(KK, F, true, true); else LAUNCH_HEAD_Q(KK, F, true, false); }           \
+                else { if (agg4) LAUNCH_HEAD_Q(KK, F, false, true); else LAUNCH_HEAD_Q(KK, F, false, false); } }         \
     else hipLaunchKernelGGL((seghead_softmax_accum_kernel<KK, F>), dim3(gx), dim3(256), 0, st, x, ss, wseg, gauss, agg, C,    \
                             P0, P1, P2, A0, A1, A2, origin[0], origin[1], origin[2], pl, lrelu_slope)
 #define LAUNCH_HEAD(KK) do { if (in16) { LAUNCH_HEAD_F(KK, true); } else { LAUNCH_HEAD_F(KK, false); } } while (0)
@@ -428,6 +478,7 @@ static int seghead_softmax_accumulate(const float* x, const float* ss, const flo
     }
 #undef LAUNCH_HEAD
 #undef LAUNCH_HEAD_F
+#undef LAUNCH_HEAD_Q
     return wmh_check_launch("seghead_softmax_accum_kernel");
 }
 extern "C" int wmh_seghead_softmax_accumulate(const float* x, const float* ss, const float* wseg, int K,
@@ -460,24 +511,25 @@ __global__ __launch_bounds__(256) void seghead_logits_kernel(const float* x, con
 // The same per voxel (identical operation order: bit-identical logits), four consecutive voxels per thread with 16-byte loads and
 // stores, eight channels' loads in flight (P % 4 == 0, 16-byte aligned x and out).  The one-voxel form read the training step's
 // five deep-supervision heads at ~1 TB/s: 0.7 ms of a 28 ms iteration.
-template <int K>
-__global__ __launch_bounds__(256) void seghead_logits4_kernel(const float* x, const float* ss, const float* wseg,
-                                                              float* out, int C, size_t P, float slope) {
+template <int K, bool HAS_SS>
+__global__ __launch_bounds__(256) void seghead_logits4_kernel(const float* __restrict__ x, const float* __restrict__ ss, const float* __restrict__ wseg,
+                                                              float* __restrict__ out, int C, size_t P, float slope) {
+    // (round 6: groups of eight channels whose loads are issued back to back, no branch between them, tables through the scalar cache --
+    //  see seghead_softmax_accum4_kernel; same operations in the same order)
     const int b = blockIdx.y;
     const float* xb = x + (size_t)b * C * P;
-    const float* ssb = ss ? ss + (size_t)b * C * 2 : nullptr;
+    const float* ssb = HAS_SS ? ss + (size_t)b * C * 2 : nullptr;
     typedef float f4v __attribute__((ext_vector_type(4)));
+    constexpr int G = 8;
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < P / 4; q += (size_t)gridDim.x * 256) {
         float lg[K][4];
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
             for (int i = 0; i < 4; ++i) lg[k][i] = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < C; ++c) {
-            const f4v v4 = *reinterpret_cast<const f4v*>(xb + (size_t)c * P + 4 * q);
+        auto use = [&](int c, const f4v v4) __attribute__((always_inline)) {
             float v[4] = {v4.x, v4.y, v4.z, v4.w};
-            if (ssb) {
+            if constexpr (HAS_SS) {
                 const float sc = ssb[2 * c], sh = ssb[2 * c + 1];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = wmh_lrelu(fmaf(v[i], sc, sh), slope);
@@ -488,7 +540,16 @@ __global__ __launch_bounds__(256) void seghead_logits4_kernel(const float* x, co
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lg[k][i] = fmaf(v[i], wk, lg[k][i]);
             }
+        };
+        int c = 0;
+        for (; c + G <= C; c += G) {
+            f4v t[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) t[j] = *reinterpret_cast<const f4v*>(xb + (size_t)(c + j) * P + 4 * q);
+#pragma unroll
+            for (int j = 0; j < G; ++j) use(c + j, t[j]);
         }
+        for (; c < C; ++c) use(c, *reinterpret_cast<const f4v*>(xb + (size_t)c * P + 4 * q));
 #pragma unroll
         for (int k = 0; k < K; ++k) *reinterpret_cast<f4v*>(out + ((size_t)b * K + k) * P + 4 * q) = f4v{lg[k][0], lg[k][1], lg[k][2], lg[k][3]};
     }
@@ -561,9 +622,12 @@ static int seghead_logits(const float* x, const float* ss, const float* wseg, in
             return wmh_check_launch("seghead_logits4s_kernel");
         }
         unsigned g4 = cdivu(spatial / 4, 256); if (g4 > 65535) g4 = 65535;
-        if (K == 2) hipLaunchKernelGGL((seghead_logits4_kernel<2>), dim3(g4, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
-        else if (K == 3) hipLaunchKernelGGL((seghead_logits4_kernel<3>), dim3(g4, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
-        else hipLaunchKernelGGL((seghead_logits4_kernel<4>), dim3(g4, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope);
+#define LAUNCH_L4(KK) do { if (ss) hipLaunchKernelGGL((seghead_logits4_kernel<KK, true>), dim3(g4, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope); \
+                           else hipLaunchKernelGGL((seghead_logits4_kernel<KK, false>), dim3(g4, n), dim3(256), 0, st, x, ss, wseg, out, C, spatial, lrelu_slope); } while (0)
+        if (K == 2) LAUNCH_L4(2);
+        else if (K == 3) LAUNCH_L4(3);
+        else LAUNCH_L4(4);
+#undef LAUNCH_L4
         return wmh_check_launch("seghead_logits4_kernel");
     }
     switch (K) {

@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from deepwmh_amd import _lib
-lib = _lib.load()
+lib = _lib.load_diag() if os.environ.get('WMH_DIAG_LIB') else _lib.load()
 n, C, P = 8, 32, (128, 128, 128)
 x = torch.randn(n, C, *P, device='cuda'); ss = torch.rand(n, C, 2, device='cuda') + 0.5
 w = torch.randn(2, C, device='cuda'); g = torch.rand(*P, device='cuda'); agg = torch.zeros(2, 160, 192, 160, device='cuda')
