@@ -247,26 +247,76 @@ def main(argv=None):
             continue
         todo.append((case, out))
 
+    # Host buffers around the GPU are page-locked and recycled (round 6): the readers decompress straight into them, the H2D copy of a case
+    # and the D2H copies of its label map / probabilities are stream-ordered DMA instead of `.to()` / `.cpu()`'s pageable staging -- without
+    # mirroring a case is 22 ms of GPU work, and the two pageable copies of a 20 MB float volume were a third of that again on the lane's
+    # thread.  WMH_PREDICT_PINNED=0 restores the pageable path.
+    import threading
+    use_pinned = os.environ.get('WMH_PREDICT_PINNED', '1') != '0'
+
+    class PinnedPool:
+        def __init__(self):
+            self.free, self.lock = {}, threading.Lock()
+
+        def get(self, shape, dtype):
+            key = (tuple(int(v) for v in shape), dtype)
+            with self.lock:
+                lst = self.free.get(key)
+                if lst:
+                    return lst.pop()
+            return torch.empty(key[0], dtype=dtype).pin_memory()
+
+        def put(self, t):
+            if t is not None:
+                with self.lock:
+                    self.free.setdefault((tuple(t.shape), t.dtype), []).append(t)
+    pool = PinnedPool()
+    tsum = dict(read=0.0, wait=0.0, pre=0.0, predict=0.0, export=0.0, write=0.0)      # seconds summed over cases (lanes / threads run side by side)
+    tlock = threading.Lock()
+
     def load(case):
         t0 = time.time()
-        vols, meta = [], None
+        vols, meta, held = [], None, [None]
         for m in range(nmod):
-            arr, mt = nifti.read(os.path.join(args.input_folder, '%s_%04d.nii.gz' % (case, m)))
+            path = os.path.join(args.input_folder, '%s_%04d.nii.gz' % (case, m))
+            if use_pinned:
+                def alloc(shape, m=m):
+                    if held[0] is None:
+                        held[0] = pool.get((nmod,) + tuple(shape), torch.float32)
+                    return held[0][m].numpy()
+                arr, mt = nifti.read(path, alloc=alloc)
+            else:
+                arr, mt = nifti.read(path)
             vols.append(arr)
             meta = meta or mt
-        return np.stack(vols), meta, time.time() - t0
+        if held[0] is not None and all(v.shape == tuple(held[0].shape[1:]) for v in vols):
+            vol = held[0]                                       # a page-locked tensor [C, z, y, x]: every modality was read into its slice
+        else:
+            pool.put(held[0]); held[0] = None
+            vol = np.stack(vols)
+        dt = time.time() - t0
+        with tlock:
+            tsum['read'] += dt
+        return vol, meta, dt
 
-    def save(out, case, seg_full, prob0, meta):
-        nifti.write(out, seg_full, like=meta, dtype=np.uint8)
-        if prob0 is not None:
-            nifti.write(os.path.join(args.output_folder, case + '_0.nii.gz'), prob0, like=meta, dtype=np.float32)
+    def save(out, case, seg_full, prob0, meta, held=()):
+        t0 = time.time()
+        try:
+            nifti.write(out, seg_full, like=meta, dtype=np.uint8)
+            if prob0 is not None:
+                nifti.write(os.path.join(args.output_folder, case + '_0.nii.gz'), prob0, like=meta, dtype=np.float32)
+        finally:
+            for t in held:
+                pool.put(t)
+            with tlock:
+                tsum['write'] += time.time() - t0
 
     # gunzip of one float32 case is ~0.2 s of one core and cannot be split, so the readers bound a --disable_tta run (0.03 s of GPU per case):
     # as many as --num_threads_preprocessing allows (nnU-Net's default is 6)
     # (round 6: with nnU-Net's default of 6 the readers delivered 30 cases/s at best and the command ran at 27.6 -- the readers were the bound,
     #  not the GPU (45 cases/s); on hosts with cores to spare their number follows the host, up to 16)
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    nread = max(1, min(max(args.num_threads_preprocessing, ncpu // 8), 16))
+    nread = max(1, int(os.environ.get('WMH_PREDICT_READERS', min(max(args.num_threads_preprocessing, ncpu // 8), 16))))
     # Cases in flight: without mirroring a case is 25 ms of GPU work between two synchronising copies (the volume in, label map and
     # probabilities out) and the host work around them -- a second case on a second stream, with its own activation buffers on the same
     # weights, fills those gaps (the Stage-II predictions, DCNN_multistage.py:331-344: 5 x N cases with --disable_tta --save_softmax).
@@ -276,8 +326,10 @@ def main(argv=None):
     for _ in range(1, min(ninflight, max(1, len(todo)))):
         e2 = eng.clone()
         lanes.append((SlidingWindowPredictor(e2, plan.patch_size, args.step_size, True, not args.disable_tta, batch=16), torch.cuda.Stream()))
-    import threading
     lock = threading.Lock()
+    # (the lanes' threads hold the GIL for a millisecond at a time -- ctypes launches -- and hand it to each other, the readers and the writers:
+    #  with CPython's default 5 ms switch interval a lane waiting for the GIL loses a fifth of a case's GPU time per hand-over)
+    sys.setswitchinterval(float(os.environ.get('WMH_PREDICT_SWITCH_S', '5e-4')))
     t_all = time.time()
     t_case_done = []
     # the label map is small; the background probability (--save_softmax) is a float32 volume: its compression is spread over the gzip pool
@@ -322,12 +374,24 @@ def main(argv=None):
                     t1 = time.time()
                     # crop, (resample,) z-score, sliding window, (resample,) argmax, un-crop: all on the device
                     data_d, props = preprocess_case_device(vol, meta['spacing'], plans, stage, 'cuda:0')
+                    ta = time.time()
                     resampled = tuple(data_d.shape[1:]) != tuple(props['shape_after_crop'])
                     seg_d, prob_d = p_k.predict_device(data_d, return_prob=args.save_softmax or resampled)
-                    seg_full, prob0 = export_prediction_device(seg_d, prob_d, props, args.save_softmax)     # synchronises this lane's stream
+                    tb = time.time()
+                    held = []
+
+                    def host_alloc(shape, dtype):
+                        held.append(pool.get(shape, dtype))
+                        return held[-1]
+                    seg_full, prob0 = export_prediction_device(seg_d, prob_d, props, args.save_softmax,
+                                                               host_alloc if use_pinned else None)         # synchronises this lane's stream
+                    if isinstance(vol, torch.Tensor):
+                        pool.put(vol)                                       # its H2D copy is behind the synchronisation above
                     t2 = time.time()
+                    with tlock:
+                        tsum['wait'] += t1 - t0; tsum['pre'] += ta - t1; tsum['predict'] += tb - ta; tsum['export'] += t2 - tb
                     with lock:
-                        saves.append(writers.submit(save, out, case, seg_full, prob0, meta))
+                        saves.append(writers.submit(save, out, case, seg_full, prob0, meta, tuple(held)))
                         t_case_done.append(time.time())
                     print('  %s: shape %s%s, read %.2f s (waited %.2f s), gpu %.2f s'
                           % (case, tuple(data_d.shape[1:]), ' (resampled)' if resampled else '', t_load, t1 - t0, t2 - t1), flush=True)
@@ -342,6 +406,11 @@ def main(argv=None):
         if len(todo) >= 4:          # rate once the pipeline is full: from the end of the first case's GPU work to the last file written
             steady = '; first case done after %.2f s, then %.2f cases/s' % (t_case_done[0] - t_all, (len(todo) - 1) / max(1e-9, time.time() - t_case_done[0]))
         print('  %d case(s) in %.2f s (%.2f cases/s%s)' % (len(todo), dt, len(todo) / dt, steady), flush=True)
+        n = float(len(todo))
+        print('  host time per case (ms; %d reader(s), %d lane(s), %d writer(s) run side by side): read %.0f | lane: wait for the read %.0f, '
+              'preprocess + H2D %.0f, queue the forwards %.0f, export + D2H (synchronises) %.0f | write %.0f'
+              % (nread, len(lanes), nwrite, 1e3 * tsum['read'] / n, 1e3 * tsum['wait'] / n, 1e3 * tsum['pre'] / n, 1e3 * tsum['predict'] / n,
+                 1e3 * tsum['export'] / n, 1e3 * tsum['write'] / n), flush=True)
     return 0
 
 

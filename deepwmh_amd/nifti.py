@@ -42,6 +42,33 @@ def _open(path, mode):
     return open(path, mode)
 
 
+def _read_all(path):
+    """The file's bytes, decompressed when it is a .gz.  zlib in ONE call per gzip member instead of gzip.GzipFile: Python 3.10's reader
+    walks the stream in 8 KB steps of Python code, taking the interpreter lock a few thousand times per 20 MB volume -- with a handful of reader
+    threads beside them, the threads that launch kernels then wait for the lock longer than the kernels run (nnUNet_predict --disable_tta:
+    14-26 ms to queue a forward that takes 1 ms to queue alone).  zlib.decompress releases the lock for the whole member."""
+    with open(path, 'rb') as f:
+        data = f.read()
+    if not str(path).endswith('.gz'):
+        return data
+    parts = []
+    while data:
+        d = zlib.decompressobj(31)                      # gzip framing; members may be concatenated (RFC 1952 2.2; our writer emits 1 MiB ones)
+        parts.append(d.decompress(data))
+        if not d.eof:
+            raise NiftiError('truncated gzip stream in %s' % path)
+        data = d.unused_data
+    if len(parts) == 1:
+        return parts[0]
+    # several members: assembled by numpy copies (which release the interpreter lock; b''.join of 20 MB holds it for milliseconds)
+    out = np.empty(sum(len(p) for p in parts), np.uint8)
+    pos = 0
+    for p in parts:
+        out[pos:pos + len(p)] = np.frombuffer(p, np.uint8)
+        pos += len(p)
+    return out.data                                     # a memoryview: read_header / np.frombuffer take it as they take bytes
+
+
 def read_header(raw):
     if len(raw) < 348:
         raise NiftiError('file too short for a NIfTI-1 header')
@@ -57,10 +84,11 @@ def read_header(raw):
     return hdr, swapped
 
 
-def read(path):
-    """Returns (array float32 (z, y, x) [or (t, z, y, x)], meta).  meta['spacing'] = (dz, dy, dx)."""
-    with _open(path, 'rb') as f:
-        raw = f.read()
+def read(path, alloc=None):
+    """Returns (array float32 (z, y, x) [or (t, z, y, x)], meta).  meta['spacing'] = (dz, dy, dx).
+    alloc: optional callable(shape) -> writable C-contiguous float32 numpy array of that shape, in which the volume is returned (a caller
+    hands out page-locked buffers this way)."""
+    raw = _read_all(path)
     hdr, swapped = read_header(raw)
     ndim = int(hdr['dim'][0])
     if not 1 <= ndim <= 7:
@@ -72,20 +100,25 @@ def read(path):
     if code not in DTYPES:
         raise NiftiError('unsupported NIfTI datatype %d' % code)
     dt = np.dtype(DTYPES[code]).newbyteorder('>' if swapped else '<')
-    off = int(hdr['vox_offset']) if bytes(hdr['magic'])[:3] == b'n+1' else 0
-    off = max(off, 352) if bytes(hdr['magic'])[:3] == b'n+1' else off
+    single = bytes(hdr['magic'])[:3] == b'n+1'
+    off = max(int(hdr['vox_offset']), 352) if single else 0
     n = int(np.prod(shape))
     if len(raw) < off + n * dt.itemsize:
         raise NiftiError('data block shorter than the header says')
     data = np.frombuffer(raw, dtype=dt, count=n, offset=off).reshape(shape[::-1])   # x fastest -> (.., z, y, x)
     slope, inter = float(hdr['scl_slope']), float(hdr['scl_inter'])
-    arr = data.astype(np.float32)
-    if slope not in (0.0, 1.0) or inter != 0.0:
-        if slope != 0.0 and np.isfinite(slope):
-            arr = arr * np.float32(slope) + np.float32(inter)
+    if alloc is not None:
+        arr = alloc(tuple(shape[::-1]))
+        arr[...] = data                                 # one pass, conversion included (numpy releases the GIL for it)
+    else:
+        arr = data.astype(np.float32)
+    if (slope not in (0.0, 1.0) or inter != 0.0) and slope != 0.0 and np.isfinite(slope):
+        arr *= np.float32(slope)
+        arr += np.float32(inter)
+    arr = np.ascontiguousarray(arr)
     pix = [float(v) for v in hdr['pixdim'][1:4]]
     meta = dict(header=hdr.copy(), spacing=tuple(pix[::-1]), shape_xyz=tuple(shape[:3]), swapped=swapped)
-    return np.ascontiguousarray(arr), meta
+    return arr, meta
 
 
 def write(path, array_zyx, like=None, spacing=None, dtype=np.float32):
@@ -114,14 +147,16 @@ def write(path, array_zyx, like=None, spacing=None, dtype=np.float32):
     hdr['scl_inter'] = 0.0
     hdr['magic'] = b'n+1\x00'
     hdr['regular'] = b'r'
-    payload = hdr.tobytes() + b'\x00\x00\x00\x00' + arr.tobytes()
+    head = hdr.tobytes() + b'\x00\x00\x00\x00'
+    body = memoryview(arr).cast('B')                    # no copy of the volume on this thread (tobytes + concatenation were two, under the lock)
     tmp = str(path) + '.tmp%d_%d' % (os.getpid(), threading.get_ident())
     with open(tmp, 'wb') as f:
         if str(path).endswith('.gz'):
-            for piece in gzip_members(payload):
+            for piece in gzip_members(body, head=head):
                 f.write(piece)
         else:
-            f.write(payload)
+            f.write(head)
+            f.write(body)
     os.replace(tmp, path)
 
 
@@ -135,21 +170,21 @@ _pool = None
 _pool_lock = threading.Lock()
 
 
-def _member(buf, level=1):
+def _member(buf, level=1, head=b''):
     c = zlib.compressobj(level, zlib.DEFLATED, 31)
-    return c.compress(buf) + c.flush()
+    return (c.compress(head) if head else b'') + c.compress(buf) + c.flush()
 
 
-def gzip_members(payload, level=1):
-    """payload (bytes) -> list of gzip members whose concatenation decompresses to it."""
+def gzip_members(payload, level=1, head=b''):
+    """payload (bytes / memoryview), preceded by `head` -> list of gzip members whose concatenation decompresses to head + payload."""
     global _pool
     view = memoryview(payload)
     if len(view) <= 2 * _MEMBER_BYTES:
-        return [_member(view, level)]
+        return [_member(view, level, head)]
     with _pool_lock:
         if _pool is None:
             from concurrent.futures import ThreadPoolExecutor
             _pool = ThreadPoolExecutor(max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))),
                                        thread_name_prefix='wmh_gzip')
     parts = [view[i:i + _MEMBER_BYTES] for i in range(0, len(view), _MEMBER_BYTES)]
-    return list(_pool.map(lambda b: _member(b, level), parts))
+    return list(_pool.map(lambda ib: _member(ib[1], level, head if ib[0] == 0 else b''), enumerate(parts)))

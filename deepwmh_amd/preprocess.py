@@ -80,7 +80,10 @@ def preprocess_case_device(volume_zyx, spacing, plans, stage=None, device='cuda:
     st_plan = stages[stage if stage is not None else (max(stages.keys()) if isinstance(stages, dict) else len(stages) - 1)]
     tf = list(plans.get('transpose_forward', [0, 1, 2]))
     data = volume_zyx[None] if volume_zyx.ndim == 3 else volume_zyx
-    x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(device)
+    if isinstance(data, torch.Tensor):          # a (page-locked) host tensor or a device tensor: the copy is stream ordered, no staging pass
+        x = data.to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
+    else:
+        x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(device)
     Cn, D, H, W = (int(v) for v in x.shape)
     n = D * H * W
     st = _lib.current_stream()
@@ -127,10 +130,13 @@ def preprocess_case_device(volume_zyx, spacing, plans, stage=None, device='cuda:
     return out, props
 
 
-def export_prediction_device(seg_d, prob_d, props, want_prob0=False):
+def export_prediction_device(seg_d, prob_d, props, want_prob0=False, host_alloc=None):
     """(seg uint8, prob fp32 [K,...]) device tensors in network geometry -> (uint8 numpy label map, P(background) numpy or
     None) in the input's geometry: transpose back, order-1 resampling of the probabilities to the cropped shape when it
-    differs (then argmax), un-crop into zeros on the device; one D2H copy of the label map."""
+    differs (then argmax), un-crop into zeros on the device; one D2H copy of the label map.
+    host_alloc: optional callable(shape, torch dtype) -> page-locked host tensor; the results are then copied into such tensors (stream
+    ordered copies + one synchronisation of the current stream) instead of through `.cpu()`'s pageable staging, and the numpy arrays returned
+    are views of them (the caller recycles the tensors once the arrays are written out)."""
     import torch
     from . import _lib
     lib = _lib.load()
@@ -157,8 +163,16 @@ def export_prediction_device(seg_d, prob_d, props, want_prob0=False):
         p0 = torch.ones((D, H, W), dtype=torch.float32, device=seg_c.device)   # outside the crop everything is background
         sl = tuple(slice(a, b) for a, b in props['bbox'])
         p0[sl] = prob[0]
-        p0 = p0.cpu().numpy()
-    return full.cpu().numpy(), p0
+    if host_alloc is None:
+        return full.cpu().numpy(), (p0.cpu().numpy() if p0 is not None else None)
+    seg_h = host_alloc((D, H, W), torch.uint8)
+    seg_h.copy_(full, non_blocking=True)
+    p0_h = None
+    if p0 is not None:
+        p0_h = host_alloc((D, H, W), torch.float32)
+        p0_h.copy_(p0, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return seg_h.numpy(), (p0_h.numpy() if p0_h is not None else None)
 
 
 def export_segmentation_device(seg_crop, props):
