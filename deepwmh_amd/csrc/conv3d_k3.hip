@@ -311,6 +311,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_first_kernel(const ConvArgs a) 
         for (int m = 0; m < TY; ++m) acc[0][m][r] = bv;
     }
     __syncthreads();
+    // (Round 6, measured and not kept: a row's stores issued right behind its 14 MFMAs, so that they drain under the next row's -- 1.05 -> 1.13 ms
+    //  at 16 patches.  The wave issues in order: once the store queue is full it waits at a store, and the MFMAs behind it wait with it; the
+    //  overlap this kernel has comes from the CU's other workgroup.)
 #pragma unroll
     for (int m = 0; m < TY; ++m) {
         const float* hp = halo + (wave * IY + m) * IX + j;
