@@ -397,10 +397,12 @@ __device__ __forceinline__ void bwd_step_upstream(const BwdStep<SRC, K>& s, cons
     dA[0] = d4.x; dA[1] = d4.y; dA[2] = d4.z; dA[3] = d4.w;
 }
 template <int SRC, int K>
-__global__ __launch_bounds__(256) void in_lrelu_bwd_reduce4_kernel(const float* __restrict__ y, const float* __restrict__ ss, const float* __restrict__ mr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void in_lrelu_bwd_reduce4_kernel(const float* __restrict__ y, const float* __restrict__ ss, const float* __restrict__ mr,
                                                                    BwdSrc src, double* __restrict__ psums, int C, size_t S, float slope, int nq) {
     __shared__ double sh[4];
-    constexpr int U = 4;                                       // steps in flight per lane
+    // steps in flight per lane (with the head's two logit planes a step is four loads: at U = 4 the register allocator, holding on to
+    // eight waves per SIMD, serialised the loads again -- 1.9 ms for the 128^3 layer where the old form took 1.05)
+    constexpr int U = (SRC & 4) ? 2 : 4;
     const size_t nc = blockIdx.y, n = nc / C;
     const int c = (int)(nc % C);
     size_t chunk = (S + gridDim.x - 1) / gridDim.x;
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_reduce4_kernel(const float* 
     }
 }
 template <int SRC, int K>
-__global__ __launch_bounds__(256) void in_lrelu_bwd_apply4_kernel(const float* __restrict__ y, const float* __restrict__ ss, const float* __restrict__ mr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void in_lrelu_bwd_apply4_kernel(const float* __restrict__ y, const float* __restrict__ ss, const float* __restrict__ mr,
                                                                   const float* __restrict__ gamma, BwdSrc src, const double* __restrict__ psums, int split,
                                                                   double* __restrict__ sums, float* __restrict__ dy, double* __restrict__ dysum, int C, size_t S,
                                                                   float slope, int nq) {
