@@ -1004,15 +1004,19 @@ def run_rank(args):
     from deepwmh_amd.sliding_window import SlidingWindowPredictor
     from deepwmh_amd.synthetic import he_init_state_dict, synthetic_flair
 
-    torch.cuda.set_device(local_rank)                  # before the process group: RCCL binds to the current device
+    # WMH_BENCH_BACKEND=gloo: the ranks may share GPUs (rank r on device r mod the visible count) -- the rehearsal of `--gpus N` on a box with
+    # fewer than N GPUs (numbers meaningless, plumbing and bit-identity real); the default, nccl = RCCL, wants one GPU per rank
+    backend = os.environ.get('WMH_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)                   # before the process group: RCCL binds to the current device
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL
-    device = 'cuda:%d' % local_rank
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    device = 'cuda:%d' % dev_index
 
     if args.legs == 'only':
         if world == 1 and not dist.is_initialized():
             os.environ.setdefault('MASTER_PORT', '29533')
-            dist.init_process_group('nccl', rank=0, world_size=1)       # one-rank RCCL group: every collective is forced through it
+            dist.init_process_group(backend, rank=0, world_size=1)      # one-rank RCCL group: every collective is forced through it
         legs = multi_gpu_legs(args, rank, world, device)
         if rank == 0:
             print('LEGS ' + json.dumps(legs), flush=True)

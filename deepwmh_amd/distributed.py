@@ -181,7 +181,16 @@ class PatchShardedPredictor:
                     mine.zero_()                             # ragged last round: a zero tile that nobody accumulates
                 gathered = recv[rd & 1]
                 # the one exchange step (output viewed as the concatenation along dim 0: accepted by RCCL and gloo)
-                work = dist.all_gather_into_tensor(gathered.view((W * K,) + tuple(P)), mine, group=self.group, async_op=True)
+                if mine.is_cuda and dist.get_backend(self.group) == 'gloo':
+                    # gloo has no all-gather of device tensors: staged through the host.  Not a production path (RCCL is): it lets W ranks
+                    # share ONE GPU, which is how the HIP arithmetic is tested under W > 1 where no multi-GPU node exists (tests/test_gpu_two_ranks.py)
+                    torch.cuda.current_stream().synchronize()
+                    host = torch.empty((W * K,) + tuple(P), dtype=mine.dtype)
+                    dist.all_gather_into_tensor(host, mine.cpu(), group=self.group)
+                    gathered.view((W * K,) + tuple(P)).copy_(host)
+                    work = None
+                else:
+                    work = dist.all_gather_into_tensor(gathered.view((W * K,) + tuple(P)), mine, group=self.group, async_op=True)
             else:                                            # one rank: nothing to overlap, and the backend may reuse its tile buffer
                 drain((None, self.b.tile(vol, origins[idx])[None], rd))
                 continue
