@@ -840,7 +840,11 @@ def legs_child():
         port = s.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    p = subprocess.run([sys.executable, os.path.abspath(__file__), '--legs', 'only', '--gpus', '1'], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), '--legs', 'only', '--gpus', '1'], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           timeout=float(os.environ.get('WMH_BENCH_LEGS_TIMEOUT_S', '420')))
+    except subprocess.TimeoutExpired:                     # (the rehearsal must never take the headline down with it)
+        return dict(error='the one-rank RCCL child did not finish in time')
     for ln in reversed(p.stdout.splitlines()):
         if ln.startswith('LEGS '):
             return json.loads(ln[5:])
