@@ -594,7 +594,10 @@ def measure_cli(plan, sd, shape, n_mirror=12, n_softmax=40, train_batches=40):
 
         def run(cmd, extra_env=None):
             t0 = time.time()
-            p = subprocess.run(cmd.split(), env=dict(env, **(extra_env or {})), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            try:
+                p = subprocess.run(cmd.split(), env=dict(env, **(extra_env or {})), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            except subprocess.TimeoutExpired as e:
+                return 124, 'timed out after 600 s: %s' % (e.stdout or '')[-300:], time.time() - t0
             return p.returncode, p.stdout, time.time() - t0
 
         def predict_leg(n, flags, outdir):
