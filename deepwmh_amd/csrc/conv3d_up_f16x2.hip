@@ -28,6 +28,10 @@
 //              of the low-resolution halo tile (4 x 6 x 18 voxels), A fragments from the chunk's 64 KB weight image in LDS (double
 //              buffered).  (First version: fragments straight from L2 through an 8-deep register ring -- every wave has its own two classes, 96 KB
 //              per chunk and CU, and the MFMA phase took 5.5 k cycles for 3.1 k of issue.)
+//              (Round 6, measured and not kept: the chunk's weight image by LDS-DMA -- global_load_lds_dwordx4 issued by the consumer waves, 8 x 1 KB per
+//              wave one chunk ahead into the other weight buffer, nothing of the weights on the loader waves; as inline asm, because with the builtin in
+//              the loop every counted lgkmcnt of the operand ring became lgkmcnt(0).  Same bits, 9.87 against 9.51 ms for the 128^3 stage, 4.36 / 4.26
+//              and 2.18 / 2.14 for the other two, same box, interleaved runs.)
 //   waves 4-7  loaders: the next chunk's halo tile as aligned quads, producer's InstanceNorm + LeakyReLU, fp16 split, two 16-byte LDS
 //              writes per voxel (the pair kernel's image: 32 bytes per voxel, hi | lo pieces, XOR-swizzled by bit 3 of x); and the next
 //              chunk's weight image, 16 x 16 bytes per thread through registers.
