@@ -438,3 +438,61 @@ def test_anisotropic_plan_matches_oracle():
     seg_o, prob_o = osw.predict_3d_tiled(net, vol, plan.patch_size, 0.5, True, True)
     assert float(np.abs(prob - prob_o).max()) <= TOL
     assert _mask_check(seg, seg_o, prob_o)[0] == 0
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'f16x2'])
+def test_two_modalities_three_classes_vs_oracle(precision):
+    """Outside DeepWMH's own configuration (one FLAIR channel, lesion / background) but inside the kernels' repertoire: two input modalities
+    (the first layer's two-channel form) and three classes (head, softmax, argmax, loss and online evaluation with K = 3) -- forward with deep
+    supervision, tiled prediction with mirroring, and one training step's loss and gradients against the oracle."""
+    from deepwmh_amd.network import UNetEngine
+    from deepwmh_amd.plan import UNetPlan
+    from deepwmh_amd.sliding_window import SlidingWindowPredictor
+    from deepwmh_amd.trainer import UNetTrainer, downsample_targets
+    from oracle import sliding_window as osw, training as ot
+    from oracle.generic_unet import unet_from_plan, perturb_like_trained, state_dict_numpy
+    torch.manual_seed(11)
+    plan = UNetPlan(2, 8, 3, [[2, 2, 2]] * 3, [[3, 3, 3]] * 4, 2, 64, [32, 32, 32])
+    net = perturb_like_trained(unet_from_plan(plan), seed=6).eval()
+    sd = state_dict_numpy(net)
+    eng = UNetEngine(plan, sd, 'cuda:0', precision=precision)
+    vol = np.concatenate([osw.synthetic_flair((40, 48, 40), seed=21), osw.synthetic_flair((40, 48, 40), seed=22)], 0)
+    x = torch.from_numpy(np.ascontiguousarray(vol[None, :, 4:36, 8:40, 2:34]))
+    with torch.no_grad():
+        net.do_ds = True
+        ref = net(x)
+        net.do_ds = False
+    got = eng.forward_logits(x.cuda(), deep_supervision=True)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert tuple(a.shape) == tuple(b.shape) and a.shape[1] == 3
+        assert float((a.cpu() - b).abs().max()) <= TOL, 'scale %d' % i
+    seg, prob = SlidingWindowPredictor(eng, do_mirroring=True).predict(vol)
+    seg_o, prob_o = osw.predict_3d_tiled(net, vol, plan.patch_size, 0.5, True, True)
+    assert prob.shape[0] == 3 and float(np.abs(prob - prob_o).max()) <= TOL
+    top2 = np.sort(prob_o, 0)
+    sure = (top2[-1] - top2[-2]) > 2 * TOL
+    assert int((seg != seg_o)[sure].sum()) == 0 and set(np.unique(seg_o)) >= {0, 1}
+    # one training step: loss and gradients against float64 autograd, online-evaluation counts against the oracle's
+    import copy
+    data = np.stack([vol[:, 4:36, 8:40, 2:34], vol[:, 8:40, 0:32, 6:38]]).astype(np.float32)
+    labels = np.stack([seg_o[4:36, 8:40, 2:34], (seg_o[8:40, 0:32, 6:38] + 1) % 3]).astype(np.uint8)
+    n64 = copy.deepcopy(net).double().train()
+    n64.do_ds = True
+    tgt = ot.downsample_targets(torch.from_numpy(labels[:, None].astype(np.float32)), plan.num_pool)
+    out64 = n64(torch.from_numpy(data).double())
+    loss = ot.multiple_output_loss(out64, [t.double() for t in tgt], ot.deep_supervision_weights(plan.num_pool))
+    loss.backward()
+    tr = UNetTrainer(plan, sd, 'cuda:0', precision=precision)
+    td = downsample_targets(torch.from_numpy(labels).cuda(), plan.num_pool)
+    tr.forward(torch.from_numpy(data).cuda())
+    l = float(tr.backward(td).cpu())
+    assert abs(l - float(loss.detach())) <= 2e-5 * (1 + abs(float(loss.detach())))
+    num = den = 0.0
+    for name, p in n64.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        num += float(((tr.g[name].double().cpu() - g) ** 2).sum()); den += float((g ** 2).sum())
+    assert (num / den) ** 0.5 <= 2e-3, (num / den) ** 0.5
+    counts = tr.online_eval(td[0]).cpu().numpy()
+    tp, fp, fn = ot.run_online_evaluation(out64[0].detach().float(), torch.from_numpy(labels[:, None].astype(np.float32)))
+    want = np.concatenate([tp, fp, fn]).astype(np.int64)
+    assert np.abs(counts - want).sum() <= 4, (counts, want)         # (argmax of logits that differ by rounding: a handful of voxels at most)

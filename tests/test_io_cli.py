@@ -152,3 +152,37 @@ def test_checkpoint_helper_process_writes_what_save_checkpoint_writes(tmp_path):
         w.drain()
     w.close()
     assert not os.path.exists(w.dir)
+
+
+def test_nifti_read_into_caller_buffers_and_multi_member_gzip(tmp_path):
+    """Round 6: read(alloc=...) places the volume in a caller's buffer (nnUNet_predict hands out page-locked ones); .gz files are decompressed
+    with one zlib call per member -- our writer's 1 MiB members, a single-member file as nibabel writes, and a truncated stream."""
+    import gzip
+    from deepwmh_amd import nifti
+    rng = np.random.default_rng(3)
+    vol = (rng.standard_normal((64, 96, 80)) * 40).round().astype(np.float32)          # 1.9 MB: below the member threshold -> one member
+    big = (rng.standard_normal((96, 128, 112)) * 40).round().astype(np.float32)         # 5.5 MB: several members
+    for name, v in (('one', vol), ('many', big)):
+        p = str(tmp_path / (name + '.nii.gz'))
+        nifti.write(p, v, spacing=(1.0, 2.0, 3.0))
+        raw = open(p, 'rb').read()
+        members = raw.count(b'\x1f\x8b\x08\x00')                                        # (a lower bound on gzip headers is enough here)
+        assert (members >= 2) == (name == 'many')
+        assert gzip.open(p).read()[352:] == v.tobytes()                                 # any gzip reader sees one stream
+        a, meta = nifti.read(p)
+        buf = np.full(v.shape, np.nan, np.float32)
+        b, _ = nifti.read(p, alloc=lambda shape: buf)
+        assert b is buf and np.array_equal(a, v) and np.array_equal(buf, v) and meta['spacing'] == (1.0, 2.0, 3.0)
+    single = str(tmp_path / 'single.nii.gz')
+    with gzip.open(single, 'wb', compresslevel=1) as f:
+        f.write(gzip.open(str(tmp_path / 'many.nii.gz')).read())
+    c, _ = nifti.read(single, alloc=lambda shape: np.empty(shape, np.float32))
+    assert np.array_equal(c, big)
+    i16 = str(tmp_path / 'i16.nii.gz')
+    nifti.write(i16, (vol / 4).astype(np.int16), dtype=np.int16)
+    d, _ = nifti.read(i16, alloc=lambda shape: np.empty(shape, np.float32))            # other datatypes are converted into the buffer
+    assert d.dtype == np.float32 and np.array_equal(d, (vol / 4).astype(np.int16).astype(np.float32))
+    cut = str(tmp_path / 'cut.nii.gz')
+    open(cut, 'wb').write(open(single, 'rb').read()[:100000])
+    with pytest.raises(nifti.NiftiError):
+        nifti.read(cut)
