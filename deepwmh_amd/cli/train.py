@@ -58,10 +58,15 @@ def main(argv=None):
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         sys.exit('nnUNet_train (deepwmh_amd): no HIP device visible')
+    # WMH_TRAIN_BACKEND=gloo: ranks may share GPUs (rank r on device r mod the visible count; gradients averaged through gloo) -- how the
+    # data-parallel command is exercised where fewer GPUs than ranks exist (tests/test_gpu_two_ranks.py); the default, nccl = RCCL, wants one each
+    backend = os.environ.get('WMH_TRAIN_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)                        # before the process group: RCCL binds to the current device
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     device = 'cuda:%d' % local
 
     tasks = [d for d in sorted(os.listdir(pre)) if d.startswith('Task%03d_' % int(args.task))] if args.task.isdigit() else [args.task]

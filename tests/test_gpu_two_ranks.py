@@ -12,6 +12,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -132,3 +133,37 @@ def test_data_parallel_training_of_two_ranks_on_the_hip_kernels():
         assert same_mean, 'the averaged arena is not the mean of the two local arenas'
         assert differs_from_local and differs_from_solo, 'no exchange took place'
         assert same_params, 'the ranks drifted apart'
+
+
+@pytest.mark.timeout(900)
+def test_nnunet_train_data_parallel_command_with_two_ranks_sharing_the_gpu(tmp_path):
+    """configs[4] behind the reference's boundary: `torch.distributed.run --nproc-per-node 2 nnUNet_train ...` (the reference itself passes one GPU:
+    /root/reference/deepwmh/pipeline/DCNN_multistage.py:292-309), both ranks on the one MI355X (WMH_TRAIN_BACKEND=gloo).  The command must train,
+    average, write rank 0's checkpoints and exit 0; the checkpoint must load and a single-rank `-c` run must continue from it."""
+    import shlex
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_train_pipeline import make_raw_dataset
+    raw, pre, res = str(tmp_path / 'raw'), str(tmp_path / 'pre'), str(tmp_path / 'results')
+    task = make_raw_dataset(raw, n=3)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, nnUNet_raw_data_base=raw, nnUNet_preprocessed=pre, RESULTS_FOLDER=res, CUDA_VISIBLE_DEVICES='0',
+               PATH=os.path.join(ROOT, 'bin') + os.pathsep + os.environ['PATH'], WMH_TRAIN_BACKEND='gloo', OMP_NUM_THREADS='4')
+    p = subprocess.run(shlex.split('nnUNet_plan_and_preprocess -t 1 --verify_dataset_integrity'), env=env, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-1500:]
+    train = 'nnUNet_train 3d_fullres nnUNetTrainerV2 1 all -e 2 -b 3 --noval --save_every_epoch --disable_postprocessing_on_folds --val_batches 2'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'bin', 'nnUNet_train')] + shlex.split(train)[1:]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert '2 rank(s)' in p.stdout and 'epoch 2/2' in p.stdout and p.stdout.count('epoch 2/2') == 1          # rank 0 reports, once
+    fdir = os.path.join(res, 'nnUNet', '3d_fullres', task, 'nnUNetTrainerV2__nnUNetPlansv2.1', 'all')
+    for f in ('model_latest.model', 'model_best.model', 'model_ep_0002.model', 'model_final_checkpoint.model'):
+        assert os.path.isfile(os.path.join(fdir, f)), f
+    from deepwmh_amd import checkpoint as ck
+    _, _, sd, info = ck.load_checkpoint(os.path.dirname(fdir), 'all', 'model_latest')
+    assert info['epoch'] == 2 and all(np.isfinite(v).all() for v in sd.values())
+    env1 = {k: v for k, v in env.items() if k != 'WMH_TRAIN_BACKEND'}
+    q = subprocess.run(shlex.split(train.replace('-e 2', '-e 3') + ' -c'), env=env1, capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0 and 'continuing from' in q.stdout and 'epoch 3/3' in q.stdout, (q.stdout[-800:], q.stderr[-1500:])
