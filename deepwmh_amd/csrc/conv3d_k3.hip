@@ -311,6 +311,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_first_kernel(const ConvArgs a) 
         for (int m = 0; m < TY; ++m) acc[0][m][r] = bv;
     }
     __syncthreads();
+    // (Round 6, measured and not kept: this layer in the f16x2 pair mode -- the 27 taps as K of v_mfma_f32_32x32x16_f16, a lane's operand gathered by
+    //  eight 2-byte LDS reads, 6 MFMAs of 32 cycles per row instead of 14 of 64; correct to 2e-6 of float64 -- 1.030 -> 1.010 ms at 16 patches: the
+    //  layer is its 4.3 GB of stores at 4.25 TB/s, two 128-byte segments per instruction, and the matrix time was already hidden by the CU's other
+    //  workgroup.)
     // (Round 6, measured and not kept: a row's stores issued right behind its 14 MFMAs, so that they drain under the next row's -- 1.05 -> 1.13 ms
     //  at 16 patches.  The wave issues in order: once the store queue is full it waits at a store, and the MFMAs behind it wait with it; the
     //  overlap this kernel has comes from the CU's other workgroup.)
