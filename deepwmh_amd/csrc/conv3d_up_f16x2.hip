@@ -42,6 +42,8 @@
 #include <string.h>
 #include <type_traits>
 #include <utility>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "conv3d_common.h"
 
@@ -440,14 +442,17 @@ extern "C" int wmh_conv3d_up_pack_weights_f16x2(const float* w3, int Cin_total, 
     const int G = (Cout + 31) / 32, NCH = (Clow + 7) / 8;
     uint16_t* out = static_cast<uint16_t*>(wimg);
     memset(out, 0, wmh_conv3d_up_packed_bytes_f16x2(Clow, Cout));
-    std::vector<double> wc((size_t)Cout * Clow);
     // the transposed convolution's weight as [q][cm][ci] doubles: the composition's inner loop then runs along contiguous ci (vectorisable);
     // as written first -- a stride of 8 Cup floats per step -- the 128-channel stage took seconds of `nnUNet_predict`'s start-up
     std::vector<double> wtT((size_t)8 * Cup * Clow);
     for (int ci = 0; ci < Clow; ++ci)
         for (int cm = 0; cm < Cup; ++cm)
             for (int q = 0; q < 8; ++q) wtT[((size_t)q * Cup + cm) * Clow + ci] = (double)wt[((size_t)ci * Cup + cm) * 8 + q];
-    for (int cls = 0; cls < 8; ++cls) {
+    // One host thread per parity class (round 6: the classes' images are disjoint; every output is formed by one thread in the same order as before,
+    // so the image does not depend on the thread count -- 0.18 s of a fresh process's first forward were this function, single-threaded).
+    std::atomic<int> bad(0);
+    auto one_class = [&](int cls) {
+        std::vector<double> wc((size_t)Cout * Clow);
         const int p[3] = {(cls >> 2) & 1, (cls >> 1) & 1, cls & 1};
         for (int tau = 0; tau < 8; ++tau) {
             const int d[3] = {(tau >> 2) & 1, (tau >> 1) & 1, tau & 1};
@@ -484,14 +489,21 @@ extern "C" int wmh_conv3d_up_pack_weights_f16x2(const float* w3, int Cin_total, 
                             v *= WMH_PAIR_WSCALE;
                             // a composed weight sums up to Cup products: it can leave fp16's range although both layers pass their own checks;
                             // refused like the other packers refuse (NaN fails the comparison too); the engine then keeps the two-kernel stage
-                            if (!(fabsf(v) < 65000.f)) return wmh_fail(WMH_EINVAL, "conv3d_up_pack_weights_f16x2: composed weight not finite or beyond fp16's range (|256 w| >= 65000)");
+                            if (!(fabsf(v) < 65000.f)) { bad.store(1); return; }
                             const _Float16 h = (_Float16)v;
                             const _Float16 l = (_Float16)(v - (float)h);
                             memcpy(&hi[e], &h, 2); memcpy(&lo[e], &l, 2);
                         }
                     }
         }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int cls = 1; cls < 8; ++cls) th.emplace_back(one_class, cls);
+        one_class(0);
+        for (auto& t : th) t.join();
     }
+    if (bad.load()) return wmh_fail(WMH_EINVAL, "conv3d_up_pack_weights_f16x2: composed weight not finite or beyond fp16's range (|256 w| >= 65000)");
     return WMH_OK;
 }
 

@@ -51,14 +51,27 @@ class _ConvLayer:
         return self._packed_bf16[cfg]
 
     def packed_f16x2(self, cfg):
+        """The layer's f16x2 weight image.  Built on the DEVICE since round 6 (the packer the trainer uses every step; bit-identical to the host packer:
+        tests/test_gpu_f16x2.py): the host loops took ~0.4 s for the BASELINE network -- most of the first forward of a fresh `nnUNet_predict`
+        process, which DeepWMH_predict starts once per case.  The device packer does not look at the values, so the range check the host packer
+        makes (finite, |256 w| < 65000) is made here; weights outside it go to the host packer, which refuses them with the reason."""
         key = ('x3', cfg)
         if key not in self._packed_bf16:
             n = self.lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, self.cin, self.cout)
-            wf = np.empty(n, dtype=np.uint16)
-            _lib.check(self.lib.wmh_conv3d_k3_pack_weights_f16x2(
-                cfg, self.w_host.ctypes.data_as(C.c_void_p), self.cin, self.cout,
-                wf.ctypes.data_as(C.c_void_p)), 'wmh_conv3d_k3_pack_weights_f16x2')
-            self._packed_bf16[key] = torch.from_numpy(wf.view(np.int16)).to(self.device)
+            amax = float(np.abs(self.w_host).max()) if self.w_host.size else 0.0
+            if self.kz == 3 and np.isfinite(amax) and amax * 256.0 < 65000.0:
+                wd = torch.from_numpy(np.ascontiguousarray(self.w_host.reshape(self.cout, self.cin, -1))).to(self.device)
+                wf = torch.empty(n, dtype=torch.int16, device=self.device)
+                _lib.check(self.lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, _lib.ptr(wd), self.cin, self.cout, 0, self.cin, 0, _lib.ptr(wf),
+                                                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'wmh_conv3d_k3_pack_weights_f16x2_device')
+                wd.record_stream(torch.cuda.current_stream())          # freed when the launch has read it
+                self._packed_bf16[key] = wf
+            else:
+                wf = np.empty(n, dtype=np.uint16)
+                _lib.check(self.lib.wmh_conv3d_k3_pack_weights_f16x2(
+                    cfg, self.w_host.ctypes.data_as(C.c_void_p), self.cin, self.cout,
+                    wf.ctypes.data_as(C.c_void_p)), 'wmh_conv3d_k3_pack_weights_f16x2')
+                self._packed_bf16[key] = torch.from_numpy(wf.view(np.int16)).to(self.device)
         return self._packed_bf16[key]
 
     def packed_f16x2_slice(self, cfg, ci_off, ci_cnt):

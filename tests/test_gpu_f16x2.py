@@ -298,3 +298,26 @@ def test_split_k_makes_small_levels_depend_on_the_batch_only_in_the_last_bits(li
     assert torch.equal(y16[0], y16[1])                               # same patch, two slots of one batch: identical bits
     rel = float((y16[0] - y1[0]).double().norm() / y1[0].double().norm())
     assert rel <= 1e-6, rel
+
+
+@pytest.mark.parametrize('cfg,Cin,Cout', [(0, 32, 32), (0, 20, 40), (21, 64, 64), (2, 256, 256), (24, 320, 320), (1, 32, 64), (25, 128, 256), (26, 256, 320)])
+def test_device_packer_builds_the_host_packers_image(lib, cfg, Cin, Cout):
+    """UNetEngine builds its f16x2 weight images with wmh_conv3d_k3_pack_weights_f16x2_device since round 6 (the host loops were most of a fresh
+    process's first forward): every configuration's image must be the host packer's, bit for bit -- ragged channel counts and weights whose low parts
+    are subnormal included."""
+    import ctypes
+    from deepwmh_amd import _lib
+    P = _lib.ptr
+    if not lib.wmh_conv3d_k3_f16x2_supported(cfg):
+        pytest.skip('configuration %d has no f16x2 kernel' % cfg)
+    rng = np.random.default_rng(cfg + Cin)
+    w = (rng.standard_normal((Cout, Cin, 27)) * np.exp(rng.uniform(-9, 3, (Cout, Cin, 27)))).astype(np.float32)
+    w = np.clip(w, -200, 200)
+    n = lib.wmh_conv3d_k3_packed_halfs_f16x2(cfg, Cin, Cout)
+    host = np.zeros(n, np.uint16)
+    _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2(cfg, w.ctypes.data_as(ctypes.c_void_p), Cin, Cout, host.ctypes.data_as(ctypes.c_void_p)), 'host pack')
+    wd = torch.from_numpy(w).cuda()
+    dev = torch.full((n,), 0x7e00, dtype=torch.int16, device='cuda')
+    _lib.check(lib.wmh_conv3d_k3_pack_weights_f16x2_device(cfg, P(wd), Cin, Cout, 0, Cin, 0, P(dev), None), 'device pack')
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy().view(np.uint16), host)
